@@ -1,0 +1,275 @@
+"""fp32 torch-CPU restatement of the reference graph -- TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Each function cites the reference lines it follows (paths relative to /root/reference).  Tensors use the
+reference's own layouts: images/latents NCHW, tokens [B,N,C], Linear weight [d_in,d_out]
+(y = x @ W + b, burn nn::Linear), conv weight [out,in,kh,kw].  ``W`` is a dict name -> torch tensor whose
+names are the reference's struct field paths (oracle/config.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .config import UNetConfig, VAEConfig, unet_block_plan
+
+Tensor = torch.Tensor
+EPS = 1e-5  # GroupNormConfig / LayerNormConfig default (groupnorm/mod.rs:13-14, layernorm/mod.rs:12-13)
+
+
+def to_torch(weights: Dict[str, "np.ndarray"]) -> Dict[str, Tensor]:  # noqa: F821
+    return {k: torch.from_numpy(v) for k, v in weights.items()}
+
+
+# ----------------------------------------------------------------------------- primitives
+
+def silu(x: Tensor) -> Tensor:
+    """src/model/silu.rs:14-16: x * sigmoid(x)."""
+    return x * torch.sigmoid(x)
+
+
+def layernorm_fn(x: Tensor, eps: float) -> Tensor:
+    """src/model/groupnorm/mod.rs:75-82 == layernorm/mod.rs:42-49:
+    u = x - mean(x, last); u / sqrt(mean(u*u, last) + eps)   (biased variance, eps inside the sqrt)."""
+    u = x - x.mean(dim=-1, keepdim=True)
+    return u / torch.sqrt((u * u).mean(dim=-1, keepdim=True) + eps)
+
+
+def group_norm(x: Tensor, gamma: Tensor, beta: Tensor, n_group: int = 32, eps: float = EPS) -> Tensor:
+    """GroupNorm::forward src/model/groupnorm/mod.rs:52-73 (x is [B,C,...])."""
+    shape = x.shape
+    b = shape[0]
+    aff = [1] * x.dim()
+    aff[1] = shape[1]
+    y = layernorm_fn(x.reshape(b, n_group, -1), eps).reshape(shape)
+    return y * gamma.reshape(aff) + beta.reshape(aff)
+
+
+def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = EPS) -> Tensor:
+    """LayerNorm::forward src/model/layernorm/mod.rs:34-40."""
+    return layernorm_fn(x, eps) * gamma + beta
+
+
+def linear(x: Tensor, W: Dict[str, Tensor], name: str) -> Tensor:
+    """burn nn::Linear: y = x @ W[d_in,d_out] (+ b)."""
+    y = x @ W[name + ".weight"]
+    b = W.get(name + ".bias")
+    return y if b is None else y + b
+
+
+def conv2d(x: Tensor, W: Dict[str, Tensor], name: str, stride: int = 1, padding: int = 0) -> Tensor:
+    return F.conv2d(x, W[name + ".weight"], W[name + ".bias"], stride=stride, padding=padding)
+
+
+def qkv_attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], n_head: int) -> Tensor:
+    """Generic path src/backend.rs:88-128: q,k each scaled by d^-0.25, softmax over keys, [B,N,H*d] in/out."""
+    n_batch, n_qctx, n_state = q.shape
+    n_ctx = k.shape[1]
+    scale = (n_state / n_head) ** -0.25
+    n_hstate = n_state // n_head
+    qh = q.reshape(n_batch, n_qctx, n_head, n_hstate).transpose(1, 2) * scale
+    kh = (k.reshape(n_batch, n_ctx, n_head, n_hstate).transpose(1, 2).transpose(-1, -2)) * scale
+    vh = v.reshape(n_batch, n_ctx, n_head, n_hstate).transpose(1, 2)
+    qk = qh @ kh
+    if mask is not None:
+        qk = qk + mask[:n_qctx, :n_ctx]
+    w = torch.softmax(qk, dim=3)
+    return (w @ vh).transpose(1, 2).flatten(2, 3)
+
+
+def attn_decoder_mask(seq_length: int) -> Tensor:
+    """src/backend.rs:130-136: -inf strictly above the diagonal, 0 elsewhere."""
+    m = torch.zeros(seq_length, seq_length)
+    return m.masked_fill(torch.ones(seq_length, seq_length, dtype=torch.bool).triu(1), float("-inf"))
+
+
+def upsample_nearest2x(x: Tensor) -> Tensor:
+    """reshape + repeat(3,2) + repeat(5,2) (unet/mod.rs:744-749, autoencoder/mod.rs:313-318)."""
+    b, c, h, w = x.shape
+    return x.reshape(b, c, h, 1, w, 1).repeat(1, 1, 1, 2, 1, 2).reshape(b, c, 2 * h, 2 * w)
+
+
+# ----------------------------------------------------------------------------- UNet
+
+def timestep_embedding(timesteps: Tensor, dim: int, max_period: int = 10000) -> Tensor:
+    """src/model/unet/mod.rs:21-39 (cos first, then sin)."""
+    half = dim // 2
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * (-math.log(max_period) / half))
+    args = timesteps.float()[:, None] * freqs[None]
+    return torch.cat([args.cos(), args.sin()], dim=1)
+
+
+def conditioning_embedding(pooled: Tensor, dim: int, size: Tensor, crop: Tensor, ar: Tensor) -> Tensor:
+    """src/model/unet/mod.rs:41-57."""
+    cat = torch.cat([size, crop, ar], dim=1)
+    b, w = cat.shape
+    emb = timestep_embedding(cat.reshape(b * w), dim, 10000).reshape(b, w * dim)
+    return torch.cat([pooled, emb], dim=1)
+
+
+def res_block(x: Tensor, emb: Tensor, W, p: str) -> Tensor:
+    """ResBlock::forward src/model/unet/mod.rs:1082-1106."""
+    h = conv2d(silu(group_norm(x, W[p + ".norm_in.gamma"], W[p + ".norm_in.beta"])), W, p + ".conv_in", padding=1)
+    e = linear(silu(emb), W, p + ".lin_embed")
+    h = h + e[:, :, None, None]
+    h = conv2d(silu(group_norm(h, W[p + ".norm_out.gamma"], W[p + ".norm_out.beta"])), W, p + ".conv_out", padding=1)
+    if (p + ".skip_connection.weight") in W:
+        return conv2d(x, W, p + ".skip_connection") + h
+    return x + h
+
+
+def multi_head_attention(x: Tensor, context: Optional[Tensor], W, p: str, n_head: int) -> Tensor:
+    """MultiHeadAttention::forward src/model/unet/mod.rs:1005-1023."""
+    xa = x if context is None else context
+    q = linear(x, W, p + ".query")
+    k = linear(xa, W, p + ".key")
+    v = linear(xa, W, p + ".value")
+    return linear(qkv_attention(q, k, v, None, n_head), W, p + ".out")
+
+
+def geglu(x: Tensor, W, p: str) -> Tensor:
+    """GEGLU::forward src/model/unet/mod.rs:942-956 (burn nn::Gelu = exact erf GELU)."""
+    pr = linear(x, W, p + ".proj")
+    n = pr.shape[-1] // 2
+    return pr[..., :n] * F.gelu(pr[..., n:])
+
+
+def transformer_block(x: Tensor, context: Tensor, W, p: str, n_head: int) -> Tensor:
+    """TransformerBlock::forward src/model/unet/mod.rs:885-891."""
+    x = x + multi_head_attention(layer_norm(x, W[p + ".norm1.gamma"], W[p + ".norm1.beta"]), None, W, p + ".attn1", n_head)
+    x = x + multi_head_attention(layer_norm(x, W[p + ".norm2.gamma"], W[p + ".norm2.beta"]), context, W, p + ".attn2", n_head)
+    h = layer_norm(x, W[p + ".norm3.gamma"], W[p + ".norm3.beta"])
+    return x + linear(geglu(h, W, p + ".mlp.geglu"), W, p + ".mlp.lin")   # MLP::forward :915-918
+
+
+def spatial_transformer(x: Tensor, context: Tensor, W, p: str, n_head: int, depth: int) -> Tensor:
+    """SpatialTransformer::forward src/model/unet/mod.rs:820-845."""
+    b, c, h, w = x.shape
+    x_in = x
+    t = group_norm(x, W[p + ".norm.gamma"], W[p + ".norm.beta"]).reshape(b, c, h * w).transpose(1, 2)
+    t = linear(t, W, p + ".proj_in")
+    for j in range(depth):
+        t = transformer_block(t, context, W, f"{p}.blocks.{j}", n_head)
+    t = linear(t, W, p + ".proj_out").transpose(1, 2).reshape(b, c, h, w)
+    return x_in + t
+
+
+def _unet_block(x, emb, ctx, W, p, b):
+    k = b["kind"]
+    if k == "Conv":
+        return conv2d(x, W, p, padding=1)
+    if k == "Down":                                  # DownsampleConfig::init unet/mod.rs:765-772
+        return conv2d(x, W, p, stride=2, padding=1)
+    if k == "Res":
+        return res_block(x, emb, W, p)
+    x = res_block(x, emb, W, p + ".res")
+    if k in ("ResT", "ResTU"):                       # :571-577, :657-664
+        x = spatial_transformer(x, ctx, W, p + ".transformer", b["n_head"], b["depth"])
+    if k in ("ResTU", "ResU"):                       # Upsample::forward :742-752
+        x = conv2d(upsample_nearest2x(x), W, p + ".upsample.conv", padding=1)
+    return x
+
+
+def unet_forward(cfg: UNetConfig, W, x: Tensor, timesteps: Tensor, context: Tensor, label: Tensor) -> Tensor:
+    """UNet::forward src/model/unet/mod.rs:450-492.  x [B,4,H,W], timesteps [B] int, context [B,77,ctx], label [B,adm]."""
+    inp, mid, out = unet_block_plan(cfg)
+    t_emb = timestep_embedding(timesteps, cfg.model_channels, 10000)
+    t_emb = linear(silu(linear(t_emb, W, "lin1_time_embed")), W, "lin2_time_embed")
+    l_emb = linear(silu(linear(label, W, "lin1_label_embed")), W, "lin2_label_embed")
+    emb = t_emb + l_emb
+    saved = []
+    for i, b in enumerate(inp):
+        x = _unet_block(x, emb, context, W, f"input_blocks.{i}", b)
+        saved.append(x)
+    x = res_block(x, emb, W, "middle_block.res1")                                   # :713-719
+    x = spatial_transformer(x, context, W, "middle_block.transformer", mid["n_head"], mid["depth"])
+    x = res_block(x, emb, W, "middle_block.res2")
+    for i, b in enumerate(out):
+        x = torch.cat([x, saved.pop()], dim=1)                                      # :484
+        x = _unet_block(x, emb, context, W, f"output_blocks.{i}", b)
+    x = silu(group_norm(x, W["norm_out.gamma"], W["norm_out.beta"]))
+    return conv2d(x, W, "conv_out", padding=1)
+
+
+# ----------------------------------------------------------------------------- VAE
+
+def vae_resnet_block(x: Tensor, W, p: str) -> Tensor:
+    """ResnetBlock::forward src/model/autoencoder/mod.rs:500-516."""
+    h = conv2d(silu(group_norm(x, W[p + ".norm1.gamma"], W[p + ".norm1.beta"])), W, p + ".conv1", padding=1)
+    h = conv2d(silu(group_norm(h, W[p + ".norm2.gamma"], W[p + ".norm2.beta"])), W, p + ".conv2", padding=1)
+    if (p + ".nin_shortcut.weight") in W:
+        return conv2d(x, W, p + ".nin_shortcut") + h
+    return x + h
+
+
+def vae_attn_block(x: Tensor, W, p: str) -> Tensor:
+    """ConvSelfAttentionBlock::forward src/model/autoencoder/mod.rs:550-586 (1 head, 1x1-conv q/k/v)."""
+    b, c, hh, ww = x.shape
+    h = group_norm(x, W[p + ".norm.gamma"], W[p + ".norm.beta"])
+    q = conv2d(h, W, p + ".q").reshape(b, c, hh * ww).transpose(1, 2)
+    k = conv2d(h, W, p + ".k").reshape(b, c, hh * ww).transpose(1, 2)
+    v = conv2d(h, W, p + ".v").reshape(b, c, hh * ww).transpose(1, 2)
+    wv = qkv_attention(q, k, v, None, 1).transpose(1, 2).reshape(b, c, hh, ww)
+    return x + conv2d(wv, W, p + ".proj_out")
+
+
+def vae_mid(x: Tensor, W, p: str) -> Tensor:
+    """Mid::forward src/model/autoencoder/mod.rs:443-449."""
+    x = vae_resnet_block(x, W, p + ".block_1")
+    x = vae_attn_block(x, W, p + ".attn")
+    return vae_resnet_block(x, W, p + ".block_2")
+
+
+def vae_decoder_forward(cfg: VAEConfig, W, x: Tensor) -> Tensor:
+    """Decoder::forward src/model/autoencoder/mod.rs:203-216; DecoderBlock::forward :306-324."""
+    x = conv2d(x, W, "decoder.conv_in", padding=1)
+    x = vae_mid(x, W, "decoder.mid")
+    n = len(cfg.dec_channels)
+    for i in range(n):
+        p = f"decoder.blocks.{i}"
+        for r in ("res1", "res2", "res3"):
+            x = vae_resnet_block(x, W, f"{p}.{r}")
+        if i != n - 1:
+            x = conv2d(upsample_nearest2x(x), W, p + ".upsampler", padding=1)
+    x = silu(group_norm(x, W["decoder.norm_out.gamma"], W["decoder.norm_out.beta"]))
+    return conv2d(x, W, "decoder.conv_out", padding=1)
+
+
+def decode_latent_vae(cfg: VAEConfig, W, latent: Tensor) -> Tensor:
+    """Autoencoder::decode_latent src/model/autoencoder/mod.rs:67-70."""
+    return vae_decoder_forward(cfg, W, conv2d(latent, W, "post_quant_conv"))
+
+
+def padded_conv2d_s2(x: Tensor, W, name: str) -> Tensor:
+    """PaddedConv2d with Padding(left 0,right 1,top 0,bottom 1), k=3, stride 2
+    (autoencoder/mod.rs:229-238, 334-407): symmetric pad 2 then slice from skip=1 -- i.e. the same taps as
+    an asymmetric (0,1,0,1) zero-pad followed by a valid stride-2 conv."""
+    b, c, h, w = x.shape
+    pad_actual = 2                     # calc_padding(0,1): ceil((1-0)/2)*2 + 0 = 2
+    desired_h = (0 + 1 + h - 3) // 2 + 1
+    desired_w = (0 + 1 + w - 3) // 2 + 1
+    skip = (pad_actual - 0) // 2
+    y = F.conv2d(x, W[name + ".weight"], W[name + ".bias"], stride=2, padding=pad_actual)
+    return y[:, :, skip:skip + desired_h, skip:skip + desired_w]
+
+
+def vae_encoder_forward(cfg: VAEConfig, W, x: Tensor) -> Tensor:
+    """Encoder::forward src/model/autoencoder/mod.rs:131-144; EncoderBlock::forward :258-268."""
+    x = conv2d(x, W, "encoder.conv_in", padding=1)
+    n = len(cfg.enc_channels)
+    for i in range(n):
+        p = f"encoder.blocks.{i}"
+        x = vae_resnet_block(x, W, p + ".res1")
+        x = vae_resnet_block(x, W, p + ".res2")
+        if i != n - 1:
+            x = padded_conv2d_s2(x, W, p + ".downsampler")
+    x = vae_mid(x, W, "encoder.mid")
+    x = silu(group_norm(x, W["encoder.norm_out.gamma"], W["encoder.norm_out.beta"]))
+    return conv2d(x, W, "encoder.conv_out", padding=1)
+
+
+def encode_image_vae(cfg: VAEConfig, W, x: Tensor) -> Tensor:
+    """Autoencoder::encode_image src/model/autoencoder/mod.rs:59-65 (channels 0..4 = the mean)."""
+    return conv2d(vae_encoder_forward(cfg, W, x), W, "quant_conv")[:, 0:4]
