@@ -1,0 +1,183 @@
+/* sdxl_mi355.h -- C ABI of the MI355X-native SDXL sampling engine (libsdxl_mi355.so).
+ *
+ * Drop-in boundary for the hot path of Gadersd/stable-diffusion-xl-burn: these are the entry points a Rust `cc` +
+ * `bindgen` shim binds so that the reference's public model API keeps its signatures while all
+ * arithmetic runs in hand-written HIP kernels for gfx950.  Each symbol cites the reference interface it replaces
+ * (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - every tensor argument is a raw DEVICE pointer to contiguous fp32 data in the reference's own layout
+ *     (NCHW images/latents, [B,N,C] tokens) unless stated otherwise; outputs go to caller-allocated device buffers;
+ *   - `stream` is a hipStream_t passed as void*; NULL selects the context's own (blocking) stream.  A handle must only
+ *     be used from one stream/thread at a time (the reference is single-threaded, src/bin/sample/main.rs:130-291);
+ *   - every function returns 0 on success, non-zero on failure; sdxl_last_error() returns the thread-local message.
+ *     Nothing aborts: the Rust shim maps non-zero to panic!/Err exactly where the reference asserts/unwraps
+ *     (unet/mod.rs:73-76, :967-972; groupnorm/mod.rs:19-24);
+ *   - weights are handed over as ONE flat fp32 buffer (host or device) holding the tensors listed by
+ *     sdxl_*_param_spec() back to back, in that order, each in the reference's layout: nn::Linear [d_in,d_out],
+ *     Conv2d [out,in,kh,kw], norm gamma/beta [C]  (python/save.py:20-25,56-72; src/model/load.rs:62-74,119-156).
+ */
+#ifndef SDXL_MI355_H
+#define SDXL_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdxl_ctx sdxl_ctx;
+typedef struct sdxl_unet sdxl_unet;
+typedef struct sdxl_diffuser sdxl_diffuser;
+typedef struct sdxl_vae sdxl_vae;
+
+enum { SDXL_OK = 0, SDXL_ERR_INVALID = 1, SDXL_ERR_RUNTIME = 2 };
+/* precision of a model instance */
+enum {
+  SDXL_DTYPE_F32 = 0,       /* strict-parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)      */
+  SDXL_DTYPE_F16 = 1,       /* fp16 storage + fp16 MFMA operands, fp32 accumulation/statistics/softmax           */
+  SDXL_DTYPE_F16_F32RES = 2 /* fp16 MFMA operands, fp32 residual stream                                         */
+};
+
+/* UNetConfig (src/model/unet/mod.rs:59-69) + DiffuserConfig.is_refiner (src/model/stablediffusion/mod.rs:269-278) */
+typedef struct {
+  int32_t adm_in_channels, in_channels, out_channels, model_channels;
+  int32_t n_levels;
+  int32_t channel_mults[8];
+  int32_t n_head_channels;
+  int32_t transformer_depths[8];
+  int32_t context_dim;
+  int32_t is_refiner;
+} sdxl_unet_config;
+
+/* AutoencoderConfig (src/model/autoencoder/mod.rs:24-44; the reference hard-codes the SDXL values) + LatentDecoderConfig */
+typedef struct {
+  int32_t n_blocks;
+  int32_t enc_in[8], enc_out[8];   /* EncoderConfig channels */
+  int32_t dec_in[8], dec_out[8];   /* DecoderConfig channels */
+  int32_t n_group, enc_out_channels;
+  double scale_factor;             /* LatentDecoderConfig.scale_factor (stablediffusion/mod.rs:176-179), 0.13025 */
+} sdxl_vae_config;
+
+/* Conditioning<B> (src/model/stablediffusion/mod.rs:544-555): device fp32 tensors, same ranks as the reference */
+typedef struct {
+  const float* unconditional_context_full;            /* [77, ctx_full]        */
+  const float* unconditional_context_open_clip;       /* [77, 1280]            */
+  const float* context_full;                          /* [n, 77, ctx_full]     */
+  const float* context_open_clip;                     /* [n, 77, 1280]         */
+  const float* unconditional_channel_context;         /* [adm]                 */
+  const float* unconditional_channel_context_refiner; /* [adm_refiner]         */
+  const float* channel_context;                       /* [n, adm]              */
+  const float* channel_context_refiner;               /* [n, adm_refiner]      */
+  int32_t n;                                          /* batch of prompts      */
+  int32_t n_ctx;                                      /* tokens (77)           */
+  int32_t height, width;                              /* resolution: [usize;2] */
+} sdxl_conditioning;
+
+/* parameter kinds reported by sdxl_*_param_spec */
+enum { SDXL_PARAM_LINEAR_W = 0, SDXL_PARAM_CONV_W = 1, SDXL_PARAM_BIAS = 2, SDXL_PARAM_GAMMA = 3, SDXL_PARAM_BETA = 4 };
+
+const char* sdxl_last_error(void);
+/* library / build identification (target arch string, e.g. "gfx950") */
+const char* sdxl_build_info(void);
+
+/* one context per GPU (the reference hard-codes LibTorchDevice::Cuda(0), src/bin/sample/main.rs:131) */
+int sdxl_ctx_create(int device_id, sdxl_ctx** out);
+void sdxl_ctx_destroy(sdxl_ctx* ctx);
+int sdxl_ctx_synchronize(sdxl_ctx* ctx);
+
+/* default configs (implied .cfg values) */
+void sdxl_unet_config_base(sdxl_unet_config* cfg);
+void sdxl_unet_config_refiner(sdxl_unet_config* cfg);
+void sdxl_vae_config_default(sdxl_vae_config* cfg);
+
+/* ---- parameter enumeration: replaces the .npy tree walk of src/model/unet/load.rs:286-401, autoencoder/load.rs:186-201 */
+int sdxl_unet_param_count(const sdxl_unet_config* cfg);
+int sdxl_unet_param_spec(const sdxl_unet_config* cfg, int index, const char** name, int* ndim, int64_t shape[4],
+                         int* kind, float* synth_scale, float* synth_mean);
+int sdxl_vae_param_count(const sdxl_vae_config* cfg, int encoder);
+int sdxl_vae_param_spec(const sdxl_vae_config* cfg, int encoder, int index, const char** name, int* ndim,
+                        int64_t shape[4], int* kind, float* synth_scale, float* synth_mean);
+
+/* ---- UNet: replaces DiffuserConfig::init + load_record (stablediffusion/mod.rs:281-305, bin/sample/main.rs:35-43) */
+int sdxl_unet_create(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const float* weights_flat, sdxl_unet** out);
+/* seeded synthetic weights generated on the device (no checkpoint needed); bit-identical to oracle/config.py */
+int sdxl_unet_create_synthetic(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, uint64_t seed, sdxl_unet** out);
+void sdxl_unet_destroy(sdxl_unet* u);
+/* UNet::forward(x, timesteps, context, label) -> Tensor<B,4>   (src/model/unet/mod.rs:450-492)
+ * x [B,in,H,W], timesteps int32 [B] (device), context [B,n_ctx,ctx_dim], label [B,adm], out [B,out,H,W] */
+int sdxl_unet_forward(sdxl_unet* u, void* stream, const float* x, const int32_t* timesteps, const float* context,
+                      const float* label, int B, int H, int W, int n_ctx, float* out);
+int sdxl_unet_set_graph(sdxl_unet* u, int enabled);   /* hipGraph replay of the forward (default on) */
+
+/* ---- Backend::qkv_attention (src/backend.rs:4-19; generic body :88-128, LibTorch override :32-79)
+ * q [B,Nq,n_head*d], k,v [B,Nk,n_head*d], mask additive [Nq,Nk] or NULL, out [B,Nq,n_head*d]; fp32 device tensors */
+int sdxl_qkv_attention(sdxl_ctx* ctx, void* stream, const float* q, const float* k, const float* v, const float* mask,
+                       int B, int Nq, int Nk, int n_state, int n_head, int dtype, float* out);
+/* Backend::attn_decoder_mask (src/backend.rs:130-136): writes the [n,n] causal mask (0 / -inf) */
+int sdxl_attn_decoder_mask(sdxl_ctx* ctx, void* stream, int seq_length, float* out);
+
+/* ---- Diffuser (src/model/stablediffusion/mod.rs:308-542); alphas_cumprod = alpha_cumulative_products param (:311) */
+int sdxl_diffuser_create(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const float* weights_flat,
+                         const float* alphas_cumprod_host, int n_train_steps, sdxl_diffuser** out);
+int sdxl_diffuser_create_synthetic(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, uint64_t seed,
+                                   const float* alphas_cumprod_host, int n_train_steps, sdxl_diffuser** out);
+void sdxl_diffuser_destroy(sdxl_diffuser* d);
+sdxl_unet* sdxl_diffuser_unet(sdxl_diffuser* d);   /* Diffuser.diffusion (:312), borrowed */
+/* Diffuser::sample_latent(conditioning, cfg, n_steps) (:317-332).  noise0 [n,4,h/8,w/8] plays gen_noise() (:378-388). */
+int sdxl_sample_latent(sdxl_diffuser* d, void* stream, const sdxl_conditioning* cond, double unconditional_guidance_scale,
+                       int n_steps, const float* noise0, float* out_latent);
+/* Diffuser::sample_latent_with_inpainting (:334-353, loop :434-483).  mask: uint8 [n,4,h/8,w/8], 1 = keep generated.
+ * step_noise [iterations, n,4,h/8,w/8]: the per-step gen_noise() of :463 (iterations = sdxl_step_count). */
+int sdxl_sample_latent_with_inpainting(sdxl_diffuser* d, void* stream, const sdxl_conditioning* cond,
+                                       double unconditional_guidance_scale, int n_steps, const float* reference,
+                                       const uint8_t* mask, const float* noise0, const float* step_noise,
+                                       float* out_latent);
+/* Diffuser::refine_latent(latent, conditioning, cfg, step_start, n_steps) (:355-376) */
+int sdxl_refine_latent(sdxl_diffuser* d, void* stream, const float* latent, const sdxl_conditioning* cond,
+                       double unconditional_guidance_scale, int step_start, int n_steps, const float* noise,
+                       float* out_latent);
+/* number of UNet evaluations of `(0..n_train-step_start).rev().step_by(n_train/n_steps)` (:400-406): 30 -> 31 */
+int sdxl_step_count(int n_steps, int step_start, int n_train_steps);
+/* per-iteration GPU milliseconds of the last trajectory (enable first); returns the number written */
+int sdxl_diffuser_enable_step_timing(sdxl_diffuser* d, int enabled);
+int sdxl_diffuser_step_times(sdxl_diffuser* d, float* out_ms, int capacity);
+
+/* ---- LatentDecoder / Autoencoder (stablediffusion/mod.rs:193-267, autoencoder/mod.rs:46-70) */
+int sdxl_vae_create(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, const float* decoder_weights_flat,
+                    const float* encoder_weights_flat, sdxl_vae** out);   /* either side may be NULL */
+int sdxl_vae_create_synthetic(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, uint64_t seed, int with_encoder,
+                              sdxl_vae** out);
+void sdxl_vae_destroy(sdxl_vae* v);
+/* LatentDecoder::decode_latent (:263-266): latent [n,4,h,w] -> image [n,3,8h,8w] */
+int sdxl_vae_decode_latent(sdxl_vae* v, void* stream, const float* latent, int n, int h, int w, float* out_image);
+/* LatentDecoder::latent_to_image (:200-237): -> RawImages.buffer, uint8 [n,8h,8w,3] (device) */
+int sdxl_latent_to_image(sdxl_vae* v, void* stream, const float* latent, int n, int h, int w, uint8_t* out_hwc);
+/* LatentDecoder::encode_image (:257-261): image [n,3,H,W] in [-1,1] -> latent [n,4,H/8,W/8] */
+int sdxl_vae_encode_image(sdxl_vae* v, void* stream, const float* image, int n, int H, int W, float* out_latent);
+/* LatentDecoder::image_to_latent (:239-255): uint8 [n,H,W,3] (device) -> latent */
+int sdxl_image_to_latent(sdxl_vae* v, void* stream, const uint8_t* image_hwc, int n, int H, int W, float* out_latent);
+
+/* ---- multi-GPU: the packed weight arena of a model, for a one-time RCCL broadcast from rank 0 (SURVEY 2.3 C-bcast) */
+int sdxl_unet_weight_arena(sdxl_unet* u, void** base, size_t* bytes);
+int sdxl_vae_weight_arena(sdxl_vae* v, void** base, size_t* bytes);
+
+/* ---- single-op entry points used by the parity tests (same kernels the models run) */
+/* GroupNorm::forward (groupnorm/mod.rs:52-73) on NCHW fp32 [B,C,H,W]; silu!=0 fuses SILU::forward (silu.rs:14-16) */
+int sdxl_group_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, int B, int C,
+                    int HW, int n_group, float eps, int silu, int dtype, float* out);
+/* LayerNorm::forward (layernorm/mod.rs:34-40) on [rows,C] */
+int sdxl_layer_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, int rows, int C,
+                    float eps, int dtype, float* out);
+/* burn Conv2d on NCHW fp32: weight [Cout,Cin,k,k], bias [Cout]; upsample!=0 applies nearest-2x first (unet/mod.rs:744-750) */
+int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight, const float* bias, int B, int Cin,
+                int H, int W, int Cout, int ksize, int stride, int pad, int upsample, int dtype, float* out);
+/* burn nn::Linear: y = x[M,K] @ W[K,N] + b; geglu!=0 returns x_half * gelu_erf(gate_half) (unet/mod.rs:942-956) */
+int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight, const float* bias, int M, int K, int N,
+                int geglu, int dtype, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDXL_MI355_H */

@@ -1,0 +1,568 @@
+"""stable-diffusion-xl-burn_amd -- MI355X-native SDXL sampling engine, host-side mirror of the reference API.
+
+The product is ``lib/libsdxl_mi355.so`` (hand-written HIP kernels for gfx950 + a C++ engine behind the C ABI of
+``include/sdxl_mi355.h``).  This module is the thin ctypes binding the test-suite and ``bench.py`` drive -- the same
+symbols a Rust ``cc``+``bindgen`` shim would bind -- exposed under the reference's own names
+(``Diffuser.sample_latent`` / ``UNet.forward`` / ``LatentDecoder.latent_to_image`` / ``Conditioning`` / ``RawImages`` /
+``qkv_attention``; reference src/model/stablediffusion/mod.rs, src/model/unet/mod.rs, src/backend.rs).
+
+PyTorch appears here only as plumbing (device buffers, streams, torch.distributed); no arithmetic of the hot path runs
+in torch, and there is NO fallback: if the HIP library is missing or no GPU is visible every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsdxl_mi355.so")
+
+DTYPE_F32 = 0        # strict parity: fp32 storage + exact fp32 MFMA
+DTYPE_F16 = 1        # fp16 storage / MFMA operands, fp32 accumulate
+DTYPE_F16_F32RES = 2  # fp16 MFMA operands, fp32 residual stream
+
+_c_p = ctypes.c_void_p
+_f_p = ctypes.c_void_p   # device pointers travel as integers
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class _UNetConfigC(ctypes.Structure):
+    _fields_ = [("adm_in_channels", ctypes.c_int32), ("in_channels", ctypes.c_int32), ("out_channels", ctypes.c_int32),
+                ("model_channels", ctypes.c_int32), ("n_levels", ctypes.c_int32), ("channel_mults", ctypes.c_int32 * 8),
+                ("n_head_channels", ctypes.c_int32), ("transformer_depths", ctypes.c_int32 * 8),
+                ("context_dim", ctypes.c_int32), ("is_refiner", ctypes.c_int32)]
+
+
+class _VaeConfigC(ctypes.Structure):
+    _fields_ = [("n_blocks", ctypes.c_int32), ("enc_in", ctypes.c_int32 * 8), ("enc_out", ctypes.c_int32 * 8),
+                ("dec_in", ctypes.c_int32 * 8), ("dec_out", ctypes.c_int32 * 8), ("n_group", ctypes.c_int32),
+                ("enc_out_channels", ctypes.c_int32), ("scale_factor", ctypes.c_double)]
+
+
+class _ConditioningC(ctypes.Structure):
+    _fields_ = [("unconditional_context_full", _f_p), ("unconditional_context_open_clip", _f_p),
+                ("context_full", _f_p), ("context_open_clip", _f_p), ("unconditional_channel_context", _f_p),
+                ("unconditional_channel_context_refiner", _f_p), ("channel_context", _f_p),
+                ("channel_context_refiner", _f_p), ("n", ctypes.c_int32), ("n_ctx", ctypes.c_int32),
+                ("height", ctypes.c_int32), ("width", ctypes.c_int32)]
+
+
+# every symbol include/sdxl_mi355.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "sdxl_last_error", "sdxl_build_info", "sdxl_ctx_create", "sdxl_ctx_destroy", "sdxl_ctx_synchronize",
+    "sdxl_unet_config_base", "sdxl_unet_config_refiner", "sdxl_vae_config_default",
+    "sdxl_unet_param_count", "sdxl_unet_param_spec", "sdxl_vae_param_count", "sdxl_vae_param_spec",
+    "sdxl_unet_create", "sdxl_unet_create_synthetic", "sdxl_unet_destroy", "sdxl_unet_forward", "sdxl_unet_set_graph",
+    "sdxl_qkv_attention", "sdxl_attn_decoder_mask",
+    "sdxl_diffuser_create", "sdxl_diffuser_create_synthetic", "sdxl_diffuser_destroy", "sdxl_diffuser_unet",
+    "sdxl_sample_latent", "sdxl_sample_latent_with_inpainting", "sdxl_refine_latent", "sdxl_step_count",
+    "sdxl_diffuser_enable_step_timing", "sdxl_diffuser_step_times",
+    "sdxl_vae_create", "sdxl_vae_create_synthetic", "sdxl_vae_destroy", "sdxl_vae_decode_latent",
+    "sdxl_latent_to_image", "sdxl_vae_encode_image", "sdxl_image_to_latent",
+    "sdxl_unet_weight_arena", "sdxl_vae_weight_arena",
+    "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear",
+]
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Loads the HIP engine; fails loudly when it has not been built (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(f"{LIB_PATH} is missing: run `python stable-diffusion-xl-burn_amd/build.py` "
+                              "(hipcc --offload-arch=gfx950). There is no fallback path.")
+        l = ctypes.CDLL(LIB_PATH)
+        l.sdxl_last_error.restype = ctypes.c_char_p
+        l.sdxl_build_info.restype = ctypes.c_char_p
+        l.sdxl_diffuser_unet.restype = ctypes.c_void_p
+        l.sdxl_diffuser_unet.argtypes = [ctypes.c_void_p]
+        for name in ("sdxl_ctx_destroy", "sdxl_unet_destroy", "sdxl_diffuser_destroy", "sdxl_vae_destroy"):
+            getattr(l, name).restype = None
+            getattr(l, name).argtypes = [ctypes.c_void_p]
+        _lib = l
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise EngineError(lib().sdxl_last_error().decode())
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _dev(t, dtype=None):
+    """contiguous CUDA tensor of the expected dtype -> (tensor kept alive, device pointer)"""
+    torch = _torch()
+    if dtype is None:
+        dtype = torch.float32
+    if not t.is_cuda:
+        raise EngineError("expected a CUDA (ROCm) tensor: the engine has no CPU path")
+    t = t.to(dtype).contiguous()
+    return t, ctypes.c_void_p(t.data_ptr())
+
+
+def _stream() -> ctypes.c_void_p:
+    s = _torch().cuda.current_stream().cuda_stream
+    return ctypes.c_void_p(s if s else None)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class UNetConfig:
+    """reference UNetConfig (unet/mod.rs:59-69) + DiffuserConfig.is_refiner (stablediffusion/mod.rs:269-278)"""
+    adm_in_channels: int
+    model_channels: int
+    channel_mults: List[int]
+    n_head_channels: int
+    transformer_depths: List[int]
+    context_dim: int
+    in_channels: int = 4
+    out_channels: int = 4
+    is_refiner: bool = False
+
+    def to_c(self) -> _UNetConfigC:
+        c = _UNetConfigC()
+        c.adm_in_channels, c.in_channels, c.out_channels = self.adm_in_channels, self.in_channels, self.out_channels
+        c.model_channels, c.n_levels = self.model_channels, len(self.channel_mults)
+        for i, (m, d) in enumerate(zip(self.channel_mults, self.transformer_depths)):
+            c.channel_mults[i] = m
+            c.transformer_depths[i] = d
+        c.n_head_channels, c.context_dim, c.is_refiner = self.n_head_channels, self.context_dim, int(self.is_refiner)
+        return c
+
+
+def sdxl_base_config() -> UNetConfig:
+    return UNetConfig(2816, 320, [1, 2, 4], 64, [0, 2, 10], 2048)
+
+
+def sdxl_refiner_config() -> UNetConfig:
+    return UNetConfig(2560, 384, [1, 2, 4, 4], 64, [0, 4, 4, 4], 1280, is_refiner=True)
+
+
+@dataclass
+class VAEConfig:
+    enc_channels: List[Tuple[int, int]] = field(default_factory=lambda: [(128, 128), (128, 256), (256, 512), (512, 512)])
+    dec_channels: List[Tuple[int, int]] = field(default_factory=lambda: [(512, 512), (512, 512), (512, 256), (256, 128)])
+    n_group: int = 32
+    enc_out_channels: int = 8
+    scale_factor: float = 0.13025
+
+    def to_c(self) -> _VaeConfigC:
+        c = _VaeConfigC()
+        c.n_blocks = len(self.dec_channels)
+        for i, ((ei, eo), (di, do)) in enumerate(zip(self.enc_channels, self.dec_channels)):
+            c.enc_in[i], c.enc_out[i], c.dec_in[i], c.dec_out[i] = ei, eo, di, do
+        c.n_group, c.enc_out_channels, c.scale_factor = self.n_group, self.enc_out_channels, self.scale_factor
+        return c
+
+
+@dataclass
+class ParamSpec:
+    name: str
+    shape: Tuple[int, ...]
+    kind: int
+    scale: float
+    mean: float
+
+
+def _specs(count_fn, spec_fn) -> List[ParamSpec]:
+    n = count_fn()
+    if n < 0:
+        raise EngineError(lib().sdxl_last_error().decode())
+    out = []
+    name = ctypes.c_char_p()
+    ndim, kind = ctypes.c_int(), ctypes.c_int()
+    shape = (ctypes.c_int64 * 4)()
+    sc, mean = ctypes.c_float(), ctypes.c_float()
+    for i in range(n):
+        _check(spec_fn(i, ctypes.byref(name), ctypes.byref(ndim), shape, ctypes.byref(kind), ctypes.byref(sc),
+                       ctypes.byref(mean)))
+        out.append(ParamSpec(name.value.decode(), tuple(int(shape[j]) for j in range(ndim.value)), kind.value,
+                             sc.value, mean.value))
+    return out
+
+
+def unet_param_specs(cfg: UNetConfig) -> List[ParamSpec]:
+    """host-only (no GPU needed): the order / layouts sdxl_unet_create expects its flat weight buffer in"""
+    c = cfg.to_c()
+    l = lib()
+    return _specs(lambda: l.sdxl_unet_param_count(ctypes.byref(c)),
+                  lambda i, *a: l.sdxl_unet_param_spec(ctypes.byref(c), i, *a))
+
+
+def vae_param_specs(cfg: VAEConfig, encoder: bool) -> List[ParamSpec]:
+    c = cfg.to_c()
+    l = lib()
+    return _specs(lambda: l.sdxl_vae_param_count(ctypes.byref(c), int(encoder)),
+                  lambda i, *a: l.sdxl_vae_param_spec(ctypes.byref(c), int(encoder), i, *a))
+
+
+def step_count(n_steps: int, step_start: int = 0, n_train: int = 1000) -> int:
+    return lib().sdxl_step_count(n_steps, step_start, n_train)
+
+
+def flatten_weights(specs: Sequence[ParamSpec], weights: dict) -> np.ndarray:
+    """name -> ndarray (reference layouts) => the flat fp32 buffer of the C ABI"""
+    parts = []
+    for p in specs:
+        w = np.asarray(weights[p.name], dtype=np.float32)
+        if tuple(w.shape) != tuple(p.shape):
+            raise EngineError(f"{p.name}: expected shape {p.shape}, got {w.shape}")
+        parts.append(w.reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+class Context:
+    """one per GPU (reference: LibTorchDevice::Cuda(0), src/bin/sample/main.rs:131)"""
+
+    def __init__(self, device_id: int = 0):
+        self.h = ctypes.c_void_p()
+        _check(lib().sdxl_ctx_create(device_id, ctypes.byref(self.h)))
+        self.device_id = device_id
+
+    def synchronize(self):
+        _check(lib().sdxl_ctx_synchronize(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h:
+            lib().sdxl_ctx_destroy(self.h)
+            self.h = None
+
+
+@dataclass
+class Conditioning:
+    """reference Conditioning<B> (stablediffusion/mod.rs:544-555); CUDA fp32 tensors of the same ranks"""
+    context_full: "object" = None                       # [n,77,ctx_full]
+    channel_context: "object" = None                    # [n,adm]
+    unconditional_context_full: "object" = None         # [77,ctx_full]
+    unconditional_channel_context: "object" = None      # [adm]
+    context_open_clip: "object" = None                  # [n,77,1280]
+    channel_context_refiner: "object" = None
+    unconditional_context_open_clip: "object" = None
+    unconditional_channel_context_refiner: "object" = None
+    resolution: Tuple[int, int] = (1024, 1024)          # (height, width)
+
+    def to_c(self):
+        keep = []
+        c = _ConditioningC()
+        first = None
+        for name in ("unconditional_context_full", "unconditional_context_open_clip", "context_full", "context_open_clip",
+                     "unconditional_channel_context", "unconditional_channel_context_refiner", "channel_context",
+                     "channel_context_refiner"):
+            t = getattr(self, name)
+            if t is None:
+                setattr(c, name, None)
+                continue
+            t, p = _dev(t)
+            keep.append(t)
+            setattr(c, name, p)
+            if name in ("context_full", "context_open_clip") and first is None:
+                first = t
+        if first is None:
+            raise EngineError("Conditioning needs context_full or context_open_clip")
+        c.n, c.n_ctx = int(first.shape[0]), int(first.shape[1])
+        c.height, c.width = int(self.resolution[0]), int(self.resolution[1])
+        return c, keep
+
+
+class UNet:
+    """reference UNet<B> (src/model/unet/mod.rs:432-493)"""
+
+    def __init__(self, ctx: Context, cfg: UNetConfig, dtype: int = DTYPE_F16, weights: Optional[np.ndarray] = None,
+                 seed: int = 0, _borrowed=None):
+        self.ctx, self.cfg, self.dtype = ctx, cfg, dtype
+        self._owned = _borrowed is None
+        if _borrowed is not None:
+            self.h = _borrowed
+            return
+        self.h = ctypes.c_void_p()
+        c = cfg.to_c()
+        if weights is None:
+            _check(lib().sdxl_unet_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), ctypes.byref(self.h)))
+        else:
+            w = np.ascontiguousarray(weights, dtype=np.float32)
+            _check(lib().sdxl_unet_create(ctx.h, ctypes.byref(c), dtype, w.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self.h)))
+
+    def forward(self, x, timesteps, context, label):
+        """UNet::forward(x[B,4,H,W], timesteps[B] int, context[B,n_ctx,ctx], label[B,adm]) -> [B,4,H,W]  (:450-492)"""
+        torch = _torch()
+        x, px = _dev(x)
+        ts, pt = _dev(timesteps, torch.int32)
+        context, pc = _dev(context)
+        label, pl = _dev(label)
+        B, _, H, W = x.shape
+        out = torch.empty((B, self.cfg.out_channels, H, W), device=x.device, dtype=torch.float32)
+        _check(lib().sdxl_unet_forward(self.h, _stream(), px, pt, pc, pl, B, H, W, int(context.shape[1]),
+                                      ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def set_graph(self, enabled: bool):
+        _check(lib().sdxl_unet_set_graph(self.h, int(enabled)))
+
+    def weight_arena(self) -> Tuple[int, int]:
+        base, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().sdxl_unet_weight_arena(self.h, ctypes.byref(base), ctypes.byref(n)))
+        return int(base.value or 0), int(n.value)
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and getattr(self, "h", None):
+            lib().sdxl_unet_destroy(self.h)
+            self.h = None
+
+
+def default_alphas_cumprod(n: int = 1000) -> np.ndarray:
+    """sgm LegacyDDPMDiscretization (reference python/dump.py:29-31): the loaded `alpha_cumulative_products` param"""
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, n, dtype=np.float64) ** 2
+    return np.cumprod(1.0 - betas).astype(np.float32)
+
+
+class Diffuser:
+    """reference Diffuser<B> (src/model/stablediffusion/mod.rs:308-542)"""
+
+    def __init__(self, ctx: Context, cfg: UNetConfig, dtype: int = DTYPE_F16, weights: Optional[np.ndarray] = None,
+                 seed: int = 0, alphas_cumprod: Optional[np.ndarray] = None):
+        self.ctx, self.cfg, self.dtype = ctx, cfg, dtype
+        a = np.ascontiguousarray(default_alphas_cumprod() if alphas_cumprod is None else alphas_cumprod, dtype=np.float32)
+        self.n_train = int(a.shape[0])
+        self.h = ctypes.c_void_p()
+        c = cfg.to_c()
+        ap = a.ctypes.data_as(ctypes.c_void_p)
+        if weights is None:
+            _check(lib().sdxl_diffuser_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), ap,
+                                                       self.n_train, ctypes.byref(self.h)))
+        else:
+            w = np.ascontiguousarray(weights, dtype=np.float32)
+            _check(lib().sdxl_diffuser_create(ctx.h, ctypes.byref(c), dtype, w.ctypes.data_as(ctypes.c_void_p), ap,
+                                             self.n_train, ctypes.byref(self.h)))
+        self.diffusion = UNet(ctx, cfg, dtype, _borrowed=ctypes.c_void_p(lib().sdxl_diffuser_unet(self.h)))
+
+    def _latent_shape(self, cond: Conditioning):
+        n = int((cond.context_full if cond.context_full is not None else cond.context_open_clip).shape[0])
+        return (n, 4, cond.resolution[0] // 8, cond.resolution[1] // 8)
+
+    def sample_latent(self, conditioning: Conditioning, unconditional_guidance_scale: float, n_steps: int, noise0):
+        """Diffuser::sample_latent (:317-332); noise0 plays gen_noise()"""
+        torch = _torch()
+        c, keep = conditioning.to_c()
+        noise0, pn = _dev(noise0)
+        assert tuple(noise0.shape) == self._latent_shape(conditioning)
+        out = torch.empty_like(noise0)
+        _check(lib().sdxl_sample_latent(self.h, _stream(), ctypes.byref(c), ctypes.c_double(unconditional_guidance_scale),
+                                       n_steps, pn, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def sample_latent_with_inpainting(self, conditioning, unconditional_guidance_scale, n_steps, reference, mask, noise0,
+                                      step_noise):
+        """Diffuser::sample_latent_with_inpainting (:334-353); mask True = keep generated; step_noise [iters,n,4,h,w]"""
+        torch = _torch()
+        c, keep = conditioning.to_c()
+        noise0, pn = _dev(noise0)
+        reference, pr = _dev(reference)
+        mask, pm = _dev(mask, torch.uint8)
+        step_noise, ps = _dev(step_noise)
+        out = torch.empty_like(noise0)
+        _check(lib().sdxl_sample_latent_with_inpainting(self.h, _stream(), ctypes.byref(c),
+                                                       ctypes.c_double(unconditional_guidance_scale), n_steps, pr, pm, pn,
+                                                       ps, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def refine_latent(self, latent, conditioning, unconditional_guidance_scale, step_start, n_steps, noise):
+        """Diffuser::refine_latent (:355-376)"""
+        torch = _torch()
+        c, keep = conditioning.to_c()
+        latent, pl = _dev(latent)
+        noise, pn = _dev(noise)
+        out = torch.empty_like(latent)
+        _check(lib().sdxl_refine_latent(self.h, _stream(), pl, ctypes.byref(c), ctypes.c_double(unconditional_guidance_scale),
+                                       step_start, n_steps, pn, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def enable_step_timing(self, enabled: bool = True):
+        _check(lib().sdxl_diffuser_enable_step_timing(self.h, int(enabled)))
+
+    def step_times_ms(self) -> List[float]:
+        buf = (ctypes.c_float * 1024)()
+        n = lib().sdxl_diffuser_step_times(self.h, buf, 1024)
+        return [float(buf[i]) for i in range(max(n, 0))]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.diffusion = None
+            lib().sdxl_diffuser_destroy(self.h)
+            self.h = None
+
+
+@dataclass
+class RawImages:
+    """reference RawImages (stablediffusion/mod.rs:170-174): u8 HWC buffers"""
+    buffer: "object"   # uint8 CUDA tensor [n, height, width, 3]
+    width: int
+    height: int
+
+
+class LatentDecoder:
+    """reference LatentDecoder<B> (src/model/stablediffusion/mod.rs:193-267) over Autoencoder (autoencoder/mod.rs:46-70)"""
+
+    def __init__(self, ctx: Context, cfg: Optional[VAEConfig] = None, dtype: int = DTYPE_F16,
+                 decoder_weights: Optional[np.ndarray] = None, encoder_weights: Optional[np.ndarray] = None,
+                 seed: int = 0, with_encoder: bool = False):
+        self.ctx, self.cfg, self.dtype = ctx, cfg or VAEConfig(), dtype
+        self.h = ctypes.c_void_p()
+        c = self.cfg.to_c()
+        if decoder_weights is None and encoder_weights is None:
+            _check(lib().sdxl_vae_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), int(with_encoder),
+                                                  ctypes.byref(self.h)))
+        else:
+            d = None if decoder_weights is None else np.ascontiguousarray(decoder_weights, dtype=np.float32)
+            e = None if encoder_weights is None else np.ascontiguousarray(encoder_weights, dtype=np.float32)
+            _check(lib().sdxl_vae_create(ctx.h, ctypes.byref(c), dtype,
+                                        None if d is None else d.ctypes.data_as(ctypes.c_void_p),
+                                        None if e is None else e.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self.h)))
+
+    def decode_latent(self, latent):
+        """LatentDecoder::decode_latent (:263-266): [n,4,h,w] -> [n,3,8h,8w]"""
+        torch = _torch()
+        latent, pl = _dev(latent)
+        n, _, h, w = latent.shape
+        out = torch.empty((n, 3, 8 * h, 8 * w), device=latent.device, dtype=torch.float32)
+        _check(lib().sdxl_vae_decode_latent(self.h, _stream(), pl, n, h, w, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def latent_to_image(self, latent) -> RawImages:
+        """LatentDecoder::latent_to_image (:200-237)"""
+        torch = _torch()
+        latent, pl = _dev(latent)
+        n, _, h, w = latent.shape
+        out = torch.empty((n, 8 * h, 8 * w, 3), device=latent.device, dtype=torch.uint8)
+        _check(lib().sdxl_latent_to_image(self.h, _stream(), pl, n, h, w, ctypes.c_void_p(out.data_ptr())))
+        return RawImages(out, 8 * w, 8 * h)
+
+    def encode_image(self, image):
+        """LatentDecoder::encode_image (:257-261): [n,3,H,W] in [-1,1] -> [n,4,H/8,W/8]"""
+        torch = _torch()
+        image, pi = _dev(image)
+        n, _, H, W = image.shape
+        out = torch.empty((n, 4, H // 8, W // 8), device=image.device, dtype=torch.float32)
+        _check(lib().sdxl_vae_encode_image(self.h, _stream(), pi, n, H, W, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def image_to_latent(self, images: RawImages):
+        """LatentDecoder::image_to_latent (:239-255)"""
+        torch = _torch()
+        buf, pb = _dev(images.buffer, torch.uint8)
+        n = buf.shape[0]
+        out = torch.empty((n, 4, images.height // 8, images.width // 8), device=buf.device, dtype=torch.float32)
+        _check(lib().sdxl_image_to_latent(self.h, _stream(), pb, n, images.height, images.width, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def weight_arena(self) -> Tuple[int, int]:
+        base, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().sdxl_vae_weight_arena(self.h, ctypes.byref(base), ctypes.byref(n)))
+        return int(base.value or 0), int(n.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().sdxl_vae_destroy(self.h)
+            self.h = None
+
+
+# ---------------------------------------------------------------------------------------------------------------- ops
+
+def qkv_attention(ctx: Context, q, k, v, mask, n_head: int, dtype: int = DTYPE_F16):
+    """Backend::qkv_attention (src/backend.rs:4-19): q [B,Nq,C], k,v [B,Nk,C], additive mask [Nq,Nk] or None"""
+    torch = _torch()
+    q, pq = _dev(q)
+    k, pk = _dev(k)
+    v, pv = _dev(v)
+    pm = None
+    if mask is not None:
+        mask, pm = _dev(mask)
+    B, Nq, C = q.shape
+    out = torch.empty_like(q)
+    _check(lib().sdxl_qkv_attention(ctx.h, _stream(), pq, pk, pv, pm, B, Nq, int(k.shape[1]), C, n_head, dtype,
+                                   ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
+def attn_decoder_mask(ctx: Context, seq_length: int):
+    """Backend::attn_decoder_mask (src/backend.rs:130-136)"""
+    torch = _torch()
+    out = torch.empty((seq_length, seq_length), device=f"cuda:{ctx.device_id}", dtype=torch.float32)
+    _check(lib().sdxl_attn_decoder_mask(ctx.h, _stream(), seq_length, ctypes.c_void_p(out.data_ptr())))
+    torch.cuda.synchronize()
+    return out
+
+
+def group_norm(ctx: Context, x, gamma, beta, n_group: int = 32, eps: float = 1e-5, silu: bool = False,
+               dtype: int = DTYPE_F16):
+    """GroupNorm::forward (groupnorm/mod.rs:52-73) on NCHW input, optional fused SILU (silu.rs:14-16)"""
+    torch = _torch()
+    x, px = _dev(x)
+    gamma, pg = _dev(gamma)
+    beta, pb = _dev(beta)
+    B, C = x.shape[0], x.shape[1]
+    HW = int(np.prod(x.shape[2:]))
+    out = torch.empty_like(x)
+    _check(lib().sdxl_group_norm(ctx.h, _stream(), px, pg, pb, B, C, HW, n_group, ctypes.c_float(eps), int(silu), dtype,
+                                ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
+def layer_norm(ctx: Context, x, gamma, beta, eps: float = 1e-5, dtype: int = DTYPE_F16):
+    """LayerNorm::forward (layernorm/mod.rs:34-40)"""
+    torch = _torch()
+    x, px = _dev(x)
+    gamma, pg = _dev(gamma)
+    beta, pb = _dev(beta)
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    _check(lib().sdxl_layer_norm(ctx.h, _stream(), px, pg, pb, int(x.numel() // C), C, ctypes.c_float(eps), dtype,
+                                ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
+def conv2d(ctx: Context, x, weight, bias, stride: int = 1, padding: int = 0, upsample: bool = False,
+           dtype: int = DTYPE_F16):
+    """burn Conv2d (weight [Cout,Cin,k,k]); upsample=True applies the reference's nearest-2x first (unet/mod.rs:744-750)"""
+    torch = _torch()
+    x, px = _dev(x)
+    weight, pw = _dev(weight)
+    pb = None
+    if bias is not None:
+        bias, pb = _dev(bias)
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = weight.shape
+    Hs, Ws = (2 * H, 2 * W) if upsample else (H, W)
+    Ho, Wo = (Hs + 2 * padding - k) // stride + 1, (Ws + 2 * padding - k) // stride + 1
+    out = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    _check(lib().sdxl_conv2d(ctx.h, _stream(), px, pw, pb, B, Cin, H, W, Cout, k, stride, padding, int(upsample), dtype,
+                            ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
+def linear(ctx: Context, x, weight, bias, geglu: bool = False, dtype: int = DTYPE_F16):
+    """burn nn::Linear: x[...,K] @ weight[K,N] + bias; geglu=True -> GEGLU::forward (unet/mod.rs:942-956)"""
+    torch = _torch()
+    x, px = _dev(x)
+    weight, pw = _dev(weight)
+    pb = None
+    if bias is not None:
+        bias, pb = _dev(bias)
+    K, N = weight.shape
+    M = int(x.numel() // K)
+    out = torch.empty(tuple(x.shape[:-1]) + ((N // 2) if geglu else N,), device=x.device, dtype=torch.float32)
+    _check(lib().sdxl_linear(ctx.h, _stream(), px, pw, pb, M, K, N, int(geglu), dtype, ctypes.c_void_p(out.data_ptr())))
+    return out

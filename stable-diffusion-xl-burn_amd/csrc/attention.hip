@@ -1,0 +1,263 @@
+// Flash-style fused attention for gfx950, head dim 64:  O = softmax(Q K^T / sqrt(d) [+ mask]) V
+// Replaces Backend::qkv_attention (reference src/backend.rs:4-19, generic body :88-128) for the UNet's 70 self-
+// and 70 cross-attention calls per forward; the score matrix is never materialised.
+//
+// CDNA4 formulation (64-lane wavefronts, 16x16 MFMA, everything between the two GEMMs stays in registers):
+//   S^T = K Q^T   : A operand = K tile rows from LDS, B operand = Q fragments held in registers.  The C/D layout
+//                   then gives every lane 4 consecutive keys of ONE query (query = lane&15), so
+//   softmax       : row max / sum are in-lane reductions + two xor-shuffles (16, 32) across the 4 lane groups;
+//   O^T = V^T P^T : the probabilities a lane holds are *already* the B-operand fragment (k index = key); the A
+//                   operand is V^T (keys contiguous), which the producing GEMM writes directly (igemm transposed
+//                   store), so no transpose and no P round trip through LDS.  O^T's layout keeps query = lane&15,
+//                   so the online-softmax rescale is a per-lane scalar.
+// Block = 4 wavefronts x 32 queries, 64-key K / V^T tiles double-buffered in LDS (XOR-swizzled 16-byte chunks),
+// next tile's global loads issued before the MFMAs, one barrier per tile.  fp32 running max / sum / accumulators.
+// T = _Float16 uses v_mfma_f32_16x16x32_f16, T = float uses v_mfma_f32_16x16x4_f32 (strict-parity mode).
+#include "kernels.h"
+
+namespace sdxl {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct AMma;
+template <> struct AMma<half_t> {
+  static __device__ __forceinline__ f32x4 run(i32x4 a, i32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+  }
+};
+template <> struct AMma<float> {
+  static __device__ __forceinline__ f32x4 run(i32x4 a, i32x4 b, f32x4 c) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], c, 0, 0, 0);
+    return c;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_d64_kernel(const AttnParams p) {
+  constexpr int D = 64, KV = 64, MQ = 2;
+  constexpr int CE = 16 / sizeof(T);           // elements per 16-byte chunk
+  constexpr int RB = 64 * sizeof(T);           // bytes per tile row (K: 64 d, V^T: 64 keys)
+  constexpr int CPR = RB / 16;                 // chunks per row: 8 (f16) / 16 (f32)
+  constexpr int NKK = D / (4 * CE);            // MFMA k-steps over d: 2 (f16) / 4 (f32)
+  constexpr int LI = 64 * CPR / 256;           // chunks per thread per tile: 2 / 4
+  constexpr int TILE = 64 * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                 // [2][TILE]
+  char* sV = smem + 2 * TILE;      // [2][TILE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, fr = lane & 15;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const T* Qg = reinterpret_cast<const T*>(p.Q) + (size_t)b * p.Nq * p.ldq + h * D;
+  const T* Kg = reinterpret_cast<const T*>(p.K) + (size_t)b * p.Nk * p.ldk + h * D;
+  const T* Vg = reinterpret_cast<const T*>(p.Vt) + ((size_t)b * p.H + h) * D * p.vt_ld;
+
+  // Q fragments (B operand of S^T): query = q0 + mq*16 + fr, d-chunk = kk*4 + g
+  i32x4 qf[MQ][NKK];
+#pragma unroll
+  for (int mq = 0; mq < MQ; ++mq) {
+    const int q = q0 + mq * 16 + fr;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      if (q < p.Nq) qf[mq][kk] = *reinterpret_cast<const i32x4*>(Qg + (size_t)q * p.ldq + (kk * 4 + g) * CE);
+      else qf[mq][kk] = i32x4{0, 0, 0, 0};
+    }
+  }
+
+  i32x4 rk[LI], rv[LI];
+  auto load_tile = [&](int t) {
+    const int k0 = t * KV;
+#pragma unroll
+    for (int i = 0; i < LI; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / CPR, cc = c - row * CPR;
+      const int key = k0 + row;
+      if (key < p.Nk) rk[i] = *reinterpret_cast<const i32x4*>(Kg + (size_t)key * p.ldk + cc * CE);
+      else rk[i] = i32x4{0, 0, 0, 0};
+      rv[i] = *reinterpret_cast<const i32x4*>(Vg + (size_t)row * p.vt_ld + k0 + cc * CE);   // zero padded to vt_ld
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LI; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / CPR, cc = c - row * CPR;
+      const int off = row * RB + ((cc ^ (row & 7)) << 4);
+      *reinterpret_cast<i32x4*>(sK + buf * TILE + off) = rk[i];
+      *reinterpret_cast<i32x4*>(sV + buf * TILE + off) = rv[i];
+    }
+  };
+
+  f32x4 ot[4][MQ];
+  float mrun[MQ], lrun[MQ];
+#pragma unroll
+  for (int mq = 0; mq < MQ; ++mq) {
+    mrun[mq] = -INFINITY; lrun[mq] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt][mq] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float sc = p.scale * 1.44269504088896340736f;   // fold log2(e): p = exp2(s*sc - m)
+  const int nt = (p.Nk + KV - 1) / KV;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) load_tile(t + 1);
+    const char* kb = sK + cur * TILE;
+    const char* vb = sV + cur * TILE;
+    // ---- S^T[key][query] = K Q^T
+    f32x4 st[4][MQ];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int mq = 0; mq < MQ; ++mq) st[kt][mq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int ch = kk * 4 + g;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int row = kt * 16 + fr;
+        const i32x4 kf = *reinterpret_cast<const i32x4*>(kb + row * RB + ((ch ^ (row & 7)) << 4));
+#pragma unroll
+        for (int mq = 0; mq < MQ; ++mq) st[kt][mq] = AMma<T>::run(kf, qf[mq][kk], st[kt][mq]);
+      }
+    }
+    // ---- online softmax per query (query = lane&15 of m-tile mq; this lane's keys: t*64 + kt*16 + g*4 + r)
+#pragma unroll
+    for (int mq = 0; mq < MQ; ++mq) {
+      const int q = q0 + mq * 16 + fr;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = t * KV + kt * 16 + g * 4 + r;
+          float s = st[kt][mq][r] * sc;
+          if (p.mask && q < p.Nq && key < p.Nk) s += p.mask[(size_t)q * p.ldmask + key] * 1.44269504088896340736f;
+          if (key >= p.Nk) s = -INFINITY;
+          st[kt][mq][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(mrun[mq], mx);
+      const float msub = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = exp2f(mrun[mq] - msub);      // mrun = -inf -> 0
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(st[kt][mq][r] - msub);
+          st[kt][mq][r] = e;
+          ps += e;
+        }
+      lrun[mq] = lrun[mq] * alpha + ps;
+      mrun[mq] = mnew;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[dt][mq][r] *= alpha;
+    }
+    // ---- O^T[d][query] += V^T P^T
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        i32x4 pf[MQ];
+#pragma unroll
+        for (int mq = 0; mq < MQ; ++mq) {
+          half8 hh;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { hh[r] = (half_t)st[2 * u][mq][r]; hh[4 + r] = (half_t)st[2 * u + 1][mq][r]; }
+          pf[mq] = __builtin_bit_cast(i32x4, hh);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int row = dt * 16 + fr;
+          // keys u*32 + g*4 .. +3 (bytes 64u+8g) and u*32+16+g*4 .. +3 (bytes 64u+32+8g)
+          const int c1 = 4 * u + (g >> 1), c2 = c1 + 2, sub = (g & 1) * 8;
+          const i32x2 v1 = *reinterpret_cast<const i32x2*>(vb + row * RB + ((c1 ^ (row & 7)) << 4) + sub);
+          const i32x2 v2 = *reinterpret_cast<const i32x2*>(vb + row * RB + ((c2 ^ (row & 7)) << 4) + sub);
+          const i32x4 vf = i32x4{v1[0], v1[1], v2[0], v2[1]};
+#pragma unroll
+          for (int mq = 0; mq < MQ; ++mq) ot[dt][mq] = AMma<T>::run(vf, pf[mq], ot[dt][mq]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int row = dt * 16 + fr;
+          const int ch = 4 * kt + g;     // keys kt*16 + g*4 .. +3 -> bytes 64kt + 16g
+          const i32x4 vf = *reinterpret_cast<const i32x4*>(vb + row * RB + ((ch ^ (row & 7)) << 4));
+#pragma unroll
+          for (int mq = 0; mq < MQ; ++mq)
+            ot[dt][mq] = AMma<T>::run(vf, __builtin_bit_cast(i32x4, st[kt][mq]), ot[dt][mq]);
+        }
+      }
+    }
+    if (t + 1 < nt) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[query = lane&15][d = dt*16 + g*4 + r]
+  T* Og = reinterpret_cast<T*>(p.O) + (size_t)b * p.Nq * p.ldo + h * D;
+#pragma unroll
+  for (int mq = 0; mq < MQ; ++mq) {
+    float l = lrun[mq];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int q = q0 + mq * 16 + fr;
+    if (q < p.Nq) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        T* dst = Og + (size_t)q * p.ldo + dt * 16 + g * 4;
+        if constexpr (sizeof(T) == 2) {
+          half4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(ot[dt][mq][r] * inv);
+          *reinterpret_cast<half4*>(dst) = o;
+        } else {
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = ot[dt][mq][r] * inv;
+          *reinterpret_cast<f32x4*>(dst) = o;
+        }
+      }
+    }
+  }
+}
+
+void launch_attention_d64(const AttnParams& p, hipStream_t s) {
+  dim3 grid((p.Nq + 127) / 128, p.B * p.H);
+  if (p.dt == DT_F16) {
+    const size_t lds = 4 * 64 * 128;
+    hipLaunchKernelGGL(attn_d64_kernel<half_t>, grid, dim3(256), lds, s, p);
+  } else {
+    const size_t lds = 4 * 64 * 256;
+    static bool set = false;
+    if (!set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_d64_kernel<float>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      set = true;
+    }
+    hipLaunchKernelGGL(attn_d64_kernel<float>, grid, dim3(256), lds, s, p);
+  }
+}
+
+}  // namespace sdxl

@@ -1,0 +1,549 @@
+// C ABI of the engine (include/sdxl_mi355.h): opaque handles, status codes + thread-local error text, never aborts.
+#include "../../include/sdxl_mi355.h"
+#include "engine.h"
+
+#include <cmath>
+#include <cstring>
+
+using namespace sdxl;
+
+struct sdxl_ctx { int device = 0; hipStream_t stream = nullptr; };
+struct sdxl_unet { sdxl_ctx* ctx = nullptr; UNet* u = nullptr; bool owned = true; };
+struct sdxl_diffuser { sdxl_ctx* ctx = nullptr; Diffuser* d = nullptr; sdxl_unet view; };
+struct sdxl_vae { sdxl_ctx* ctx = nullptr; Vae* v = nullptr; };
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& m) { g_err = m; return code; }
+#define API_BEGIN try {
+#define API_END                                                              \
+  return SDXL_OK;                                                            \
+  } catch (const sdxl::Error& e) { return fail(SDXL_ERR_RUNTIME, e.what()); } \
+  catch (const std::exception& e) { return fail(SDXL_ERR_RUNTIME, e.what()); } \
+  catch (...) { return fail(SDXL_ERR_RUNTIME, "unknown error"); }
+
+hipStream_t pick(sdxl_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
+void use(sdxl_ctx* c) { SDXL_HIP(hipSetDevice(c->device)); }
+
+UNetCfg to_cfg(const sdxl_unet_config* c) {
+  SDXL_REQUIRE(c != nullptr, "null config");
+  SDXL_REQUIRE(c->n_levels >= 1 && c->n_levels <= 8, "n_levels out of range");
+  UNetCfg u;
+  u.adm_in_channels = c->adm_in_channels; u.in_channels = c->in_channels; u.out_channels = c->out_channels;
+  u.model_channels = c->model_channels; u.n_head_channels = c->n_head_channels; u.context_dim = c->context_dim;
+  u.is_refiner = c->is_refiner != 0;
+  for (int i = 0; i < c->n_levels; ++i) { u.channel_mults.push_back(c->channel_mults[i]); u.transformer_depths.push_back(c->transformer_depths[i]); }
+  SDXL_REQUIRE(u.model_channels > 0 && u.n_head_channels > 0 && u.context_dim > 0 && u.adm_in_channels > 0, "bad UNet config");
+  return u;
+}
+VaeCfg to_vcfg(const sdxl_vae_config* c) {
+  SDXL_REQUIRE(c != nullptr, "null config");
+  SDXL_REQUIRE(c->n_blocks >= 1 && c->n_blocks <= 8, "n_blocks out of range");
+  VaeCfg v; v.enc.clear(); v.dec.clear();
+  for (int i = 0; i < c->n_blocks; ++i) { v.enc.push_back({c->enc_in[i], c->enc_out[i]}); v.dec.push_back({c->dec_in[i], c->dec_out[i]}); }
+  v.n_group = c->n_group; v.enc_out = c->enc_out_channels; v.scale_factor = c->scale_factor;
+  return v;
+}
+void dtypes(int dtype, int& cdt, int& sdt) {
+  switch (dtype) {
+    case SDXL_DTYPE_F32: cdt = DT_F32; sdt = DT_F32; break;
+    case SDXL_DTYPE_F16: cdt = DT_F16; sdt = DT_F16; break;
+    case SDXL_DTYPE_F16_F32RES: cdt = DT_F16; sdt = DT_F32; break;
+    default: throw Error("unknown dtype");
+  }
+}
+int spec_out(const std::vector<ParamSpec>& specs, int index, const char** name, int* ndim, int64_t shape[4], int* kind,
+             float* sc, float* mean) {
+  if (index < 0 || index >= (int)specs.size()) return fail(SDXL_ERR_INVALID, "parameter index out of range");
+  static thread_local std::string keep;
+  const ParamSpec& p = specs[index];
+  keep = p.name;
+  if (name) *name = keep.c_str();
+  if (ndim) *ndim = (int)p.shape.size();
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = i < (int)p.shape.size() ? p.shape[i] : 1;
+  if (kind) *kind = p.kind;
+  if (sc) *sc = p.scale;
+  if (mean) *mean = p.mean;
+  return SDXL_OK;
+}
+struct Tmp {   // scoped device scratch for the single-op entry points
+  std::vector<void*> ptrs;
+  ~Tmp() { for (void* p : ptrs) (void)hipFree(p); }
+  void* get(size_t bytes) { void* p = nullptr; SDXL_HIP(hipMalloc(&p, bytes ? bytes : 16)); ptrs.push_back(p); return p; }
+};
+
+__global__ void transpose_pad_kernel(const float* src, int lds_, int rows, int C, void* dst, int dt, int ldd) {
+  // dst[c][r] = src[r][c]   (dst rows of ldd elements, caller zero-fills the padding)
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * C) return;
+  const int r = i / C, c = i - (size_t)r * C;
+  const float v = src[(size_t)r * lds_ + c];
+  if (dt == DT_F16) reinterpret_cast<_Float16*>(dst)[(size_t)c * ldd + r] = (_Float16)v;
+  else reinterpret_cast<float*>(dst)[(size_t)c * ldd + r] = v;
+}
+__global__ void causal_mask_kernel(float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * n) return;
+  const int r = i / n, c = i - r * n;
+  out[i] = c > r ? -INFINITY : 0.f;
+}
+}  // namespace
+
+extern "C" {
+
+const char* sdxl_last_error(void) { return g_err.c_str(); }
+const char* sdxl_build_info(void) { return "sdxl_mi355 engine, HIP kernels for gfx950 (CDNA4, wave64, MFMA 16x16x32 f16 / 16x16x4 f32)"; }
+
+int sdxl_ctx_create(int device_id, sdxl_ctx** out) {
+  API_BEGIN
+  SDXL_REQUIRE(out != nullptr, "null out");
+  int n = 0;
+  SDXL_HIP(hipGetDeviceCount(&n));
+  SDXL_REQUIRE(n > 0, "no HIP device visible: the MI355X engine has no CPU fallback");
+  SDXL_REQUIRE(device_id >= 0 && device_id < n, "device id out of range");
+  SDXL_HIP(hipSetDevice(device_id));
+  sdxl_ctx* c = new sdxl_ctx();
+  c->device = device_id;
+  SDXL_HIP(hipStreamCreate(&c->stream));
+  *out = c;
+  API_END
+}
+void sdxl_ctx_destroy(sdxl_ctx* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+int sdxl_ctx_synchronize(sdxl_ctx* c) {
+  API_BEGIN
+  use(c);
+  SDXL_HIP(hipDeviceSynchronize());
+  API_END
+}
+
+void sdxl_unet_config_base(sdxl_unet_config* c) {
+  std::memset(c, 0, sizeof(*c));
+  c->adm_in_channels = 2816; c->in_channels = 4; c->out_channels = 4; c->model_channels = 320; c->n_levels = 3;
+  const int m[3] = {1, 2, 4}, d[3] = {0, 2, 10};
+  for (int i = 0; i < 3; ++i) { c->channel_mults[i] = m[i]; c->transformer_depths[i] = d[i]; }
+  c->n_head_channels = 64; c->context_dim = 2048; c->is_refiner = 0;
+}
+void sdxl_unet_config_refiner(sdxl_unet_config* c) {
+  std::memset(c, 0, sizeof(*c));
+  c->adm_in_channels = 2560; c->in_channels = 4; c->out_channels = 4; c->model_channels = 384; c->n_levels = 4;
+  const int m[4] = {1, 2, 4, 4}, d[4] = {0, 4, 4, 4};
+  for (int i = 0; i < 4; ++i) { c->channel_mults[i] = m[i]; c->transformer_depths[i] = d[i]; }
+  c->n_head_channels = 64; c->context_dim = 1280; c->is_refiner = 1;
+}
+void sdxl_vae_config_default(sdxl_vae_config* c) {
+  std::memset(c, 0, sizeof(*c));
+  c->n_blocks = 4;
+  const int ei[4] = {128, 128, 256, 512}, eo[4] = {128, 256, 512, 512}, di[4] = {512, 512, 512, 256}, dn[4] = {512, 512, 256, 128};
+  for (int i = 0; i < 4; ++i) { c->enc_in[i] = ei[i]; c->enc_out[i] = eo[i]; c->dec_in[i] = di[i]; c->dec_out[i] = dn[i]; }
+  c->n_group = 32; c->enc_out_channels = 8; c->scale_factor = 0.13025;
+}
+
+int sdxl_unet_param_count(const sdxl_unet_config* cfg) {
+  try { return (int)unet_param_specs(to_cfg(cfg)).size(); } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int sdxl_unet_param_spec(const sdxl_unet_config* cfg, int index, const char** name, int* ndim, int64_t shape[4], int* kind,
+                         float* sc, float* mean) {
+  API_BEGIN
+  static thread_local std::vector<ParamSpec> cache; static thread_local sdxl_unet_config key;
+  if (cache.empty() || std::memcmp(&key, cfg, sizeof(key)) != 0) { cache = unet_param_specs(to_cfg(cfg)); key = *cfg; }
+  return spec_out(cache, index, name, ndim, shape, kind, sc, mean);
+  API_END
+}
+int sdxl_vae_param_count(const sdxl_vae_config* cfg, int encoder) {
+  try { return (int)(encoder ? vae_encoder_param_specs(to_vcfg(cfg)) : vae_decoder_param_specs(to_vcfg(cfg))).size(); }
+  catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int sdxl_vae_param_spec(const sdxl_vae_config* cfg, int encoder, int index, const char** name, int* ndim, int64_t shape[4],
+                        int* kind, float* sc, float* mean) {
+  API_BEGIN
+  const std::vector<ParamSpec> specs = encoder ? vae_encoder_param_specs(to_vcfg(cfg)) : vae_decoder_param_specs(to_vcfg(cfg));
+  return spec_out(specs, index, name, ndim, shape, kind, sc, mean);
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------- UNet
+static int unet_create_impl(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, WeightSource& src, sdxl_unet** out) {
+  SDXL_REQUIRE(ctx && out, "null argument");
+  use(ctx);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  sdxl_unet* h = new sdxl_unet();
+  h->ctx = ctx;
+  try { h->u = new UNet(to_cfg(cfg), cdt, sdt, src, ctx->stream); } catch (...) { delete h; throw; }
+  *out = h;
+  return SDXL_OK;
+}
+int sdxl_unet_create(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const float* weights_flat, sdxl_unet** out) {
+  API_BEGIN
+  SDXL_REQUIRE(weights_flat != nullptr, "null weights");
+  const std::vector<ParamSpec> specs = unet_param_specs(to_cfg(cfg));
+  FlatSource src(weights_flat, specs);
+  return unet_create_impl(ctx, cfg, dtype, src, out);
+  API_END
+}
+int sdxl_unet_create_synthetic(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, uint64_t seed, sdxl_unet** out) {
+  API_BEGIN
+  SyntheticSource src(seed);
+  return unet_create_impl(ctx, cfg, dtype, src, out);
+  API_END
+}
+void sdxl_unet_destroy(sdxl_unet* u) {
+  if (!u) return;
+  if (u->owned) delete u->u;
+  delete u;
+}
+int sdxl_unet_forward(sdxl_unet* u, void* stream, const float* x, const int32_t* timesteps, const float* context,
+                      const float* label, int B, int H, int W, int n_ctx, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(u && x && timesteps && context && label && out, "null argument");
+  use(u->ctx);
+  u->u->forward_nchw(x, timesteps, context, n_ctx, label, B, H, W, out, pick(u->ctx, stream));
+  API_END
+}
+int sdxl_unet_set_graph(sdxl_unet* u, int enabled) {
+  API_BEGIN
+  SDXL_REQUIRE(u != nullptr, "null argument");
+  u->u->set_use_graph(enabled != 0);
+  API_END
+}
+int sdxl_unet_weight_arena(sdxl_unet* u, void** base, size_t* bytes) {
+  API_BEGIN
+  SDXL_REQUIRE(u && base && bytes, "null argument");
+  *base = u->u->weight_base(); *bytes = u->u->weight_bytes();
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------- attention op
+int sdxl_qkv_attention(sdxl_ctx* ctx, void* stream, const float* q, const float* k, const float* v, const float* mask, int B,
+                       int Nq, int Nk, int n_state, int n_head, int dtype, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && q && k && v && out, "null argument");
+  SDXL_REQUIRE(n_head > 0 && n_state % n_head == 0, "State size must be a multiple of head size");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  const int d = n_state / n_head;
+  const size_t es = dt_size(cdt);
+  Tmp tmp;
+  if (d == 64) {
+    const int npad = (int)round_up(Nk, 64);
+    void* qd = tmp.get((size_t)B * Nq * n_state * es);
+    void* kd = tmp.get((size_t)B * Nk * n_state * es);
+    void* vt = tmp.get((size_t)B * n_state * npad * es);
+    void* od = tmp.get((size_t)B * Nq * n_state * es);
+    launch_copy_rows(q, DT_F32, n_state, qd, cdt, n_state, B * Nq, n_state, s);
+    launch_copy_rows(k, DT_F32, n_state, kd, cdt, n_state, B * Nk, n_state, s);
+    launch_fill_zero(vt, (size_t)B * n_state * npad * es, s);
+    for (int b = 0; b < B; ++b) {
+      const size_t tot = (size_t)Nk * n_state;
+      hipLaunchKernelGGL(transpose_pad_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, v + (size_t)b * Nk * n_state, n_state,
+                         Nk, n_state, (char*)vt + (size_t)b * n_state * npad * es, cdt, npad);
+    }
+    AttnParams p{};
+    p.Q = qd; p.ldq = n_state; p.K = kd; p.ldk = n_state; p.Vt = vt; p.vt_ld = npad; p.O = od; p.ldo = n_state;
+    p.dt = cdt; p.B = B; p.H = n_head; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = mask; p.ldmask = Nk;
+    launch_attention_d64(p, s);
+    launch_copy_rows(od, cdt, n_state, out, DT_F32, n_state, B * Nq, n_state, s);
+  } else {
+    // generic head dim: QK^T GEMM -> row softmax -> PV GEMM per (batch, head)
+    const int kt = cdt == DT_F16 ? 64 : 32;
+    const int dpad = (int)round_up(d, kt), kpad = (int)round_up(Nk, kt);
+    const int rows_k = (int)round_up(Nk, 128), rows_v = (int)round_up(d, 128);
+    void* qh = tmp.get((size_t)Nq * dpad * es);
+    void* kh = tmp.get((size_t)rows_k * dpad * es);
+    void* vt = tmp.get((size_t)rows_v * kpad * es);
+    float* S = (float*)tmp.get((size_t)Nq * Nk * sizeof(float));
+    void* P = tmp.get((size_t)Nq * kpad * es);
+    launch_fill_zero(qh, (size_t)Nq * dpad * es, s);
+    launch_fill_zero(kh, (size_t)rows_k * dpad * es, s);
+    launch_fill_zero(vt, (size_t)rows_v * kpad * es, s);
+    Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
+    const float scale = (float)(1.0 / std::sqrt((double)d));
+    for (int b = 0; b < B; ++b)
+      for (int h = 0; h < n_head; ++h) {
+        const float* qs = q + (size_t)b * Nq * n_state + h * d;
+        const float* ks = k + (size_t)b * Nk * n_state + h * d;
+        const float* vs = v + (size_t)b * Nk * n_state + h * d;
+        launch_copy_rows(qs, DT_F32, n_state, qh, cdt, dpad, Nq, d, s);
+        launch_copy_rows(ks, DT_F32, n_state, kh, cdt, dpad, Nk, d, s);
+        const size_t tot = (size_t)Nk * d;
+        hipLaunchKernelGGL(transpose_pad_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, vs, n_state, Nk, d, vt, cdt, kpad);
+        Lin lk; lk.w = kh; lk.N = Nk; lk.K = dpad; lk.Kpad = dpad; lk.Npad = rows_k; lk.cin = dpad;
+        run_linear(ex, lk, Act(qh, dpad, cdt), Nq, Act(S, Nk, DT_F32));
+        launch_softmax_rows(S, Nk, P, cdt, kpad, Nq, Nk, kpad, scale, mask, Nk, Nq, s);
+        Lin lv; lv.w = vt; lv.N = d; lv.K = Nk; lv.Kpad = kpad; lv.Npad = rows_v; lv.cin = Nk;
+        run_linear(ex, lv, Act(P, kpad, cdt), Nq, Act(out + (size_t)b * Nq * n_state + h * d, n_state, DT_F32));
+      }
+  }
+  SDXL_HIP(hipStreamSynchronize(s));
+  API_END
+}
+int sdxl_attn_decoder_mask(sdxl_ctx* ctx, void* stream, int n, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && out && n > 0, "bad argument");
+  use(ctx);
+  hipLaunchKernelGGL(causal_mask_kernel, dim3((n * n + 255) / 256), dim3(256), 0, pick(ctx, stream), out, n);
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------- Diffuser
+static int diffuser_create_impl(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, WeightSource& src, const float* alphas,
+                                int n_train, sdxl_diffuser** out) {
+  SDXL_REQUIRE(ctx && out && alphas && n_train > 0, "bad argument");
+  use(ctx);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  sdxl_diffuser* h = new sdxl_diffuser();
+  h->ctx = ctx;
+  try { h->d = new Diffuser(to_cfg(cfg), cdt, sdt, src, alphas, n_train, ctx->stream); } catch (...) { delete h; throw; }
+  h->view.ctx = ctx; h->view.u = &h->d->unet(); h->view.owned = false;
+  *out = h;
+  return SDXL_OK;
+}
+int sdxl_diffuser_create(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const float* weights_flat, const float* alphas,
+                         int n_train, sdxl_diffuser** out) {
+  API_BEGIN
+  SDXL_REQUIRE(weights_flat != nullptr, "null weights");
+  const std::vector<ParamSpec> specs = unet_param_specs(to_cfg(cfg));
+  FlatSource src(weights_flat, specs);
+  return diffuser_create_impl(ctx, cfg, dtype, src, alphas, n_train, out);
+  API_END
+}
+int sdxl_diffuser_create_synthetic(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, uint64_t seed, const float* alphas,
+                                   int n_train, sdxl_diffuser** out) {
+  API_BEGIN
+  SyntheticSource src(seed);
+  return diffuser_create_impl(ctx, cfg, dtype, src, alphas, n_train, out);
+  API_END
+}
+void sdxl_diffuser_destroy(sdxl_diffuser* d) {
+  if (!d) return;
+  delete d->d;
+  delete d;
+}
+sdxl_unet* sdxl_diffuser_unet(sdxl_diffuser* d) { return d ? &d->view : nullptr; }
+
+static Conditioning to_cond(const sdxl_conditioning* c) {
+  SDXL_REQUIRE(c != nullptr, "null conditioning");
+  Conditioning o;
+  o.unconditional_context_full = c->unconditional_context_full;
+  o.unconditional_context_open_clip = c->unconditional_context_open_clip;
+  o.context_full = c->context_full; o.context_open_clip = c->context_open_clip;
+  o.unconditional_channel_context = c->unconditional_channel_context;
+  o.unconditional_channel_context_refiner = c->unconditional_channel_context_refiner;
+  o.channel_context = c->channel_context; o.channel_context_refiner = c->channel_context_refiner;
+  o.n = c->n; o.n_ctx = c->n_ctx; o.height = c->height; o.width = c->width;
+  SDXL_REQUIRE(o.n >= 1 && o.n_ctx >= 1 && o.height >= 8 && o.width >= 8 && o.height % 8 == 0 && o.width % 8 == 0,
+               "bad conditioning shape");
+  return o;
+}
+int sdxl_sample_latent(sdxl_diffuser* d, void* stream, const sdxl_conditioning* cond, double cfg, int n_steps,
+                       const float* noise0, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(d && noise0 && out, "null argument");
+  use(d->ctx);
+  d->d->sample_latent(to_cond(cond), cfg, n_steps, noise0, out, pick(d->ctx, stream));
+  API_END
+}
+int sdxl_sample_latent_with_inpainting(sdxl_diffuser* d, void* stream, const sdxl_conditioning* cond, double cfg, int n_steps,
+                                       const float* reference, const uint8_t* mask, const float* noise0,
+                                       const float* step_noise, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(d && noise0 && out, "null argument");
+  use(d->ctx);
+  d->d->sample_latent_inpaint(to_cond(cond), cfg, n_steps, reference, mask, noise0, step_noise, out, pick(d->ctx, stream));
+  API_END
+}
+int sdxl_refine_latent(sdxl_diffuser* d, void* stream, const float* latent, const sdxl_conditioning* cond, double cfg,
+                       int step_start, int n_steps, const float* noise, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(d && latent && noise && out, "null argument");
+  use(d->ctx);
+  d->d->refine_latent(latent, to_cond(cond), cfg, step_start, n_steps, noise, out, pick(d->ctx, stream));
+  API_END
+}
+int sdxl_step_count(int n_steps, int step_start, int n_train) {
+  try { return (int)Diffuser::step_schedule(n_steps, step_start, n_train).size(); }
+  catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int sdxl_diffuser_enable_step_timing(sdxl_diffuser* d, int enabled) {
+  API_BEGIN
+  SDXL_REQUIRE(d != nullptr, "null argument");
+  d->d->time_steps = enabled != 0;
+  API_END
+}
+int sdxl_diffuser_step_times(sdxl_diffuser* d, float* out_ms, int capacity) {
+  if (!d || !out_ms) return -1;
+  const int n = (int)d->d->step_ms.size() < capacity ? (int)d->d->step_ms.size() : capacity;
+  for (int i = 0; i < n; ++i) out_ms[i] = d->d->step_ms[i];
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------- VAE
+int sdxl_vae_create(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, const float* dec_w, const float* enc_w, sdxl_vae** out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && out && (dec_w || enc_w), "bad argument");
+  use(ctx);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  const VaeCfg vc = to_vcfg(cfg);
+  const std::vector<ParamSpec> ds = vae_decoder_param_specs(vc), es = vae_encoder_param_specs(vc);
+  std::unique_ptr<FlatSource> d, e;
+  if (dec_w) d.reset(new FlatSource(dec_w, ds));
+  if (enc_w) e.reset(new FlatSource(enc_w, es));
+  sdxl_vae* h = new sdxl_vae();
+  h->ctx = ctx;
+  try { h->v = new Vae(vc, cdt, d.get(), e.get(), ctx->stream); } catch (...) { delete h; throw; }
+  *out = h;
+  API_END
+}
+int sdxl_vae_create_synthetic(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, uint64_t seed, int with_encoder, sdxl_vae** out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && out, "bad argument");
+  use(ctx);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  SyntheticSource src(seed);
+  sdxl_vae* h = new sdxl_vae();
+  h->ctx = ctx;
+  try { h->v = new Vae(to_vcfg(cfg), cdt, &src, with_encoder ? &src : nullptr, ctx->stream); } catch (...) { delete h; throw; }
+  *out = h;
+  API_END
+}
+void sdxl_vae_destroy(sdxl_vae* v) {
+  if (!v) return;
+  delete v->v;
+  delete v;
+}
+int sdxl_vae_decode_latent(sdxl_vae* v, void* stream, const float* latent, int n, int h, int w, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(v && latent && out, "null argument");
+  use(v->ctx);
+  v->v->decode_nchw(latent, n, h, w, out, pick(v->ctx, stream));
+  API_END
+}
+int sdxl_latent_to_image(sdxl_vae* v, void* stream, const float* latent, int n, int h, int w, uint8_t* out) {
+  API_BEGIN
+  SDXL_REQUIRE(v && latent && out, "null argument");
+  use(v->ctx);
+  v->v->latent_to_image(latent, n, h, w, out, pick(v->ctx, stream));
+  API_END
+}
+int sdxl_vae_encode_image(sdxl_vae* v, void* stream, const float* image, int n, int H, int W, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(v && image && out, "null argument");
+  SDXL_REQUIRE(H % 8 == 0 && W % 8 == 0, "image size must be a multiple of 8");
+  use(v->ctx);
+  v->v->encode_nchw(image, n, H, W, out, pick(v->ctx, stream));
+  API_END
+}
+int sdxl_image_to_latent(sdxl_vae* v, void* stream, const uint8_t* image, int n, int H, int W, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(v && image && out, "null argument");
+  SDXL_REQUIRE(H % 8 == 0 && W % 8 == 0, "image size must be a multiple of 8");
+  use(v->ctx);
+  v->v->image_to_latent(image, n, H, W, out, pick(v->ctx, stream));
+  API_END
+}
+int sdxl_vae_weight_arena(sdxl_vae* v, void** base, size_t* bytes) {
+  API_BEGIN
+  SDXL_REQUIRE(v && base && bytes, "null argument");
+  *base = v->v->weight_base(); *bytes = v->v->weight_bytes();
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------- single ops
+int sdxl_group_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, int B, int C, int HW,
+                    int n_group, float eps, int silu, int dtype, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && x && gamma && beta && out, "null argument");
+  SDXL_REQUIRE(n_group > 0 && C % n_group == 0, "The number of channels must be divisible by the number of groups");
+  SDXL_REQUIRE(C % 8 == 0 && n_group <= 256, "unsupported GroupNorm shape");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  Tmp tmp;
+  void* xi = tmp.get((size_t)B * HW * C * dt_size(sdt));
+  void* yo = tmp.get((size_t)B * HW * C * dt_size(cdt));
+  float* part = (float*)tmp.get((size_t)B * n_group * 128 * 3 * sizeof(float));
+  launch_nchw_to_nhwc(x, C * HW, xi, sdt, B, C, HW, C, 1.0f, s);
+  GroupNormParams p{};
+  p.X = xi; p.x_dt = sdt; p.ldx = C; p.Y = yo; p.y_dt = cdt; p.ldy = C; p.gamma = gamma; p.beta = beta; p.partial = part;
+  p.B = B; p.HW = HW; p.C = C; p.G = n_group; p.eps = eps; p.silu = silu;
+  launch_groupnorm(p, s);
+  launch_nhwc_to_nchw(yo, cdt, C, out, B, C, HW, 1.0f, s);
+  SDXL_HIP(hipStreamSynchronize(s));
+  API_END
+}
+int sdxl_layer_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, int rows, int C,
+                    float eps, int dtype, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && x && gamma && beta && out, "null argument");
+  SDXL_REQUIRE(C % 8 == 0, "unsupported LayerNorm width");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  Tmp tmp;
+  void* xi = tmp.get((size_t)rows * C * dt_size(sdt));
+  void* yo = tmp.get((size_t)rows * C * dt_size(cdt));
+  launch_copy_rows(x, DT_F32, C, xi, sdt, C, rows, C, s);
+  LayerNormParams p{};
+  p.X = xi; p.x_dt = sdt; p.ldx = C; p.Y = yo; p.y_dt = cdt; p.ldy = C; p.gamma = gamma; p.beta = beta; p.rows = rows; p.C = C; p.eps = eps;
+  launch_layernorm(p, s);
+  launch_copy_rows(yo, cdt, C, out, DT_F32, C, rows, C, s);
+  SDXL_HIP(hipStreamSynchronize(s));
+  API_END
+}
+int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight, const float* bias, int B, int Cin, int H,
+                int W, int Cout, int ksize, int stride, int pad, int upsample, int dtype, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && x && weight && out, "null argument");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  const int Hs = upsample ? 2 * H : H, Ws = upsample ? 2 * W : W;
+  const int Ho = (Hs + 2 * pad - ksize) / stride + 1, Wo = (Ws + 2 * pad - ksize) / stride + 1;
+  const int kt = cdt == DT_F16 ? 64 : 32;
+  Lin l; l.N = Cout; l.cin = Cin; l.ksize = ksize; l.K = Cin * ksize * ksize;
+  l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(Cout, 128);
+  Tmp tmp;
+  void* wp = tmp.get((size_t)l.Npad * l.Kpad * dt_size(cdt));
+  float* bp = (float*)tmp.get((size_t)l.Npad * sizeof(float));
+  void* xi = tmp.get((size_t)B * H * W * Cin * dt_size(sdt));
+  float* yo = (float*)tmp.get((size_t)B * Ho * Wo * Cout * sizeof(float));
+  launch_pack_conv(weight, wp, cdt, Cout, Cin, ksize, l.Kpad, l.Npad, s);
+  launch_pack_bias(bias, bp, Cout, l.Npad, 0, 0, s);
+  l.w = wp; l.b = bp;
+  launch_nchw_to_nhwc(x, Cin * H * W, xi, sdt, B, Cin, H * W, Cin, 1.0f, s);
+  Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
+  run_conv(ex, l, Act(xi, Cin, sdt), Cin, ConvGeom{B, H, W, Ho, Wo, ksize, stride, pad, upsample ? 1 : 0}, Act(yo, Cout, DT_F32));
+  launch_nhwc_to_nchw(yo, DT_F32, Cout, out, B, Cout, Ho * Wo, 1.0f, s);
+  SDXL_HIP(hipStreamSynchronize(s));
+  API_END
+}
+int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight, const float* bias, int M, int K, int N,
+                int geglu, int dtype, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && x && weight && out, "null argument");
+  SDXL_REQUIRE(!geglu || (N % 32 == 0), "GEGLU width must be a multiple of 32");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  const int kt = cdt == DT_F16 ? 64 : 32;
+  Lin l; l.N = N; l.K = K; l.cin = K; l.ksize = 1; l.Kpad = (int)round_up(K, kt); l.Npad = (int)round_up(N, 128);
+  Tmp tmp;
+  void* wp = tmp.get((size_t)l.Npad * l.Kpad * dt_size(cdt));
+  float* bp = (float*)tmp.get((size_t)l.Npad * sizeof(float));
+  void* xi = tmp.get((size_t)M * K * dt_size(sdt));
+  launch_pack_linear(weight, wp, cdt, K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, s);
+  launch_pack_bias(bias, bp, N, l.Npad, geglu ? 1 : 0, 0, s);
+  l.w = wp; l.b = bp;
+  launch_copy_rows(x, DT_F32, K, xi, sdt, K, M, K, s);
+  Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
+  Epi e; e.act = geglu ? 1 : 0;
+  run_linear(ex, l, Act(xi, K, sdt), M, Act(out, geglu ? N / 2 : N, DT_F32), e);
+  SDXL_HIP(hipStreamSynchronize(s));
+  API_END
+}
+
+}  // extern "C"

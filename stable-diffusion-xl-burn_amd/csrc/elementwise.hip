@@ -1,0 +1,335 @@
+// Small HBM-/launch-bound kernels of the SDXL hot path for gfx950: GEMV (M<=8 linears), row softmax (unfused
+// attention path), sinusoidal timestep embedding, layout conversion at the NCHW API boundary, the fused
+// CFG-combine + DDIM update, image <-> activation conversion, synthetic weight fill and weight packing.
+#include "kernels.h"
+
+namespace sdxl {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ld_f(const void* p, size_t i, int dt) {
+  return dt == DT_F16 ? (float)reinterpret_cast<const half_t*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_f(void* p, size_t i, int dt, float v) {
+  if (dt == DT_F16) reinterpret_cast<half_t*>(p)[i] = (half_t)v; else reinterpret_cast<float*>(p)[i] = v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------------------
+// GEMV: one wavefront per output column n, all Bm (<=8) rows at once; weights streamed once with 16-byte loads.
+// (time / label embedding MLPs unet/mod.rs:458-468 and the ResBlock lin_embed(silu(emb)) :1088-1089)
+template <typename WT>
+__global__ __launch_bounds__(256) void gemv_kernel(const GemvParams p) {
+  constexpr int CE = 16 / sizeof(WT);
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= p.N) return;
+  const WT* w = reinterpret_cast<const WT*>(p.W) + (size_t)n * p.Kpad;
+  float acc[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+  for (int k0 = lane * CE; k0 < p.K; k0 += 64 * CE) {
+    float wv[CE];
+    if constexpr (sizeof(WT) == 2) {
+      half8 h = *reinterpret_cast<const half8*>(w + k0);
+#pragma unroll
+      for (int j = 0; j < CE; ++j) wv[j] = (float)h[j];
+    } else {
+      f32x4 f = *reinterpret_cast<const f32x4*>(w + k0);
+#pragma unroll
+      for (int j = 0; j < CE; ++j) wv[j] = f[j];
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if (b < p.Bm) {
+#pragma unroll
+        for (int j = 0; j < CE; ++j) {
+          const int k = k0 + j;
+          if (k < p.K) {
+            float x = p.X[(size_t)b * p.ldx + k];
+            if (p.silu_in) x = silu_f(x);
+            acc[b] += x * wv[j];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[b] += __shfl_xor(acc[b], o);
+  }
+  if (lane == 0) {
+    for (int b = 0; b < p.Bm; ++b) {
+      float v = acc[b] + (p.bias ? p.bias[n] : 0.f);
+      if (p.silu_out) v = silu_f(v);
+      if (p.Yadd) v += p.Yadd[(size_t)b * p.ldy + n];
+      p.Y[(size_t)b * p.ldy + n] = v;
+    }
+  }
+}
+void launch_gemv(const GemvParams& p, hipStream_t s) {
+  dim3 g((p.N + 3) / 4);
+  if (p.w_dt == DT_F16) hipLaunchKernelGGL(gemv_kernel<half_t>, g, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(gemv_kernel<float>, g, dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// row softmax (one 256-thread block per row)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int lds_, void* P, int p_dt, int ldp, int n,
+                                                           int npad, float scale, const float* mask, int ldmask,
+                                                           int mask_rows) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* s = S + (size_t)row * lds_;
+  const float* mk = mask ? mask + (size_t)(row % mask_rows) * ldmask : nullptr;
+  float mx = -INFINITY;
+  for (int i = tid; i < n; i += 256) mx = fmaxf(mx, s[i] * scale + (mk ? mk[i] : 0.f));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = tid; i < n; i += 256) sum += expf(s[i] * scale + (mk ? mk[i] : 0.f) - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  sum = red[4] + red[5] + red[6] + red[7];
+  const float inv = 1.0f / sum;
+  for (int i = tid; i < npad; i += 256) {
+    const float v = i < n ? expf(s[i] * scale + (mk ? mk[i] : 0.f) - mx) * inv : 0.f;
+    st_f(P, (size_t)row * ldp + i, p_dt, v);
+  }
+}
+void launch_softmax_rows(const float* S, int lds_, void* P, int p_dt, int ldp, int rows, int n, int npad, float scale,
+                         const float* mask, int ldmask, int mask_rows, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, lds_, P, p_dt, ldp, n, npad, scale, mask,
+                     ldmask, mask_rows > 0 ? mask_rows : 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// timestep embedding, unet/mod.rs:21-39:  freqs = exp(arange(half) * (-ln(max_period)/half)); [cos | sin]
+__global__ void temb_kernel(const float* t_dev, int t_stride, float* out, int Bm, int dim) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Bm * half) return;
+  const int b = i / half, j = i - b * half;
+  const float coef = (float)(-9.210340371976184 / (double)half);   // -ln(10000)/half rounded to f32 (burn: f64 scalar -> elem)
+  const float f = expf((float)j * coef);
+  const float a = t_dev[(size_t)b * t_stride] * f;
+  out[(size_t)b * dim + j] = cosf(a);
+  out[(size_t)b * dim + half + j] = sinf(a);
+}
+void launch_timestep_embedding(const float* t_dev, int t_stride, float* out, int Bm, int dim, hipStream_t s) {
+  const int n = Bm * (dim / 2);
+  hipLaunchKernelGGL(temb_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t_dev, t_stride, out, Bm, dim);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* src, int sbs, void* dst, int dt, int B, int C, int HW, int ldd, float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * HW * C;
+  if (i >= total) return;
+  const int c = i % C;
+  const size_t pix = i / C;
+  const int b = pix / HW;
+  const int hw = pix - (size_t)b * HW;
+  st_f(dst, pix * ldd + c, dt, src[(size_t)b * sbs + (size_t)c * HW + hw] * scale);
+}
+void launch_nchw_to_nhwc(const float* src, int sbs, void* dst, int dt, int B, int C, int HW, int ldd, float scale,
+                         hipStream_t s) {
+  const size_t total = (size_t)B * HW * C;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, sbs, dst, dt, B, C, HW, ldd, scale);
+}
+__global__ void nhwc_to_nchw_kernel(const void* src, int dt, int lds_, float* dst, int B, int C, int HW, float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * HW * C;
+  if (i >= total) return;
+  const int hw = i % HW;
+  const size_t bc = i / HW;
+  const int c = bc % C;
+  const int b = bc / C;
+  dst[i] = ld_f(src, ((size_t)b * HW + hw) * lds_ + c, dt) * scale;
+}
+void launch_nhwc_to_nchw(const void* src, int dt, int lds_, float* dst, int B, int C, int HW, float scale, hipStream_t s) {
+  const size_t total = (size_t)B * HW * C;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dt, lds_, dst, B, C, HW, scale);
+}
+__global__ void copy_rows_kernel(const void* src, int sdt, int lds_, void* dst, int ddt, int ldd, size_t rows, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const size_t r = i / C;
+  const int c = i - r * C;
+  st_f(dst, r * ldd + c, ddt, ld_f(src, r * lds_ + c, sdt));
+}
+void launch_copy_rows(const void* src, int sdt, int lds_, void* dst, int ddt, int ldd, int rows, int C, hipStream_t s) {
+  const size_t total = (size_t)rows * C;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, sdt, lds_, dst, ddt, ldd, (size_t)rows, C);
+}
+__global__ void i32_to_f32_kernel(const int* src, float* dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s) {
+  hipLaunchKernelGGL(i32_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
+}
+void launch_fill_zero(void* p, size_t bytes, hipStream_t s) { (void)hipMemsetAsync(p, 0, bytes, s); }
+
+// ---------------------------------------------------------------------------------------------------------
+// CFG combine + DDIM (eta = 0) update + inpaint blend + next-UNet-input refresh, one thread per latent pixel.
+// stablediffusion/mod.rs:423-428 (update), :539-540 (CFG), :463-465 (mask_where blend).
+__global__ void ddim_kernel(const DdimParams p, int do_update) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)p.n * p.HW) return;
+  const int b = i / p.HW;
+  const int hw = i - (size_t)b * p.HW;
+  const int idx = *p.step_idx;
+  const int next = do_update ? idx + 1 : 0;
+  float x[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) x[c] = p.latent[((size_t)b * 4 + c) * p.HW + hw];
+  if (do_update) {
+    const StepCoef k = p.table[idx];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float ec = ld_f(p.eps, ((size_t)b * p.HW + hw) * p.eps_ld + c, p.eps_dt);
+      float e = ec;
+      if (p.use_cfg) {
+        const float eu = ld_f(p.eps, ((size_t)(p.n + b) * p.HW + hw) * p.eps_ld + c, p.eps_dt);
+        e = eu + (ec - eu) * k.cfg;
+      }
+      const float x0 = (x[c] - e * k.sqrt_1ma) / k.sqrt_a;
+      x[c] = x0 * k.sqrt_ap + e * k.sqrt_1map;
+    }
+  }
+  if (p.mask && next < p.n_steps_total) {
+    const StepCoef kn = p.table[next];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t e = ((size_t)b * 4 + c) * p.HW + hw;
+      if (!p.mask[e]) x[c] = p.ref[e] * kn.sqrt_a + p.step_noise[(size_t)next * p.n * 4 * p.HW + e] * kn.sqrt_1ma;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) p.latent[((size_t)b * 4 + c) * p.HW + hw] = x[c];
+  for (int r = 0; r < p.in_rep; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) st_f(p.unet_in, ((size_t)(r * p.n + b) * p.HW + hw) * p.in_ld + c, p.in_dt, x[c]);
+}
+__global__ void ddim_advance_kernel(const StepCoef* table, int* step_idx, float* t_out, int do_update) {
+  const int next = do_update ? *step_idx + 1 : 0;
+  *step_idx = next;
+  *t_out = table[next].t;     // table carries one sentinel entry past the last step
+}
+void launch_ddim_step(const DdimParams& p, int do_update, hipStream_t s) {
+  const size_t total = (size_t)p.n * p.HW;
+  hipLaunchKernelGGL(ddim_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p, do_update);
+  hipLaunchKernelGGL(ddim_advance_kernel, dim3(1), dim3(1), 0, s, p.table, p.step_idx, p.t_out, do_update);
+}
+__global__ void axpby_kernel(float* dst, const float* a, float sa, const float* b, float sb, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = a[i] * sa + b[i] * sb;
+}
+void launch_axpby(float* dst, const float* a, float sa, const float* b, float sb, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, a, sa, b, sb, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// image post-process, stablediffusion/mod.rs:210-230: ((x+1)/2)*255 -> clamp [0,255] -> truncating u8 cast
+__global__ void to_u8_kernel(const void* src, int dt, int lds_, unsigned char* dst, size_t pixels) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pixels * 3) return;
+  const size_t pix = i / 3;
+  const int c = i - pix * 3;
+  float v = ld_f(src, pix * lds_ + c, dt);
+  v = ((v + 1.0f) / 2.0f) * 255.0f;
+  v = fminf(fmaxf(v, 0.0f), 255.0f);
+  dst[i] = (unsigned char)v;
+}
+void launch_to_u8_image(const void* src, int dt, int lds_, unsigned char* dst, size_t pixels, hipStream_t s) {
+  hipLaunchKernelGGL(to_u8_kernel, dim3((pixels * 3 + 255) / 256), dim3(256), 0, s, src, dt, lds_, dst, pixels);
+}
+// image_to_latent pre-processing :239-255: (u8/255)*2 - 1
+__global__ void from_u8_kernel(const unsigned char* src, void* dst, int dt, int ldd, size_t pixels) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pixels * 3) return;
+  const size_t pix = i / 3;
+  const int c = i - pix * 3;
+  st_f(dst, pix * ldd + c, dt, ((float)src[i] / 255.0f) * 2.0f - 1.0f);
+}
+void launch_from_u8_image(const unsigned char* src, void* dst, int dt, int ldd, size_t pixels, hipStream_t s) {
+  hipLaunchKernelGGL(from_u8_kernel, dim3((pixels * 3 + 255) / 256), dim3(256), 0, s, src, dst, dt, ldd, pixels);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// synthetic weights: bit-identical to oracle/config.py::synth_values (integer hash, one fp32 mul, one fp32 add)
+__global__ void synth_fill_kernel(float* dst, size_t numel, uint64_t key, float scale, float mean) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numel) return;
+  uint64_t z = key + (uint64_t)i * 0xD1342543DE82EF95ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const float u = (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;   // * 2^-24, exact
+  dst[i] = __fadd_rn(__fmul_rn(u - 0.5f, scale), mean);
+}
+void launch_synth_fill(float* dst, size_t numel, uint64_t key, float scale, float mean, hipStream_t s) {
+  hipLaunchKernelGGL(synth_fill_kernel, dim3((numel + 255) / 256), dim3(256), 0, s, dst, numel, key, scale, mean);
+}
+
+__device__ __forceinline__ int geglu_unpermute(int pcol, int N) {
+  // packed column -> original column: 32-wide groups = 16 x columns then their 16 gate columns
+  const int g = pcol >> 5, w = pcol & 31, nh = N >> 1;
+  return w < 16 ? g * 16 + w : nh + g * 16 + (w - 16);
+}
+__global__ void pack_linear_kernel(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu,
+                                   int n_offset) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)Npad * Kpad) return;
+  const int np = i / Kpad;
+  const int k = i - (size_t)np * Kpad;
+  float v = 0.f;
+  if (np < N && k < K) {
+    const int n = geglu ? geglu_unpermute(np, N) : np;
+    v = src[(size_t)k * N + n];
+  }
+  st_f(dst, ((size_t)n_offset + np) * Kpad + k, dt, v);
+}
+void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu, int n_offset,
+                        hipStream_t s) {
+  const size_t total = (size_t)Npad * Kpad;
+  hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, K, N, Kpad, Npad, geglu, n_offset);
+}
+__global__ void pack_conv_kernel(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)Npad * Kpad) return;
+  const int n = i / Kpad;
+  const int k = i - (size_t)n * Kpad;
+  float v = 0.f;
+  if (n < Cout && k < ks * ks * Cin) {
+    const int tap = k / Cin, c = k - tap * Cin;
+    const int ky = tap / ks, kx = tap - ky * ks;
+    v = src[(((size_t)n * Cin + c) * ks + ky) * ks + kx];
+  }
+  st_f(dst, i, dt, v);
+}
+void launch_pack_conv(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad, hipStream_t s) {
+  const size_t total = (size_t)Npad * Kpad;
+  hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, Cout, Cin, ks, Kpad, Npad);
+}
+__global__ void pack_bias_kernel(const float* src, float* dst, int N, int Npad, int geglu, int n_offset) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Npad) return;
+  float v = 0.f;
+  if (i < N && src) v = src[geglu ? geglu_unpermute(i, N) : i];
+  dst[n_offset + i] = v;
+}
+void launch_pack_bias(const float* src, float* dst, int N, int Npad, int geglu, int n_offset, hipStream_t s) {
+  hipLaunchKernelGGL(pack_bias_kernel, dim3((Npad + 255) / 256), dim3(256), 0, s, src, dst, N, Npad, geglu, n_offset);
+}
+
+}  // namespace sdxl

@@ -1,0 +1,309 @@
+// Host-side engine of the MI355X SDXL sampler: parameter enumeration, weight packing into a device arena,
+// static per-shape execution plans (bump-allocated activation arena -> stable addresses -> hipGraph replay),
+// UNet / VAE / DDIM sampler drivers.  The C ABI in capi.cpp is a thin shell over these classes.
+#pragma once
+#include "kernels.h"
+
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace sdxl {
+
+struct Error : std::runtime_error {
+  explicit Error(const std::string& m) : std::runtime_error(m) {}
+};
+#define SDXL_HIP(x)                                                                                   \
+  do {                                                                                                \
+    hipError_t e__ = (x);                                                                             \
+    if (e__ != hipSuccess) throw ::sdxl::Error(std::string(#x) + " failed: " + hipGetErrorString(e__)); \
+  } while (0)
+#define SDXL_REQUIRE(cond, msg)                          \
+  do {                                                   \
+    if (!(cond)) throw ::sdxl::Error(std::string(msg));  \
+  } while (0)
+
+static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------ configs / specs
+// mirrors the reference's UNetConfig (unet/mod.rs:59-69) + DiffuserConfig.is_refiner (stablediffusion/mod.rs:269-278)
+struct UNetCfg {
+  int adm_in_channels = 0, in_channels = 4, out_channels = 4, model_channels = 0;
+  std::vector<int> channel_mults;
+  int n_head_channels = 64;
+  std::vector<int> transformer_depths;
+  int context_dim = 0;
+  bool is_refiner = false;
+};
+// AutoencoderConfig::init hard-codes the SDXL values (autoencoder/mod.rs:27-35); kept configurable for tiny tests
+struct VaeCfg {
+  std::vector<std::pair<int, int>> enc{{128, 128}, {128, 256}, {256, 512}, {512, 512}};
+  std::vector<std::pair<int, int>> dec{{512, 512}, {512, 512}, {512, 256}, {256, 128}};
+  int n_group = 32;
+  int enc_out = 8;
+  double scale_factor = 0.13025;
+};
+
+enum ParamKind { PK_LINEAR_W = 0, PK_CONV_W = 1, PK_BIAS = 2, PK_GAMMA = 3, PK_BETA = 4 };
+struct ParamSpec {
+  std::string name;
+  std::vector<int> shape;
+  int kind;
+  float scale, mean;   // synthetic init: value = (u - 0.5)*scale + mean
+  size_t numel() const { size_t n = 1; for (int d : shape) n *= (size_t)d; return n; }
+};
+enum BlockKind { BK_CONV, BK_RES, BK_DOWN, BK_REST, BK_RESTU, BK_RESU };
+struct BlockDesc { int kind = 0, c_in = 0, c_emb = 0, c_out = 0, n_head = 0, depth = 0; };
+void unet_block_plan(const UNetCfg& cfg, std::vector<BlockDesc>& inp, BlockDesc& mid, std::vector<BlockDesc>& out);
+std::vector<ParamSpec> unet_param_specs(const UNetCfg& cfg);
+std::vector<ParamSpec> vae_decoder_param_specs(const VaeCfg& cfg);
+std::vector<ParamSpec> vae_encoder_param_specs(const VaeCfg& cfg);
+uint64_t fnv1a64(const std::string& s);
+
+// ------------------------------------------------------------------------------------------ memory
+struct DeviceArena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool dry = false;     // dry run: hand out offsets from a null base, only track the peak
+  ~DeviceArena();
+  void reserve(size_t bytes);
+  void* alloc(size_t bytes);
+  size_t mark() const { return off; }
+  void reset(size_t m) { off = m; }
+};
+
+// where canonical (reference-layout fp32) parameter tensors come from
+struct WeightSource {
+  virtual ~WeightSource() {}
+  virtual void fetch(const ParamSpec& s, size_t index, float* dst_dev, hipStream_t st) = 0;
+};
+struct SyntheticSource : WeightSource {
+  uint64_t seed;
+  explicit SyntheticSource(uint64_t s) : seed(s) {}
+  void fetch(const ParamSpec& s, size_t index, float* dst_dev, hipStream_t st) override;
+};
+struct FlatSource : WeightSource {   // flat fp32 buffer (host or device) in spec order
+  const float* base; std::vector<size_t> offsets;
+  FlatSource(const float* b, const std::vector<ParamSpec>& specs);
+  void fetch(const ParamSpec& s, size_t index, float* dst_dev, hipStream_t st) override;
+};
+
+struct Lin {        // packed dense weight: [Npad][Kpad] compute dtype + fp32 bias [Npad]
+  const void* w = nullptr; const float* b = nullptr;
+  int N = 0, K = 0, Kpad = 0, Npad = 0, ksize = 1, cin = 0;
+};
+struct NormW { const float* gamma = nullptr; const float* beta = nullptr; int C = 0; };
+
+struct WeightBuilder {
+  const std::vector<ParamSpec>& specs;
+  std::map<std::string, size_t> index;
+  WeightSource& src;
+  DeviceArena& arena;
+  int dt;
+  hipStream_t st;
+  float* tmp = nullptr; size_t tmp_numel = 0;
+  WeightBuilder(const std::vector<ParamSpec>& sp, WeightSource& s, DeviceArena& a, int dtype, hipStream_t stream);
+  ~WeightBuilder();
+  static size_t arena_bound(const std::vector<ParamSpec>& specs, int dt);
+  const ParamSpec& spec(const std::string& name, size_t* idx = nullptr) const;
+  bool has(const std::string& name) const { return index.count(name) != 0; }
+  const float* fetch(const std::string& name);            // canonical fp32 tensor in tmp
+  Lin linear(const std::string& name, bool geglu = false);                  // name.weight [K,N] (+ name.bias)
+  Lin fused_linear(const std::vector<std::string>& names);                  // concatenated along N (same K)
+  Lin conv(const std::string& name);                                        // name.weight [Cout,Cin,k,k] + bias
+  NormW norm(const std::string& name);
+};
+
+// activation view: rows of `ld` elements
+struct Act {
+  void* p = nullptr; int ld = 0; int dt = DT_F16;
+  Act() {}
+  Act(void* p_, int ld_, int dt_) : p(p_), ld(ld_), dt(dt_) {}
+  Act cols(int c0) const { return Act((char*)p + (size_t)c0 * dt_size(dt), ld, dt); }
+};
+
+struct Exec {
+  hipStream_t s = nullptr;
+  bool dry = false;
+  int cdt = DT_F16;      // compute dtype (MFMA operands)
+  int sdt = DT_F16;      // residual-stream dtype
+  DeviceArena* act = nullptr;
+  float* gn_partial = nullptr;
+  Act alloc(size_t rows, int C, int dt) {
+    return Act(act->alloc(rows * (size_t)C * dt_size(dt)), C, dt);
+  }
+};
+
+// thin launch helpers shared by unet.cpp / vae.cpp (skip the launch on dry runs)
+struct ConvGeom { int B, Hin, Win, Hout, Wout, ksize, stride, pad, up; };
+struct Epi {
+  const float* ebias = nullptr; int ebias_ld = 0;
+  int act = 0;
+  Act R;             // residual (p == nullptr -> none)
+  int n_split = -1;  // >=0: columns >= n_split go transposed into Ct
+  void* Ct = nullptr; int ct_rows = 0, ct_ld = 0;
+  int rpb = 0;       // rows per batch for ebias / transposed store (0 -> Hout*Wout)
+};
+void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());
+void run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());
+void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups = 32);
+void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y);
+
+// ------------------------------------------------------------------------------------------ UNet
+struct ResBlockW { NormW norm_in, norm_out; Lin conv_in, conv_out, skip; bool has_skip = false; int emb_off = 0, cin = 0, cout = 0; };
+struct TBlockW { NormW n1, n2, n3; Lin qkv, out1, q2, kv2, out2, geglu, ff; };
+struct STW { NormW norm; Lin proj_in, proj_out; std::vector<TBlockW> blocks; int C = 0, heads = 0; };
+struct BlockW { BlockDesc d; ResBlockW res; STW st; Lin conv; };
+
+class UNet {
+ public:
+  UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st);
+  ~UNet();
+  const UNetCfg& cfg() const { return cfg_; }
+  // conditioning that is constant over a trajectory: context [B][n_ctx][ctx_dim] fp32 (device), label [B][adm] fp32.
+  // Projects the cross-attention K / V^T of all transformer blocks once (reference recomputes them every step,
+  // unet/mod.rs:1010-1011) and the label embedding MLP (:464-466).
+  void set_context(const float* context, int n_ctx, const float* label, int B, hipStream_t s);
+  // x: NHWC [B][H*W][in_ch] in compute dtype at unet_in(); t: device fp32 per batch entry (stride t_stride);
+  // result: NHWC [B][H*W][out_ch] fp32 at eps_out().
+  void forward(int B, int H, int W, const float* t_dev, int t_stride, hipStream_t s);
+  // reference-shaped entry (unet/mod.rs:450-456): NCHW fp32 in/out, int32 device timesteps
+  void forward_nchw(const float* x, const int* timesteps, const float* context, int n_ctx, const float* label,
+                    int B, int H, int W, float* out, hipStream_t s);
+  void* unet_in(int B, int H, int W);     // ensures the plan exists
+  float* eps_out() { return eps_; }
+  int compute_dt() const { return cdt_; }
+  void set_use_graph(bool g) { use_graph_ = g; }
+  size_t weight_bytes() const { return warena_.off; }
+  void* weight_base() const { return warena_.base; }
+
+ private:
+  void build_weights(WeightSource& src, hipStream_t st);
+  void ensure_plan(int B, int H, int W);
+  void run(Exec& ex, const float* t_dev, int t_stride);
+  void res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, int H, int W, const Act& out);
+  void spatial_transformer(Exec& ex, const STW& w, int st_index, const Act& x, int B, int H, int W);
+
+  UNetCfg cfg_;
+  int cdt_, sdt_;
+  DeviceArena warena_;
+  std::vector<BlockW> inp_, out_;
+  BlockW mid_res1_, mid_res2_;   // middle_block: res1 -> transformer (in mid_res1_.st) -> res2
+  Lin lin1_t_, lin2_t_, lin1_l_, lin2_l_, embcat_;
+  NormW norm_out_; Lin conv_out_;
+  int emb_total_ = 0;
+  // cross-attention K / V^T caches (one per transformer block, in execution order)
+  struct KV { void* k = nullptr; void* vt = nullptr; };
+  std::vector<std::vector<KV>> kv_;     // [spatial transformer][block]
+  std::vector<const STW*> st_list_;
+  DeviceArena ctx_arena_;
+  int ctx_B_ = 0, n_ctx_ = 0, vt_ld_ctx_ = 0;
+  float* label_emb_ = nullptr;           // [B][4mc]
+  // plan
+  int pB_ = 0, pH_ = 0, pW_ = 0;
+  DeviceArena act_;
+  void* in_ = nullptr; float* eps_ = nullptr;
+  float *temb_ = nullptr, *g1_ = nullptr, *emb_ = nullptr, *ebias_ = nullptr, *gn_partial_ = nullptr, *tconv_ = nullptr;
+  bool use_graph_ = true;
+  hipGraphExec_t graph_ = nullptr;
+  const float* graph_t_ = nullptr; int graph_ts_ = 0; int plan_runs_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------ VAE
+struct VaeResW { NormW n1, n2; Lin c1, c2, nin; bool has_nin = false; int cin = 0, cout = 0; };
+struct VaeMidW { VaeResW b1, b2; NormW an; Lin q, k, v, proj; int C = 0; };
+
+class Vae {
+ public:
+  Vae(const VaeCfg& cfg, int compute_dt, WeightSource* dec_src, WeightSource* enc_src, hipStream_t st);
+  ~Vae();
+  const VaeCfg& cfg() const { return cfg_; }
+  // LatentDecoder::decode_latent (stablediffusion/mod.rs:263-266): latent NCHW fp32 [n,4,h,w] -> NHWC image [n][8h*8w][3]
+  // (fp32, internal buffer); returns the buffer
+  const float* decode(const float* latent_nchw, int n, int h, int w, hipStream_t s);
+  void decode_nchw(const float* latent_nchw, int n, int h, int w, float* out_nchw, hipStream_t s);
+  void latent_to_image(const float* latent_nchw, int n, int h, int w, unsigned char* out_hwc, hipStream_t s);
+  // LatentDecoder::encode_image / image_to_latent (:239-261): -> latent NCHW fp32 [n,4,H/8,W/8]
+  void encode_nchw(const float* img_nchw, int n, int H, int W, float* latent_out, hipStream_t s);
+  void image_to_latent(const unsigned char* img_hwc, int n, int H, int W, float* latent_out, hipStream_t s);
+  size_t weight_bytes() const { return warena_.off; }
+  void* weight_base() const { return warena_.base; }
+
+ private:
+  void res_block(Exec& ex, const VaeResW& w, const Act& x, int B, int H, int W, const Act& out);
+  void mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W);
+  void run_decode(Exec& ex, const Act& in, int n, int h, int w, const Act& out);
+  void run_encode(Exec& ex, const Act& in, int n, int H, int W, const Act& out);
+  VaeResW load_res(WeightBuilder& wb, const std::string& p, int cin, int cout);
+  VaeMidW load_mid(WeightBuilder& wb, const std::string& p, int c);
+
+  VaeCfg cfg_;
+  int cdt_;
+  DeviceArena warena_;
+  bool has_dec_ = false, has_enc_ = false;
+  // decoder
+  Lin post_quant_, d_conv_in_, d_conv_out_; NormW d_norm_out_; VaeMidW d_mid_;
+  struct DecBlk { VaeResW r[3]; Lin up; bool has_up = false; };
+  std::vector<DecBlk> d_blocks_;
+  // encoder
+  Lin quant_, e_conv_in_, e_conv_out_; NormW e_norm_out_; VaeMidW e_mid_;
+  struct EncBlk { VaeResW r[2]; Lin down; bool has_down = false; };
+  std::vector<EncBlk> e_blocks_;
+  DeviceArena act_;
+  size_t act_peak_ = 0;
+  float* gn_partial_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------ sampler
+// mirrors Conditioning<B> (stablediffusion/mod.rs:544-555); all device fp32
+struct Conditioning {
+  const float* unconditional_context_full = nullptr;        // [77][ctx_full]
+  const float* unconditional_context_open_clip = nullptr;   // [77][1280]
+  const float* context_full = nullptr;                      // [n][77][ctx_full]
+  const float* context_open_clip = nullptr;                 // [n][77][1280]
+  const float* unconditional_channel_context = nullptr;     // [adm]
+  const float* unconditional_channel_context_refiner = nullptr;
+  const float* channel_context = nullptr;                   // [n][adm]
+  const float* channel_context_refiner = nullptr;
+  int n = 1, n_ctx = 77, height = 1024, width = 1024;
+};
+
+class Diffuser {
+ public:
+  Diffuser(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, const float* alphas_host, int n_train,
+           hipStream_t st);
+  ~Diffuser();
+  UNet& unet() { return *unet_; }
+  // Diffuser::sample_latent (stablediffusion/mod.rs:317-332); noise0 plays gen_noise(); out: NCHW fp32 [n,4,h/8,w/8]
+  void sample_latent(const Conditioning& c, double cfg_scale, int n_steps, const float* noise0, float* out, hipStream_t s);
+  // Diffuser::sample_latent_with_inpainting (:334-353, :434-483); mask u8 (1 = keep generated), step_noise [iters][n,4,h,w]
+  void sample_latent_inpaint(const Conditioning& c, double cfg_scale, int n_steps, const float* reference,
+                             const unsigned char* mask, const float* noise0, const float* step_noise, float* out,
+                             hipStream_t s);
+  // Diffuser::refine_latent (:355-376)
+  void refine_latent(const float* latent, const Conditioning& c, double cfg_scale, int step_start, int n_steps,
+                     const float* noise, float* out, hipStream_t s);
+  static std::vector<int> step_schedule(int n_steps, int step_start, int n_train);
+  std::vector<float> step_ms;   // per-iteration GPU time of the last trajectory (hipEvent), for "UNet step ms p50"
+  bool time_steps = false;
+
+ private:
+  void diffuse(float* latent, const Conditioning& c, int step_start, int n_steps, double cfg_scale, const float* reference,
+               const unsigned char* mask, const float* step_noise, hipStream_t s);
+  std::unique_ptr<UNet> unet_;
+  std::vector<double> alphas_;
+  int n_train_;
+  bool is_refiner_;
+  // device state
+  float* latent_ = nullptr; size_t latent_cap_ = 0;
+  StepCoef* table_ = nullptr; int table_cap_ = 0;
+  int* step_idx_ = nullptr; float* t_dev_ = nullptr;
+  float* ctx_buf_ = nullptr; size_t ctx_cap_ = 0;     // [2n][77][ctx] cond then uncond
+  float* y_buf_ = nullptr; size_t y_cap_ = 0;
+  const void* cached_ctx_key_[4] = {nullptr, nullptr, nullptr, nullptr}; int cached_n_ = 0;
+};
+
+}  // namespace sdxl

@@ -1,0 +1,148 @@
+// Kernel launch interface of the MI355X (gfx950) SDXL engine.  Everything here is device-side HIP written
+// for CDNA4 (64-lane wavefronts, MFMA, LDS); the host engine (unet.cpp / vae.cpp / sampler.cpp) only calls
+// these launchers.  Layout convention everywhere: activations are NHWC / token-major [rows][channels] with
+// an explicit row stride ("ld", in elements), so a tensor can live inside a wider (concat) buffer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdxl {
+
+// compute precision of a model instance
+enum DType : int { DT_F32 = 0, DT_F16 = 1 };
+
+static inline size_t dt_size(int dt) { return dt == DT_F16 ? 2 : 4; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Implicit GEMM:  C[M,N] = gather(A)[M,K] * Wp[N,K]^T   (conv3x3 / conv1x1 / linear; NHWC; K = taps*Cin)
+// Replaces burn Conv2d / nn::Linear call sites (reference unet/mod.rs:116-120,1036-1053,729-731,765-770,
+// 793,801,903,929,975-984,1041; autoencoder/mod.rs:161-180,281-283,461-472,526-529).
+struct IgemmParams {
+  const void* A;        // source activations [B][Hin][Win] rows of lda elements (dtype a_dt)
+  const void* W;        // packed weights [Npad][Kpad] in compute dtype, K order = (tap, cin), zero padded
+  int a_dt;             // dtype of A in memory (DT_F16 / DT_F32); converted to compute dtype while staging
+  int B, Hin, Win, Cin, lda;
+  int Hout, Wout;       // M = B*Hout*Wout
+  int ksize, stride, pad, up;   // up=1: nearest-2x upsample of the source fused into the gather
+  int M, N, K, Kpad;    // N = logical packed columns (<= Npad)
+  // epilogue:  v = acc + bias[n] + ebias[b*ebias_ld + n];  act;  + R;  store
+  const float* bias;    // [Npad] fp32 (packed order) or null
+  const float* ebias;   // [B][ebias_ld] fp32 or null (ResBlock time-embedding add, unet/mod.rs:1092)
+  int ebias_ld;
+  int rpb;              // rows per batch element (Hout*Wout or tokens) for ebias / transposed store
+  int act;              // 0 none, 1 GEGLU: packed column pairs (x,gate) in 16-wide groups -> x*gelu_erf(gate)
+  const void* R; int ldr; int r_dt;     // residual added after act (same logical shape as output)
+  void* C; int ldc; int c_dt;           // output for columns n < n_split (after GEGLU: n/2)
+  int n_split;          // columns >= n_split go to the transposed output (set = N when unused)
+  void* Ct; int ct_rows; int ct_ld;     // Ct[b][n - n_split][key]  (ct_rows rows per batch, row stride ct_ld), dtype c_dt
+};
+void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------
+// GroupNorm (32 groups, NHWC) -- reference groupnorm/mod.rs:52-82 (+ SiLU silu.rs:14-16)
+struct GroupNormParams {
+  const void* X; int x_dt; int ldx;    // [B][HW] rows, C channels
+  void* Y; int y_dt; int ldy;
+  const float* gamma; const float* beta;
+  float* partial;      // workspace: [B][32][nsplit][3] (count, mean, M2)
+  int B, HW, C, G;
+  float eps;
+  int silu;            // fuse x*sigmoid(x) after the affine
+  int nsplit;          // filled by the launcher helper
+};
+int  groupnorm_nsplit(int B, int HW, int C);
+void launch_groupnorm(const GroupNormParams& p, hipStream_t s);
+
+// LayerNorm over the last dim -- reference layernorm/mod.rs:34-49
+struct LayerNormParams {
+  const void* X; int x_dt; int ldx;
+  void* Y; int y_dt; int ldy;
+  const float* gamma; const float* beta;
+  int rows, C; float eps;
+};
+void launch_layernorm(const LayerNormParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused attention softmax(Q K^T * scale) V, head dim 64 -- reference backend.rs:88-128 (Backend::qkv_attention)
+struct AttnParams {
+  const void* Q; int ldq;      // [B][Nq] rows, head h at columns h*64..
+  const void* K; int ldk;      // [B][Nk] rows
+  const void* Vt; int vt_ld;   // V transposed: [B][H*64][vt_ld], keys contiguous, zero beyond Nk
+  void* O; int ldo;
+  int dt;                      // dtype of Q,K,Vt,O (compute dtype)
+  int B, H, Nq, Nk;
+  float scale;                 // 1/sqrt(d)
+  const float* mask; int ldmask;   // optional additive [Nq][Nk] fp32 (0 / -inf), null in UNet/VAE
+};
+void launch_attention_d64(const AttnParams& p, hipStream_t s);
+
+// row softmax for the unfused attention path (VAE mid block, d=512, 1 head): P[r][:] = softmax(S[r][:]*scale + mask)
+// S fp32 [rows][lds] (scores from igemm), P in dtype p_dt [rows][ldp]; columns n..npad-1 of P are zero filled.
+void launch_softmax_rows(const float* S, int lds, void* P, int p_dt, int ldp, int rows, int n, int npad, float scale,
+                         const float* mask, int ldmask, int mask_rows, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------
+// Small-M linear (GEMV): Y[b][n] = act_in(X[b][:]) . Wp[n][:] + bias[n]   (time/label/emb MLPs, M<=8)
+struct GemvParams {
+  const float* X; int ldx;     // fp32 [Bm][K]
+  const void* W; int w_dt; int Kpad;   // packed [N][Kpad]
+  const float* bias;           // fp32 or null
+  float* Y; int ldy;           // fp32 [Bm][N]
+  const float* Yadd;           // optional fp32 [Bm][N] added to the result (t_emb + label_emb)
+  int Bm, N, K;
+  int silu_in;                 // apply SiLU to X while loading
+  int silu_out;                // apply SiLU to the result
+};
+void launch_gemv(const GemvParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------
+// elementwise / layout
+// sinusoidal embedding (unet/mod.rs:21-39): out[b][0:half]=cos(t*f), [half:]=sin(t*f); t read from device
+void launch_timestep_embedding(const float* t_dev, int t_stride, float* out, int Bm, int dim, hipStream_t s);
+// NCHW fp32 -> NHWC (dtype dt), optional batch replication (src batch stride 0)
+void launch_nchw_to_nhwc(const float* src, int src_batch_stride, void* dst, int dt, int B, int C, int HW, int ldd,
+                         float scale, hipStream_t s);
+void launch_nhwc_to_nchw(const void* src, int dt, int lds, float* dst, int B, int C, int HW, float scale, hipStream_t s);
+// generic cast copy rows: dst[r][c] = src[r][c]
+void launch_copy_rows(const void* src, int sdt, int lds, void* dst, int ddt, int ldd, int rows, int C, hipStream_t s);
+void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s);
+
+// DDIM step table entry (host f64 -> f32): stablediffusion/mod.rs:407-428
+struct StepCoef { float t; float sqrt_a; float sqrt_1ma; float sqrt_ap; float sqrt_1map; float cfg; float pad0, pad1; };
+// eps = u + (c-u)*cfg (or c when !use_cfg); x0 = (x - eps*sqrt_1ma)/sqrt_a; x = x0*sqrt_ap + eps*sqrt_1map
+// eps_nhwc: UNet output [Bu][HW][4] fp32-or-T rows; latent NCHW fp32 [n][4][HW].  Also refreshes the UNet input
+// (NHWC, replicated for cond/uncond) and advances *step_idx.
+struct DdimParams {
+  float* latent;             // [n][4][HW] fp32 NCHW (state)
+  const void* eps; int eps_dt; int eps_ld;   // UNet output NHWC rows: cond batch entries [0,n), uncond [n,2n)
+  const StepCoef* table; int* step_idx;
+  int n, HW; int use_cfg;
+  // inpainting (optional): before the *next* UNet call latent = mask ? latent : ref*sqrt_a(next)+noise*sqrt_1ma(next)
+  const float* ref; const unsigned char* mask; const float* step_noise; int n_steps_total;
+  void* unet_in; int in_dt; int in_ld; int in_rep;   // next UNet input NHWC [in_rep*n][HW][4]
+  float* t_out;              // device scalar(s): timestep for the next UNet call
+};
+// do_update=0: first call of a trajectory -- sets *step_idx = 0, applies the step-0 inpaint blend, writes the UNet
+// input and timestep.  do_update=1: DDIM update with table[*step_idx], blend for the next step, then advances.
+void launch_ddim_step(const DdimParams& p, int do_update, hipStream_t s);
+// noised = latent*sa + noise*sb   (refine_latent :363-367)
+void launch_axpby(float* dst, const float* a, float sa, const float* b, float sb, size_t n, hipStream_t s);
+// image post-process (stablediffusion/mod.rs:210-230): u8 = trunc(clamp(((x+1)/2)*255, 0, 255)), NHWC rows of 3
+void launch_to_u8_image(const void* src, int dt, int lds, unsigned char* dst, size_t pixels, hipStream_t s);
+// u8 HWC image -> NHWC activation (x/255)*2-1  (image_to_latent :239-255)
+void launch_from_u8_image(const unsigned char* src, void* dst, int dt, int ldd, size_t pixels, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------
+// weights: synthetic fill (bit-identical to oracle/config.py synth_values) and packing into device layouts
+void launch_synth_fill(float* dst, size_t numel, uint64_t key, float scale, float mean, hipStream_t s);
+// canonical Linear [K][N] fp32 (burn layout) -> packed [Npad][Kpad] (dt); optional GEGLU interleave
+void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu,
+                        int n_offset, hipStream_t s);
+// canonical conv [Cout][Cin][kh][kw] fp32 -> packed [Npad][Kpad], k = (kh*kw_idx)*Cin + c
+void launch_pack_conv(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad,
+                      hipStream_t s);
+// bias vector permuted the same way as GEGLU-packed columns (fp32 -> fp32)
+void launch_pack_bias(const float* src, float* dst, int N, int Npad, int geglu, int n_offset, hipStream_t s);
+
+}  // namespace sdxl

@@ -1,0 +1,262 @@
+// GroupNorm(32)+SiLU and LayerNorm for gfx950, NHWC / token-major rows.  HBM-bound kernels: 16-byte vector
+// loads, fp32 statistics, one read for the statistics + one read/write for the apply.
+//
+// Reference semantics (groupnorm/mod.rs:75-82, layernorm/mod.rs:42-49): u = x - mean; y = u / sqrt(mean(u*u) + eps)
+// (biased variance, eps inside the sqrt), then *gamma + beta (+ SiLU, silu.rs:14-16).  The reference computes the
+// variance from mean-subtracted values (two passes); to keep that numerical behaviour in ONE pass over HBM the
+// statistics kernel runs per-channel Welford updates and merges partial (count, mean, M2) triples with Chan's
+// formula (row lanes -> channels -> groups -> row splits), never E[x^2]-E[x]^2.
+#include "kernels.h"
+
+namespace sdxl {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename XT> __device__ __forceinline__ void load8(const XT* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<half_t>(const half_t* p, float (&v)[8]) {
+  half8 h = *reinterpret_cast<const half8*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+template <typename YT> __device__ __forceinline__ void store8(YT* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<half_t>(half_t* p, const float (&v)[8]) {
+  half8 h;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+  *reinterpret_cast<half8*>(p) = h;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a[j] = v[j]; b[j] = v[4 + j]; }
+  *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+// Chan merge of (nb, mb, M2b) into (na, ma, M2a)
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& m2a, float nb, float mb, float m2b) {
+  if (nb == 0.f) return;
+  const float n = na + nb;
+  const float d = mb - ma;
+  const float f = nb / n;
+  ma = ma + d * f;
+  m2a = m2a + m2b + d * d * na * f;
+  na = n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// statistics: grid (nsplit, B), 256 threads.  thread -> (row lane rl, vector column vc); 8 channels per vector.
+template <typename XT>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = p.C, NV = C >> 3;
+  const int VPR = NV < 256 ? NV : 256;
+  const int RL = 256 / VPR;
+  float* chMean = sm;                 // [C]
+  float* chM2 = sm + C;               // [C]
+  float* tmpMean = sm + 2 * C;        // [RL][VPR*8]
+  float* tmpM2 = tmpMean + RL * VPR * 8;
+  float* tmpCnt = tmpM2 + RL * VPR * 8;   // [RL]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, s = blockIdx.x;
+  const int rps = (p.HW + p.nsplit - 1) / p.nsplit;
+  const int row_begin = s * rps;
+  const int row_end = min(p.HW, row_begin + rps);
+  const int rl = tid / VPR, vl = tid - rl * VPR;
+  const XT* X = reinterpret_cast<const XT*>(p.X) + (size_t)b * p.HW * p.ldx;
+  const int npass = (NV + VPR - 1) / VPR;
+  float total_rows = (float)max(0, row_end - row_begin);
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int vc = pass * VPR + vl;
+    const bool active = rl < RL && vc < NV;
+    float mean[8], m2[8], cnt = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mean[j] = 0.f; m2[j] = 0.f; }
+    if (active) {
+      for (int row = row_begin + rl; row < row_end; row += RL) {
+        float v[8];
+        load8<XT>(X + (size_t)row * p.ldx + vc * 8, v);
+        cnt += 1.f;
+        const float inv = 1.f / cnt;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = v[j] - mean[j];
+          mean[j] += d * inv;
+          m2[j] += d * (v[j] - mean[j]);
+        }
+      }
+    }
+    if (rl < RL) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        tmpMean[(rl * VPR + vl) * 8 + j] = mean[j];
+        tmpM2[(rl * VPR + vl) * 8 + j] = m2[j];
+      }
+      if (vl == 0) tmpCnt[rl] = cnt;
+    }
+    __syncthreads();
+    if (rl == 0 && vc < NV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float na = 0.f, ma = 0.f, qa = 0.f;
+        for (int r = 0; r < RL; ++r)
+          chan_merge(na, ma, qa, tmpCnt[r], tmpMean[(r * VPR + vl) * 8 + j], tmpM2[(r * VPR + vl) * 8 + j]);
+        chMean[vc * 8 + j] = ma;
+        chM2[vc * 8 + j] = qa;
+      }
+    }
+    __syncthreads();
+  }
+  // channels -> groups (every channel of this block has total_rows samples)
+  const int cpg = C / p.G;
+  if (tid < p.G) {
+    float na = 0.f, ma = 0.f, qa = 0.f;
+    if (total_rows > 0.f)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) chan_merge(na, ma, qa, total_rows, chMean[c], chM2[c]);
+    float* out = p.partial + (((size_t)b * p.G + tid) * p.nsplit + s) * 3;
+    out[0] = na; out[1] = ma; out[2] = qa;
+  }
+}
+
+// apply: grid (row chunks, B).  per-channel (mean_g, rstd_g*gamma, beta) staged in LDS.
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = p.C;
+  float* cMean = sm;            // [C]
+  float* cScale = sm + C;       // [C]
+  float* cBeta = sm + 2 * C;    // [C]
+  float* gMean = sm + 3 * C;    // [G]
+  float* gRstd = gMean + p.G;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid < p.G) {
+    const float* part = p.partial + ((size_t)b * p.G + tid) * p.nsplit * 3;
+    float na = 0.f, ma = 0.f, qa = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) chan_merge(na, ma, qa, part[s * 3], part[s * 3 + 1], part[s * 3 + 2]);
+    gMean[tid] = ma;
+    gRstd[tid] = 1.0f / sqrtf(qa / na + p.eps);
+  }
+  __syncthreads();
+  const int cpg = C / p.G;
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    cMean[c] = gMean[g];
+    cScale[c] = gRstd[g] * p.gamma[c];
+    cBeta[c] = p.beta[c];
+  }
+  __syncthreads();
+  const int NV = C >> 3;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int nrows = min(rows_per_block, p.HW - row0);
+  const XT* X = reinterpret_cast<const XT*>(p.X) + ((size_t)b * p.HW + row0) * p.ldx;
+  YT* Y = reinterpret_cast<YT*>(p.Y) + ((size_t)b * p.HW + row0) * p.ldy;
+  const int total = nrows * NV;
+  for (int i = tid; i < total; i += 256) {
+    const int row = i / NV, vc = i - row * NV;
+    float v[8];
+    load8<XT>(X + (size_t)row * p.ldx + vc * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = vc * 8 + j;
+      float y = (v[j] - cMean[c]) * cScale[c] + cBeta[c];
+      if (p.silu) y = y / (1.0f + __expf(-y));
+      v[j] = y;
+    }
+    store8<YT>(Y + (size_t)row * p.ldy + vc * 8, v);
+  }
+}
+
+int groupnorm_nsplit(int B, int HW, int C) {
+  (void)B; (void)C;
+  int n = HW / 32;
+  if (n < 1) n = 1;
+  if (n > 128) n = 128;
+  return n;
+}
+
+void launch_groupnorm(const GroupNormParams& pin, hipStream_t s) {
+  GroupNormParams p = pin;
+  p.nsplit = groupnorm_nsplit(p.B, p.HW, p.C);
+  const int NV = p.C >> 3;
+  const int VPR = NV < 256 ? NV : 256;
+  const int RL = 256 / VPR;
+  const size_t lds_stats = (size_t)(2 * p.C + 2 * RL * VPR * 8 + RL) * sizeof(float);
+  dim3 g1(p.nsplit, p.B);
+  if (p.x_dt == DT_F16) hipLaunchKernelGGL(gn_stats_kernel<half_t>, g1, dim3(256), lds_stats, s, p);
+  else hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds_stats, s, p);
+  // apply
+  int rows_per_block = (256 * 4) / NV;      // ~4 vectors per thread
+  if (rows_per_block < 1) rows_per_block = 1;
+  if (rows_per_block > 64) rows_per_block = 64;
+  dim3 g2((p.HW + rows_per_block - 1) / rows_per_block, p.B);
+  const size_t lds_apply = (size_t)(3 * p.C + 2 * p.G) * sizeof(float);
+  if (p.x_dt == DT_F16 && p.y_dt == DT_F16)
+    hipLaunchKernelGGL((gn_apply_kernel<half_t, half_t>), g2, dim3(256), lds_apply, s, p, rows_per_block);
+  else if (p.x_dt == DT_F32 && p.y_dt == DT_F16)
+    hipLaunchKernelGGL((gn_apply_kernel<float, half_t>), g2, dim3(256), lds_apply, s, p, rows_per_block);
+  else if (p.x_dt == DT_F32 && p.y_dt == DT_F32)
+    hipLaunchKernelGGL((gn_apply_kernel<float, float>), g2, dim3(256), lds_apply, s, p, rows_per_block);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<half_t, float>), g2, dim3(256), lds_apply, s, p, rows_per_block);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm: one wavefront per row, two-pass statistics from registers-or-L1 re-reads (rows are <= a few KB)
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const XT* x = reinterpret_cast<const XT*>(p.X) + (size_t)row * p.ldx;
+  YT* y = reinterpret_cast<YT*>(p.Y) + (size_t)row * p.ldy;
+  const int NV = p.C >> 3;
+  float sum = 0.f;
+  for (int vc = lane; vc < NV; vc += 64) {
+    float v[8];
+    load8<XT>(x + vc * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += v[j];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)p.C;
+  float sq = 0.f;
+  for (int vc = lane; vc < NV; vc += 64) {
+    float v[8];
+    load8<XT>(x + vc * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float u = v[j] - mean; sq += u * u; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = 1.0f / sqrtf(sq / (float)p.C + p.eps);
+  for (int vc = lane; vc < NV; vc += 64) {
+    float v[8];
+    load8<XT>(x + vc * 8, v);
+    f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + vc * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + vc * 8 + 4);
+    f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + vc * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + vc * 8 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = (v[j] - mean) * rstd * g0[j] + b0[j];
+      v[4 + j] = (v[4 + j] - mean) * rstd * g1[j] + b1[j];
+    }
+    store8<YT>(y + vc * 8, v);
+  }
+}
+
+void launch_layernorm(const LayerNormParams& p, hipStream_t s) {
+  dim3 g((p.rows + 3) / 4);
+  if (p.x_dt == DT_F16 && p.y_dt == DT_F16) hipLaunchKernelGGL((layernorm_kernel<half_t, half_t>), g, dim3(256), 0, s, p);
+  else if (p.x_dt == DT_F32 && p.y_dt == DT_F16) hipLaunchKernelGGL((layernorm_kernel<float, half_t>), g, dim3(256), 0, s, p);
+  else if (p.x_dt == DT_F32 && p.y_dt == DT_F32) hipLaunchKernelGGL((layernorm_kernel<float, float>), g, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((layernorm_kernel<half_t, float>), g, dim3(256), 0, s, p);
+}
+
+}  // namespace sdxl

@@ -1,0 +1,174 @@
+// DDIM (eta = 0) sampler with classifier-free guidance -- reference Diffuser (stablediffusion/mod.rs:308-542).
+//
+// What changes relative to the reference's loop, without changing its arithmetic:
+//   * the CFG pair runs as ONE batch-2n UNet forward (cond entries [0,n), uncond [n,2n)) instead of two sequential
+//     batch-n forwards (:523-537): weights stream from HBM once per step and every GEMM has 2x the rows to fill 256 CUs.
+//     Per-sample ops (GroupNorm, attention, LayerNorm) never mix batch entries, so results equal two separate calls.
+//   * alpha lookups (:407-412, two blocking device->host scalar reads per step in the reference) become a per-trajectory
+//     coefficient table computed on the host in f64 and uploaded once; the step index lives on the device, so every
+//     iteration is the same captured graph + one fused CFG/DDIM/inpaint kernel, with no host sync inside the loop.
+//   * noise is an explicit input (the reference's generator is unseeded, gen_noise :378-388); sigma = 0 so the per-step
+//     gen_noise()*sigma term (:427) contributes nothing and is not drawn.
+#include "engine.h"
+
+#include <cmath>
+
+namespace sdxl {
+
+std::vector<int> Diffuser::step_schedule(int n_steps, int step_start, int n_train) {
+  // (0..n_train-step_start).rev().step_by(n_train / n_steps)   (:400-406); n_steps=30 -> 31 iterations
+  SDXL_REQUIRE(n_steps >= 1 && n_steps <= n_train, "n_steps out of range");
+  const int step = n_train / n_steps;
+  std::vector<int> ts;
+  for (int t = n_train - step_start - 1; t >= 0; t -= step) ts.push_back(t);
+  return ts;
+}
+
+Diffuser::Diffuser(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, const float* alphas_host,
+                   int n_train, hipStream_t st)
+    : n_train_(n_train), is_refiner_(cfg.is_refiner) {
+  unet_.reset(new UNet(cfg, compute_dt, stream_dt, src, st));
+  alphas_.resize(n_train);
+  for (int i = 0; i < n_train; ++i) alphas_[i] = (double)alphas_host[i];   // get_alpha :485-492 (elem -> f64)
+  SDXL_HIP(hipMalloc((void**)&step_idx_, sizeof(int)));
+  SDXL_HIP(hipMalloc((void**)&t_dev_, 8 * sizeof(float)));
+}
+Diffuser::~Diffuser() {
+  for (void* p : {(void*)latent_, (void*)table_, (void*)step_idx_, (void*)t_dev_, (void*)ctx_buf_, (void*)y_buf_})
+    if (p) (void)hipFree(p);
+}
+
+void Diffuser::diffuse(float* latent, const Conditioning& c, int step_start, int n_steps, double cfg_scale,
+                       const float* reference, const unsigned char* mask, const float* step_noise, hipStream_t s) {
+  // diffuse_latent :390-432 / diffuse_latent_with_inpainting :434-483
+  UNet& u = *unet_;
+  const UNetCfg& uc = u.cfg();
+  const int n = c.n, B = is_refiner_ ? n : 2 * n;
+  SDXL_REQUIRE(n >= 1 && B <= 8, "batch out of range");
+  const int h = c.height / 8, w = c.width / 8, HW = h * w;
+  const int ctx_dim = uc.context_dim, adm = uc.adm_in_channels;
+  // --- contexts of the batched CFG pair (forward_diffuser :506-537)
+  const float* ctx = is_refiner_ ? c.context_open_clip : c.context_full;
+  const float* uctx = is_refiner_ ? c.unconditional_context_open_clip : c.unconditional_context_full;
+  const float* y = is_refiner_ ? c.channel_context_refiner : c.channel_context;
+  const float* uy = is_refiner_ ? c.unconditional_channel_context_refiner : c.unconditional_channel_context;
+  SDXL_REQUIRE(ctx && y, "conditioning tensors missing");
+  SDXL_REQUIRE(is_refiner_ || (uctx && uy), "unconditional conditioning tensors missing");
+  const size_t ctx_elems = (size_t)c.n_ctx * ctx_dim;
+  if ((size_t)B * ctx_elems > ctx_cap_) {
+    if (ctx_buf_) SDXL_HIP(hipFree(ctx_buf_));
+    SDXL_HIP(hipMalloc((void**)&ctx_buf_, (size_t)B * ctx_elems * sizeof(float)));
+    ctx_cap_ = (size_t)B * ctx_elems;
+  }
+  if ((size_t)B * adm > y_cap_) {
+    if (y_buf_) SDXL_HIP(hipFree(y_buf_));
+    SDXL_HIP(hipMalloc((void**)&y_buf_, (size_t)B * adm * sizeof(float)));
+    y_cap_ = (size_t)B * adm;
+  }
+  SDXL_HIP(hipMemcpyAsync(ctx_buf_, ctx, (size_t)n * ctx_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+  SDXL_HIP(hipMemcpyAsync(y_buf_, y, (size_t)n * adm * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (!is_refiner_)
+    for (int i = 0; i < n; ++i) {   // unconditional_context.unsqueeze().repeat(0, n_batch) :535-536
+      SDXL_HIP(hipMemcpyAsync(ctx_buf_ + (size_t)(n + i) * ctx_elems, uctx, ctx_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+      SDXL_HIP(hipMemcpyAsync(y_buf_ + (size_t)(n + i) * adm, uy, adm * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+  void* unet_in = u.unet_in(B, h, w);
+  u.set_context(ctx_buf_, c.n_ctx, y_buf_, B, s);
+
+  // --- coefficient table (host f64, exactly the reference's scalar arithmetic :407-414, :423-426)
+  const std::vector<int> ts = step_schedule(n_steps, step_start, n_train_);
+  const int iters = (int)ts.size();
+  const int step_size = n_train_ / n_steps;
+  std::vector<StepCoef> tab(iters + 1);
+  for (int i = 0; i < iters; ++i) {
+    const int t = ts[i];
+    const double a = alphas_[t];
+    const double ap = t >= step_size ? alphas_[t - step_size] : 1.0;
+    StepCoef k{};
+    k.t = (float)t;
+    k.sqrt_a = (float)std::sqrt(a);
+    k.sqrt_1ma = (float)std::sqrt(1.0 - a);
+    k.sqrt_ap = (float)std::sqrt(ap);
+    k.sqrt_1map = (float)std::sqrt(1.0 - ap - 0.0);
+    k.cfg = (float)cfg_scale;
+    tab[i] = k;
+  }
+  tab[iters] = StepCoef{};
+  if (iters + 1 > table_cap_) {
+    if (table_) SDXL_HIP(hipFree(table_));
+    SDXL_HIP(hipMalloc((void**)&table_, (size_t)(iters + 1) * sizeof(StepCoef)));
+    table_cap_ = iters + 1;
+  }
+  SDXL_HIP(hipMemcpyAsync(table_, tab.data(), (size_t)(iters + 1) * sizeof(StepCoef), hipMemcpyHostToDevice, s));
+  SDXL_HIP(hipStreamSynchronize(s));   // tab is a stack-owned host buffer
+
+  DdimParams p{};
+  p.latent = latent;
+  p.eps = u.eps_out(); p.eps_dt = DT_F32; p.eps_ld = uc.out_channels;
+  p.table = table_; p.step_idx = step_idx_;
+  p.n = n; p.HW = HW; p.use_cfg = is_refiner_ ? 0 : 1;
+  p.ref = reference; p.mask = mask; p.step_noise = step_noise; p.n_steps_total = iters;
+  p.unet_in = unet_in; p.in_dt = u.compute_dt(); p.in_ld = uc.in_channels; p.in_rep = is_refiner_ ? 1 : 2;
+  p.t_out = t_dev_;
+  launch_ddim_step(p, 0, s);
+
+  std::vector<hipEvent_t> ev;
+  if (time_steps) {
+    ev.resize(iters + 1);
+    for (auto& e : ev) SDXL_HIP(hipEventCreate(&e));
+    SDXL_HIP(hipEventRecord(ev[0], s));
+  }
+  for (int i = 0; i < iters; ++i) {
+    u.forward(B, h, w, t_dev_, 0, s);     // one timestep shared by every batch entry (:416)
+    launch_ddim_step(p, 1, s);
+    if (time_steps) SDXL_HIP(hipEventRecord(ev[i + 1], s));
+  }
+  if (time_steps) {
+    SDXL_HIP(hipEventSynchronize(ev[iters]));
+    step_ms.assign(iters, 0.f);
+    for (int i = 0; i < iters; ++i) SDXL_HIP(hipEventElapsedTime(&step_ms[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+}
+
+static void ensure_latent(float*& buf, size_t& cap, size_t elems) {
+  if (elems > cap) {
+    if (buf) SDXL_HIP(hipFree(buf));
+    SDXL_HIP(hipMalloc((void**)&buf, elems * sizeof(float)));
+    cap = elems;
+  }
+}
+
+void Diffuser::sample_latent(const Conditioning& c, double cfg_scale, int n_steps, const float* noise0, float* out,
+                             hipStream_t s) {
+  const size_t elems = (size_t)c.n * 4 * (c.height / 8) * (c.width / 8);
+  ensure_latent(latent_, latent_cap_, elems);
+  SDXL_HIP(hipMemcpyAsync(latent_, noise0, elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+  diffuse(latent_, c, 0, n_steps, cfg_scale, nullptr, nullptr, nullptr, s);
+  SDXL_HIP(hipMemcpyAsync(out, latent_, elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+}
+
+void Diffuser::sample_latent_inpaint(const Conditioning& c, double cfg_scale, int n_steps, const float* reference,
+                                     const unsigned char* mask, const float* noise0, const float* step_noise, float* out,
+                                     hipStream_t s) {
+  SDXL_REQUIRE(reference && mask && step_noise, "inpainting needs reference, mask and per-step noise");
+  const size_t elems = (size_t)c.n * 4 * (c.height / 8) * (c.width / 8);
+  ensure_latent(latent_, latent_cap_, elems);
+  SDXL_HIP(hipMemcpyAsync(latent_, noise0, elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+  diffuse(latent_, c, 0, n_steps, cfg_scale, reference, mask, step_noise, s);
+  SDXL_HIP(hipMemcpyAsync(out, latent_, elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+}
+
+void Diffuser::refine_latent(const float* latent, const Conditioning& c, double cfg_scale, int step_start, int n_steps,
+                             const float* noise, float* out, hipStream_t s) {
+  // :355-376: re-noise the finished latent to t = n_train - step_start, then denoise from there
+  SDXL_REQUIRE(step_start >= 1 && step_start <= n_train_, "step_start out of range");
+  const size_t elems = (size_t)c.n * 4 * (c.height / 8) * (c.width / 8);
+  ensure_latent(latent_, latent_cap_, elems);
+  const double a = alphas_[n_train_ - step_start];
+  launch_axpby(latent_, latent, (float)std::sqrt(a), noise, (float)std::sqrt(1.0 - a), elems, s);
+  diffuse(latent_, c, step_start, n_steps, cfg_scale, nullptr, nullptr, nullptr, s);
+  SDXL_HIP(hipMemcpyAsync(out, latent_, elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+}
+
+}  // namespace sdxl

@@ -1,0 +1,411 @@
+// SDXL UNet forward on MI355X -- the sampling loop's hot path (reference UNet::forward, unet/mod.rs:450-492).
+//
+// Design (not a translation of the burn module tree):
+//   * NHWC / token-major everywhere, so ResBlock convs, the SpatialTransformer's linears and attention share one
+//     activation layout and the reference's NCHW<->[B,N,C] transposes (unet/mod.rs:827-829,837-841) disappear.
+//   * torch.cat of the skip connections (:484) is eliminated: every input block writes its output straight into the
+//     channel slice [C_x, C_x+C_skip) of the concat buffer its matching output block will read, and the previous
+//     output block writes the [0, C_x) slice.
+//   * nearest-2x upsample (:744-749) is an index >>1 inside the conv's gather; the time-embedding add (:1092), the
+//     residual adds (:1098-1102, :887-889, :843) and GEGLU (:944-955) live in GEMM epilogues.
+//   * everything that is constant over a trajectory is hoisted out of the step: cross-attention K / V^T projections of
+//     the 70 transformer blocks and the label-embedding MLP are computed once per prompt (set_context).
+//   * the 17+ per-ResBlock lin_embed(silu(emb)) GEMVs (:1088-1089) are one GEMV over a concatenated weight.
+//   * static shapes -> bump-allocated activation arena with scoped reuse (working set stays inside the 256 MB
+//     Infinity Cache) -> stable addresses -> the whole forward is captured once into a hipGraph and replayed.
+#include "engine.h"
+
+#include <cmath>
+
+namespace sdxl {
+
+namespace {
+ResBlockW load_res(WeightBuilder& wb, const std::string& p, int cin, int cout, std::vector<std::string>& emb_names,
+                   int& emb_off) {
+  ResBlockW r;
+  r.cin = cin; r.cout = cout;
+  r.norm_in = wb.norm(p + ".norm_in");
+  r.conv_in = wb.conv(p + ".conv_in");
+  r.norm_out = wb.norm(p + ".norm_out");
+  r.conv_out = wb.conv(p + ".conv_out");
+  r.has_skip = wb.has(p + ".skip_connection.weight");
+  if (r.has_skip) r.skip = wb.conv(p + ".skip_connection");
+  r.emb_off = emb_off;
+  emb_names.push_back(p + ".lin_embed");
+  emb_off += cout;
+  return r;
+}
+STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth) {
+  STW s;
+  s.C = C; s.heads = heads;
+  s.norm = wb.norm(p + ".norm");
+  s.proj_in = wb.linear(p + ".proj_in");
+  for (int j = 0; j < depth; ++j) {
+    const std::string q = p + ".blocks." + std::to_string(j);
+    TBlockW t;
+    t.n1 = wb.norm(q + ".norm1");
+    t.qkv = wb.fused_linear({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"});
+    t.out1 = wb.linear(q + ".attn1.out");
+    t.n2 = wb.norm(q + ".norm2");
+    t.q2 = wb.linear(q + ".attn2.query");
+    t.kv2 = wb.fused_linear({q + ".attn2.key", q + ".attn2.value"});
+    t.out2 = wb.linear(q + ".attn2.out");
+    t.n3 = wb.norm(q + ".norm3");
+    t.geglu = wb.linear(q + ".mlp.geglu.proj", true);
+    t.ff = wb.linear(q + ".mlp.lin");
+    s.blocks.push_back(t);
+  }
+  s.proj_out = wb.linear(p + ".proj_out");
+  return s;
+}
+void gemv(Exec& ex, const Lin& w, const float* x, int ldx, float* y, int ldy, int Bm, bool silu_in, bool silu_out,
+          const float* yadd = nullptr) {
+  if (ex.dry) return;
+  GemvParams p{};
+  p.X = x; p.ldx = ldx; p.W = w.w; p.w_dt = ex.cdt; p.Kpad = w.Kpad; p.bias = w.b;
+  p.Y = y; p.ldy = ldy; p.Yadd = yadd; p.Bm = Bm; p.N = w.N; p.K = w.K;
+  p.silu_in = silu_in; p.silu_out = silu_out;
+  launch_gemv(p, ex.s);
+}
+void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, const Act& o, int B, int H, int Nq,
+               int Nk) {
+  if (ex.dry) return;
+  AttnParams p{};
+  p.Q = q.p; p.ldq = q.ld; p.K = k.p; p.ldk = k.ld; p.Vt = vt; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
+  p.dt = ex.cdt; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+  launch_attention_d64(p, ex.s);
+}
+}  // namespace
+
+UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st)
+    : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt) {
+  SDXL_REQUIRE(cfg.n_head_channels == 64, "this engine's fused attention kernel is specialised for 64 channels per head");
+  SDXL_REQUIRE(!(compute_dt == DT_F32 && stream_dt != DT_F32), "f32 compute implies an f32 residual stream");
+  SDXL_REQUIRE(cfg.model_channels % 32 == 0, "GroupNorm(32) needs model_channels % 32 == 0");
+  build_weights(src, st);
+}
+UNet::~UNet() {
+  if (graph_) (void)hipGraphExecDestroy(graph_);
+}
+
+void UNet::build_weights(WeightSource& src, hipStream_t st) {
+  const std::vector<ParamSpec> specs = unet_param_specs(cfg_);
+  warena_.reserve(WeightBuilder::arena_bound(specs, cdt_));
+  WeightBuilder wb(specs, src, warena_, cdt_, st);
+  lin1_t_ = wb.linear("lin1_time_embed");
+  lin2_t_ = wb.linear("lin2_time_embed");
+  lin1_l_ = wb.linear("lin1_label_embed");
+  lin2_l_ = wb.linear("lin2_label_embed");
+  std::vector<BlockDesc> inp, out; BlockDesc mid;
+  unet_block_plan(cfg_, inp, mid, out);
+  std::vector<std::string> emb_names;
+  int emb_off = 0;
+  auto load_block = [&](const std::string& p, const BlockDesc& d) {
+    BlockW b; b.d = d;
+    switch (d.kind) {
+      case BK_CONV: case BK_DOWN: b.conv = wb.conv(p); break;
+      case BK_RES: b.res = load_res(wb, p, d.c_in, d.c_out, emb_names, emb_off); break;
+      default:
+        b.res = load_res(wb, p + ".res", d.c_in, d.c_out, emb_names, emb_off);
+        if (d.kind == BK_REST || d.kind == BK_RESTU) b.st = load_st(wb, p + ".transformer", d.c_out, d.n_head, d.depth);
+        if (d.kind == BK_RESTU || d.kind == BK_RESU) b.conv = wb.conv(p + ".upsample.conv");
+    }
+    return b;
+  };
+  for (size_t i = 0; i < inp.size(); ++i) inp_.push_back(load_block("input_blocks." + std::to_string(i), inp[i]));
+  mid_res1_.d = mid;
+  mid_res1_.res = load_res(wb, "middle_block.res1", mid.c_in, mid.c_out, emb_names, emb_off);
+  mid_res1_.st = load_st(wb, "middle_block.transformer", mid.c_out, mid.n_head, mid.depth);
+  mid_res2_.d = mid;
+  mid_res2_.res = load_res(wb, "middle_block.res2", mid.c_in, mid.c_out, emb_names, emb_off);
+  for (size_t i = 0; i < out.size(); ++i) out_.push_back(load_block("output_blocks." + std::to_string(i), out[i]));
+  norm_out_ = wb.norm("norm_out");
+  conv_out_ = wb.conv("conv_out");
+  embcat_ = wb.fused_linear(emb_names);
+  emb_total_ = emb_off;
+  SDXL_HIP(hipStreamSynchronize(st));
+  // execution order of the spatial transformers (for the K/V caches)
+  for (BlockW& b : inp_) if (!b.st.blocks.empty()) st_list_.push_back(&b.st);
+  st_list_.push_back(&mid_res1_.st);
+  for (BlockW& b : out_) if (!b.st.blocks.empty()) st_list_.push_back(&b.st);
+}
+
+// ------------------------------------------------------------------------------------------ conditioning
+void UNet::set_context(const float* context, int n_ctx, const float* label, int B, hipStream_t s) {
+  SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
+  const int vt_ld = (int)round_up(n_ctx, 64);
+  const int emb = 4 * cfg_.model_channels;
+  if (B != ctx_B_ || n_ctx != n_ctx_) {
+    // (re)allocate the caches; captured graphs hold these addresses
+    if (graph_) { (void)hipGraphExecDestroy(graph_); graph_ = nullptr; plan_runs_ = 0; }
+    size_t bytes = 1 << 16;
+    for (const STW* st : st_list_)
+      bytes += st->blocks.size() * (round_up((size_t)B * n_ctx * st->C * dt_size(cdt_), 256) +
+                                    round_up((size_t)B * st->C * vt_ld * dt_size(cdt_), 256) + 512);
+    bytes += 3 * round_up((size_t)B * emb * sizeof(float), 256);
+    ctx_arena_.reserve(bytes);
+    ctx_arena_.off = 0;
+    SDXL_HIP(hipMemsetAsync(ctx_arena_.base, 0, bytes, s));   // V^T key padding must be zero
+    kv_.clear();
+    for (const STW* st : st_list_) {
+      std::vector<KV> v;
+      for (size_t j = 0; j < st->blocks.size(); ++j) {
+        KV kv;
+        kv.k = ctx_arena_.alloc((size_t)B * n_ctx * st->C * dt_size(cdt_));
+        kv.vt = ctx_arena_.alloc((size_t)B * st->C * vt_ld * dt_size(cdt_));
+        v.push_back(kv);
+      }
+      kv_.push_back(v);
+    }
+    label_emb_ = (float*)ctx_arena_.alloc((size_t)B * emb * sizeof(float));
+    ctx_B_ = B; n_ctx_ = n_ctx; vt_ld_ctx_ = vt_ld;
+  }
+  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &ctx_arena_;
+  const Act ctx((void*)context, cfg_.context_dim, DT_F32);
+  for (size_t si = 0; si < st_list_.size(); ++si) {
+    const STW* st = st_list_[si];
+    for (size_t j = 0; j < st->blocks.size(); ++j) {
+      Epi e; e.n_split = st->C; e.Ct = kv_[si][j].vt; e.ct_rows = st->C; e.ct_ld = vt_ld; e.rpb = n_ctx;
+      run_linear(ex, st->blocks[j].kv2, ctx, B * n_ctx, Act(kv_[si][j].k, st->C, cdt_), e);
+    }
+  }
+  // label embedding MLP (unet/mod.rs:464-466); scratch after the caches
+  const size_t m = ctx_arena_.mark();
+  float* l1 = (float*)ctx_arena_.alloc((size_t)B * emb * sizeof(float));
+  gemv(ex, lin1_l_, label, cfg_.adm_in_channels, l1, emb, B, false, true);
+  gemv(ex, lin2_l_, l1, emb, label_emb_, emb, B, false, false);
+  ctx_arena_.reset(m);
+}
+
+// ------------------------------------------------------------------------------------------ blocks
+void UNet::res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, int H, int W, const Act& out) {
+  // ResBlock::forward unet/mod.rs:1082-1106
+  const size_t mk = ex.act->mark();
+  const size_t M = (size_t)B * H * W;
+  const ConvGeom g3{B, H, W, H, W, 3, 1, 1, 0}, g1{B, H, W, H, W, 1, 1, 0, 0};
+  Act gn1 = ex.alloc(M, w.cin, ex.cdt);
+  run_groupnorm(ex, w.norm_in, x, B, H * W, gn1, true);
+  Act h = ex.alloc(M, w.cout, ex.cdt);
+  Epi e1; e1.ebias = ebias_ + w.emb_off; e1.ebias_ld = emb_total_;
+  run_conv(ex, w.conv_in, gn1, w.cin, g3, h, e1);
+  Act gn2 = ex.alloc(M, w.cout, ex.cdt);
+  run_groupnorm(ex, w.norm_out, h, B, H * W, gn2, true);
+  Epi e2;
+  if (w.has_skip) { run_conv(ex, w.skip, x, w.cin, g1, out); e2.R = out; }
+  else e2.R = x;
+  run_conv(ex, w.conv_out, gn2, w.cout, g3, out, e2);
+  ex.act->reset(mk);
+}
+
+void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int B, int H, int W) {
+  // SpatialTransformer::forward unet/mod.rs:820-845, TransformerBlock::forward :885-891 -- in place on x
+  const size_t mk = ex.act->mark();
+  const int HW = H * W, C = w.C;
+  const size_t M = (size_t)B * HW;
+  SDXL_REQUIRE(C == w.heads * 64, "head dim must be 64");
+  const int npad = (int)round_up(HW, 64);
+  Act gn = ex.alloc(M, C, ex.cdt);
+  run_groupnorm(ex, w.norm, x, B, HW, gn, false);
+  Act t = ex.alloc(M, C, ex.sdt);
+  run_linear(ex, w.proj_in, gn, (int)M, t);
+  Act ln = ex.alloc(M, C, ex.cdt);
+  Act qk = ex.alloc(M, 2 * C, ex.cdt);
+  void* vt = ex.act->alloc((size_t)B * C * npad * dt_size(ex.cdt));
+  Act ao = ex.alloc(M, C, ex.cdt);
+  Act q = ex.alloc(M, C, ex.cdt);
+  Act gg = ex.alloc(M, 4 * C, ex.cdt);
+  if (npad != HW && !ex.dry) launch_fill_zero(vt, (size_t)B * C * npad * dt_size(ex.cdt), ex.s);
+  for (size_t j = 0; j < w.blocks.size(); ++j) {
+    const TBlockW& b = w.blocks[j];
+    run_layernorm(ex, b.n1, t, (int)M, ln);
+    Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW;
+    run_linear(ex, b.qkv, ln, (int)M, qk, eq);
+    attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
+    Epi er; er.R = t;
+    run_linear(ex, b.out1, ao, (int)M, t, er);
+    run_layernorm(ex, b.n2, t, (int)M, ln);
+    run_linear(ex, b.q2, ln, (int)M, q);
+    attention(ex, q, Act(kv_[si][j].k, C, ex.cdt), kv_[si][j].vt, vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
+    run_linear(ex, b.out2, ao, (int)M, t, er);
+    run_layernorm(ex, b.n3, t, (int)M, ln);
+    Epi eg; eg.act = 1;
+    run_linear(ex, b.geglu, ln, (int)M, gg, eg);
+    run_linear(ex, b.ff, gg, (int)M, t, er);
+  }
+  Epi eo; eo.R = x;
+  run_linear(ex, w.proj_out, t, (int)M, x, eo);
+  ex.act->reset(mk);
+}
+
+// ------------------------------------------------------------------------------------------ forward
+void UNet::run(Exec& ex, const float* t_dev, int t_stride) {
+  const int B = pB_, H = pH_, W = pW_;
+  const int mc = cfg_.model_channels, emb = 4 * mc;
+  // --- embeddings (unet/mod.rs:458-468)
+  if (!ex.dry) launch_timestep_embedding(t_dev, t_stride, temb_, B, mc, ex.s);
+  gemv(ex, lin1_t_, temb_, mc, g1_, emb, B, false, true);
+  gemv(ex, lin2_t_, g1_, emb, emb_, emb, B, false, false, label_emb_);
+  gemv(ex, embcat_, emb_, emb, ebias_, emb_total_, B, true, false);
+
+  // --- geometry of the skip / concat buffers
+  const int n_in = (int)inp_.size(), n_out = (int)out_.size();
+  SDXL_REQUIRE(n_in == n_out, "input/output block count mismatch");
+  std::vector<int> hs_h(n_in), hs_w(n_in), hs_c(n_in);
+  {
+    int h = H, w = W;
+    for (int i = 0; i < n_in; ++i) {
+      const BlockDesc& d = inp_[i].d;
+      if (d.kind == BK_DOWN) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+      hs_h[i] = h; hs_w[i] = w; hs_c[i] = d.c_out;
+    }
+  }
+  std::vector<Act> cat(n_out);
+  std::vector<int> cx(n_out);
+  for (int j = 0; j < n_out; ++j) {
+    const int i = n_in - 1 - j;
+    cx[j] = out_[j].d.c_in - hs_c[i];
+    SDXL_REQUIRE(cx[j] > 0, "bad concat geometry");
+    cat[j] = ex.alloc((size_t)B * hs_h[i] * hs_w[i], out_[j].d.c_in, ex.sdt);
+  }
+  // --- input blocks (:474-477)
+  Act cur(in_, cfg_.in_channels, ex.cdt);
+  int h = H, w = W, cur_c = cfg_.in_channels;
+  int si = 0;
+  for (int i = 0; i < n_in; ++i) {
+    const BlockW& b = inp_[i];
+    const int j = n_in - 1 - i;
+    const Act dest = cat[j].cols(cx[j]);
+    switch (b.d.kind) {
+      case BK_CONV: run_conv(ex, b.conv, cur, cur_c, ConvGeom{B, h, w, h, w, 3, 1, 1, 0}, dest); break;
+      case BK_DOWN: {
+        const int h2 = (h - 1) / 2 + 1, w2 = (w - 1) / 2 + 1;
+        run_conv(ex, b.conv, cur, cur_c, ConvGeom{B, h, w, h2, w2, 3, 2, 1, 0}, dest);
+        h = h2; w = w2;
+        break;
+      }
+      case BK_RES: res_block(ex, b.res, cur, B, h, w, dest); break;
+      case BK_REST:
+        res_block(ex, b.res, cur, B, h, w, dest);
+        spatial_transformer(ex, b.st, si++, dest, B, h, w);
+        break;
+      default: throw Error("unexpected input block kind");
+    }
+    cur = dest; cur_c = b.d.c_out;
+  }
+  // --- middle block (:480, :713-719)
+  {
+    const size_t mk = ex.act->mark();
+    Act m1 = ex.alloc((size_t)B * h * w, mid_res1_.d.c_out, ex.sdt);
+    res_block(ex, mid_res1_.res, cur, B, h, w, m1);
+    spatial_transformer(ex, mid_res1_.st, si++, m1, B, h, w);
+    res_block(ex, mid_res2_.res, m1, B, h, w, cat[0].cols(0));
+    ex.act->reset(mk);
+  }
+  // --- output blocks (:483-486)
+  Act last = ex.alloc((size_t)B * H * W, mc, ex.sdt);
+  for (int j = 0; j < n_out; ++j) {
+    const BlockW& b = out_[j];
+    const bool up = b.d.kind == BK_RESTU || b.d.kind == BK_RESU;
+    const Act next = j + 1 < n_out ? cat[j + 1].cols(0) : last;
+    const size_t mk = ex.act->mark();
+    Act dest = up ? ex.alloc((size_t)B * h * w, b.d.c_out, ex.sdt) : next;
+    res_block(ex, b.res, cat[j], B, h, w, dest);
+    if (b.d.kind == BK_REST || b.d.kind == BK_RESTU) spatial_transformer(ex, b.st, si++, dest, B, h, w);
+    if (up) {   // Upsample::forward :742-752 -- nearest 2x fused into the conv gather
+      run_conv(ex, b.conv, dest, b.d.c_out, ConvGeom{B, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next);
+      h *= 2; w *= 2;
+    }
+    ex.act->reset(mk);
+  }
+  SDXL_REQUIRE(h == H && w == W, "UNet input height/width must be divisible by 2^(levels-1)");
+  // --- out (:488-490)
+  {
+    const size_t mk = ex.act->mark();
+    Act gn = ex.alloc((size_t)B * H * W, mc, ex.cdt);
+    run_groupnorm(ex, norm_out_, last, B, H * W, gn, true);
+    run_conv(ex, conv_out_, gn, mc, ConvGeom{B, H, W, H, W, 3, 1, 1, 0}, Act(eps_, cfg_.out_channels, DT_F32));
+    ex.act->reset(mk);
+  }
+}
+
+void UNet::ensure_plan(int B, int H, int W) {
+  if (B == pB_ && H == pH_ && W == pW_) return;
+  SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
+  const int div = 1 << (cfg_.channel_mults.size() - 1);
+  SDXL_REQUIRE(H >= div && W >= div && H % div == 0 && W % div == 0,
+               "UNet input height/width must be divisible by 2^(levels-1)");
+  if (graph_) { (void)hipGraphExecDestroy(graph_); graph_ = nullptr; }
+  plan_runs_ = 0;
+  pB_ = B; pH_ = H; pW_ = W;
+  const int mc = cfg_.model_channels, emb = 4 * mc;
+  auto persist = [&]() {
+    in_ = act_.alloc((size_t)B * H * W * cfg_.in_channels * dt_size(cdt_));
+    eps_ = (float*)act_.alloc((size_t)B * H * W * cfg_.out_channels * sizeof(float));
+    temb_ = (float*)act_.alloc((size_t)B * mc * sizeof(float));
+    g1_ = (float*)act_.alloc((size_t)B * emb * sizeof(float));
+    emb_ = (float*)act_.alloc((size_t)B * emb * sizeof(float));
+    ebias_ = (float*)act_.alloc((size_t)B * emb_total_ * sizeof(float));
+    gn_partial_ = (float*)act_.alloc((size_t)B * 32 * 128 * 3 * sizeof(float));
+    tconv_ = (float*)act_.alloc(8 * sizeof(float));
+  };
+  // dry run for the peak, then the real arena
+  act_.dry = true; act_.off = 0; act_.peak = 0;
+  persist();
+  Exec ex; ex.dry = true; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_;
+  const size_t m = act_.mark();
+  const bool had_kv = !kv_.empty();
+  if (!had_kv) {   // plan built before set_context: fake cache entries for the dry run
+    kv_.assign(st_list_.size(), std::vector<KV>());
+    for (size_t i = 0; i < st_list_.size(); ++i) kv_[i].assign(st_list_[i]->blocks.size(), KV());
+  }
+  run(ex, nullptr, 0);
+  if (!had_kv) kv_.clear();
+  act_.reset(m);
+  const size_t peak = act_.peak;
+  act_.dry = false;
+  act_.reserve(peak + 4096);
+  act_.off = 0; act_.peak = 0;
+  persist();
+}
+
+void* UNet::unet_in(int B, int H, int W) { ensure_plan(B, H, W); return in_; }
+
+void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStream_t s) {
+  ensure_plan(B, H, W);
+  SDXL_REQUIRE(ctx_B_ == B && !kv_.empty(), "set_context must be called with the same batch before forward");
+  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_;
+  const size_t m = act_.mark();
+  if (use_graph_ && graph_ && (graph_t_ != t_dev || graph_ts_ != t_stride)) {
+    (void)hipGraphExecDestroy(graph_); graph_ = nullptr;
+  }
+  if (use_graph_ && !graph_ && plan_runs_ >= 1) {
+    // capture the whole forward (~1.3k launches) once; replay costs one launch per forward
+    hipGraph_t g = nullptr;
+    SDXL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    try { run(ex, t_dev, t_stride); } catch (...) { (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); act_.reset(m); throw; }
+    SDXL_HIP(hipStreamEndCapture(s, &g));
+    SDXL_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
+    SDXL_HIP(hipGraphDestroy(g));
+    graph_t_ = t_dev; graph_ts_ = t_stride;
+    act_.reset(m);
+  }
+  if (use_graph_ && graph_) {
+    SDXL_HIP(hipGraphLaunch(graph_, s));
+  } else {
+    run(ex, t_dev, t_stride);
+    act_.reset(m);
+  }
+  ++plan_runs_;
+}
+
+void UNet::forward_nchw(const float* x, const int* timesteps, const float* context, int n_ctx, const float* label, int B,
+                        int H, int W, float* out, hipStream_t s) {
+  ensure_plan(B, H, W);
+  set_context(context, n_ctx, label, B, s);
+  launch_nchw_to_nhwc(x, cfg_.in_channels * H * W, in_, cdt_, B, cfg_.in_channels, H * W, cfg_.in_channels, 1.0f, s);
+  launch_i32_to_f32(timesteps, tconv_, B, s);
+  forward(B, H, W, tconv_, 1, s);
+  launch_nhwc_to_nchw(eps_, DT_F32, cfg_.out_channels, out, B, cfg_.out_channels, H * W, 1.0f, s);
+}
+
+}  // namespace sdxl

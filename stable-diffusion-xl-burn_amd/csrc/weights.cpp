@@ -1,0 +1,182 @@
+// Device arenas, weight sources (synthetic / flat buffer) and packing of canonical (reference-layout) parameters
+// into the MFMA-friendly device layout: dense weights as [Npad][Kpad] (k contiguous, K order = (tap, cin) for convs,
+// zero padded to 128 x 64), GEGLU projections column-interleaved (16 x | 16 gate) so the GEMM epilogue can apply
+// x*gelu(gate) in registers, QKV / KV / time-embedding projections concatenated along N.  Also the launch helpers
+// shared by the UNet and VAE drivers.
+#include "engine.h"
+
+namespace sdxl {
+
+// ------------------------------------------------------------------------------------------ arena
+DeviceArena::~DeviceArena() { if (base) (void)hipFree(base); }
+void DeviceArena::reserve(size_t bytes) {
+  if (bytes <= cap && base) return;
+  if (base) { SDXL_HIP(hipFree(base)); base = nullptr; }
+  SDXL_HIP(hipMalloc((void**)&base, bytes));
+  cap = bytes;
+}
+void* DeviceArena::alloc(size_t bytes) {
+  const size_t a = round_up(off, 256);
+  off = a + bytes;
+  if (off > peak) peak = off;
+  if (dry) return (void*)(uintptr_t)(a + 256);   // fake, never dereferenced
+  if (off > cap) throw Error("device arena overflow (" + std::to_string(off) + " > " + std::to_string(cap) + ")");
+  return base + a;
+}
+
+// ------------------------------------------------------------------------------------------ sources
+void SyntheticSource::fetch(const ParamSpec& s, size_t, float* dst, hipStream_t st) {
+  const uint64_t key = fnv1a64(s.name) ^ (seed * 0x9E3779B97F4A7C15ull);
+  launch_synth_fill(dst, s.numel(), key, s.scale, s.mean, st);
+}
+FlatSource::FlatSource(const float* b, const std::vector<ParamSpec>& specs) : base(b) {
+  size_t o = 0;
+  for (const ParamSpec& p : specs) { offsets.push_back(o); o += p.numel(); }
+}
+void FlatSource::fetch(const ParamSpec& s, size_t index, float* dst, hipStream_t st) {
+  SDXL_HIP(hipMemcpyAsync(dst, base + offsets[index], s.numel() * sizeof(float), hipMemcpyDefault, st));
+  SDXL_HIP(hipStreamSynchronize(st));   // pageable host memory: keep the staging copy simple and safe
+}
+
+// ------------------------------------------------------------------------------------------ builder
+WeightBuilder::WeightBuilder(const std::vector<ParamSpec>& sp, WeightSource& s, DeviceArena& a, int dtype, hipStream_t stream)
+    : specs(sp), src(s), arena(a), dt(dtype), st(stream) {
+  for (size_t i = 0; i < specs.size(); ++i) {
+    index[specs[i].name] = i;
+    if (specs[i].numel() > tmp_numel) tmp_numel = specs[i].numel();
+  }
+  SDXL_HIP(hipMalloc((void**)&tmp, tmp_numel * sizeof(float)));
+}
+WeightBuilder::~WeightBuilder() { if (tmp) (void)hipFree(tmp); }
+
+size_t WeightBuilder::arena_bound(const std::vector<ParamSpec>& specs, int dt) {
+  size_t total = 1 << 20;
+  for (const ParamSpec& p : specs) {
+    if (p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * round_up(p.shape[0], 64) * dt_size(dt) + 256;
+    else if (p.kind == PK_CONV_W)
+      total += round_up(p.shape[0], 128) * round_up((size_t)p.shape[1] * p.shape[2] * p.shape[3], 64) * dt_size(dt) + 256;
+    else total += round_up(p.numel(), 128) * sizeof(float) + 256;
+    if (p.kind == PK_LINEAR_W || p.kind == PK_CONV_W) total += round_up(p.kind == PK_LINEAR_W ? p.shape[1] : p.shape[0], 128) * 4 + 256;
+  }
+  return total;
+}
+const ParamSpec& WeightBuilder::spec(const std::string& name, size_t* idx) const {
+  auto it = index.find(name);
+  if (it == index.end()) throw Error("unknown parameter '" + name + "'");
+  if (idx) *idx = it->second;
+  return specs[it->second];
+}
+const float* WeightBuilder::fetch(const std::string& name) {
+  size_t i; const ParamSpec& s = spec(name, &i);
+  src.fetch(s, i, tmp, st);
+  return tmp;
+}
+Lin WeightBuilder::linear(const std::string& name, bool geglu) {
+  const ParamSpec& s = spec(name + ".weight");
+  Lin l; l.K = s.shape[0]; l.N = s.shape[1]; l.ksize = 1; l.cin = l.K;
+  const int kt = dt == DT_F16 ? 64 : 32;
+  l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
+  void* w = arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
+  float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
+  launch_pack_linear(fetch(name + ".weight"), w, dt, l.K, l.N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st);
+  const float* bsrc = has(name + ".bias") ? fetch(name + ".bias") : nullptr;
+  launch_pack_bias(bsrc, b, l.N, l.Npad, geglu ? 1 : 0, 0, st);
+  l.w = w; l.b = b;
+  return l;
+}
+Lin WeightBuilder::fused_linear(const std::vector<std::string>& names) {
+  Lin l; l.ksize = 1;
+  int ntot = 0;
+  for (const std::string& n : names) {
+    const ParamSpec& s = spec(n + ".weight");
+    if (l.K == 0) l.K = s.shape[0];
+    SDXL_REQUIRE(l.K == s.shape[0], "fused_linear: K mismatch");
+    ntot += s.shape[1];
+  }
+  l.N = ntot; l.cin = l.K;
+  const int kt = dt == DT_F16 ? 64 : 32;
+  l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
+  char* w = (char*)arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
+  float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
+  SDXL_HIP(hipMemsetAsync(w, 0, (size_t)l.Npad * l.Kpad * dt_size(dt), st));
+  SDXL_HIP(hipMemsetAsync(b, 0, (size_t)l.Npad * sizeof(float), st));
+  int off = 0;
+  for (const std::string& n : names) {
+    const ParamSpec& s = spec(n + ".weight");
+    const int N = s.shape[1];
+    launch_pack_linear(fetch(n + ".weight"), w, dt, l.K, N, l.Kpad, N, 0, off, st);   // exactly N rows at row offset
+    const float* bsrc = has(n + ".bias") ? fetch(n + ".bias") : nullptr;
+    launch_pack_bias(bsrc, b, N, N, 0, off, st);
+    off += N;
+  }
+  l.w = w; l.b = b;
+  return l;
+}
+Lin WeightBuilder::conv(const std::string& name) {
+  const ParamSpec& s = spec(name + ".weight");
+  Lin l; l.N = s.shape[0]; l.cin = s.shape[1]; l.ksize = s.shape[2];
+  l.K = l.cin * l.ksize * l.ksize;
+  const int kt = dt == DT_F16 ? 64 : 32;
+  l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
+  void* w = arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
+  float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
+  launch_pack_conv(fetch(name + ".weight"), w, dt, l.N, l.cin, l.ksize, l.Kpad, l.Npad, st);
+  launch_pack_bias(fetch(name + ".bias"), b, l.N, l.Npad, 0, 0, st);
+  l.w = w; l.b = b;
+  return l;
+}
+NormW WeightBuilder::norm(const std::string& name) {
+  const ParamSpec& s = spec(name + ".gamma");
+  NormW n; n.C = s.shape[0];
+  float* g = (float*)arena.alloc((size_t)n.C * sizeof(float));
+  float* b = (float*)arena.alloc((size_t)n.C * sizeof(float));
+  SDXL_HIP(hipMemcpyAsync(g, fetch(name + ".gamma"), n.C * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SDXL_HIP(hipMemcpyAsync(b, fetch(name + ".beta"), n.C * sizeof(float), hipMemcpyDeviceToDevice, st));
+  n.gamma = g; n.beta = b;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------ launch helpers
+void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e) {
+  if (ex.dry) return;
+  SDXL_REQUIRE(cin == w.cin, "run_conv: channel mismatch");
+  IgemmParams p{};
+  p.A = a.p; p.W = w.w; p.a_dt = a.dt;
+  p.B = g.B; p.Hin = g.Hin; p.Win = g.Win; p.Cin = cin; p.lda = a.ld;
+  p.Hout = g.Hout; p.Wout = g.Wout;
+  p.ksize = g.ksize; p.stride = g.stride; p.pad = g.pad; p.up = g.up;
+  p.M = g.B * g.Hout * g.Wout; p.N = w.N; p.K = w.K; p.Kpad = w.Kpad;
+  p.bias = w.b; p.ebias = e.ebias; p.ebias_ld = e.ebias_ld;
+  p.rpb = e.rpb ? e.rpb : g.Hout * g.Wout;
+  p.act = e.act;
+  p.R = e.R.p; p.ldr = e.R.ld; p.r_dt = e.R.dt;
+  p.C = out.p; p.ldc = out.ld; p.c_dt = out.dt;
+  p.n_split = e.n_split >= 0 ? e.n_split : w.N;
+  p.Ct = e.Ct; p.ct_rows = e.ct_rows; p.ct_ld = e.ct_ld;
+  SDXL_REQUIRE(!(ex.cdt == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
+  launch_igemm(p, ex.cdt, ex.s);
+}
+void run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e) {
+  ConvGeom g{1, M, 1, M, 1, 1, 1, 0, 0};
+  Epi e2 = e;
+  if (e2.rpb == 0) e2.rpb = M;
+  run_conv(ex, w, a, w.cin, g, out, e2);
+}
+void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups) {
+  if (ex.dry) return;
+  GroupNormParams p{};
+  p.X = x.p; p.x_dt = x.dt; p.ldx = x.ld;
+  p.Y = y.p; p.y_dt = y.dt; p.ldy = y.ld;
+  p.gamma = n.gamma; p.beta = n.beta; p.partial = ex.gn_partial;
+  p.B = B; p.HW = HW; p.C = n.C; p.G = groups; p.eps = 1e-5f; p.silu = silu ? 1 : 0;
+  launch_groupnorm(p, ex.s);
+}
+void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y) {
+  if (ex.dry) return;
+  LayerNormParams p{};
+  p.X = x.p; p.x_dt = x.dt; p.ldx = x.ld; p.Y = y.p; p.y_dt = y.dt; p.ldy = y.ld;
+  p.gamma = n.gamma; p.beta = n.beta; p.rows = rows; p.C = n.C; p.eps = 1e-5f;
+  launch_layernorm(p, ex.s);
+}
+
+}  // namespace sdxl

@@ -1,0 +1,196 @@
+"""Model-level parity through the C ABI: UNet::forward, Diffuser::{sample_latent, refine_latent,
+sample_latent_with_inpainting}, LatentDecoder::{decode_latent, latent_to_image, encode_image, image_to_latent}
+against the CPU oracle on seeded synthetic weights (tiny architectures of the SDXL family, so the oracle runs in
+seconds; full-size properties are in test_gpu_fullsize.py).
+
+Tolerances: BASELINE.json's north_star asks for latents within 1e-3 (per-pixel, fp32) of the CPU reference.
+  * DTYPE_F32 (strict-parity mode) is held to 1e-3 absolute on latents after the whole trajectory and 1e-4 relative on
+    a single UNet forward.
+  * DTYPE_F16 / DTYPE_F16_F32RES are reported against looser, explicitly stated bounds (fp16 operand rounding,
+    2^-11 per element, through ~40 layers and 4..8 DDIM steps); the reference's own f16 GPU path (sample/main.rs:122)
+    rounds at least as much.  The measured errors are printed (run pytest -s) and recorded in DESIGN.md.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import config as OC, model as OM, pipeline as OP
+from util import max_abs, rel_err, seeded, to_pkg_cfg, to_pkg_vcfg, unet_weights
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = {0: 1e-4, 1: 3e-2, 2: 2e-2}
+LAT_TOL = {0: 1e-3, 1: 1.5e-1, 2: 1e-1}
+
+
+def _cond(ocfg, n, res, n_ctx=9, refiner=False, seed=30):
+    c = dict(ctx=seeded(n, n_ctx, ocfg.context_dim, seed=seed), uctx=seeded(n_ctx, ocfg.context_dim, seed=seed + 1),
+             y=seeded(n, ocfg.adm_in_channels, seed=seed + 2), uy=seeded(ocfg.adm_in_channels, seed=seed + 3))
+    if refiner:
+        oc = OP.Conditioning(None, c["uctx"], None, c["ctx"], None, c["uy"], None, c["y"], res)
+    else:
+        oc = OP.Conditioning(c["uctx"], None, c["ctx"], None, c["uy"], None, c["y"], None, res)
+    return c, oc
+
+
+def _pkg_cond(pkg, c, res, refiner=False):
+    if refiner:
+        return pkg.Conditioning(context_open_clip=c["ctx"].cuda(), channel_context_refiner=c["y"].cuda(),
+                                unconditional_context_open_clip=c["uctx"].cuda(),
+                                unconditional_channel_context_refiner=c["uy"].cuda(), resolution=res)
+    return pkg.Conditioning(context_full=c["ctx"].cuda(), channel_context=c["y"].cuda(),
+                            unconditional_context_full=c["uctx"].cuda(), unconditional_channel_context=c["uy"].cuda(),
+                            resolution=res)
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("which", ["tiny", "tiny_refiner"])
+def test_unet_forward(pkg, ctx, dtype, which):
+    ocfg = OC.tiny_config() if which == "tiny" else OC.tiny_refiner_config()
+    W = unet_weights(ocfg)
+    B, H, Wd = 2, 16, 16
+    x = torch.from_numpy(OC.arb_tensor(B, 4, H, Wd))          # reference probe recipe, bin/test/main.rs:133
+    context = torch.from_numpy(OC.arb_tensor(B, 5, ocfg.context_dim))
+    y = torch.from_numpy(OC.arb_tensor(B, ocfg.adm_in_channels))
+    t = torch.tensor([999, 1], dtype=torch.int32)
+    ref = OM.unet_forward(ocfg, W, x, t.long(), context, y)
+    specs = pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg))
+    flat = pkg.flatten_weights(specs, {k: v.numpy() for k, v in W.items()})
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, weights=flat)
+    outs = [u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu() for _ in range(3)]   # eager, capture, replay
+    e = rel_err(outs[0], ref)
+    print(f"unet_forward[{which}] dtype={dtype}: rel err {e:.3e}")
+    assert e < FWD_TOL[dtype]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "hipGraph replay differs from eager run"
+    # device-side synthetic weights are bit-identical to the oracle's numpy recipe -> identical output
+    u2 = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    out2 = u2.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu()
+    assert torch.equal(out2, outs[0]), "synthetic device weights differ from the oracle's"
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_unet_forward_batch_independence(pkg, ctx, dtype):
+    # the engine batches the CFG pair; per-sample results must not depend on what else is in the batch
+    ocfg = OC.tiny_config()
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    x, c, y = seeded(2, 4, 8, 8, seed=1), seeded(2, 5, ocfg.context_dim, seed=2), seeded(2, ocfg.adm_in_channels, seed=3)
+    t = torch.tensor([500, 20], dtype=torch.int32)
+    both = u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu()
+    for i in range(2):
+        one = u.forward(x[i:i + 1].cuda(), t[i:i + 1].cuda(), c[i:i + 1].cuda(), y[i:i + 1].cuda()).cpu()
+        assert torch.equal(one[0], both[i])
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("n,n_steps,cfg_scale", [(1, 4, 7.5), (2, 8, 1.0)])
+def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
+    ocfg = OC.tiny_config()
+    res = (64, 96)
+    c, oc = _cond(ocfg, n, res)
+    noise = seeded(n, 4, res[0] // 8, res[1] // 8, seed=40)
+    trace = []
+    ref = OP.Diffuser(ocfg, unet_weights(ocfg), OC.alphas_cumprod()).sample_latent(oc, cfg_scale, n_steps, noise, trace)
+    assert len(trace) == pkg.step_count(n_steps)
+    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    out = d.sample_latent(_pkg_cond(pkg, c, res), cfg_scale, n_steps, noise.cuda()).cpu()
+    e = max_abs(out, ref)
+    print(f"sample_latent n={n} steps={n_steps} dtype={dtype}: latent max-abs err {e:.3e} (|latent| max {ref.abs().max():.2f})")
+    assert np.isfinite(e) and e < LAT_TOL[dtype]
+    out2 = d.sample_latent(_pkg_cond(pkg, c, res), cfg_scale, n_steps, noise.cuda()).cpu()
+    assert torch.equal(out, out2), "trajectory is not deterministic"
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_refine_latent(pkg, ctx, dtype):
+    ocfg = OC.tiny_refiner_config()
+    res = (64, 64)
+    c, oc = _cond(ocfg, 1, res, refiner=True)
+    latent, noise = seeded(1, 4, 8, 8, seed=41), seeded(1, 4, 8, 8, seed=42)
+    ref = OP.Diffuser(ocfg, unet_weights(ocfg), OC.alphas_cumprod()).refine_latent(latent, oc, 7.5, 800, 50, noise)
+    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    out = d.refine_latent(latent.cuda(), _pkg_cond(pkg, c, res, True), 7.5, 800, 50, noise.cuda()).cpu()
+    e = max_abs(out, ref)
+    print(f"refine_latent dtype={dtype}: max-abs err {e:.3e}")
+    assert e < LAT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_sample_latent_with_inpainting(pkg, ctx, dtype):
+    ocfg = OC.tiny_config()
+    res = (64, 64)
+    n_steps = 5
+    iters = pkg.step_count(n_steps)
+    c, oc = _cond(ocfg, 1, res)
+    noise0, reference = seeded(1, 4, 8, 8, seed=43), seeded(1, 4, 8, 8, seed=44)
+    step_noise = seeded(iters, 1, 4, 8, 8, seed=45)
+    mask = torch.zeros(1, 4, 8, 8, dtype=torch.bool)
+    mask[:, :, 0:3, :] = True      # crop rows in latent coords, broadcast to 4 channels (sample/main.rs:164-185)
+    ref = OP.Diffuser(ocfg, unet_weights(ocfg), OC.alphas_cumprod()).sample_latent_with_inpainting(
+        oc, 7.5, n_steps, reference, mask, noise0, [step_noise[i] for i in range(iters)])
+    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    out = d.sample_latent_with_inpainting(_pkg_cond(pkg, c, res), 7.5, n_steps, reference.cuda(), mask.cuda(),
+                                          noise0.cuda(), step_noise.cuda()).cpu()
+    e = max_abs(out, ref)
+    print(f"inpainting dtype={dtype}: max-abs err {e:.3e}")
+    assert e < LAT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_vae_decode_and_image(pkg, ctx, dtype):
+    v = OC.tiny_vae_config()
+    Wd = OM.to_torch(OC.synth_weights(OC.vae_decoder_param_specs(v)))
+    old = OP.LatentDecoder(v, Wd)
+    latent = seeded(2, 4, 8, 8, seed=50) * 0.5
+    ref = old.decode_latent(latent)
+    ld = pkg.LatentDecoder(ctx, to_pkg_vcfg(pkg, v), dtype, seed=0)
+    out = ld.decode_latent(latent.cuda()).cpu()
+    e = rel_err(out, ref)
+    print(f"vae decode dtype={dtype}: rel err {e:.3e}")
+    assert e < (1e-4 if dtype == 0 else 3e-2)
+    img = ld.latent_to_image(latent.cuda())
+    assert (img.width, img.height) == (64, 64)
+    ref8 = old.latent_to_image(latent)
+    d8 = np.abs(img.buffer.cpu().numpy().astype(np.int32) - ref8.astype(np.int32))
+    # truncating u8 cast: a float error of 1e-5 can flip a value sitting on an integer boundary
+    assert d8.max() <= (1 if dtype == 0 else 8)
+    assert (d8 > 0).mean() < (0.01 if dtype == 0 else 0.5)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_vae_encode(pkg, ctx, dtype):
+    v = OC.tiny_vae_config()
+    We = OM.to_torch(OC.synth_weights(OC.vae_encoder_param_specs(v)))
+    old = OP.LatentDecoder(v, We)
+    img = (seeded(1, 32, 48, 3, seed=51).clamp(-2, 2) * 60 + 128).clamp(0, 255).to(torch.uint8)
+    ref = old.image_to_latent(img.numpy())
+    ld = pkg.LatentDecoder(ctx, to_pkg_vcfg(pkg, v), dtype, seed=0, with_encoder=True)
+    out = ld.image_to_latent(pkg.RawImages(img.cuda(), 48, 32)).cpu()
+    e = rel_err(out, ref)
+    print(f"vae encode dtype={dtype}: rel err {e:.3e}")
+    assert out.shape == ref.shape and e < (1e-4 if dtype == 0 else 3e-2)
+    x = torch.from_numpy(img.numpy().astype(np.float32) / 255.0).permute(0, 3, 1, 2) * 2 - 1
+    out2 = ld.encode_image(x.cuda()).cpu()
+    assert rel_err(out2, ref) < (1e-4 if dtype == 0 else 3e-2)
+
+
+def test_host_weights_equal_synthetic(pkg, ctx):
+    # sdxl_vae_create (flat host buffer in sdxl_vae_param_spec order) == sdxl_vae_create_synthetic
+    v = OC.tiny_vae_config()
+    vc = to_pkg_vcfg(pkg, v)
+    W = OC.synth_weights(OC.vae_decoder_param_specs(v))
+    flat = pkg.flatten_weights(pkg.vae_param_specs(vc, False), W)
+    a = pkg.LatentDecoder(ctx, vc, 0, decoder_weights=flat)
+    b = pkg.LatentDecoder(ctx, vc, 0, seed=0)
+    latent = seeded(1, 4, 4, 4, seed=52).cuda()
+    assert torch.equal(a.decode_latent(latent), b.decode_latent(latent))
+
+
+def test_errors_are_reported_not_fatal(pkg, ctx):
+    bad = pkg.UNetConfig(128, 48, [1, 2, 4], 64, [0, 1, 2], 128)     # 48 % 64 != 0 -> reference asserts (unet/mod.rs:73-76)
+    with pytest.raises(pkg.EngineError):
+        pkg.UNet(ctx, bad, 0, seed=0)
+    ocfg = OC.tiny_config()
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), 0, seed=0)
+    with pytest.raises(pkg.EngineError):   # height not divisible by 4
+        u.forward(torch.zeros(1, 4, 6, 8).cuda(), torch.zeros(1, dtype=torch.int32).cuda(),
+                  torch.zeros(1, 3, ocfg.context_dim).cuda(), torch.zeros(1, ocfg.adm_in_channels).cuda())

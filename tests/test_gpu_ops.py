@@ -1,0 +1,150 @@
+"""Per-op parity: HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (max-abs error relative to the output's max-abs):
+  * DTYPE_F32 (exact-fp32 MFMA, fp32 storage): 2e-5 -- fp32 round-off class (summation order differs from libtorch).
+  * DTYPE_F16 (fp16 operands, fp32 accumulate): 4e-3 -- one fp16 rounding of the operands (2^-11 = 4.9e-4 each) plus
+    the fp16 rounding of the stored result.
+Inputs follow the reference's probe recipe arb_tensor = sin(arange) (src/bin/test/main.rs:51-54) or a seeded normal.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import config as OC, model as OM
+from util import rel_err, seeded
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 2e-5, 1: 4e-3, 2: 4e-3}
+DTYPES = [0, 1, 2]
+
+
+def arb(*shape):
+    return torch.from_numpy(OC.arb_tensor(*shape))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,C,H,W,silu", [(2, 64, 8, 8, True), (1, 320, 16, 16, True), (2, 32, 4, 4, False),
+                                          (1, 2560, 8, 8, True), (1, 128, 64, 32, False), (3, 960, 5, 7, True)])
+def test_group_norm(pkg, ctx, dtype, B, C, H, W, silu):
+    x = seeded(B, C, H, W, seed=1) * 3.0 + 0.7 + arb(B, C, H, W)
+    gamma, beta = 1 + 0.1 * seeded(C, seed=2), 0.1 * seeded(C, seed=3)
+    ref = OM.group_norm(x, gamma, beta)
+    if silu:
+        ref = OM.silu(ref)
+    out = pkg.group_norm(ctx, x.cuda(), gamma.cuda(), beta.cuda(), 32, 1e-5, silu, dtype)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_group_norm_large_mean(pkg, ctx, dtype):
+    # |mean| >> std: the case a sum / sum-of-squares variance gets wrong; Welford + Chan merge must not
+    x = seeded(1, 64, 32, 32, seed=5) * 0.05 + 40.0
+    gamma, beta = torch.ones(64), torch.zeros(64)
+    ref = OM.group_norm(x, gamma, beta)
+    out = pkg.group_norm(ctx, x.cuda(), gamma.cuda(), beta.cuda(), 32, 1e-5, False, 0 if dtype == 0 else 2)
+    assert rel_err(out, ref) < (2e-3 if dtype == 0 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(7, 64), (300, 640), (64, 1280), (5, 1536), (2, 2048 + 64)])
+def test_layer_norm(pkg, ctx, dtype, rows, C):
+    x = seeded(rows, C, seed=4) * 2.0 + 0.3
+    gamma, beta = 1 + 0.1 * seeded(C, seed=5), 0.1 * seeded(C, seed=6)
+    ref = OM.layer_norm(x, gamma, beta)
+    out = pkg.layer_norm(ctx, x.cuda(), gamma.cuda(), beta.cuda(), 1e-5, dtype)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N", [(1, 64, 64), (77, 128, 192), (130, 20, 8), (256, 320, 1280), (1000, 640, 100),
+                                   (64, 2816, 1280), (4096, 64, 64)])
+def test_linear(pkg, ctx, dtype, M, K, N):
+    x = seeded(M, K, seed=7)
+    w = seeded(K, N, seed=8) / math.sqrt(K)
+    b = 0.1 * seeded(N, seed=9)
+    ref = x @ w + b
+    out = pkg.linear(ctx, x.cuda(), w.cuda(), b.cuda(), False, dtype)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_asymmetric_identity(pkg, ctx, dtype):
+    # A = I with an asymmetric B catches a transposed / mis-mapped MFMA C layout (guide rule 16)
+    n = 128
+    x = torch.eye(n)
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) / 251.0
+    out = pkg.linear(ctx, x.cuda(), w.cuda(), None, False, dtype)
+    assert rel_err(out, w) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N", [(64, 64, 128), (300, 640, 2 * 4 * 640 // 8), (33, 128, 64)])
+def test_geglu(pkg, ctx, dtype, M, K, N):
+    x = seeded(M, K, seed=10)
+    w = seeded(K, N, seed=11) / math.sqrt(K)
+    b = 0.1 * seeded(N, seed=12)
+    pr = x @ w + b
+    ref = pr[:, : N // 2] * F.gelu(pr[:, N // 2:])
+    out = pkg.linear(ctx, x.cuda(), w.cuda(), b.cuda(), True, dtype)
+    assert rel_err(out, ref) < TOL[dtype] * 2
+
+
+CONVS = [  # B, Cin, H, W, Cout, k, stride, pad, upsample
+    (1, 64, 8, 8, 64, 3, 1, 1, False),
+    (2, 128, 16, 12, 192, 3, 1, 1, False),
+    (1, 4, 16, 16, 64, 3, 1, 1, False),      # stem: per-element gather path
+    (1, 64, 16, 16, 4, 3, 1, 1, False),      # conv_out: N=4
+    (2, 64, 16, 16, 64, 3, 2, 1, False),     # Downsample (unet/mod.rs:765-772)
+    (1, 64, 9, 7, 128, 3, 2, 1, False),      # odd sizes
+    (1, 128, 8, 8, 64, 1, 1, 0, False),      # skip_connection 1x1
+    (2, 64, 8, 8, 64, 3, 1, 1, True),        # Upsample::forward (:742-752)
+    (1, 64, 16, 16, 64, 3, 2, 0, False),     # stride-2, pad 0 window (the PaddedConv2d taps, cropped)
+    (1, 320, 32, 32, 320, 3, 1, 1, False),
+    (1, 3, 16, 16, 32, 3, 1, 1, False),      # VAE encoder stem
+    (1, 96, 8, 8, 64, 3, 1, 1, False),       # Cin % 64 != 0 -> generic gather
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,pad,up", CONVS)
+def test_conv2d(pkg, ctx, dtype, B, Cin, H, W, Cout, k, stride, pad, up):
+    x = seeded(B, Cin, H, W, seed=13)
+    w = seeded(Cout, Cin, k, k, seed=14) / math.sqrt(Cin * k * k)
+    b = 0.1 * seeded(Cout, seed=15)
+    xi = OM.upsample_nearest2x(x) if up else x
+    ref = F.conv2d(xi, w, b, stride=stride, padding=pad)
+    out = pkg.conv2d(ctx, x.cuda(), w.cuda(), b.cuda(), stride, pad, up, dtype)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("B,Nq,Nk,C,heads,masked", [
+    (1, 64, 64, 64, 1, False), (2, 256, 256, 128, 2, False), (2, 300, 77, 640, 10, False),   # cross-attn Nk=77
+    (1, 77, 77, 128, 2, True),                                                              # CLIP-style causal mask
+    (1, 1024, 1024, 1280, 20, False), (1, 50, 130, 64, 2, False),                           # generic head dim 32
+    (1, 96, 96, 512, 1, False),                                                             # VAE mid: 1 head, d=512
+    (1, 40, 40, 96, 2, True)])
+def test_qkv_attention(pkg, ctx, dtype, B, Nq, Nk, C, heads, masked):
+    q, k, v = seeded(B, Nq, C, seed=16), seeded(B, Nk, C, seed=17), seeded(B, Nk, C, seed=18)
+    mask = OM.attn_decoder_mask(max(Nq, Nk))[:Nq, :Nk].contiguous() if masked else None
+    ref = OM.qkv_attention(q, k, v, mask, heads)
+    out = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None if mask is None else mask.cuda(), heads, dtype)
+    assert rel_err(out, ref) < (1e-4 if dtype == 0 else 6e-3)
+
+
+def test_qkv_attention_online_softmax_rescale(pkg, ctx):
+    # one key far above the rest in a LATE tile forces the running-max rescale branch (guide rule 26)
+    B, N, C = 1, 256, 64
+    q, k, v = seeded(B, N, C, seed=19), seeded(B, N, C, seed=20), seeded(B, N, C, seed=21)
+    k[0, 200] = q[0, 3] * 6.0
+    ref = OM.qkv_attention(q, k, v, None, 1)
+    out = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, 1, 0)
+    assert rel_err(out, ref) < 1e-4
+
+
+def test_attn_decoder_mask(pkg, ctx):
+    assert torch.equal(pkg.attn_decoder_mask(ctx, 77).cpu(), OM.attn_decoder_mask(77))
