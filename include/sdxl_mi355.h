@@ -159,9 +159,18 @@ int sdxl_vae_encode_image(sdxl_vae* v, void* stream, const float* image, int n, 
 /* LatentDecoder::image_to_latent (:239-255): uint8 [n,H,W,3] (device) -> latent */
 int sdxl_image_to_latent(sdxl_vae* v, void* stream, const uint8_t* image_hwc, int n, int H, int W, float* out_latent);
 
-/* ---- multi-GPU: the packed weight arena of a model, for a one-time RCCL broadcast from rank 0 (SURVEY 2.3 C-bcast) */
+/* ---- multi-GPU: the packed weight arena of a model, for a one-time RCCL broadcast from rank 0 (SURVEY 2.3 C-bcast).
+ * Replica ranks create the model "empty" (identical arena layout, contents undefined) and receive the bytes. */
 int sdxl_unet_weight_arena(sdxl_unet* u, void** base, size_t* bytes);
 int sdxl_vae_weight_arena(sdxl_vae* v, void** base, size_t* bytes);
+int sdxl_diffuser_create_empty(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const float* alphas_cumprod_host,
+                               int n_train_steps, sdxl_diffuser** out);
+int sdxl_vae_create_empty(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, int with_encoder, sdxl_vae** out);
+
+/* ---- measurement: one eager UNet forward of the current plan/context with hipEvents around every launch, summed per
+ * kernel class (index: 0 implicit-GEMM conv/linear, 1 fused attention, 2 GroupNorm, 3 LayerNorm, 4 other); arrays of 5 */
+int sdxl_unet_profile(sdxl_unet* u, void* stream, int B, int H, int W, float class_ms[5], int class_launches[5],
+                      double class_flops[5]);
 
 /* ---- single-op entry points used by the parity tests (same kernels the models run) */
 /* GroupNorm::forward (groupnorm/mod.rs:52-73) on NCHW fp32 [B,C,H,W]; silu!=0 fuses SILU::forward (silu.rs:14-16) */

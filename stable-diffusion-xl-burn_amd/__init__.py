@@ -66,7 +66,8 @@ ABI_SYMBOLS = [
     "sdxl_diffuser_enable_step_timing", "sdxl_diffuser_step_times",
     "sdxl_vae_create", "sdxl_vae_create_synthetic", "sdxl_vae_destroy", "sdxl_vae_decode_latent",
     "sdxl_latent_to_image", "sdxl_vae_encode_image", "sdxl_image_to_latent",
-    "sdxl_unet_weight_arena", "sdxl_vae_weight_arena",
+    "sdxl_unet_weight_arena", "sdxl_vae_weight_arena", "sdxl_diffuser_create_empty", "sdxl_vae_create_empty",
+    "sdxl_unet_profile",
     "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear",
 ]
 
@@ -237,8 +238,8 @@ class Context:
         _check(lib().sdxl_ctx_synchronize(self.h))
 
     def __del__(self):
-        if getattr(self, "h", None) and self.h:
-            lib().sdxl_ctx_destroy(self.h)
+        if getattr(self, "h", None) and self.h and _lib is not None:
+            _lib.sdxl_ctx_destroy(self.h)
             self.h = None
 
 
@@ -317,10 +318,32 @@ class UNet:
         _check(lib().sdxl_unet_weight_arena(self.h, ctypes.byref(base), ctypes.byref(n)))
         return int(base.value or 0), int(n.value)
 
+    def weight_arena_tensor(self):
+        """zero-copy uint8 view of the packed weight arena (for the one-time RCCL broadcast from rank 0)"""
+        return arena_as_tensor(*self.weight_arena(), self.ctx.device_id)
+
+    PROFILE_CLASSES = ("igemm", "attention", "groupnorm", "layernorm", "other")
+
+    def profile(self, B: int, H: int, W: int):
+        """one eager forward with hipEvents around every launch -> {class: (ms, launches, flops)}"""
+        ms, ln, fl = (ctypes.c_float * 5)(), (ctypes.c_int * 5)(), (ctypes.c_double * 5)()
+        _check(lib().sdxl_unet_profile(self.h, _stream(), B, H, W, ms, ln, fl))
+        return {c: (float(ms[i]), int(ln[i]), float(fl[i])) for i, c in enumerate(self.PROFILE_CLASSES)}
+
     def __del__(self):
-        if getattr(self, "_owned", False) and getattr(self, "h", None):
-            lib().sdxl_unet_destroy(self.h)
+        if getattr(self, "_owned", False) and getattr(self, "h", None) and _lib is not None:
+            _lib.sdxl_unet_destroy(self.h)
             self.h = None
+
+
+class _ArenaView:
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def arena_as_tensor(ptr: int, nbytes: int, device_id: int = 0):
+    torch = _torch()
+    return torch.as_tensor(_ArenaView(ptr, nbytes), device=f"cuda:{device_id}")
 
 
 def default_alphas_cumprod(n: int = 1000) -> np.ndarray:
@@ -333,14 +356,16 @@ class Diffuser:
     """reference Diffuser<B> (src/model/stablediffusion/mod.rs:308-542)"""
 
     def __init__(self, ctx: Context, cfg: UNetConfig, dtype: int = DTYPE_F16, weights: Optional[np.ndarray] = None,
-                 seed: int = 0, alphas_cumprod: Optional[np.ndarray] = None):
+                 seed: int = 0, alphas_cumprod: Optional[np.ndarray] = None, empty: bool = False):
         self.ctx, self.cfg, self.dtype = ctx, cfg, dtype
         a = np.ascontiguousarray(default_alphas_cumprod() if alphas_cumprod is None else alphas_cumprod, dtype=np.float32)
         self.n_train = int(a.shape[0])
         self.h = ctypes.c_void_p()
         c = cfg.to_c()
         ap = a.ctypes.data_as(ctypes.c_void_p)
-        if weights is None:
+        if empty:   # replica rank: arena laid out, contents arrive by broadcast
+            _check(lib().sdxl_diffuser_create_empty(ctx.h, ctypes.byref(c), dtype, ap, self.n_train, ctypes.byref(self.h)))
+        elif weights is None:
             _check(lib().sdxl_diffuser_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), ap,
                                                        self.n_train, ctypes.byref(self.h)))
         else:
@@ -399,9 +424,9 @@ class Diffuser:
         return [float(buf[i]) for i in range(max(n, 0))]
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and _lib is not None:
             self.diffusion = None
-            lib().sdxl_diffuser_destroy(self.h)
+            _lib.sdxl_diffuser_destroy(self.h)
             self.h = None
 
 
@@ -418,11 +443,13 @@ class LatentDecoder:
 
     def __init__(self, ctx: Context, cfg: Optional[VAEConfig] = None, dtype: int = DTYPE_F16,
                  decoder_weights: Optional[np.ndarray] = None, encoder_weights: Optional[np.ndarray] = None,
-                 seed: int = 0, with_encoder: bool = False):
+                 seed: int = 0, with_encoder: bool = False, empty: bool = False):
         self.ctx, self.cfg, self.dtype = ctx, cfg or VAEConfig(), dtype
         self.h = ctypes.c_void_p()
         c = self.cfg.to_c()
-        if decoder_weights is None and encoder_weights is None:
+        if empty:
+            _check(lib().sdxl_vae_create_empty(ctx.h, ctypes.byref(c), dtype, int(with_encoder), ctypes.byref(self.h)))
+        elif decoder_weights is None and encoder_weights is None:
             _check(lib().sdxl_vae_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), int(with_encoder),
                                                   ctypes.byref(self.h)))
         else:
@@ -473,9 +500,12 @@ class LatentDecoder:
         _check(lib().sdxl_vae_weight_arena(self.h, ctypes.byref(base), ctypes.byref(n)))
         return int(base.value or 0), int(n.value)
 
+    def weight_arena_tensor(self):
+        return arena_as_tensor(*self.weight_arena(), self.ctx.device_id)
+
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().sdxl_vae_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.sdxl_vae_destroy(self.h)
             self.h = None
 
 

@@ -318,6 +318,33 @@ int sdxl_diffuser_create_synthetic(sdxl_ctx* ctx, const sdxl_unet_config* cfg, i
   return diffuser_create_impl(ctx, cfg, dtype, src, alphas, n_train, out);
   API_END
 }
+int sdxl_diffuser_create_empty(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const float* alphas, int n_train,
+                               sdxl_diffuser** out) {
+  API_BEGIN
+  NullSource src;
+  return diffuser_create_impl(ctx, cfg, dtype, src, alphas, n_train, out);
+  API_END
+}
+int sdxl_vae_create_empty(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, int with_encoder, sdxl_vae** out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && out, "bad argument");
+  use(ctx);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  NullSource src;
+  sdxl_vae* h = new sdxl_vae();
+  h->ctx = ctx;
+  try { h->v = new Vae(to_vcfg(cfg), cdt, &src, with_encoder ? &src : nullptr, ctx->stream); } catch (...) { delete h; throw; }
+  *out = h;
+  API_END
+}
+int sdxl_unet_profile(sdxl_unet* u, void* stream, int B, int H, int W, float class_ms[5], int class_launches[5],
+                      double class_flops[5]) {
+  API_BEGIN
+  SDXL_REQUIRE(u && class_ms && class_launches && class_flops, "null argument");
+  use(u->ctx);
+  u->u->profile(B, H, W, class_ms, class_launches, class_flops, pick(u->ctx, stream));
+  API_END
+}
 void sdxl_diffuser_destroy(sdxl_diffuser* d) {
   if (!d) return;
   delete d->d;

@@ -268,6 +268,7 @@ void launch_from_u8_image(const unsigned char* src, void* dst, int dt, int ldd, 
 // ---------------------------------------------------------------------------------------------------------
 // synthetic weights: bit-identical to oracle/config.py::synth_values (integer hash, one fp32 mul, one fp32 add)
 __global__ void synth_fill_kernel(float* dst, size_t numel, uint64_t key, float scale, float mean) {
+#pragma clang fp contract(off)   // numpy rounds the product and the sum separately; an FMA here would differ by 1 ulp
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= numel) return;
   uint64_t z = key + (uint64_t)i * 0xD1342543DE82EF95ull;
@@ -275,7 +276,9 @@ __global__ void synth_fill_kernel(float* dst, size_t numel, uint64_t key, float 
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
   const float u = (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;   // * 2^-24, exact
-  dst[i] = __fadd_rn(__fmul_rn(u - 0.5f, scale), mean);
+  const float t = u - 0.5f;                                                // exact
+  const float prod = t * scale;
+  dst[i] = prod + mean;
 }
 void launch_synth_fill(float* dst, size_t numel, uint64_t key, float scale, float mean, hipStream_t s) {
   hipLaunchKernelGGL(synth_fill_kernel, dim3((numel + 255) / 256), dim3(256), 0, s, dst, numel, key, scale, mean);

@@ -79,6 +79,11 @@ struct DeviceArena {
 struct WeightSource {
   virtual ~WeightSource() {}
   virtual void fetch(const ParamSpec& s, size_t index, float* dst_dev, hipStream_t st) = 0;
+  virtual bool empty() const { return false; }   // true: lay the arena out but leave its contents to a later broadcast
+};
+struct NullSource : WeightSource {   // replica ranks: same arena layout, contents arrive by RCCL broadcast from rank 0
+  void fetch(const ParamSpec&, size_t, float*, hipStream_t) override {}
+  bool empty() const override { return true; }
 };
 struct SyntheticSource : WeightSource {
   uint64_t seed;
@@ -125,7 +130,18 @@ struct Act {
   Act cols(int c0) const { return Act((char*)p + (size_t)c0 * dt_size(dt), ld, dt); }
 };
 
+// per-kernel-class hipEvent profiler (eager runs only): live measurement of the dominant kernel for bench.py's roofline
+struct Profiler {
+  enum { IGEMM = 0, ATTENTION = 1, GROUPNORM = 2, LAYERNORM = 3, OTHER = 4, NCLS = 5 };
+  struct Rec { hipEvent_t a, b; int cls; double flops; };
+  std::vector<Rec> recs;
+  void begin(int cls, double flops, hipStream_t s);
+  void end(hipStream_t s);
+  void collect(float ms[NCLS], int launches[NCLS], double flops[NCLS]);   // synchronises, then frees the events
+};
+
 struct Exec {
+  Profiler* prof = nullptr;
   hipStream_t s = nullptr;
   bool dry = false;
   int cdt = DT_F16;      // compute dtype (MFMA operands)
@@ -177,6 +193,9 @@ class UNet {
   float* eps_out() { return eps_; }
   int compute_dt() const { return cdt_; }
   void set_use_graph(bool g) { use_graph_ = g; }
+  // one eager forward of the current plan/context with hipEvents around every launch, summed per kernel class
+  void profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[Profiler::NCLS], double flops[Profiler::NCLS],
+               hipStream_t s);
   size_t weight_bytes() const { return warena_.off; }
   void* weight_base() const { return warena_.base; }
 

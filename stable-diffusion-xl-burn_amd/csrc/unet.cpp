@@ -65,7 +65,9 @@ void gemv(Exec& ex, const Lin& w, const float* x, int ldx, float* y, int ldy, in
   p.X = x; p.ldx = ldx; p.W = w.w; p.w_dt = ex.cdt; p.Kpad = w.Kpad; p.bias = w.b;
   p.Y = y; p.ldy = ldy; p.Yadd = yadd; p.Bm = Bm; p.N = w.N; p.K = w.K;
   p.silu_in = silu_in; p.silu_out = silu_out;
+  if (ex.prof) ex.prof->begin(Profiler::OTHER, 2.0 * Bm * (double)w.N * w.K, ex.s);
   launch_gemv(p, ex.s);
+  if (ex.prof) ex.prof->end(ex.s);
 }
 void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, const Act& o, int B, int H, int Nq,
                int Nk) {
@@ -73,7 +75,9 @@ void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, 
   AttnParams p{};
   p.Q = q.p; p.ldq = q.ld; p.K = k.p; p.ldk = k.ld; p.Vt = vt; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
   p.dt = ex.cdt; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+  if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s);
   launch_attention_d64(p, ex.s);
+  if (ex.prof) ex.prof->end(ex.s);
 }
 }  // namespace
 
@@ -396,6 +400,21 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     act_.reset(m);
   }
   ++plan_runs_;
+}
+
+void UNet::profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[Profiler::NCLS],
+                   double flops[Profiler::NCLS], hipStream_t s) {
+  ensure_plan(B, H, W);
+  SDXL_REQUIRE(ctx_B_ == B && !kv_.empty(), "set_context must be called with the same batch before profile");
+  const float t500[8] = {500.f, 500.f, 500.f, 500.f, 500.f, 500.f, 500.f, 500.f};
+  SDXL_HIP(hipMemcpyAsync(tconv_, t500, sizeof(t500), hipMemcpyHostToDevice, s));
+  SDXL_HIP(hipStreamSynchronize(s));
+  Profiler prof;
+  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.prof = &prof;
+  const size_t m = act_.mark();
+  run(ex, tconv_, 1);
+  act_.reset(m);
+  prof.collect(ms, launches, flops);
 }
 
 void UNet::forward_nchw(const float* x, const int* timesteps, const float* context, int n_ctx, const float* label, int B,

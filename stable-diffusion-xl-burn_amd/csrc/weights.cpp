@@ -24,6 +24,26 @@ void* DeviceArena::alloc(size_t bytes) {
   return base + a;
 }
 
+// ------------------------------------------------------------------------------------------ profiler
+void Profiler::begin(int cls, double flops, hipStream_t s) {
+  Rec r; r.cls = cls; r.flops = flops;
+  SDXL_HIP(hipEventCreate(&r.a)); SDXL_HIP(hipEventCreate(&r.b));
+  SDXL_HIP(hipEventRecord(r.a, s));
+  recs.push_back(r);
+}
+void Profiler::end(hipStream_t s) { SDXL_HIP(hipEventRecord(recs.back().b, s)); }
+void Profiler::collect(float ms[NCLS], int launches[NCLS], double flops[NCLS]) {
+  for (int i = 0; i < NCLS; ++i) { ms[i] = 0.f; launches[i] = 0; flops[i] = 0.0; }
+  for (Rec& r : recs) {
+    SDXL_HIP(hipEventSynchronize(r.b));
+    float t = 0.f;
+    SDXL_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.cls] += t; launches[r.cls] += 1; flops[r.cls] += r.flops;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  recs.clear();
+}
+
 // ------------------------------------------------------------------------------------------ sources
 void SyntheticSource::fetch(const ParamSpec& s, size_t, float* dst, hipStream_t st) {
   const uint64_t key = fnv1a64(s.name) ^ (seed * 0x9E3779B97F4A7C15ull);
@@ -78,10 +98,11 @@ Lin WeightBuilder::linear(const std::string& name, bool geglu) {
   l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
   void* w = arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
+  l.w = w; l.b = b;
+  if (src.empty()) return l;
   launch_pack_linear(fetch(name + ".weight"), w, dt, l.K, l.N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st);
   const float* bsrc = has(name + ".bias") ? fetch(name + ".bias") : nullptr;
   launch_pack_bias(bsrc, b, l.N, l.Npad, geglu ? 1 : 0, 0, st);
-  l.w = w; l.b = b;
   return l;
 }
 Lin WeightBuilder::fused_linear(const std::vector<std::string>& names) {
@@ -98,6 +119,8 @@ Lin WeightBuilder::fused_linear(const std::vector<std::string>& names) {
   l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
   char* w = (char*)arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
+  l.w = w; l.b = b;
+  if (src.empty()) return l;
   SDXL_HIP(hipMemsetAsync(w, 0, (size_t)l.Npad * l.Kpad * dt_size(dt), st));
   SDXL_HIP(hipMemsetAsync(b, 0, (size_t)l.Npad * sizeof(float), st));
   int off = 0;
@@ -120,9 +143,10 @@ Lin WeightBuilder::conv(const std::string& name) {
   l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
   void* w = arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
+  l.w = w; l.b = b;
+  if (src.empty()) return l;
   launch_pack_conv(fetch(name + ".weight"), w, dt, l.N, l.cin, l.ksize, l.Kpad, l.Npad, st);
   launch_pack_bias(fetch(name + ".bias"), b, l.N, l.Npad, 0, 0, st);
-  l.w = w; l.b = b;
   return l;
 }
 NormW WeightBuilder::norm(const std::string& name) {
@@ -130,9 +154,10 @@ NormW WeightBuilder::norm(const std::string& name) {
   NormW n; n.C = s.shape[0];
   float* g = (float*)arena.alloc((size_t)n.C * sizeof(float));
   float* b = (float*)arena.alloc((size_t)n.C * sizeof(float));
+  n.gamma = g; n.beta = b;
+  if (src.empty()) return n;
   SDXL_HIP(hipMemcpyAsync(g, fetch(name + ".gamma"), n.C * sizeof(float), hipMemcpyDeviceToDevice, st));
   SDXL_HIP(hipMemcpyAsync(b, fetch(name + ".beta"), n.C * sizeof(float), hipMemcpyDeviceToDevice, st));
-  n.gamma = g; n.beta = b;
   return n;
 }
 
@@ -154,7 +179,9 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.n_split = e.n_split >= 0 ? e.n_split : w.N;
   p.Ct = e.Ct; p.ct_rows = e.ct_rows; p.ct_ld = e.ct_ld;
   SDXL_REQUIRE(!(ex.cdt == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
+  if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s);
   launch_igemm(p, ex.cdt, ex.s);
+  if (ex.prof) ex.prof->end(ex.s);
 }
 void run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e) {
   ConvGeom g{1, M, 1, M, 1, 1, 1, 0, 0};
@@ -169,14 +196,18 @@ void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const 
   p.Y = y.p; p.y_dt = y.dt; p.ldy = y.ld;
   p.gamma = n.gamma; p.beta = n.beta; p.partial = ex.gn_partial;
   p.B = B; p.HW = HW; p.C = n.C; p.G = groups; p.eps = 1e-5f; p.silu = silu ? 1 : 0;
+  if (ex.prof) ex.prof->begin(Profiler::GROUPNORM, 0.0, ex.s);
   launch_groupnorm(p, ex.s);
+  if (ex.prof) ex.prof->end(ex.s);
 }
 void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y) {
   if (ex.dry) return;
   LayerNormParams p{};
   p.X = x.p; p.x_dt = x.dt; p.ldx = x.ld; p.Y = y.p; p.y_dt = y.dt; p.ldy = y.ld;
   p.gamma = n.gamma; p.beta = n.beta; p.rows = rows; p.C = n.C; p.eps = 1e-5f;
+  if (ex.prof) ex.prof->begin(Profiler::LAYERNORM, 0.0, ex.s);
   launch_layernorm(p, ex.s);
+  if (ex.prof) ex.prof->end(ex.s);
 }
 
 }  // namespace sdxl

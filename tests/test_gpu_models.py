@@ -20,7 +20,12 @@ from util import max_abs, rel_err, seeded, to_pkg_cfg, to_pkg_vcfg, unet_weights
 pytestmark = pytest.mark.gpu
 
 FWD_TOL = {0: 1e-4, 1: 3e-2, 2: 2e-2}
-LAT_TOL = {0: 1e-3, 1: 1.5e-1, 2: 1e-1}
+LAT_ABS_F32 = 1e-3           # north_star: latents within 1e-3 of the fp32 CPU reference (strict-parity mode)
+LAT_REL_F16 = 3e-2           # fp16-operand modes: max-abs error relative to max|latent| (CFG 7.5 amplifies eps error 7.5x)
+
+
+def lat_tol(dtype, ref):
+    return LAT_ABS_F32 if dtype == 0 else LAT_REL_F16 * float(ref.abs().max())
 
 
 def _cond(ocfg, n, res, n_ctx=9, refiner=False, seed=30):
@@ -60,11 +65,13 @@ def test_unet_forward(pkg, ctx, dtype, which):
     outs = [u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu() for _ in range(3)]   # eager, capture, replay
     e = rel_err(outs[0], ref)
     print(f"unet_forward[{which}] dtype={dtype}: rel err {e:.3e}")
+    print(f"  replay diffs {max_abs(outs[0], outs[1]):.3e} {max_abs(outs[1], outs[2]):.3e}")
     assert e < FWD_TOL[dtype]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "hipGraph replay differs from eager run"
     # device-side synthetic weights are bit-identical to the oracle's numpy recipe -> identical output
     u2 = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
     out2 = u2.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu()
+    print(f"  synthetic-vs-host max diff {max_abs(out2, outs[0]):.3e}; replay diffs {max_abs(outs[0], outs[1]):.3e} {max_abs(outs[1], outs[2]):.3e}")
     assert torch.equal(out2, outs[0]), "synthetic device weights differ from the oracle's"
 
 
@@ -95,7 +102,7 @@ def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
     out = d.sample_latent(_pkg_cond(pkg, c, res), cfg_scale, n_steps, noise.cuda()).cpu()
     e = max_abs(out, ref)
     print(f"sample_latent n={n} steps={n_steps} dtype={dtype}: latent max-abs err {e:.3e} (|latent| max {ref.abs().max():.2f})")
-    assert np.isfinite(e) and e < LAT_TOL[dtype]
+    assert np.isfinite(e) and e < lat_tol(dtype, ref)
     out2 = d.sample_latent(_pkg_cond(pkg, c, res), cfg_scale, n_steps, noise.cuda()).cpu()
     assert torch.equal(out, out2), "trajectory is not deterministic"
 
@@ -111,7 +118,7 @@ def test_refine_latent(pkg, ctx, dtype):
     out = d.refine_latent(latent.cuda(), _pkg_cond(pkg, c, res, True), 7.5, 800, 50, noise.cuda()).cpu()
     e = max_abs(out, ref)
     print(f"refine_latent dtype={dtype}: max-abs err {e:.3e}")
-    assert e < LAT_TOL[dtype]
+    assert e < lat_tol(dtype, ref)
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -132,7 +139,7 @@ def test_sample_latent_with_inpainting(pkg, ctx, dtype):
                                           noise0.cuda(), step_noise.cuda()).cpu()
     e = max_abs(out, ref)
     print(f"inpainting dtype={dtype}: max-abs err {e:.3e}")
-    assert e < LAT_TOL[dtype]
+    assert e < lat_tol(dtype, ref)
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -173,6 +180,30 @@ def test_vae_encode(pkg, ctx, dtype):
     assert rel_err(out2, ref) < (1e-4 if dtype == 0 else 3e-2)
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_against_committed_golden_fixture(pkg, ctx, dtype):
+    # tests/golden/tiny_unet_arb.npz (oracle/make_golden.py): reference probe inputs arb_tensor = sin(arange)
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_unet_arb.npz"))
+    ocfg = OC.tiny_config()
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    x = torch.from_numpy(OC.arb_tensor(1, 4, 8, 8)).cuda()
+    c = torch.from_numpy(OC.arb_tensor(1, 1, ocfg.context_dim)).cuda()
+    y = torch.from_numpy(OC.arb_tensor(1, ocfg.adm_in_channels)).cuda()
+    out = u.forward(x, torch.tensor([1], dtype=torch.int32).cuda(), c, y).cpu()
+    assert rel_err(out, torch.from_numpy(g["unet_out"])) < FWD_TOL[dtype]
+    v = OC.tiny_vae_config()
+    ld = pkg.LatentDecoder(ctx, to_pkg_vcfg(pkg, v), dtype, seed=0, with_encoder=True)
+    # Decoder::forward alone (no 1/scale_factor, no post_quant) is not exported; check the trajectory fixture instead
+    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    cond = pkg.Conditioning(context_full=c, channel_context=y, unconditional_context_full=c[0],
+                            unconditional_channel_context=y[0] * 0.5, resolution=(64, 64))
+    lat = d.sample_latent(cond, 1.0, 4, torch.from_numpy(OC.arb_tensor(1, 4, 8, 8)).cuda()).cpu()
+    ref = torch.from_numpy(g["traj"][-1])
+    assert max_abs(lat, ref) < lat_tol(dtype, ref)
+    del ld
+
+
 def test_host_weights_equal_synthetic(pkg, ctx):
     # sdxl_vae_create (flat host buffer in sdxl_vae_param_spec order) == sdxl_vae_create_synthetic
     v = OC.tiny_vae_config()
@@ -182,7 +213,9 @@ def test_host_weights_equal_synthetic(pkg, ctx):
     a = pkg.LatentDecoder(ctx, vc, 0, decoder_weights=flat)
     b = pkg.LatentDecoder(ctx, vc, 0, seed=0)
     latent = seeded(1, 4, 4, 4, seed=52).cuda()
-    assert torch.equal(a.decode_latent(latent), b.decode_latent(latent))
+    oa, ob, oa2 = a.decode_latent(latent), b.decode_latent(latent), a.decode_latent(latent)
+    print(f"host-vs-synth diff {max_abs(oa, ob):.3e}, same-object rerun diff {max_abs(oa, oa2):.3e}")
+    assert torch.equal(oa, ob)
 
 
 def test_errors_are_reported_not_fatal(pkg, ctx):
