@@ -171,6 +171,12 @@ int sdxl_vae_create_empty(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, 
  * kernel class (index: 0 implicit-GEMM conv/linear, 1 fused attention, 2 GroupNorm, 3 LayerNorm, 4 other); arrays of 5 */
 int sdxl_unet_profile(sdxl_unet* u, void* stream, int B, int H, int W, float class_ms[5], int class_launches[5],
                       double class_flops[5]);
+/* times the implicit-GEMM kernel alone (conv ksize x ksize, pad ksize/2, stride 1; ksize = 1 -> linear over B*H*W rows)
+ * on seeded random f16 data; avg_ms = mean launch duration over `iters` back-to-back launches (hipEvents) */
+int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, int Cout, int ksize, int geglu, int iters,
+                     float* avg_ms);
+/* benchmarking / debugging knobs ("igemm_variant": -1 generic kernel only, 0 auto, 1..3 forced fast-path tile) */
+int sdxl_debug_set(const char* key, int value);
 
 /* ---- single-op entry points used by the parity tests (same kernels the models run) */
 /* GroupNorm::forward (groupnorm/mod.rs:52-73) on NCHW fp32 [B,C,H,W]; silu!=0 fuses SILU::forward (silu.rs:14-16) */

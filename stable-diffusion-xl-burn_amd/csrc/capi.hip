@@ -105,7 +105,59 @@ int sdxl_ctx_create(int device_id, sdxl_ctx** out) {
   sdxl_ctx* c = new sdxl_ctx();
   c->device = device_id;
   SDXL_HIP(hipStreamCreate(&c->stream));
+  igemm_glds_init();
   *out = c;
+  API_END
+}
+int sdxl_debug_set(const char* key, int value) {
+  API_BEGIN
+  SDXL_REQUIRE(key != nullptr, "null key");
+  if (std::strcmp(key, "igemm_variant") == 0) igemm_set_variant(value);
+  else throw Error(std::string("unknown debug key ") + key);
+  API_END
+}
+int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, int Cout, int ksize, int geglu, int iters,
+                     float* avg_ms) {
+  // times the implicit-GEMM kernel alone on seeded random f16 data: conv ksize x ksize (pad ksize/2) or, with ksize = 1,
+  // a linear over B*H*W rows.  Epilogue: bias (+ GEGLU when geglu != 0).  Used by tools/igemm_sweep.py.
+  API_BEGIN
+  SDXL_REQUIRE(ctx && avg_ms && iters > 0, "bad argument");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  Tmp tmp;
+  Lin l; l.N = Cout; l.cin = Cin; l.ksize = ksize; l.K = Cin * ksize * ksize;
+  l.Kpad = (int)round_up(l.K, 64); l.Npad = (int)round_up(Cout, 128);
+  const size_t M = (size_t)B * H * W;
+  float* wsrc = (float*)tmp.get((size_t)Cout * l.K * sizeof(float));
+  float* bsrc = (float*)tmp.get((size_t)Cout * sizeof(float));
+  float* xsrc = (float*)tmp.get(M * Cin * sizeof(float));
+  void* wp = tmp.get((size_t)l.Npad * l.Kpad * 2);
+  float* bp = (float*)tmp.get((size_t)l.Npad * sizeof(float));
+  void* xi = tmp.get(M * Cin * 2);
+  void* yo = tmp.get(M * Cout * 2);
+  launch_synth_fill(wsrc, (size_t)Cout * l.K, 0x1234, 3.4641f / std::sqrt((float)l.K), 0.f, s);
+  launch_synth_fill(bsrc, Cout, 0x99, 0.1f, 0.f, s);
+  launch_synth_fill(xsrc, M * Cin, 0x777, 3.4641f, 0.f, s);
+  if (ksize == 1) launch_pack_linear(wsrc, wp, DT_F16, l.K, Cout, l.Kpad, l.Npad, geglu ? 1 : 0, 0, s);   // [K][N] random == fine
+  else launch_pack_conv(wsrc, wp, DT_F16, Cout, Cin, ksize, l.Kpad, l.Npad, s);
+  launch_pack_bias(bsrc, bp, Cout, l.Npad, geglu ? 1 : 0, 0, s);
+  launch_copy_rows(xsrc, DT_F32, Cin, xi, DT_F16, Cin, (int)M, Cin, s);
+  l.w = wp; l.b = bp;
+  Exec ex; ex.s = s; ex.cdt = DT_F16; ex.sdt = DT_F16;
+  Epi e; e.act = geglu ? 1 : 0;
+  const ConvGeom g{B, H, W, H, W, ksize, 1, ksize / 2, 0};
+  const Act out(yo, geglu ? Cout / 2 : Cout, DT_F16);
+  for (int i = 0; i < 3; ++i) run_conv(ex, l, Act(xi, Cin, DT_F16), Cin, g, out, e);
+  hipEvent_t a, b;
+  SDXL_HIP(hipEventCreate(&a)); SDXL_HIP(hipEventCreate(&b));
+  SDXL_HIP(hipEventRecord(a, s));
+  for (int i = 0; i < iters; ++i) run_conv(ex, l, Act(xi, Cin, DT_F16), Cin, g, out, e);
+  SDXL_HIP(hipEventRecord(b, s));
+  SDXL_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  SDXL_HIP(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  *avg_ms = ms / iters;
   API_END
 }
 void sdxl_ctx_destroy(sdxl_ctx* c) {

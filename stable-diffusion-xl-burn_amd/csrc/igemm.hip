@@ -332,8 +332,13 @@ static void launch_tiles(const IgemmParams& p, hipStream_t s) {
   }
 }
 
+bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s);   // igemm_glds.hip
+static int g_igemm_variant = 0;   // -1: generic kernel only; 0: auto; >0: forced fast-path tile
+void igemm_set_variant(int v) { g_igemm_variant = v; }
+
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return;
+  if (compute_dt == DT_F16 && g_igemm_variant >= 0 && launch_igemm_glds(p, g_igemm_variant, s)) return;
   if (compute_dt == DT_F16) {
     if (p.a_dt == DT_F16) launch_tiles<half_t, half_t>(p, s);
     else launch_tiles<half_t, float>(p, s);

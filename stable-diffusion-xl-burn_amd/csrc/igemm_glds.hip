@@ -1,0 +1,263 @@
+// Fast-path implicit GEMM for gfx950: f16 operands, direct-to-LDS staging.
+//
+// Same contract as igemm_kernel (igemm.hip) for the shapes that dominate the SDXL step (f16 activations, Cin % 64 == 0,
+// 16-byte aligned rows); everything else stays on the generic kernel.  Differences, all CDNA4-specific:
+//   * HBM/L2 -> LDS without a VGPR round trip: every wave issues `global_load_lds_dwordx4` (16 B per lane, 1 KiB per wave
+//     instruction = 8 tile rows of 128 B).  The LDS image is lane-linear, so the bank-conflict swizzle is applied to the
+//     per-lane SOURCE address (chunk ^ f(row)) and again on the fragment read; halo / tail rows fetch from a zero page.
+//     The conv gather (tap, stride, fused nearest-2x upsample) is still just a per-lane source address.
+//   * LDS double buffer, ONE barrier per k-tile: wait(vmcnt 0)+barrier -> issue next tile's DMA -> MFMA on current tile,
+//     so a full MFMA phase covers the DMA latency.
+//   * v_mfma_f32_32x32x16_f16, wave tile (BM/2)x(BN/2) >= 64x32: LDS read traffic stays <= 75 % of the 256 B/clk/CU budget.
+//   * operand roles swapped (weights = MFMA A operand, activations = B operand): the accumulator layout then gives each
+//     lane 4 CONSECUTIVE output columns of one row -> 8-byte packed stores, vector bias / residual loads, and GEGLU pairs
+//     (x, gate) sit in the same lane of the same accumulator tile.
+//   * swizzle f(row) = (row>>1)&7 makes the ds_read_b128 fragment reads of 32 rows conflict-free across the four 16-lane
+//     service groups (two 128-byte tile rows share one 256-byte bank row).
+#include "kernels.h"
+
+namespace sdxl {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float ldf(const void* p, size_t i, int dt) {
+  return dt == DT_F16 ? (float)reinterpret_cast<const half_t*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, const void* zeros) {
+  constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
+  constexpr int AJ = BM / 32, BJ = BN / 32;   // DMA instructions per wave per k-tile (8 rows each, 4 waves)
+  constexpr int KT = 64;                      // f16 elements per k-tile = one 128-byte row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                            // [2][BM][128 B]
+  char* sB = smem + 2 * BM * 128;             // [2][BN][128 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tilesN, tn = bid - tm * tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- DMA geometry: instruction j of this wave covers tile rows (j*4 + wave)*8 .. +7; lane -> (row, slot)
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int HWo = p.Hout * p.Wout;
+  const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+  int rb[AJ], ry[AJ], rx[AJ], rsw[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int row = (j * 4 + wave) * 8 + lrow;
+    const int m = m0 + row;
+    rsw[j] = (slot ^ ((row >> 1) & 7)) * 8;       // source chunk (elements) that lands in this lane's LDS slot
+    if (m < p.M) {
+      const int b = m / HWo;
+      const int rem = m - b * HWo;
+      const int oy = rem / p.Wout;
+      rb[j] = b; ry[j] = oy * p.stride - p.pad; rx[j] = (rem - oy * p.Wout) * p.stride - p.pad;
+    } else { rb[j] = -1; ry[j] = 0; rx[j] = 0; }
+  }
+  const half_t* Ag = reinterpret_cast<const half_t*>(p.A);
+  const half_t* wsrc[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int row = (j * 4 + wave) * 8 + lrow;
+    wsrc[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * 8;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    const int kbase = kt * KT;
+    const int tap = kbase / p.Cin;
+    const int c0 = kbase - tap * p.Cin;
+    const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
+    char* la = sA + buf * BM * 128 + wave * 1024;
+    char* lb = sB + buf * BN * 128 + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int iy = ry[j] + dy, ix = rx[j] + dx;
+      const bool ok = rb[j] >= 0 && iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
+      const half_t* src = reinterpret_cast<const half_t*>(zeros);
+      if (ok) src = Ag + (((size_t)rb[j] * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up)) * p.lda + c0 + rsw[j];
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(la + j * 4096), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + kbase), (lptr_t)(lb + j * 4096), 16, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.Kpad / KT;
+  const int fr = lane & 31, fh = lane >> 5;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                      // tile kt landed (all waves); everyone finished reading buffer cur^1
+    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    const char* a = sA + cur * BM * 128;
+    const char* b = sB + cur * BN * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ch = kk * 2 + fh;
+      half8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WM + i * 32 + fr;
+        fa[i] = *reinterpret_cast<const half8*>(a + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WN + j * 32 + fr;
+        fb[j] = *reinterpret_cast<const half8*>(b + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)   // weights as the A operand (rows = n), activations as B (cols = m)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue.  acc[i][j][reg]: m = m_tile + (lane&31); n = n_tile + 8*(reg>>2) + 4*(lane>>5) + (reg&3)
+  const bool geglu = p.act == 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 32 + fr;
+    if (m >= p.M) continue;
+    const int bidx = m / p.rpb;
+    const int key = m - bidx * p.rpb;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nt = n0 + wn * WN + j * 32;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (geglu && q >= 2) continue;            // gate groups are consumed with their x group
+        const int nb = nt + 8 * q + 4 * fh;       // packed column of element r = 0
+        if (nb >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q * 4 + r];
+        if (p.bias) {
+          const f32x4 bz = *reinterpret_cast<const f32x4*>(p.bias + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bz[r];
+        }
+        if (p.ebias) {
+          const f32x4 ez = *reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx * p.ebias_ld + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += ez[r];
+        }
+        int nout = nb;
+        if (geglu) {
+          f32x4 gz = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) gz = *reinterpret_cast<const f32x4*>(p.bias + nb + 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(acc[i][j][(q + 2) * 4 + r] + gz[r]);
+          nout = (nt >> 1) + 8 * q + 4 * fh;
+        }
+        const int nlim = geglu ? (p.N >> 1) : p.N;
+        if (geglu || nb < p.n_split) {
+          if (p.R) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (nout + r < nlim) v[r] += ldf(p.R, (size_t)m * p.ldr + nout + r, p.r_dt);
+          }
+          if (nout + 3 < nlim && p.c_dt == DT_F16 && ((p.ldc | nout) & 3) == 0) {
+            half4 h; h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
+            *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + nout) = h;
+          } else if (nout + 3 < nlim && p.c_dt == DT_F32 && ((p.ldc | nout) & 3) == 0) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nout) = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (nout + r < nlim) {
+                if (p.c_dt == DT_F16) reinterpret_cast<half_t*>(p.C)[(size_t)m * p.ldc + nout + r] = (half_t)v[r];
+                else reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + nout + r] = v[r];
+              }
+          }
+        } else {
+          // transposed store Ct[b][n - n_split][key]: lanes 0..31 hold 32 consecutive keys of each row
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nb + r < p.N) {
+              const size_t o = ((size_t)bidx * p.ct_rows + (nb + r - p.n_split)) * p.ct_ld + key;
+              if (p.c_dt == DT_F16) reinterpret_cast<half_t*>(p.Ct)[o] = (half_t)v[r];
+              else reinterpret_cast<float*>(p.Ct)[o] = v[r];
+            }
+        }
+      }
+    }
+  }
+}
+
+static const void* g_zero_page = nullptr;
+void igemm_glds_init() {
+  if (g_zero_page) return;
+  void* z = nullptr;
+  if (hipMalloc(&z, 4096) != hipSuccess) return;
+  (void)hipMemset(z, 0, 4096);
+  g_zero_page = z;
+}
+
+template <int BM, int BN>
+static void launch_glds(const IgemmParams& p, hipStream_t s) {
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
+  const size_t lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
+}
+
+// variant: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 256x128 ... ; returns false when the shape needs the generic kernel
+bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
+  if (!g_zero_page) return false;
+  if (p.a_dt != DT_F16 || (p.Cin % 64) != 0 || (p.lda % 8) != 0 || (p.Kpad % 64) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
+  if (p.n_split < p.N && (p.n_split & 3) != 0) return false;
+  if (p.bias == nullptr && p.act == 1) return false;
+  // the DMA reads weight rows up to the tile edge: Npad is a multiple of 128 for every packed weight (pack_* kernels)
+  if (variant == 0) {
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const int rem = p.N % 128;
+    if (t128 >= 384 && (rem == 0 || rem > 64)) variant = 1;     // enough 128x128 tiles for 1.5 blocks per CU
+    else variant = 2;
+  }
+  switch (variant) {
+    case 1: launch_glds<128, 128>(p, s); break;
+    case 2: launch_glds<128, 64>(p, s); break;
+    case 3: launch_glds<64, 128>(p, s); break;
+    default: return false;
+  }
+  return true;
+}
+
+}  // namespace sdxl

@@ -37,6 +37,8 @@ struct IgemmParams {
   void* Ct; int ct_rows; int ct_ld;     // Ct[b][n - n_split][key]  (ct_rows rows per batch, row stride ct_ld), dtype c_dt
 };
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
+void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
+void igemm_glds_init();          // allocates the zero page the DMA fast path reads halo pixels from (call once per process)
 
 // ---------------------------------------------------------------------------------------------------------
 // GroupNorm (32 groups, NHWC) -- reference groupnorm/mod.rs:52-82 (+ SiLU silu.rs:14-16)
