@@ -243,8 +243,201 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const AttnParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// f16 production variant: same math and register layout as attn_d64_kernel<half>, with the CDNA4 staging path:
+//   * K and V^T tiles go HBM/L2 -> LDS by `global_load_lds_dwordx4` (lane-linear image, swizzle on the source address,
+//     keys beyond Nk read a zero page), double-buffered, one raw barrier per 64-key tile;
+//   * Q fragments are pre-multiplied by scale*log2(e) once, so the per-score work is max / sub / v_exp_f32 / add;
+//   * key-tail masking only runs on the last tile (wave-uniform branch); the optional additive mask likewise.
+typedef const __attribute__((address_space(1))) void* agptr_t;
+typedef __attribute__((address_space(3))) void* alptr_t;
+
+__global__ __launch_bounds__(256) void attn_d64_f16_kernel(const AttnParams p, const void* zeros) {
+  constexpr int D = 64, KV = 64, MQ = 2, TILE = 64 * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V^T tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, fr = lane & 15;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const half_t* Qg = reinterpret_cast<const half_t*>(p.Q) + (size_t)b * p.Nq * p.ldq + h * D;
+  const half_t* Kg = reinterpret_cast<const half_t*>(p.K) + (size_t)b * p.Nk * p.ldk + h * D;
+  const half_t* Vg = reinterpret_cast<const half_t*>(p.Vt) + ((size_t)b * p.H + h) * D * p.vt_ld;
+  const float sc = p.scale * 1.44269504088896340736f;
+
+  i32x4 qf[MQ][2];
+#pragma unroll
+  for (int mq = 0; mq < MQ; ++mq) {
+    const int q = q0 + mq * 16 + fr;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8 v;
+      if (q < p.Nq) v = *reinterpret_cast<const half8*>(Qg + (size_t)q * p.ldq + (kk * 4 + g) * 8);
+      else v = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * sc);
+      qf[mq][kk] = __builtin_bit_cast(i32x4, v);
+    }
+  }
+  // DMA geometry: wave w stages tile rows [16w, 16w+16) of K and of V^T, two 1-KiB instructions each
+  const int lrow = lane >> 3, slot = lane & 7;
+  auto stage = [&](int t, int buf) {
+    const int k0 = t * KV;
+    char* lk = smem + buf * 2 * TILE + wave * 2048;
+    char* lv = lk + TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wave * 16 + j * 8 + lrow;
+      const int ch = (slot ^ (row & 7)) * 8;
+      const int key = k0 + row;
+      const half_t* ks = key < p.Nk ? Kg + (size_t)key * p.ldk + ch : reinterpret_cast<const half_t*>(zeros);
+      __builtin_amdgcn_global_load_lds((agptr_t)ks, (alptr_t)(lk + j * 1024), 16, 0, 0);
+      const half_t* vs = Vg + (size_t)row * p.vt_ld + k0 + ch;      // V^T rows are zero padded to vt_ld
+      __builtin_amdgcn_global_load_lds((agptr_t)vs, (alptr_t)(lv + j * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 ot[4][MQ];
+  float mrun[MQ], lrun[MQ];
+#pragma unroll
+  for (int mq = 0; mq < MQ; ++mq) {
+    mrun[mq] = -INFINITY; lrun[mq] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt][mq] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nt = (p.Nk + KV - 1) / KV;
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < nt) stage(t + 1, cur ^ 1);
+    const char* kb = smem + cur * 2 * TILE;
+    const char* vb = kb + TILE;
+    f32x4 st[4][MQ];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int mq = 0; mq < MQ; ++mq) st[kt][mq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = kk * 4 + g;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int row = kt * 16 + fr;
+        const i32x4 kf = *reinterpret_cast<const i32x4*>(kb + row * 128 + ((ch ^ (row & 7)) << 4));
+#pragma unroll
+        for (int mq = 0; mq < MQ; ++mq) st[kt][mq] = AMma<half_t>::run(kf, qf[mq][kk], st[kt][mq]);
+      }
+    }
+    const bool tail = (t == nt - 1) && (p.Nk & 63) != 0;
+#pragma unroll
+    for (int mq = 0; mq < MQ; ++mq) {
+      if (p.mask) {
+        const int q = q0 + mq * 16 + fr;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = t * KV + kt * 16 + g * 4 + r;
+            if (q < p.Nq && key < p.Nk) st[kt][mq][r] += p.mask[(size_t)q * p.ldmask + key] * 1.44269504088896340736f;
+          }
+      }
+      if (tail) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (t * KV + kt * 16 + g * 4 + r >= p.Nk) st[kt][mq][r] = -INFINITY;
+      }
+      float mx = fmaxf(fmaxf(st[0][mq][0], st[0][mq][1]), fmaxf(st[0][mq][2], st[0][mq][3]));
+#pragma unroll
+      for (int kt = 1; kt < 4; ++kt)
+        mx = fmaxf(mx, fmaxf(fmaxf(st[kt][mq][0], st[kt][mq][1]), fmaxf(st[kt][mq][2], st[kt][mq][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(mrun[mq], mx);
+      const float msub = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = __builtin_amdgcn_exp2f(mrun[mq] - msub);
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(st[kt][mq][r] - msub);
+          st[kt][mq][r] = e;
+          ps += e;
+        }
+      lrun[mq] = lrun[mq] * alpha + ps;
+      mrun[mq] = mnew;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[dt][mq][r] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      i32x4 pf[MQ];
+#pragma unroll
+      for (int mq = 0; mq < MQ; ++mq) {
+        half8 hh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { hh[r] = (half_t)st[2 * u][mq][r]; hh[4 + r] = (half_t)st[2 * u + 1][mq][r]; }
+        pf[mq] = __builtin_bit_cast(i32x4, hh);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int row = dt * 16 + fr;
+        const int c1 = 4 * u + (g >> 1), c2 = c1 + 2, sub = (g & 1) * 8;
+        const i32x2 v1 = *reinterpret_cast<const i32x2*>(vb + row * 128 + ((c1 ^ (row & 7)) << 4) + sub);
+        const i32x2 v2 = *reinterpret_cast<const i32x2*>(vb + row * 128 + ((c2 ^ (row & 7)) << 4) + sub);
+        const i32x4 vf = i32x4{v1[0], v1[1], v2[0], v2[1]};
+#pragma unroll
+        for (int mq = 0; mq < MQ; ++mq) ot[dt][mq] = AMma<half_t>::run(vf, pf[mq], ot[dt][mq]);
+      }
+    }
+  }
+  half_t* Og = reinterpret_cast<half_t*>(p.O) + (size_t)b * p.Nq * p.ldo + h * D;
+#pragma unroll
+  for (int mq = 0; mq < MQ; ++mq) {
+    float l = lrun[mq];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int q = q0 + mq * 16 + fr;
+    if (q < p.Nq) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        half4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)(ot[dt][mq][r] * inv);
+        *reinterpret_cast<half4*>(Og + (size_t)q * p.ldo + dt * 16 + g * 4) = o;
+      }
+    }
+  }
+}
+
+static const void* g_attn_zero = nullptr;
+static int g_attn_variant = 0;   // -1: generic kernel only
+void attention_set_variant(int v) { g_attn_variant = v; }
+void attention_init() {
+  if (g_attn_zero) return;
+  void* z = nullptr;
+  if (hipMalloc(&z, 4096) != hipSuccess) return;
+  (void)hipMemset(z, 0, 4096);
+  g_attn_zero = z;
+}
+
 void launch_attention_d64(const AttnParams& p, hipStream_t s) {
   dim3 grid((p.Nq + 127) / 128, p.B * p.H);
+  const bool aligned = ((p.ldq | p.ldk | p.vt_ld | p.ldo) & 7) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
+                         reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) == 0;
+  if (p.dt == DT_F16 && g_attn_variant >= 0 && g_attn_zero && aligned) {
+    hipLaunchKernelGGL(attn_d64_f16_kernel, grid, dim3(256), 4 * 64 * 128, s, p, g_attn_zero);
+    return;
+  }
   if (p.dt == DT_F16) {
     const size_t lds = 4 * 64 * 128;
     hipLaunchKernelGGL(attn_d64_kernel<half_t>, grid, dim3(256), lds, s, p);

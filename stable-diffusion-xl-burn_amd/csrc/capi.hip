@@ -106,6 +106,7 @@ int sdxl_ctx_create(int device_id, sdxl_ctx** out) {
   c->device = device_id;
   SDXL_HIP(hipStreamCreate(&c->stream));
   igemm_glds_init();
+  attention_init();
   *out = c;
   API_END
 }
@@ -113,6 +114,7 @@ int sdxl_debug_set(const char* key, int value) {
   API_BEGIN
   SDXL_REQUIRE(key != nullptr, "null key");
   if (std::strcmp(key, "igemm_variant") == 0) igemm_set_variant(value);
+  else if (std::strcmp(key, "attn_variant") == 0) attention_set_variant(value);
   else throw Error(std::string("unknown debug key ") + key);
   API_END
 }

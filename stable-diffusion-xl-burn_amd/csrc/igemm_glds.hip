@@ -1,4 +1,4 @@
-// Fast-path implicit GEMM for gfx950: f16 operands, direct-to-LDS staging.
+// Fast-path implicit GEMM for gfx950: f16 operands, direct-to-LDS staging through an NS-deep ring.
 //
 // Same contract as igemm_kernel (igemm.hip) for the shapes that dominate the SDXL step (f16 activations, Cin % 64 == 0,
 // 16-byte aligned rows); everything else stays on the generic kernel.  Differences, all CDNA4-specific:
@@ -6,8 +6,9 @@
 //     instruction = 8 tile rows of 128 B).  The LDS image is lane-linear, so the bank-conflict swizzle is applied to the
 //     per-lane SOURCE address (chunk ^ f(row)) and again on the fragment read; halo / tail rows fetch from a zero page.
 //     The conv gather (tap, stride, fused nearest-2x upsample) is still just a per-lane source address.
-//   * LDS double buffer, ONE barrier per k-tile: wait(vmcnt 0)+barrier -> issue next tile's DMA -> MFMA on current tile,
-//     so a full MFMA phase covers the DMA latency.
+//   * NS-deep LDS ring with COUNTED waits: tile kt+NS-1 is issued while tile kt is multiplied, `s_waitcnt vmcnt(N)` leaves
+//     NS-2 tiles in flight across the (raw) s_barrier, so HBM latency is covered even at one block per CU -- the regime of
+//     the M=2048 transformer GEMMs (160..480 tiles on 256 CUs).  One barrier per k-tile.
 //   * v_mfma_f32_32x32x16_f16, wave tile (BM/2)x(BN/2) >= 64x32: LDS read traffic stays <= 75 % of the 256 B/clk/CU budget.
 //   * operand roles swapped (weights = MFMA A operand, activations = B operand): the accumulator layout then gives each
 //     lane 4 CONSECUTIVE output columns of one row -> 8-byte packed stores, vector bias / residual loads, and GEGLU pairs
@@ -23,25 +24,23 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float ldf(const void* p, size_t i, int dt) {
-  return dt == DT_F16 ? (float)reinterpret_cast<const half_t*>(p)[i] : reinterpret_cast<const float*>(p)[i];
-}
 
-template <int BM, int BN>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, const void* zeros) {
   constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
   constexpr int AJ = BM / 32, BJ = BN / 32;   // DMA instructions per wave per k-tile (8 rows each, 4 waves)
+  constexpr int PER = AJ + BJ;                // DMA instructions per wave per stage
   constexpr int KT = 64;                      // f16 elements per k-tile = one 128-byte row
+  constexpr int STAGE = (BM + BN) * 128;      // bytes per ring slot: A tile then B tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;                            // [2][BM][128 B]
-  char* sB = smem + 2 * BM * 128;             // [2][BN][128 B]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,7 +53,13 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid / tilesN, tn = bid - tm * tilesN;
+  // Each XCD (private 4 MiB L2) owns a contiguous run of remapped ids.  Walk that run so the LARGER operand is read from
+  // HBM by one XCD only: weights bigger than activations (the M=2048 transformer GEMMs) -> an XCD owns a range of weight
+  // column tiles and sweeps all row tiles; otherwise (convs at 64^2/128^2, VAE) it owns row tiles and sweeps the weights.
+  const int tilesM = (p.M + BM - 1) / BM;
+  int tm, tn;
+  if ((size_t)p.N * p.K > (size_t)p.M * p.Cin) { tn = bid / tilesM; tm = bid - tn * tilesM; }
+  else { tm = bid / tilesN; tn = bid - tm * tilesN; }
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- DMA geometry: instruction j of this wave covers tile rows (j*4 + wave)*8 .. +7; lane -> (row, slot)
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
       const int rem = m - b * HWo;
       const int oy = rem / p.Wout;
       rb[j] = b; ry[j] = oy * p.stride - p.pad; rx[j] = (rem - oy * p.Wout) * p.stride - p.pad;
-    } else { rb[j] = -1; ry[j] = 0; rx[j] = 0; }
+    } else { rb[j] = -1; ry[j] = -(1 << 28); rx[j] = 0; }
   }
   const half_t* Ag = reinterpret_cast<const half_t*>(p.A);
   const half_t* wsrc[BJ];
@@ -87,14 +92,14 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
     const int tap = kbase / p.Cin;
     const int c0 = kbase - tap * p.Cin;
     const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
-    char* la = sA + buf * BM * 128 + wave * 1024;
-    char* lb = sB + buf * BN * 128 + wave * 1024;
+    char* la = smem + buf * STAGE + wave * 1024;
+    char* lb = la + BM * 128;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int iy = ry[j] + dy, ix = rx[j] + dx;
-      const bool ok = rb[j] >= 0 && iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
-      const half_t* src = reinterpret_cast<const half_t*>(zeros);
-      if (ok) src = Ag + (((size_t)rb[j] * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up)) * p.lda + c0 + rsw[j];
+      const bool ok = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;   // rows beyond M carry iy << 0
+      const size_t off = (((size_t)(rb[j] < 0 ? 0 : rb[j]) * p.Hin + ((ok ? iy : 0) >> p.up)) * p.Win + ((ok ? ix : 0) >> p.up)) * p.lda + c0 + rsw[j];
+      const half_t* src = ok ? Ag + off : reinterpret_cast<const half_t*>(zeros);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(la + j * 4096), 16, 0, 0);
     }
 #pragma unroll
@@ -112,14 +117,21 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
 
   const int nk = p.Kpad / KT;
   const int fr = lane & 31, fh = lane >> 5;
-  stage(0, 0);
+  // prologue: NS-1 tiles in flight
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) stage(s, s);
+  int cur = 0;                 // ring slot of tile kt
+  int nxt = NS - 1;            // ring slot tile kt+NS-1 goes to (= slot of tile kt-1)
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                      // tile kt landed (all waves); everyone finished reading buffer cur^1
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-    const char* a = sA + cur * BM * 128;
-    const char* b = sB + cur * BN * 128;
+    // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight (only if they were really issued)
+    if (kt + NS - 2 < nk) wait_vmcnt<PER * (NS - 2)>(); else wait_vmcnt<0>();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // all waves: tile kt visible, compute(kt-1) finished -> slot `nxt` is free
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt);
+    const char* a = smem + cur * STAGE;
+    const char* b = a + BM * 128;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int ch = kk * 2 + fh;
@@ -140,10 +152,13 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
         for (int j = 0; j < TN; ++j)   // weights as the A operand (rows = n), activations as B (cols = m)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
+    nxt = cur;
+    cur = cur + 1 == NS ? 0 : cur + 1;
   }
 
   // ---- epilogue.  acc[i][j][reg]: m = m_tile + (lane&31); n = n_tile + 8*(reg>>2) + 4*(lane>>5) + (reg&3)
   const bool geglu = p.act == 1;
+  const int nlim = geglu ? (p.N >> 1) : p.N;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * WM + i * 32 + fr;
@@ -179,17 +194,29 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
           for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(acc[i][j][(q + 2) * 4 + r] + gz[r]);
           nout = (nt >> 1) + 8 * q + 4 * fh;
         }
-        const int nlim = geglu ? (p.N >> 1) : p.N;
         if (geglu || nb < p.n_split) {
+          const bool vec = nout + 3 < nlim && (nout & 3) == 0;
           if (p.R) {
+            if (vec && p.r_dt == DT_F16 && (p.ldr & 3) == 0) {
+              const half4 rr = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.R) + (size_t)m * p.ldr + nout);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (nout + r < nlim) v[r] += ldf(p.R, (size_t)m * p.ldr + nout + r, p.r_dt);
+              for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            } else if (vec && p.r_dt == DT_F32 && (p.ldr & 3) == 0) {
+              const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + nout);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (nout + r < nlim)
+                  v[r] += p.r_dt == DT_F16 ? (float)reinterpret_cast<const half_t*>(p.R)[(size_t)m * p.ldr + nout + r]
+                                           : reinterpret_cast<const float*>(p.R)[(size_t)m * p.ldr + nout + r];
+            }
           }
-          if (nout + 3 < nlim && p.c_dt == DT_F16 && ((p.ldc | nout) & 3) == 0) {
+          if (vec && p.c_dt == DT_F16 && (p.ldc & 3) == 0) {
             half4 h; h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
             *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + nout) = h;
-          } else if (nout + 3 < nlim && p.c_dt == DT_F32 && ((p.ldc | nout) & 3) == 0) {
+          } else if (vec && p.c_dt == DT_F32 && (p.ldc & 3) == 0) {
             f32x4 o = {v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nout) = o;
           } else {
@@ -224,37 +251,44 @@ void igemm_glds_init() {
   g_zero_page = z;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NS>
 static void launch_glds(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
-  const size_t lds = 2 * (BM + BN) * 128;
+  const size_t lds = (size_t)NS * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, NS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
+  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
 }
 
-// variant: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 256x128 ... ; returns false when the shape needs the generic kernel
+// variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
+// 6 = 64x128 ring 2; 7 = 128x128 ring 4; 8 = 64x128 ring 3.  Returns false when the shape needs the generic kernel.
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if (!g_zero_page) return false;
   if (p.a_dt != DT_F16 || (p.Cin % 64) != 0 || (p.lda % 8) != 0 || (p.Kpad % 64) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
   if (p.n_split < p.N && (p.n_split & 3) != 0) return false;
-  if (p.bias == nullptr && p.act == 1) return false;
+  if (p.ebias && (p.ebias_ld & 3) != 0) return false;
   // the DMA reads weight rows up to the tile edge: Npad is a multiple of 128 for every packed weight (pack_* kernels)
   if (variant == 0) {
+    // measured on MI355X (tools/igemm_sweep.py, profiles/r01_igemm_sweep.txt): the 2-deep ring at 2..4 blocks/CU beats the
+    // deeper rings (occupancy hides latency better than prefetch depth at these sizes); 128x128 tiles once there are
+    // >= ~1.5 tiles per CU, 64x128 below that (the M=2048 / N=1280 transformer GEMMs and the 32^2 / 64^2 convs).
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const int rem = p.N % 128;
-    if (t128 >= 384 && (rem == 0 || rem > 64)) variant = 1;     // enough 128x128 tiles for 1.5 blocks per CU
-    else variant = 2;
+    variant = t128 >= 400 ? 4 : 6;
   }
   switch (variant) {
-    case 1: launch_glds<128, 128>(p, s); break;
-    case 2: launch_glds<128, 64>(p, s); break;
-    case 3: launch_glds<64, 128>(p, s); break;
+    case 1: launch_glds<128, 128, 3>(p, s); break;
+    case 2: launch_glds<128, 64, 4>(p, s); break;
+    case 3: launch_glds<64, 128, 4>(p, s); break;
+    case 4: launch_glds<128, 128, 2>(p, s); break;
+    case 5: launch_glds<128, 64, 2>(p, s); break;
+    case 6: launch_glds<64, 128, 2>(p, s); break;
+    case 7: launch_glds<128, 128, 4>(p, s); break;
+    case 8: launch_glds<64, 128, 3>(p, s); break;
     default: return false;
   }
   return true;

@@ -125,59 +125,64 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormParams p) 
   }
 }
 
-// apply: grid (row chunks, B).  per-channel (mean_g, rstd_g*gamma, beta) staged in LDS.
+// finalize: one thread per (batch, group) merges the row-split partials -> (mean, rstd) at partial[b][g][0..1] of a
+// second region (stat), so the apply blocks do not each redo the merge.
+__global__ void gn_finalize_kernel(const GroupNormParams p, float* stat) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.B * p.G) return;
+  const float* part = p.partial + (size_t)i * p.nsplit * 3;
+  float na = 0.f, ma = 0.f, qa = 0.f;
+  for (int s = 0; s < p.nsplit; ++s) chan_merge(na, ma, qa, part[s * 3], part[s * 3 + 1], part[s * 3 + 2]);
+  stat[i * 2] = ma;
+  stat[i * 2 + 1] = 1.0f / sqrtf(qa / na + p.eps);
+}
+
+// apply: grid (row chunks, B).  thread -> (row lane, fixed vector column): the 8 channels' (mean, rstd*gamma, beta)
+// stay in registers while the thread walks its rows, so the inner loop is load / 8 FMA(+SiLU) / store.
 template <typename XT, typename YT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, int rows_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int C = p.C;
-  float* cMean = sm;            // [C]
-  float* cScale = sm + C;       // [C]
-  float* cBeta = sm + 2 * C;    // [C]
-  float* gMean = sm + 3 * C;    // [G]
-  float* gRstd = gMean + p.G;
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, const float* stat, int rows_per_block) {
+  const int C = p.C, NV = C >> 3;
+  const int VPR = NV < 256 ? NV : 256;
+  const int RL = 256 / VPR;
   const int tid = threadIdx.x, b = blockIdx.y;
-  if (tid < p.G) {
-    const float* part = p.partial + ((size_t)b * p.G + tid) * p.nsplit * 3;
-    float na = 0.f, ma = 0.f, qa = 0.f;
-    for (int s = 0; s < p.nsplit; ++s) chan_merge(na, ma, qa, part[s * 3], part[s * 3 + 1], part[s * 3 + 2]);
-    gMean[tid] = ma;
-    gRstd[tid] = 1.0f / sqrtf(qa / na + p.eps);
-  }
-  __syncthreads();
+  const int rl = tid / VPR, vl = tid - rl * VPR;
   const int cpg = C / p.G;
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    cMean[c] = gMean[g];
-    cScale[c] = gRstd[g] * p.gamma[c];
-    cBeta[c] = p.beta[c];
-  }
-  __syncthreads();
-  const int NV = C >> 3;
   const int row0 = blockIdx.x * rows_per_block;
-  const int nrows = min(rows_per_block, p.HW - row0);
-  const XT* X = reinterpret_cast<const XT*>(p.X) + ((size_t)b * p.HW + row0) * p.ldx;
-  YT* Y = reinterpret_cast<YT*>(p.Y) + ((size_t)b * p.HW + row0) * p.ldy;
-  const int total = nrows * NV;
-  for (int i = tid; i < total; i += 256) {
-    const int row = i / NV, vc = i - row * NV;
-    float v[8];
-    load8<XT>(X + (size_t)row * p.ldx + vc * 8, v);
+  const int row1 = min(p.HW, row0 + rows_per_block);
+  const XT* X = reinterpret_cast<const XT*>(p.X) + (size_t)b * p.HW * p.ldx;
+  YT* Y = reinterpret_cast<YT*>(p.Y) + (size_t)b * p.HW * p.ldy;
+  const int npass = (NV + VPR - 1) / VPR;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int vc = pass * VPR + vl;
+    if (rl >= RL || vc >= NV) continue;
+    float mean[8], scale[8], beta[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = vc * 8 + j;
-      float y = (v[j] - cMean[c]) * cScale[c] + cBeta[c];
-      if (p.silu) y = y / (1.0f + __expf(-y));
-      v[j] = y;
+      const int g = c / cpg;
+      mean[j] = stat[((size_t)b * p.G + g) * 2];
+      scale[j] = stat[((size_t)b * p.G + g) * 2 + 1] * p.gamma[c];
+      beta[j] = p.beta[c];
     }
-    store8<YT>(Y + (size_t)row * p.ldy + vc * 8, v);
+    for (int row = row0 + rl; row < row1; row += RL) {
+      float v[8];
+      load8<XT>(X + (size_t)row * p.ldx + vc * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float y = (v[j] - mean[j]) * scale[j] + beta[j];
+        if (p.silu) y = y / (1.0f + __expf(-y));
+        v[j] = y;
+      }
+      store8<YT>(Y + (size_t)row * p.ldy + vc * 8, v);
+    }
   }
 }
 
 int groupnorm_nsplit(int B, int HW, int C) {
   (void)B; (void)C;
-  int n = HW / 32;
+  int n = HW / 64;
   if (n < 1) n = 1;
-  if (n > 128) n = 128;
+  if (n > 64) n = 64;
   return n;
 }
 
@@ -191,20 +196,22 @@ void launch_groupnorm(const GroupNormParams& pin, hipStream_t s) {
   dim3 g1(p.nsplit, p.B);
   if (p.x_dt == DT_F16) hipLaunchKernelGGL(gn_stats_kernel<half_t>, g1, dim3(256), lds_stats, s, p);
   else hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds_stats, s, p);
-  // apply
-  int rows_per_block = (256 * 4) / NV;      // ~4 vectors per thread
-  if (rows_per_block < 1) rows_per_block = 1;
-  if (rows_per_block > 64) rows_per_block = 64;
+  // (mean, rstd) per (batch, group) live right after the partials: workspace is [B][G][128][3] floats, nsplit <= 64
+  float* stat = p.partial + (size_t)p.B * p.G * 64 * 3;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.G + 63) / 64), dim3(64), 0, s, p, stat);
+  // apply: aim for >= ~512 blocks, each row lane walking >= 4 rows
+  int rows_per_block = (int)(((long)p.B * p.HW + 511) / 512);
+  if (rows_per_block < 4 * RL) rows_per_block = 4 * RL;
+  if (rows_per_block > p.HW) rows_per_block = p.HW;
   dim3 g2((p.HW + rows_per_block - 1) / rows_per_block, p.B);
-  const size_t lds_apply = (size_t)(3 * p.C + 2 * p.G) * sizeof(float);
   if (p.x_dt == DT_F16 && p.y_dt == DT_F16)
-    hipLaunchKernelGGL((gn_apply_kernel<half_t, half_t>), g2, dim3(256), lds_apply, s, p, rows_per_block);
+    hipLaunchKernelGGL((gn_apply_kernel<half_t, half_t>), g2, dim3(256), 0, s, p, stat, rows_per_block);
   else if (p.x_dt == DT_F32 && p.y_dt == DT_F16)
-    hipLaunchKernelGGL((gn_apply_kernel<float, half_t>), g2, dim3(256), lds_apply, s, p, rows_per_block);
+    hipLaunchKernelGGL((gn_apply_kernel<float, half_t>), g2, dim3(256), 0, s, p, stat, rows_per_block);
   else if (p.x_dt == DT_F32 && p.y_dt == DT_F32)
-    hipLaunchKernelGGL((gn_apply_kernel<float, float>), g2, dim3(256), lds_apply, s, p, rows_per_block);
+    hipLaunchKernelGGL((gn_apply_kernel<float, float>), g2, dim3(256), 0, s, p, stat, rows_per_block);
   else
-    hipLaunchKernelGGL((gn_apply_kernel<half_t, float>), g2, dim3(256), lds_apply, s, p, rows_per_block);
+    hipLaunchKernelGGL((gn_apply_kernel<half_t, float>), g2, dim3(256), 0, s, p, stat, rows_per_block);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -251,8 +258,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
   }
 }
 
+// register-cached variant (C <= 8*64*MAXV): the row is read from memory exactly once
+template <typename XT, typename YT, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_cached_kernel(const LayerNormParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const XT* x = reinterpret_cast<const XT*>(p.X) + (size_t)row * p.ldx;
+  YT* y = reinterpret_cast<YT*>(p.Y) + (size_t)row * p.ldy;
+  const int NV = p.C >> 3;
+  float v[MAXV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vc = lane + 64 * i;
+    if (vc < NV) {
+      load8<XT>(x + vc * 8, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)p.C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (lane + 64 * i < NV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float u = v[i][j] - mean; sq += u * u; }
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = 1.0f / sqrtf(sq / (float)p.C + p.eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vc = lane + 64 * i;
+    if (vc < NV) {
+      f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + vc * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + vc * 8 + 4);
+      f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + vc * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + vc * 8 + 4);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (v[i][j] - mean) * rstd * g0[j] + b0[j];
+        o[4 + j] = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+      }
+      store8<YT>(y + vc * 8, o);
+    }
+  }
+}
+
 void launch_layernorm(const LayerNormParams& p, hipStream_t s) {
   dim3 g((p.rows + 3) / 4);
+  if (p.C <= 8 * 64 * 3) {
+    if (p.x_dt == DT_F16 && p.y_dt == DT_F16) hipLaunchKernelGGL((layernorm_cached_kernel<half_t, half_t, 3>), g, dim3(256), 0, s, p);
+    else if (p.x_dt == DT_F32 && p.y_dt == DT_F16) hipLaunchKernelGGL((layernorm_cached_kernel<float, half_t, 3>), g, dim3(256), 0, s, p);
+    else if (p.x_dt == DT_F32 && p.y_dt == DT_F32) hipLaunchKernelGGL((layernorm_cached_kernel<float, float, 3>), g, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((layernorm_cached_kernel<half_t, float, 3>), g, dim3(256), 0, s, p);
+    return;
+  }
   if (p.x_dt == DT_F16 && p.y_dt == DT_F16) hipLaunchKernelGGL((layernorm_kernel<half_t, half_t>), g, dim3(256), 0, s, p);
   else if (p.x_dt == DT_F32 && p.y_dt == DT_F16) hipLaunchKernelGGL((layernorm_kernel<float, half_t>), g, dim3(256), 0, s, p);
   else if (p.x_dt == DT_F32 && p.y_dt == DT_F32) hipLaunchKernelGGL((layernorm_kernel<float, float>), g, dim3(256), 0, s, p);
