@@ -133,9 +133,9 @@ struct Act {
 // per-kernel-class hipEvent profiler (eager runs only): live measurement of the dominant kernel for bench.py's roofline
 struct Profiler {
   enum { IGEMM = 0, ATTENTION = 1, GROUPNORM = 2, LAYERNORM = 3, OTHER = 4, NCLS = 5 };
-  struct Rec { hipEvent_t a, b; int cls; double flops; };
+  struct Rec { hipEvent_t a, b; int cls; double flops; int m, n, k, ks; };
   std::vector<Rec> recs;
-  void begin(int cls, double flops, hipStream_t s);
+  void begin(int cls, double flops, hipStream_t s, int m = 0, int n = 0, int k = 0, int ks = 0);
   void end(hipStream_t s);
   void collect(float ms[NCLS], int launches[NCLS], double flops[NCLS]);   // synchronises, then frees the events
 };

@@ -80,31 +80,49 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
     } else { rb[j] = -1; ry[j] = -(1 << 28); rx[j] = 0; }
   }
   const half_t* Ag = reinterpret_cast<const half_t*>(p.A);
-  const half_t* wsrc[BJ];
+  // Incremental DMA source pointers: stage() is called for k-tiles 0,1,2,... in order, so the per-lane source address of
+  // every tile row is a running pointer that advances by 64 elements per k-tile and is recomputed (bounds test, pixel
+  // address) only when the k-tile crosses into the next filter tap -- no per-tile integer division or 64-bit multiply.
+  const half_t* wptr[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int row = (j * 4 + wave) * 8 + lrow;
-    wsrc[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * 8;
+    wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * 8;
   }
+  const half_t* aptr[AJ];
+  int aadv[AJ];
+  int s_c0 = 0, s_dy = 0, s_dx = 0;      // wave-uniform tap walk state
+  auto retap = [&]() {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int iy = ry[j] + s_dy, ix = rx[j] + s_dx;
+      const bool ok = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;   // rows beyond M carry iy << 0
+      const size_t off = (((size_t)(rb[j] < 0 ? 0 : rb[j]) * p.Hin + ((ok ? iy : 0) >> p.up)) * p.Win + ((ok ? ix : 0) >> p.up)) * p.lda + rsw[j];
+      aptr[j] = ok ? Ag + off : reinterpret_cast<const half_t*>(zeros);
+      aadv[j] = ok ? KT : 0;
+    }
+  };
+  retap();
 
-  auto stage = [&](int kt, int buf) {
-    const int kbase = kt * KT;
-    const int tap = kbase / p.Cin;
-    const int c0 = kbase - tap * p.Cin;
-    const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
+  auto stage = [&](int buf) {
     char* la = smem + buf * STAGE + wave * 1024;
     char* lb = la + BM * 128;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const int iy = ry[j] + dy, ix = rx[j] + dx;
-      const bool ok = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;   // rows beyond M carry iy << 0
-      const size_t off = (((size_t)(rb[j] < 0 ? 0 : rb[j]) * p.Hin + ((ok ? iy : 0) >> p.up)) * p.Win + ((ok ? ix : 0) >> p.up)) * p.lda + c0 + rsw[j];
-      const half_t* src = ok ? Ag + off : reinterpret_cast<const half_t*>(zeros);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(la + j * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(la + j * 4096), 16, 0, 0);
+      aptr[j] += aadv[j];
     }
 #pragma unroll
-    for (int j = 0; j < BJ; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + kbase), (lptr_t)(lb + j * 4096), 16, 0, 0);
+    for (int j = 0; j < BJ; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(lb + j * 4096), 16, 0, 0);
+      wptr[j] += KT;
+    }
+    s_c0 += KT;
+    if (s_c0 == p.Cin) {                 // next k-tile starts a new tap (uniform branch)
+      s_c0 = 0;
+      if (++s_dx == p.ksize) { s_dx = 0; ++s_dy; }
+      retap();
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
   // prologue: NS-1 tiles in flight
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) stage(s, s);
+    if (s < nk) stage(s);
   int cur = 0;                 // ring slot of tile kt
   int nxt = NS - 1;            // ring slot tile kt+NS-1 goes to (= slot of tile kt-1)
   for (int kt = 0; kt < nk; ++kt) {
@@ -129,7 +147,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();          // all waves: tile kt visible, compute(kt-1) finished -> slot `nxt` is free
     asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nk) stage(kt + NS - 1, nxt);
+    if (kt + NS - 1 < nk) stage(nxt);
     const char* a = smem + cur * STAGE;
     const char* b = a + BM * 128;
 #pragma unroll

@@ -75,7 +75,7 @@ void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, 
   AttnParams p{};
   p.Q = q.p; p.ldq = q.ld; p.K = k.p; p.ldk = k.ld; p.Vt = vt; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
   p.dt = ex.cdt; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
-  if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s);
+  if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0);
   launch_attention_d64(p, ex.s);
   if (ex.prof) ex.prof->end(ex.s);
 }

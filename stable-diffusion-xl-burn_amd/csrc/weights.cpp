@@ -5,6 +5,9 @@
 // shared by the UNet and VAE drivers.
 #include "engine.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace sdxl {
 
 // ------------------------------------------------------------------------------------------ arena
@@ -25,8 +28,8 @@ void* DeviceArena::alloc(size_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------ profiler
-void Profiler::begin(int cls, double flops, hipStream_t s) {
-  Rec r; r.cls = cls; r.flops = flops;
+void Profiler::begin(int cls, double flops, hipStream_t s, int m, int n, int k, int ks) {
+  Rec r; r.cls = cls; r.flops = flops; r.m = m; r.n = n; r.k = k; r.ks = ks;
   SDXL_HIP(hipEventCreate(&r.a)); SDXL_HIP(hipEventCreate(&r.b));
   SDXL_HIP(hipEventRecord(r.a, s));
   recs.push_back(r);
@@ -34,14 +37,19 @@ void Profiler::begin(int cls, double flops, hipStream_t s) {
 void Profiler::end(hipStream_t s) { SDXL_HIP(hipEventRecord(recs.back().b, s)); }
 void Profiler::collect(float ms[NCLS], int launches[NCLS], double flops[NCLS]) {
   for (int i = 0; i < NCLS; ++i) { ms[i] = 0.f; launches[i] = 0; flops[i] = 0.0; }
+  const char* dump = std::getenv("SDXL_PROFILE_DUMP");   // optional per-launch CSV (class, M, N, K, ksize, ms)
+  FILE* f = dump ? std::fopen(dump, "w") : nullptr;
+  if (f) std::fprintf(f, "class,M,N,K,ksize,ms\n");
   for (Rec& r : recs) {
     SDXL_HIP(hipEventSynchronize(r.b));
     float t = 0.f;
     SDXL_HIP(hipEventElapsedTime(&t, r.a, r.b));
     ms[r.cls] += t; launches[r.cls] += 1; flops[r.cls] += r.flops;
+    if (f) std::fprintf(f, "%d,%d,%d,%d,%d,%.4f\n", r.cls, r.m, r.n, r.k, r.ks, t);
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   recs.clear();
+  if (f) std::fclose(f);
 }
 
 // ------------------------------------------------------------------------------------------ sources
@@ -179,7 +187,7 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.n_split = e.n_split >= 0 ? e.n_split : w.N;
   p.Ct = e.Ct; p.ct_rows = e.ct_rows; p.ct_ld = e.ct_ld;
   SDXL_REQUIRE(!(ex.cdt == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
-  if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s);
+  if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize);
   launch_igemm(p, ex.cdt, ex.s);
   if (ex.prof) ex.prof->end(ex.s);
 }
