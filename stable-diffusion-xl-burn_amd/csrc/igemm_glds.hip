@@ -16,6 +16,7 @@
 //   * swizzle f(row) = (row>>1)&7 makes the ds_read_b128 fragment reads of 32 rows conflict-free across the four 16-lane
 //     service groups (two 128-byte tile rows share one 256-byte bank row).
 #include "kernels.h"
+#include <type_traits>
 
 namespace sdxl {
 
@@ -31,6 +32,95 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+// ---- shared epilogue.  acc[i][j][reg] of a wave whose tile starts at (mw, nw):  m = mw + i*32 + (lane&31);
+// n = nw + j*32 + 8*(reg>>2) + 4*(lane>>5) + (reg&3)   (weights were the MFMA A operand, activations the B operand)
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int fr, int fh) {
+  const bool geglu = p.act == 1;
+  const int nlim = geglu ? (p.N >> 1) : p.N;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mw + i * 32 + fr;
+    if (m >= p.M) continue;
+    const int bidx = m / p.rpb;
+    const int key = m - bidx * p.rpb;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nt = nw + j * 32;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (geglu && q >= 2) continue;            // gate groups are consumed with their x group
+        const int nb = nt + 8 * q + 4 * fh;       // packed column of element r = 0
+        if (nb >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q * 4 + r];
+        if (p.bias) {
+          const f32x4 bz = *reinterpret_cast<const f32x4*>(p.bias + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bz[r];
+        }
+        if (p.ebias) {
+          const f32x4 ez = *reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx * p.ebias_ld + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += ez[r];
+        }
+        int nout = nb;
+        if (geglu) {
+          f32x4 gz = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) gz = *reinterpret_cast<const f32x4*>(p.bias + nb + 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(acc[i][j][(q + 2) * 4 + r] + gz[r]);
+          nout = (nt >> 1) + 8 * q + 4 * fh;
+        }
+        if (geglu || nb < p.n_split) {
+          const bool vec = nout + 3 < nlim && (nout & 3) == 0;
+          if (p.R) {
+            if (vec && p.r_dt == DT_F16 && (p.ldr & 3) == 0) {
+              const half4 rr = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.R) + (size_t)m * p.ldr + nout);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            } else if (vec && p.r_dt == DT_F32 && (p.ldr & 3) == 0) {
+              const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + nout);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (nout + r < nlim)
+                  v[r] += p.r_dt == DT_F16 ? (float)reinterpret_cast<const half_t*>(p.R)[(size_t)m * p.ldr + nout + r]
+                                           : reinterpret_cast<const float*>(p.R)[(size_t)m * p.ldr + nout + r];
+            }
+          }
+          if (vec && p.c_dt == DT_F16 && (p.ldc & 3) == 0) {
+            half4 h; h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
+            *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + nout) = h;
+          } else if (vec && p.c_dt == DT_F32 && (p.ldc & 3) == 0) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nout) = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (nout + r < nlim) {
+                if (p.c_dt == DT_F16) reinterpret_cast<half_t*>(p.C)[(size_t)m * p.ldc + nout + r] = (half_t)v[r];
+                else reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + nout + r] = v[r];
+              }
+          }
+        } else {
+          // transposed store Ct[b][n - n_split][key]: lanes 0..31 hold 32 consecutive keys of each row
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nb + r < p.N) {
+              const size_t o = ((size_t)bidx * p.ct_rows + (nb + r - p.n_split)) * p.ct_ld + key;
+              if (p.c_dt == DT_F16) reinterpret_cast<half_t*>(p.Ct)[o] = (half_t)v[r];
+              else reinterpret_cast<float*>(p.Ct)[o] = v[r];
+            }
+        }
+      }
+    }
+  }
+}
 
 template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, const void* zeros) {
@@ -174,90 +264,228 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
 
-  // ---- epilogue.  acc[i][j][reg]: m = m_tile + (lane&31); n = n_tile + 8*(reg>>2) + 4*(lane>>5) + (reg&3)
-  const bool geglu = p.act == 1;
-  const int nlim = geglu ? (p.N >> 1) : p.N;
+  igemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, fr, fh);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 8-wave software-pipelined variant (one 512-thread workgroup per CU, two waves per SIMD).
+//
+// Why a second structure: in the 4-wave kernel above every kk-step is {4 ds_read_b128 -> lgkmcnt(0) -> 4 MFMA} on ONE
+// fragment register set and every k-tile starts with vmcnt(0), so LDS latency and DMA latency are both exposed and the
+// matrix pipe idles ~2/3 of the time (measured 25..35 % MFMA utilisation).  Here the k-loop is hand ordered:
+//   * fragments are double buffered in registers: the ds_reads of step kk+1 are issued before the MFMAs of step kk and
+//     waited for with a COUNTED lgkmcnt (hipcc only emits lgkmcnt(0) across the loop back edge, so the reads are inline
+//     asm and every wait is followed by sched_barrier(0) so no MFMA is hoisted above it);
+//   * the ring is NS >= 3 deep and the DMA wait is counted too: at the single barrier of k-tile kt (between its third and
+//     fourth kk-step) a wave waits only for its own pieces of tile kt+1; the pieces of tile kt+NS-1 -- issued two per
+//     kk-step BETWEEN the MFMAs of the first three steps, into the slot the previous barrier freed -- stay in flight
+//     across the raw s_barrier.  After the barrier the first fragments of tile kt+1 are prefetched under the fourth step;
+//   * 256x128 block tile (wave tile 64x64, 4x2 waves): 48 KiB of DMA per 16 MFMA per wave -> 47 B/clk/CU of the 64 B/clk
+//     vector-memory path at full MFMA rate (the 128x128 tile needs all 64); 128x128 (wave tile 32x64) for small grids;
+//   * optional s_setprio(1) around the MFMA clusters so the partner wave's DMA / ds_read issue yields to MFMA issue.
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+template <int OFF> __device__ __forceinline__ half8 lds_read128(unsigned addr) {
+  half8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int BM, int BN, int NS, bool PRIO>
+__global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
+  constexpr int WM = BM / 4, WN = BN / 2;     // wave tile, waves arranged 4 (M) x 2 (N)
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NF = TM + TN;                 // ds_read_b128 per kk-step
+  constexpr int AJ = BM / 64, BJ = BN / 64;   // DMA pieces per wave per k-tile (8 rows each, 8 waves)
+  constexpr int PER = AJ + BJ;
+  constexpr int KT = 64;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(NS >= 3, "counted-wait pipeline needs a ring of at least 3 slots");
+  static_assert(BM * 128 + (TN - 1) * 4096 < 65536, "fragment offsets must fit the ds_read immediate");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  if ((size_t)p.N * p.K > (size_t)p.M * p.Cin) { tn = bid / tilesM; tm = bid - tn * tilesM; }
+  else { tm = bid / tilesN; tn = bid - tm * tilesN; }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- DMA geometry: piece j of this wave covers tile rows (j*8 + wave)*8 .. +7; lane -> (row, slot)
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int HWo = p.Hout * p.Wout;
+  const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+  int rb[AJ], ry[AJ], rx[AJ], rsw[AJ];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * WM + i * 32 + fr;
-    if (m >= p.M) continue;
-    const int bidx = m / p.rpb;
-    const int key = m - bidx * p.rpb;
+  for (int j = 0; j < AJ; ++j) {
+    const int row = (j * 8 + wave) * 8 + lrow;
+    const int m = m0 + row;
+    rsw[j] = (slot ^ ((row >> 1) & 7)) * 8;
+    if (m < p.M) {
+      const int b = m / HWo;
+      const int rem = m - b * HWo;
+      const int oy = rem / p.Wout;
+      rb[j] = b; ry[j] = oy * p.stride - p.pad; rx[j] = (rem - oy * p.Wout) * p.stride - p.pad;
+    } else { rb[j] = -1; ry[j] = -(1 << 28); rx[j] = 0; }
+  }
+  const half_t* Ag = reinterpret_cast<const half_t*>(p.A);
+  const half_t* wptr[BJ];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int nt = n0 + wn * WN + j * 32;
+  for (int j = 0; j < BJ; ++j) {
+    const int row = (j * 8 + wave) * 8 + lrow;
+    wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * 8;
+  }
+  const half_t* aptr[AJ];
+  int aadv[AJ];
+  int s_c0 = 0, s_dy = 0, s_dx = 0;
+  auto retap = [&]() {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (geglu && q >= 2) continue;            // gate groups are consumed with their x group
-        const int nb = nt + 8 * q + 4 * fh;       // packed column of element r = 0
-        if (nb >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q * 4 + r];
-        if (p.bias) {
-          const f32x4 bz = *reinterpret_cast<const f32x4*>(p.bias + nb);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += bz[r];
-        }
-        if (p.ebias) {
-          const f32x4 ez = *reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx * p.ebias_ld + nb);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += ez[r];
-        }
-        int nout = nb;
-        if (geglu) {
-          f32x4 gz = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) gz = *reinterpret_cast<const f32x4*>(p.bias + nb + 16);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(acc[i][j][(q + 2) * 4 + r] + gz[r]);
-          nout = (nt >> 1) + 8 * q + 4 * fh;
-        }
-        if (geglu || nb < p.n_split) {
-          const bool vec = nout + 3 < nlim && (nout & 3) == 0;
-          if (p.R) {
-            if (vec && p.r_dt == DT_F16 && (p.ldr & 3) == 0) {
-              const half4 rr = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(p.R) + (size_t)m * p.ldr + nout);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            } else if (vec && p.r_dt == DT_F32 && (p.ldr & 3) == 0) {
-              const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + nout);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += rr[r];
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (nout + r < nlim)
-                  v[r] += p.r_dt == DT_F16 ? (float)reinterpret_cast<const half_t*>(p.R)[(size_t)m * p.ldr + nout + r]
-                                           : reinterpret_cast<const float*>(p.R)[(size_t)m * p.ldr + nout + r];
-            }
-          }
-          if (vec && p.c_dt == DT_F16 && (p.ldc & 3) == 0) {
-            half4 h; h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
-            *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + nout) = h;
-          } else if (vec && p.c_dt == DT_F32 && (p.ldc & 3) == 0) {
-            f32x4 o = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nout) = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (nout + r < nlim) {
-                if (p.c_dt == DT_F16) reinterpret_cast<half_t*>(p.C)[(size_t)m * p.ldc + nout + r] = (half_t)v[r];
-                else reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + nout + r] = v[r];
-              }
-          }
+    for (int j = 0; j < AJ; ++j) {
+      const int iy = ry[j] + s_dy, ix = rx[j] + s_dx;
+      const bool ok = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
+      const size_t off = (((size_t)(rb[j] < 0 ? 0 : rb[j]) * p.Hin + ((ok ? iy : 0) >> p.up)) * p.Win + ((ok ? ix : 0) >> p.up)) * p.lda + rsw[j];
+      aptr[j] = ok ? Ag + off : reinterpret_cast<const half_t*>(zeros);
+      aadv[j] = ok ? KT : 0;
+    }
+  };
+  retap();
+  // pieces q of one k-tile: q < AJ -> activation piece q, else weight piece q - AJ.  PH selects the pieces with q % 3 == PH
+  // (PH < 0: all of them); the tap walk advances once per k-tile, after the last piece (tile_done).
+  auto issue = [&](int buf, auto PH) {
+    constexpr int ph = decltype(PH)::value;
+    char* la = smem + buf * STAGE + wave * 1024;
+    char* lb = la + BM * 128;
+    static_for<PER>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      if constexpr (ph < 0 || q % 3 == ph) {
+        if constexpr (q < AJ) {
+          __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(la + q * 8192), 16, 0, 0);
+          aptr[q] += aadv[q];
         } else {
-          // transposed store Ct[b][n - n_split][key]: lanes 0..31 hold 32 consecutive keys of each row
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (nb + r < p.N) {
-              const size_t o = ((size_t)bidx * p.ct_rows + (nb + r - p.n_split)) * p.ct_ld + key;
-              if (p.c_dt == DT_F16) reinterpret_cast<half_t*>(p.Ct)[o] = (half_t)v[r];
-              else reinterpret_cast<float*>(p.Ct)[o] = v[r];
-            }
+          __builtin_amdgcn_global_load_lds((gptr_t)wptr[q - AJ], (lptr_t)(lb + (q - AJ) * 8192), 16, 0, 0);
+          wptr[q - AJ] += KT;
         }
       }
+    });
+  };
+  auto tile_done = [&]() {
+    s_c0 += KT;
+    if (s_c0 == p.Cin) {
+      s_c0 = 0;
+      if (++s_dx == p.ksize) { s_dx = 0; ++s_dy; }
+      retap();
     }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.Kpad / KT;
+  const int fr = lane & 31, fh = lane >> 5;
+  // per-lane fragment address inside a stage: A rows wm*WM + i*32 + fr (i -> +4096 B immediate), B rows likewise behind
+  // the A tile.  sw(row) = (row>>1)&7 is the same for rows 32 apart, so one base per operand; step kk flips chunk bits
+  // 1..2:  chunk(kk) = (kk*2 + fh) ^ sw = (fh ^ sw) ^ (kk << 1)  ->  byte offset ^ (kk << 5)
+  unsigned basea, baseb;
+  {
+    const int ra = wm * WM + fr, rbw = wn * WN + fr;
+    basea = lds0 + ra * 128 + ((fh ^ ((ra >> 1) & 7)) << 4);
+    baseb = lds0 + BM * 128 + rbw * 128 + ((fh ^ ((rbw >> 1) & 7)) << 4);
   }
+  half8 fA[2][TM], fB[2][TN];
+  auto ldfrag = [&](unsigned so, int kk, auto SET) {
+    constexpr int set = decltype(SET)::value;
+    const unsigned aa = (basea ^ (kk << 5)) + so, ab = (baseb ^ (kk << 5)) + so;
+    static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<decltype(I)::value * 4096>(aa); });
+    static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<decltype(J)::value * 4096>(ab); });
+  };
+  // MFMAs of one kk-step from fragment set SET; DMA pieces PH (or none, PH = 3) are issued between them
+  auto mma = [&](auto SET, int buf, auto PH, bool more) {
+    constexpr int set = decltype(SET)::value;
+    constexpr int ph = decltype(PH)::value;
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][0], fA[set][0], acc[0][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ph < 3) {
+      if (more) issue(buf, PH);            // wave-uniform branch around the DMA pieces only, never around MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][j], fA[set][i], acc[i][j], 0, 0, 0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using IALL = std::integral_constant<int, -1>;
+
+  // ---- prologue: tiles 0 .. NS-2 in flight, wait for tile 0 only
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) { issue(s, IALL{}); tile_done(); }
+  if (NS - 1 <= nk) wait_vmcnt<PER * (NS - 2)>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  ldfrag(0, 0, I0{});
+  int cur = 0;                      // ring slot of tile kt
+  int fill = NS - 1;                // ring slot tile kt+NS-1 goes to (the slot tile kt-1 occupied)
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned so = cur * STAGE;
+    const int nslot = cur + 1 == NS ? 0 : cur + 1;
+    const bool more = kt + NS - 1 < nk;           // tile kt+NS-1 exists -> stage it during steps 0..2 (uniform)
+    ldfrag(so, 1, I1{});
+    wait_lgkmcnt<NF>();
+    mma(I0{}, fill, I0{}, more);
+    ldfrag(so, 2, I0{});
+    wait_lgkmcnt<NF>();
+    mma(I1{}, fill, I1{}, more);
+    ldfrag(so, 3, I1{});
+    wait_lgkmcnt<NF>();
+    mma(I0{}, fill, I2{}, more);
+    if (more) tile_done();
+    if (kt + 1 < nk) {
+      // own pieces of tile kt+1 landed (tiles kt+2 .. kt+NS-1 may stay in flight); own reads of tile kt complete
+      if (more) wait_vmcnt<PER * (NS - 2)>(); else wait_vmcnt<0>();
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      ldfrag(nslot * STAGE, 0, I0{});
+    } else {
+      wait_lgkmcnt<0>();
+    }
+    mma(I1{}, fill, I3{}, false);
+    fill = cur;
+    cur = nslot;
+  }
+  igemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, fr, fh);
 }
 
 static const void* g_zero_page = nullptr;
@@ -280,6 +508,19 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
+}
+
+template <int BM, int BN, int NS, bool PRIO>
+static void launch_pipe(const IgemmParams& p, hipStream_t s) {
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
+  const size_t lds = (size_t)NS * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_page);
 }
 
 // variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
@@ -307,6 +548,11 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 6: launch_glds<64, 128, 2>(p, s); break;
     case 7: launch_glds<128, 128, 4>(p, s); break;
     case 8: launch_glds<64, 128, 3>(p, s); break;
+    case 10: launch_pipe<256, 128, 3, false>(p, s); break;   // 8-wave pipelined kernels
+    case 11: launch_pipe<256, 128, 3, true>(p, s); break;
+    case 12: launch_pipe<128, 128, 4, false>(p, s); break;
+    case 13: launch_pipe<128, 128, 4, true>(p, s); break;
+    case 14: launch_pipe<128, 128, 3, true>(p, s); break;
     default: return false;
   }
   return true;

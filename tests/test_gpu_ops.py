@@ -148,3 +148,66 @@ def test_qkv_attention_online_softmax_rescale(pkg, ctx):
 
 def test_attn_decoder_mask(pkg, ctx):
     assert torch.equal(pkg.attn_decoder_mask(ctx, 77).cpu(), OM.attn_decoder_mask(77))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# every fast-path implicit-GEMM tile / pipeline variant is forced in turn over shapes that exercise: fewer k-tiles than
+# ring slots, ragged M / N tiles, GEGLU pairs, 3x3 taps with halo zero-fill, stride 2 and the fused nearest-2x gather
+IGEMM_VARIANTS = [4, 6, 1, 8, 10, 11, 12, 13, 14]
+
+
+@pytest.fixture
+def igemm_variant(pkg):
+    def set_variant(v):
+        pkg.debug_set("igemm_variant", v)
+    yield set_variant
+    pkg.debug_set("igemm_variant", 0)
+
+
+@pytest.mark.parametrize("variant", IGEMM_VARIANTS)
+def test_igemm_variants_linear(pkg, ctx, igemm_variant, variant):
+    igemm_variant(variant)
+    for (M, K, N, geglu) in [(300, 640, 320, False), (2048, 64, 128, False), (520, 128, 200, False), (257, 192, 136, False),
+                             (300, 640, 640, True), (1024, 1280, 512, True), (4096, 320, 1280, False)]:
+        x = seeded(M, K, seed=40)
+        w = seeded(K, N, seed=41) / math.sqrt(K)
+        b = 0.1 * seeded(N, seed=42)
+        pr = x @ w + b
+        ref = pr[:, : N // 2] * F.gelu(pr[:, N // 2:]) if geglu else pr
+        out = pkg.linear(ctx, x.cuda(), w.cuda(), b.cuda(), geglu, 1)
+        e = rel_err(out, ref)
+        assert e < TOL[1] * (2 if geglu else 1), f"variant {variant} M={M} K={K} N={N} geglu={geglu}: rel err {e}"
+
+
+@pytest.mark.parametrize("variant", IGEMM_VARIANTS)
+def test_igemm_variants_conv(pkg, ctx, igemm_variant, variant):
+    igemm_variant(variant)
+    for (B, Cin, H, W, Cout, k, stride, pad, up) in [(1, 128, 20, 20, 192, 3, 1, 1, False), (2, 64, 16, 16, 64, 3, 2, 1, False),
+                                                     (2, 64, 8, 8, 64, 3, 1, 1, True), (1, 320, 32, 32, 320, 3, 1, 1, False),
+                                                     (1, 128, 9, 7, 64, 1, 1, 0, False), (2, 192, 17, 13, 128, 3, 1, 1, False)]:
+        x = seeded(B, Cin, H, W, seed=43)
+        w = seeded(Cout, Cin, k, k, seed=44) / math.sqrt(Cin * k * k)
+        b = 0.1 * seeded(Cout, seed=45)
+        xi = OM.upsample_nearest2x(x) if up else x
+        ref = F.conv2d(xi, w, b, stride=stride, padding=pad)
+        out = pkg.conv2d(ctx, x.cuda(), w.cuda(), b.cuda(), stride, pad, up, 1)
+        e = rel_err(out, ref)
+        assert e < TOL[1], f"variant {variant} conv {(B, Cin, H, W, Cout, k, stride, pad, up)}: rel err {e}"
+
+
+@pytest.mark.parametrize("variant", [11, 13])
+def test_igemm_variants_unet(pkg, ctx, igemm_variant, variant):
+    # residual / time-embedding / transposed-V^T epilogues of the pipelined kernels, through a whole tiny UNet
+    from util import to_pkg_cfg, unet_weights
+    igemm_variant(variant)
+    ocfg = OC.tiny_config()
+    W = unet_weights(ocfg)
+    B, H, Wd = 2, 16, 16
+    x = torch.from_numpy(OC.arb_tensor(B, 4, H, Wd))
+    context = torch.from_numpy(OC.arb_tensor(B, 5, ocfg.context_dim))
+    y = torch.from_numpy(OC.arb_tensor(B, ocfg.adm_in_channels))
+    t = torch.tensor([999, 1], dtype=torch.int32)
+    ref = OM.unet_forward(ocfg, W, x, t.long(), context, y)
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), 1, seed=0)
+    out = u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu()
+    assert rel_err(out, ref) < 3e-2
