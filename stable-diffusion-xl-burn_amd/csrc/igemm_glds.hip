@@ -496,7 +496,13 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BM, int BN, int NS, bool PRIO>
+// DMODE: 0 = pieces of tile kt+NS-1 spread over the first three kk-steps of k-tile kt (slot freed by the previous barrier);
+//        1 = pieces of tile kt+NS issued right after the barrier of k-tile kt, between the MFMAs of its fourth kk-step
+//            (slot freed by THIS barrier; prefetch distance ~NS-1 full k-tiles instead of ~NS-2 + 1/3);
+//        2 = measurement only: as 1 but the DMA sources never advance along k (every k-tile re-reads the block's first
+//            one from L2) -- the compute-only ceiling of the loop.  Results are wrong by construction.
+//        3 = measurement only: as 1 but NO DMA is issued inside the loop at all (ds_read + MFMA + barrier only).
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0>
 __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
   constexpr int WM = BM / 4, WN = BN / 2;     // wave tile, waves arranged 4 (M) x 2 (N)
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -573,18 +579,21 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     char* lb = la + BM * 128;
     static_for<PER>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
-      if constexpr (ph < 0 || q % 3 == ph) {
+      constexpr int NM = TM * TN;                                   // MFMAs per kk-step
+      constexpr int PPG = (PER + (NM > 1 ? NM - 2 : 0)) / (NM > 1 ? NM - 1 : 1);   // pieces per MFMA gap (early mode)
+      if constexpr (ph < 0 || (ph < 3 && q % 3 == ph) || (ph >= 10 && q / PPG == ph - 10)) {
         if constexpr (q < AJ) {
           __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(la + q * 8192), 16, 0, 0);
-          aptr[q] += aadv[q];
+          if constexpr (DMODE != 2) aptr[q] += aadv[q];
         } else {
           __builtin_amdgcn_global_load_lds((gptr_t)wptr[q - AJ], (lptr_t)(lb + (q - AJ) * 8192), 16, 0, 0);
-          wptr[q - AJ] += KT;
+          if constexpr (DMODE != 2) wptr[q - AJ] += KT;
         }
       }
     });
   };
   auto tile_done = [&]() {
+    if constexpr (DMODE == 2) return;
     s_c0 += KT;
     if (s_c0 == p.Cin) {
       s_c0 = 0;
@@ -630,23 +639,33 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
       if (more) issue(buf, PH);            // wave-uniform branch around the DMA pieces only, never around MFMAs
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][j], fA[set][i], acc[i][j], 0, 0, 0);
+    if constexpr (ph == 4) {               // early mode: gap 0 pieces here, gap g pieces after MFMA g
+      if (more) issue(buf, std::integral_constant<int, 10>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<TM * TN - 1>([&](auto X) {
+      constexpr int x = decltype(X)::value + 1, i = x / TN, j = x % TN;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][j], fA[set][i], acc[i][j], 0, 0, 0);
+      if constexpr (ph == 4 && x < TM * TN - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(buf, std::integral_constant<int, 10 + x>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
   using IALL = std::integral_constant<int, -1>;
+  constexpr int NPRO = DMODE == 0 ? NS - 1 : NS;   // tiles staged by the prologue
 
-  // ---- prologue: tiles 0 .. NS-2 in flight, wait for tile 0 only
+  // ---- prologue: tiles 0 .. NPRO-1 in flight, wait for tile 0 only
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
+  for (int s = 0; s < NPRO; ++s)
     if (s < nk) { issue(s, IALL{}); tile_done(); }
-  if (NS - 1 <= nk) wait_vmcnt<PER * (NS - 2)>(); else wait_vmcnt<0>();
+  if (NPRO <= nk) wait_vmcnt<PER * (NPRO - 1)>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -656,17 +675,17 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned so = cur * STAGE;
     const int nslot = cur + 1 == NS ? 0 : cur + 1;
-    const bool more = kt + NS - 1 < nk;           // tile kt+NS-1 exists -> stage it during steps 0..2 (uniform)
+    const bool more = kt + NS - 1 < nk;           // tile kt+NS-1 exists (uniform): DMODE 0 stages it during steps 0..2
+    const bool more1 = DMODE == 3 ? false : kt + NS < nk;   // tile kt+NS exists: DMODE 1 stages it after this k-tile's barrier
     ldfrag(so, 1, I1{});
     wait_lgkmcnt<NF>();
-    mma(I0{}, fill, I0{}, more);
+    if constexpr (DMODE == 0) mma(I0{}, fill, I0{}, more); else mma(I0{}, fill, I3{}, false);
     ldfrag(so, 2, I0{});
     wait_lgkmcnt<NF>();
-    mma(I1{}, fill, I1{}, more);
+    if constexpr (DMODE == 0) mma(I1{}, fill, I1{}, more); else mma(I1{}, fill, I3{}, false);
     ldfrag(so, 3, I1{});
     wait_lgkmcnt<NF>();
-    mma(I0{}, fill, I2{}, more);
-    if (more) tile_done();
+    if constexpr (DMODE == 0) { mma(I0{}, fill, I2{}, more); if (more) tile_done(); } else mma(I0{}, fill, I3{}, false);
     if (kt + 1 < nk) {
       // own pieces of tile kt+1 landed (tiles kt+2 .. kt+NS-1 may stay in flight); own reads of tile kt complete
       if (more) wait_vmcnt<PER * (NS - 2)>(); else wait_vmcnt<0>();
@@ -678,7 +697,8 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     } else {
       wait_lgkmcnt<0>();
     }
-    mma(I1{}, fill, I3{}, false);
+    if constexpr (DMODE == 0) mma(I1{}, fill, I3{}, false);
+    else { mma(I1{}, cur, I4{}, more1); if (more1) tile_done(); }
     fill = cur;
     cur = nslot;
   }
@@ -709,17 +729,17 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
 }
 
-template <int BM, int BN, int NS, bool PRIO>
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NS * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_page);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_page);
 }
 
 // variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
@@ -732,11 +752,17 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if (p.ebias && (p.ebias_ld & 3) != 0) return false;
   // the DMA reads weight rows up to the tile edge: Npad is a multiple of 128 for every packed weight (pack_* kernels)
   if (variant == 0) {
-    // measured on MI355X (tools/igemm_sweep.py, profiles/r01_igemm_sweep.txt): the 2-deep ring at 2..4 blocks/CU beats the
-    // deeper rings (occupancy hides latency better than prefetch depth at these sizes); 128x128 tiles once there are
-    // >= ~1.5 tiles per CU, 64x128 below that (the M=2048 / N=1280 transformer GEMMs and the 32^2 / 64^2 convs).
+    // measured on MI355X (tools/igemm_sweep.py, profiles/r01_igemm_sweep.txt).  The global->LDS path sustains ~22 B/clk/CU,
+    // so the MFMA rate of a tile is ~ BM*BN/(BM+BN) flop per DMA byte: 256x128 (8 waves, pipelined) beats 128x128 wherever
+    // its grid still fills the chip; grids of <= 256 tiles run as ONE round, where the 8-wave 128x128 pipeline (one
+    // workgroup per CU, counted waits) beats two co-resident 4-wave blocks; ragged multi-round grids keep the 4-wave kernels
+    // (2..3 co-resident blocks per CU smooth the tail).
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    variant = t128 >= 400 ? 4 : 6;
+    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+    const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+    if (t128 <= 256) variant = 13;
+    else if (t256 <= 256 || eff256 >= 0.8) variant = 11;
+    else variant = t128 >= 400 ? 4 : 6;
   }
   switch (variant) {
     case 1: launch_glds<128, 128, 3>(p, s); break;
@@ -752,6 +778,10 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 12: launch_pipe<128, 128, 4, false>(p, s); break;
     case 13: launch_pipe<128, 128, 4, true>(p, s); break;
     case 14: launch_pipe<128, 128, 3, true>(p, s); break;
+    case 15: launch_pipe<256, 128, 3, true, 1>(p, s); break;    // early DMA issue (after the barrier)
+    case 16: launch_pipe<128, 128, 4, true, 1>(p, s); break;
+    case 17: launch_pipe<256, 128, 3, true, 2>(p, s); break;    // measurement only: no k advance (WRONG results)
+    case 18: launch_pipe<256, 128, 3, true, 3>(p, s); break;    // measurement only: no DMA in the loop (WRONG results)
     default: return false;
   }
   return true;
