@@ -175,6 +175,8 @@ int sdxl_unet_profile(sdxl_unet* u, void* stream, int B, int H, int W, float cla
  * on seeded random f16 data; avg_ms = mean launch duration over `iters` back-to-back launches (hipEvents) */
 int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, int Cout, int ksize, int geglu, int iters,
                      float* avg_ms);
+/* times the fused attention kernel alone (head dim 64, f16) on seeded random data: B*H heads, Nq queries, Nk keys */
+int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int Nk, int iters, float* avg_ms);
 /* benchmarking / debugging knobs ("igemm_variant": -1 generic kernel only, 0 auto, 1..3 forced fast-path tile) */
 int sdxl_debug_set(const char* key, int value);
 

@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "sdxl_vae_create", "sdxl_vae_create_synthetic", "sdxl_vae_destroy", "sdxl_vae_decode_latent",
     "sdxl_latent_to_image", "sdxl_vae_encode_image", "sdxl_image_to_latent",
     "sdxl_unet_weight_arena", "sdxl_vae_weight_arena", "sdxl_diffuser_create_empty", "sdxl_vae_create_empty",
-    "sdxl_unet_profile", "sdxl_bench_igemm", "sdxl_debug_set",
+    "sdxl_unet_profile", "sdxl_bench_igemm", "sdxl_bench_attention", "sdxl_debug_set",
     "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear",
 ]
 
@@ -355,6 +355,13 @@ def bench_igemm(ctx: "Context", B: int, H: int, W: int, Cin: int, Cout: int, ksi
     """mean launch duration (ms) of the implicit-GEMM kernel alone on seeded random f16 data"""
     ms = ctypes.c_float()
     _check(lib().sdxl_bench_igemm(ctx.h, None, B, H, W, Cin, Cout, ksize, int(geglu), iters, ctypes.byref(ms)))
+    return float(ms.value)
+
+
+def bench_attention(ctx: "Context", B: int, H: int, Nq: int, Nk: int, iters: int = 20) -> float:
+    """mean launch duration (ms) of the fused d=64 f16 attention kernel alone on seeded random data"""
+    ms = ctypes.c_float()
+    _check(lib().sdxl_bench_attention(ctx.h, None, B, H, Nq, Nk, iters, ctypes.byref(ms)))
     return float(ms.value)
 
 

@@ -418,6 +418,183 @@ __global__ __launch_bounds__(256) void attn_d64_f16_kernel(const AttnParams p, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// f16 production variant 2 (no additive mask): 32x32x16 MFMA, deferred running max, 3-slot DMA ring, coalesced output.
+//   * S^T = K Q^T with v_mfma_f32_32x32x16_f16: a lane owns ONE query (lane&31) and 32 of the tile's 64 keys, its partner
+//     lane^32 the other 32 -> the row max is 16 v_max3 in-lane; the cross-lane exchange and the O / l rescale only run when
+//     some query's tile max exceeds the running reference by more than 2^THR (wave-uniform vote).  Between such events the
+//     reference m is folded into the accumulator init (acc = -m), so the MFMA output is already s - m and the per-score
+//     work is one v_exp_f32, one add and half a cvt_pk.  P <= 2^THR fits fp16 with full relative precision; l and O are fp32.
+//   * P stays in registers as the B operand of O^T = V^T P^T (key order of a k-step = the two 4-key runs a lane holds).
+//   * K / V^T tiles: global_load_lds into a 3-slot ring, counted vmcnt (two tiles in flight), one raw barrier per tile.
+//   * O is normalised, parked in LDS per wave and written as whole 128-byte rows.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void attn_d64_v2_kernel(const AttnParams p, const void* zeros) {
+  constexpr int KV = 64, TILE = 64 * 128, NS = 3;
+  constexpr float THR = 8.0f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][K tile | V^T tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const half_t* Qg = reinterpret_cast<const half_t*>(p.Q) + (size_t)b * p.Nq * p.ldq + hd * 64;
+  const half_t* Kg = reinterpret_cast<const half_t*>(p.K) + (size_t)b * p.Nk * p.ldk + hd * 64;
+  const half_t* Vg = reinterpret_cast<const half_t*>(p.Vt) + ((size_t)b * p.H + hd) * 64 * p.vt_ld;
+  const float sc = p.scale * 1.44269504088896340736f;
+
+  // Q fragments (B operand of S^T): query = q0 + fr, d = ks*16 + h*8 .. +7, pre-multiplied by scale*log2(e)
+  half8 qf[4];
+  {
+    const int q = q0 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      half8 v = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < p.Nq) v = *reinterpret_cast<const half8*>(Qg + (size_t)q * p.ldq + ks * 16 + h * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * sc);
+      qf[ks] = v;
+    }
+  }
+  // DMA geometry: wave w stages tile rows [16w, 16w+16) of K and of V^T, two 1-KiB pieces each
+  const int lrow = lane >> 3, slot = lane & 7;
+  auto stage = [&](int t, int buf) {
+    const int k0 = t * KV;
+    char* lk = smem + buf * 2 * TILE + wave * 2048;
+    char* lv = lk + TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wave * 16 + j * 8 + lrow;
+      const int key = k0 + row;
+      const half_t* ks = key < p.Nk ? Kg + (size_t)key * p.ldk + (slot ^ ((row >> 1) & 7)) * 8 : reinterpret_cast<const half_t*>(zeros);
+      __builtin_amdgcn_global_load_lds((agptr_t)ks, (alptr_t)(lk + j * 1024), 16, 0, 0);
+      const half_t* vs = Vg + (size_t)row * p.vt_ld + k0 + (slot ^ ((row ^ (row >> 3)) & 7)) * 8;   // rows zero padded to vt_ld
+      __builtin_amdgcn_global_load_lds((agptr_t)vs, (alptr_t)(lv + j * 1024), 16, 0, 0);
+    }
+  };
+  // fragment byte offsets inside a tile
+  int koff[2], voff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = u * 32 + fr;
+    koff[u] = row * 128 + ((h ^ ((row >> 1) & 7)) << 4);          // K chunk of k-step ks: ^ (ks << 5)
+    voff[u] = row * 128;                                           // V^T row dt*32 + fr; chunk swizzle below
+  }
+  const int vsw[2] = {(fr ^ (fr >> 3)) & 7, ((32 + fr) ^ ((32 + fr) >> 3)) & 7};
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m = 0.f, l = 0.f;
+  const int nt = (p.Nk + KV - 1) / KV;
+  stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < nt) stage(t + 2, cur == 0 ? 2 : cur - 1);       // slot of tile t-1
+    const char* kb = smem + cur * 2 * TILE;
+    const char* vb = kb + TILE;
+    // ---- S^T - m
+    f32x16 sv[2];
+    const float init = t == 0 ? 0.f : -m;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[u][r] = init;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const half8 kf = *reinterpret_cast<const half8*>(kb + (koff[u] ^ (ks << 5)));
+        sv[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sv[u], 0, 0, 0);
+      }
+    if (t == nt - 1 && (p.Nk & 63) != 0) {                      // key tail (wave-uniform branch)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * KV + u * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= p.Nk) sv[u][r] = -INFINITY;
+    }
+    float lmax = sv[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) lmax = fmaxf(lmax, sv[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lmax = fmaxf(lmax, sv[1][r]);
+    if (t == 0 || __any(lmax > THR)) {                          // rare after the first tiles; wave-uniform
+      const float pm = fmaxf(lmax, __shfl_xor(lmax, 32));
+      const float delta = t == 0 ? pm : fmaxf(pm, 0.f);         // never lower the reference
+      const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+      m = t == 0 ? delta : m + delta;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[u][r] -= delta;
+    }
+    // ---- P = exp2(S - m), row sums, fp16 B fragments: k-step s4 = u*2 + hf holds registers 8*hf .. 8*hf+7 of key tile u
+    half8 pf[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        half8 hh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(sv[u][8 * hf + e]);
+          l += pe;
+          hh[e] = (half_t)pe;
+        }
+        pf[u * 2 + hf] = hh;
+      }
+    // ---- O^T += V^T P^T: k-step s4 covers keys base + {4h..4h+3, 8+4h..8+4h+3}, base = u*32 + 16*hf
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int base = (s4 >> 1) * 32 + (s4 & 1) * 16;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int b1 = (base + 4 * h) * 2, b2 = b1 + 16;           // byte offsets of the two 4-key runs in the row
+        const i32x2 v1 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b1 >> 4)) ^ vsw[dt]) << 4) + (b1 & 15));
+        const i32x2 v2 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b2 >> 4)) ^ vsw[dt]) << 4) + (b2 & 15));
+        const i32x4 vf = i32x4{v1[0], v1[1], v2[0], v2[1]};
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, vf), pf[s4], o[dt], 0, 0, 0);
+      }
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  // ---- normalise, park per wave in LDS ([query][d] fp16, 16-byte chunks swizzled by query&7), store whole rows
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+  __syncthreads();
+  char* ob = smem + wave * 4096;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      half4 hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hv[r] = (half_t)(o[dt][g * 4 + r] * inv);
+      *reinterpret_cast<half4*>(ob + fr * 128 + (((dt * 4 + g) ^ (fr & 7)) << 4) + 8 * h) = hv;
+    }
+  half_t* Og = reinterpret_cast<half_t*>(p.O) + (size_t)b * p.Nq * p.ldo + hd * 64;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3), piece = lane & 7;
+    const i32x4 v = *reinterpret_cast<const i32x4*>(ob + row * 128 + ((piece ^ (row & 7)) << 4));
+    const int q = q0 + row;
+    if (q < p.Nq) *reinterpret_cast<i32x4*>(Og + (size_t)q * p.ldo + piece * 8) = v;
+  }
+}
+
 static const void* g_attn_zero = nullptr;
 static int g_attn_variant = 0;   // -1: generic kernel only
 void attention_set_variant(int v) { g_attn_variant = v; }
@@ -434,6 +611,10 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
   const bool aligned = ((p.ldq | p.ldk | p.vt_ld | p.ldo) & 7) == 0 &&
                        ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
                          reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) == 0;
+  if (p.dt == DT_F16 && (g_attn_variant == 0 || g_attn_variant == 2) && g_attn_zero && aligned && !p.mask) {
+    hipLaunchKernelGGL(attn_d64_v2_kernel, grid, dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
+    return;
+  }
   if (p.dt == DT_F16 && g_attn_variant >= 0 && g_attn_zero && aligned) {
     hipLaunchKernelGGL(attn_d64_f16_kernel, grid, dim3(256), 4 * 64 * 128, s, p, g_attn_zero);
     return;

@@ -162,6 +162,40 @@ int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, 
   *avg_ms = ms / iters;
   API_END
 }
+int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int Nk, int iters, float* avg_ms) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && avg_ms && iters > 0, "bad argument");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  Tmp tmp;
+  const int C = H * 64, npad = (int)round_up(Nk, 64);
+  float* src = (float*)tmp.get((size_t)B * std::max(Nq, npad) * C * sizeof(float));
+  void* q = tmp.get((size_t)B * Nq * C * 2);
+  void* k = tmp.get((size_t)B * Nk * C * 2);
+  void* vt = tmp.get((size_t)B * C * npad * 2);
+  void* o = tmp.get((size_t)B * Nq * C * 2);
+  launch_synth_fill(src, (size_t)B * Nq * C, 0x51, 3.4641f, 0.f, s);
+  launch_copy_rows(src, DT_F32, C, q, DT_F16, C, B * Nq, C, s);
+  launch_synth_fill(src, (size_t)B * Nk * C, 0x52, 3.4641f, 0.f, s);
+  launch_copy_rows(src, DT_F32, C, k, DT_F16, C, B * Nk, C, s);
+  launch_synth_fill(src, (size_t)B * C * npad, 0x53, 3.4641f, 0.f, s);
+  launch_copy_rows(src, DT_F32, npad, vt, DT_F16, npad, B * C, npad, s);   // random V^T (padding columns included: timing only)
+  AttnParams p{};
+  p.Q = q; p.ldq = C; p.K = k; p.ldk = C; p.Vt = vt; p.vt_ld = npad; p.O = o; p.ldo = C;
+  p.dt = DT_F16; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+  for (int i = 0; i < 3; ++i) launch_attention_d64(p, s);
+  hipEvent_t a, b;
+  SDXL_HIP(hipEventCreate(&a)); SDXL_HIP(hipEventCreate(&b));
+  SDXL_HIP(hipEventRecord(a, s));
+  for (int i = 0; i < iters; ++i) launch_attention_d64(p, s);
+  SDXL_HIP(hipEventRecord(b, s));
+  SDXL_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  SDXL_HIP(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  *avg_ms = ms / iters;
+  API_END
+}
 void sdxl_ctx_destroy(sdxl_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamDestroy(c->stream);

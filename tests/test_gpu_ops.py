@@ -136,14 +136,36 @@ def test_qkv_attention(pkg, ctx, dtype, B, Nq, Nk, C, heads, masked):
     assert rel_err(out, ref) < (1e-4 if dtype == 0 else 6e-3)
 
 
-def test_qkv_attention_online_softmax_rescale(pkg, ctx):
-    # one key far above the rest in a LATE tile forces the running-max rescale branch (guide rule 26)
-    B, N, C = 1, 256, 64
+@pytest.mark.parametrize("dtype,variant", [(0, 0), (1, 0), (1, 1), (1, 2)])
+def test_qkv_attention_online_softmax_rescale(pkg, ctx, dtype, variant):
+    # keys far above the rest in LATE tiles force the running-max rescale branch (guide rule 26): for the deferred-max
+    # f16 kernel both the "exceeds the threshold" path (spikes) and the "stays below it" path (all other tiles) run
+    B, N, C = 1, 320, 64
     q, k, v = seeded(B, N, C, seed=19), seeded(B, N, C, seed=20), seeded(B, N, C, seed=21)
     k[0, 200] = q[0, 3] * 6.0
+    k[0, 290] = q[0, 77] * 2.5
+    k[0, 10] = q[0, 130] * 9.0        # spike in the FIRST tile: later tiles sit far below the reference
     ref = OM.qkv_attention(q, k, v, None, 1)
-    out = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, 1, 0)
-    assert rel_err(out, ref) < 1e-4
+    pkg.debug_set("attn_variant", variant)
+    try:
+        out = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, 1, dtype)
+    finally:
+        pkg.debug_set("attn_variant", 0)
+    assert rel_err(out, ref) < (1e-4 if dtype == 0 else 6e-3)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("B,Nq,Nk,C,heads", [(2, 256, 256, 128, 2), (2, 300, 77, 640, 10), (1, 1024, 1024, 1280, 20),
+                                             (1, 130, 200, 64, 1), (2, 64, 1, 64, 1)])
+def test_qkv_attention_f16_variants(pkg, ctx, variant, B, Nq, Nk, C, heads):
+    q, k, v = seeded(B, Nq, C, seed=16), seeded(B, Nk, C, seed=17), seeded(B, Nk, C, seed=18)
+    ref = OM.qkv_attention(q, k, v, None, heads)
+    pkg.debug_set("attn_variant", variant)
+    try:
+        out = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, heads, 1)
+    finally:
+        pkg.debug_set("attn_variant", 0)
+    assert rel_err(out, ref) < 6e-3
 
 
 def test_attn_decoder_mask(pkg, ctx):

@@ -19,6 +19,7 @@ for p in $PARTS; do
         find /tmp/pmc$i -name '*counter_collection*' -exec cp {} $OUT/pmc_${PMC_TAG:-x}_$i.csv \;
       done; ls $OUT;;
     ksweep) timeout 600 python tools/igemm_ksweep.py ${KSWEEP_VARIANTS:-0,11} > $OUT/ksweep.txt 2>&1; cat $OUT/ksweep.txt;;
+    attn) timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "attention or geglu" > $OUT/attn_tests.log 2>&1; tail -3 $OUT/attn_tests.log; timeout 300 python tools/attn_bench.py ${ATTN_VARIANTS:-1,2} > $OUT/attn_bench.txt 2>&1; cat $OUT/attn_bench.txt;;
     tests) timeout 900 python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; echo "tests rc=$?" >> $OUT/tests.log; tail -3 $OUT/tests.log;;
     sweep) timeout 600 python tools/igemm_sweep.py ${SWEEP_VARIANTS:--1,0,4,6,1,8} > $OUT/igemm_sweep.txt 2>&1; tail -25 $OUT/igemm_sweep.txt;;
     prof)  SDXL_PROFILE_DUMP=$OUT/step_launches.csv timeout 600 python tools/profile_step.py > $OUT/profile_step.txt 2>&1; tail -3 $OUT/profile_step.txt;;
