@@ -42,7 +42,7 @@ template <> struct AMma<float> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_d64_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_d64_kernel(const AttnParams p) {
   constexpr int D = 64, KV = 64, MQ = 2;
   constexpr int CE = 16 / sizeof(T);           // elements per 16-byte chunk
   constexpr int RB = 64 * sizeof(T);           // bytes per tile row (K: 64 d, V^T: 64 keys)
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const AttnParams p) {
 typedef const __attribute__((address_space(1))) void* agptr_t;
 typedef __attribute__((address_space(3))) void* alptr_t;
 
-__global__ __launch_bounds__(256) void attn_d64_f16_kernel(const AttnParams p, const void* zeros) {
+__global__ __launch_bounds__(256, 2) void attn_d64_f16_kernel(const AttnParams p, const void* zeros) {
   constexpr int D = 64, KV = 64, MQ = 2, TILE = 64 * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -430,15 +430,29 @@ __global__ __launch_bounds__(256) void attn_d64_f16_kernel(const AttnParams p, c
 //   * O is normalised, parked in LDS per wave and written as whole 128-byte rows.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void attn_d64_v2_kernel(const AttnParams p, const void* zeros) {
-  constexpr int KV = 64, TILE = 64 * 128, NS = 3;
+template <int NS>
+// launch bound 2 waves/SIMD: with a 256-register budget hipcc keeps the MFMA accumulators in VGPRs; at the default
+// bound it parks S and O in AGPRs and pays ~240 v_accvgpr_read/write per 64-key tile around the softmax (measured: VALU
+// active 1370 cycles per wave-tile, 2.7x the MFMA time)
+__global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p, const void* zeros) {
+  constexpr int KV = 64, TILE = 64 * 128;
   constexpr float THR = 8.0f;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // 1-D grid, XCD-aware: hardware block b runs on XCD b % 8; remap so that every XCD owns a CONTIGUOUS range of logical
+  // ids = whole heads (all query blocks of a head), i.e. a head's K / V^T (2 x Nk x 128 B) is fetched into ONE XCD's L2
+  // and re-read there by its Nq/128 query blocks, instead of every XCD streaming every head from the Infinity Cache.
+  const int nqb = (p.Nq + 127) / 128;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bh = bid / nqb, qb = bid - bh * nqb;
+  const int b = bh / p.H, hd = bh - b * p.H;
+  const int q0 = qb * 128 + wave * 32;
   const half_t* Qg = reinterpret_cast<const half_t*>(p.Q) + (size_t)b * p.Nq * p.ldq + hd * 64;
   const half_t* Kg = reinterpret_cast<const half_t*>(p.K) + (size_t)b * p.Nk * p.ldk + hd * 64;
   const half_t* Vg = reinterpret_cast<const half_t*>(p.Vt) + ((size_t)b * p.H + hd) * 64 * p.vt_ld;
@@ -490,14 +504,17 @@ __global__ __launch_bounds__(256) void attn_d64_v2_kernel(const AttnParams p, co
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = 0.f, l = 0.f;
   const int nt = (p.Nk + KV - 1) / KV;
-  stage(0, 0);
-  if (nt > 1) stage(1, 1);
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nt) stage(s0, s0);
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // own pieces of tile t landed; tiles t+1 .. t+NS-2 (4 pieces each) may stay in flight
+    if (t + NS - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < nt) stage(t + 2, cur == 0 ? 2 : cur - 1);       // slot of tile t-1
+    if (t + NS - 1 < nt) stage(t + NS - 1, cur == 0 ? NS - 1 : cur - 1);       // slot of tile t-1
     const char* kb = smem + cur * 2 * TILE;
     const char* vb = kb + TILE;
     // ---- S^T - m
@@ -548,12 +565,14 @@ __global__ __launch_bounds__(256) void attn_d64_v2_kernel(const AttnParams p, co
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         half8 hh;
+        float ls = 0.f;                       // per-fragment partial sum: four short add chains instead of one of 32
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float pe = __builtin_amdgcn_exp2f(sv[u][8 * hf + e]);
-          l += pe;
+          ls += pe;
           hh[e] = (half_t)pe;
         }
+        l += ls;
         pf[u * 2 + hf] = hh;
       }
     // ---- O^T += V^T P^T: k-step s4 covers keys base + {4h..4h+3, 8+4h..8+4h+3}, base = u*32 + 16*hf
@@ -569,7 +588,7 @@ __global__ __launch_bounds__(256) void attn_d64_v2_kernel(const AttnParams p, co
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, vf), pf[s4], o[dt], 0, 0, 0);
       }
     }
-    cur = cur == 2 ? 0 : cur + 1;
+    cur = cur == NS - 1 ? 0 : cur + 1;
   }
   // ---- normalise, park per wave in LDS ([query][d] fp16, 16-byte chunks swizzled by query&7), store whole rows
   l += __shfl_xor(l, 32);
@@ -612,7 +631,19 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
                        ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
                          reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) == 0;
   if (p.dt == DT_F16 && (g_attn_variant == 0 || g_attn_variant == 2) && g_attn_zero && aligned && !p.mask) {
-    hipLaunchKernelGGL(attn_d64_v2_kernel, grid, dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
+    const dim3 g1(grid.x * grid.y);
+    if (p.Nk > 128) {
+      constexpr int NS = 4;
+      static bool set = false;
+      if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_d64_v2_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  NS * 2 * 64 * 128);
+        set = true;
+      }
+      hipLaunchKernelGGL(attn_d64_v2_kernel<NS>, g1, dim3(256), NS * 2 * 64 * 128, s, p, g_attn_zero);
+    } else {
+      hipLaunchKernelGGL(attn_d64_v2_kernel<3>, g1, dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
+    }
     return;
   }
   if (p.dt == DT_F16 && g_attn_variant >= 0 && g_attn_zero && aligned) {

@@ -15,7 +15,7 @@ for p in $PARTS; do
       IFS=';' read -ra GRPS <<< "${PMC_GROUPS:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE;SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM;TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum;GRBM_GUI_ACTIVE GRBM_COUNT}"
       for grp in "${GRPS[@]}"; do
         i=$((i+1))
-        (cd /tmp && timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc$i -o p -- python $GRAFT_REPO_ROOT/tools/igemm_one.py $PMC_ARGS > $GRAFT_REPO_ROOT/$OUT/pmc_${PMC_TAG:-x}_$i.log 2>&1)
+        (cd /tmp && timeout 90 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc$i -o p -- ${PMC_CMD:-python $GRAFT_REPO_ROOT/tools/igemm_one.py $PMC_ARGS} > $GRAFT_REPO_ROOT/$OUT/pmc_${PMC_TAG:-x}_$i.log 2>&1)
         find /tmp/pmc$i -name '*counter_collection*' -exec cp {} $OUT/pmc_${PMC_TAG:-x}_$i.csv \;
       done; ls $OUT;;
     ksweep) timeout 600 python tools/igemm_ksweep.py ${KSWEEP_VARIANTS:-0,11} > $OUT/ksweep.txt 2>&1; cat $OUT/ksweep.txt;;
