@@ -290,7 +290,7 @@ __device__ __forceinline__ int geglu_unpermute(int pcol, int N) {
   return w < 16 ? g * 16 + w : nh + g * 16 + (w - 16);
 }
 __global__ void pack_linear_kernel(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu,
-                                   int n_offset) {
+                                   int n_offset, const float* kscale) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)Npad * Kpad) return;
   const int np = i / Kpad;
@@ -299,13 +299,39 @@ __global__ void pack_linear_kernel(const float* src, void* dst, int dt, int K, i
   if (np < N && k < K) {
     const int n = geglu ? geglu_unpermute(np, N) : np;
     v = src[(size_t)k * N + n];
+    if (kscale) v *= kscale[k];       // LayerNorm gamma folded into the projection (W' = diag(gamma) W)
   }
   st_f(dst, ((size_t)n_offset + np) * Kpad + k, dt, v);
 }
 void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu, int n_offset,
-                        hipStream_t s) {
+                        hipStream_t s, const float* kscale) {
   const size_t total = (size_t)Npad * Kpad;
-  hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, K, N, Kpad, Npad, geglu, n_offset);
+  hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, K, N, Kpad, Npad, geglu, n_offset,
+                     kscale);
+}
+// cs[r] = sum_k packed[r][k] over the ROUNDED packed values (what the MFMA really multiplies), one wave per packed row
+__global__ void colsum_packed_kernel(const void* wp, int dt, int Kpad, int nrows, float* cs) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  float acc = 0.f;
+  for (int k = lane; k < Kpad; k += 64) acc += ld_f(wp, (size_t)row * Kpad + k, dt);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) cs[row] = acc;
+}
+void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_packed_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, wp, dt, Kpad, nrows, cs);
+}
+// out[n] = sum_k beta[k] * W[k][n] + bias[n]   (canonical column order; W is the burn [K][N] layout)
+__global__ void beta_dot_kernel(const float* w, const float* beta, const float* bias, float* out, int K, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float acc = bias ? bias[n] : 0.f;
+  for (int k = 0; k < K; ++k) acc += beta[k] * w[(size_t)k * N + n];
+  out[n] = acc;
+}
+void launch_beta_dot(const float* w, const float* beta, const float* bias, float* out, int K, int N, hipStream_t s) {
+  hipLaunchKernelGGL(beta_dot_kernel, dim3((N + 255) / 256), dim3(256), 0, s, w, beta, bias, out, K, N);
 }
 __global__ void pack_conv_kernel(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -99,6 +99,9 @@ struct FlatSource : WeightSource {   // flat fp32 buffer (host or device) in spe
 struct Lin {        // packed dense weight: [Npad][Kpad] compute dtype + fp32 bias [Npad]
   const void* w = nullptr; const float* b = nullptr;
   int N = 0, K = 0, Kpad = 0, Npad = 0, ksize = 1, cin = 0;
+  // LayerNorm folded in (linear_ln / fused_linear_ln): w = diag(gamma) W, b = beta W + bias, cs = column sums of the
+  // packed rows; the GEMM then takes the RAW rows plus their (sum, sum^2) statistics -- see IgemmParams::ln_stat
+  const float* cs = nullptr;
 };
 struct NormW { const float* gamma = nullptr; const float* beta = nullptr; int C = 0; };
 
@@ -118,6 +121,11 @@ struct WeightBuilder {
   const float* fetch(const std::string& name);            // canonical fp32 tensor in tmp
   Lin linear(const std::string& name, bool geglu = false);                  // name.weight [K,N] (+ name.bias)
   Lin fused_linear(const std::vector<std::string>& names);                  // concatenated along N (same K)
+  // the same with the preceding LayerNorm(gamma, beta) folded into weight / bias / column sums
+  Lin linear_ln(const std::string& name, bool geglu, const std::string& norm);
+  Lin fused_linear_ln(const std::vector<std::string>& names, const std::string& norm);
+  Lin fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu);
+  float* tmp2 = nullptr; size_t tmp2_numel = 0;   // scratch for folded biases (device)
   Lin conv(const std::string& name);                                        // name.weight [Cout,Cin,k,k] + bias
   NormW norm(const std::string& name);
 };
@@ -141,6 +149,13 @@ struct Profiler {
 };
 
 struct Exec {
+  // persistent [rows][2] fp32 statistics buffers of the folded LayerNorms, handed out in execution order
+  char* stat_base = nullptr; size_t stat_off = 0;
+  float* stat_alloc(size_t rows) {
+    float* p = stat_base ? reinterpret_cast<float*>(stat_base + stat_off) : nullptr;
+    stat_off += round_up(rows * 2 * sizeof(float), 256);
+    return p;
+  }
   Profiler* prof = nullptr;
   hipStream_t s = nullptr;
   bool dry = false;
@@ -156,6 +171,8 @@ struct Exec {
 // thin launch helpers shared by unet.cpp / vae.cpp (skip the launch on dry runs)
 struct ConvGeom { int B, Hin, Win, Hout, Wout, ksize, stride, pad, up; };
 struct Epi {
+  const float* ln_stat = nullptr;   // (sum, sum^2) of the A rows: the weight is LayerNorm-folded (Lin::cs)
+  float* stat_out = nullptr;        // accumulate (sum, sum^2) of the output rows for the next folded LayerNorm
   const float* ebias = nullptr; int ebias_ld = 0;
   int act = 0;
   Act R;             // residual (p == nullptr -> none)
@@ -226,6 +243,8 @@ class UNet {
   DeviceArena act_;
   void* in_ = nullptr; float* eps_ = nullptr;
   float *temb_ = nullptr, *g1_ = nullptr, *emb_ = nullptr, *ebias_ = nullptr, *gn_partial_ = nullptr, *tconv_ = nullptr;
+  bool fuse_ln_ = false;                 // f16 compute + f16 residual stream: LayerNorms are folded into the GEMMs
+  char* ln_stat_ = nullptr; size_t ln_stat_bytes_ = 0;
   bool use_graph_ = true;
   hipGraphExec_t graph_ = nullptr;
   const float* graph_t_ = nullptr; int graph_ts_ = 0; int plan_runs_ = 0;

@@ -17,6 +17,7 @@
 //   * fused epilogue: bias, per-batch time-embedding bias, GEGLU (x*gelu_erf(gate) on interleaved column
 //     pairs), residual add, dtype conversion, and an optional transposed store (V^T for the attention kernel).
 #include "kernels.h"
+#include <stdexcept>
 #include <hip/hip_fp16.h>
 
 namespace sdxl {
@@ -339,6 +340,9 @@ void igemm_set_variant(int v) { g_igemm_variant = v; }
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return;
   if (compute_dt == DT_F16 && g_igemm_variant >= 0 && launch_igemm_glds(p, g_igemm_variant, s)) return;
+  if (compute_dt == DT_F16 && g_igemm_variant > 0 && launch_igemm_glds(p, 0, s)) return;   // forced tile refused the shape
+  if (p.ln_stat || p.stat_out)
+    throw std::runtime_error("LayerNorm-folded GEMM (ln_stat / stat_out) needs the f16 direct-to-LDS kernels");
   if (compute_dt == DT_F16) {
     if (p.a_dt == DT_F16) launch_tiles<half_t, half_t>(p, s);
     else launch_tiles<half_t, float>(p, s);

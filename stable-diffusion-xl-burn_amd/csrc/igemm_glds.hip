@@ -45,6 +45,18 @@ __device__ __forceinline__ float gelu_erf2(float x) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
+// LayerNorm-folded GEMM: per output row m the epilogue needs a = rstd and c = -rstd*mu from the producer's row sums
+__device__ __forceinline__ void ln_row_coef(const IgemmParams& p, int m, float& a, float& c) {
+  a = 1.f; c = 0.f;
+  if (p.ln_stat && m < p.M) {
+    const float s1 = p.ln_stat[2 * (size_t)m], s2 = p.ln_stat[2 * (size_t)m + 1];
+    const float mu = s1 * p.ln_invc;
+    const float var = fmaxf(s2 * p.ln_invc - mu * mu, 0.f);     // biased variance, eps inside the sqrt (layernorm/mod.rs:42-49)
+    a = 1.0f / sqrtf(var + p.ln_eps);
+    c = -a * mu;
+  }
+}
+
 // ---- shared epilogue.  acc[i][j][reg] of a wave whose tile starts at (mw, nw):  m = mw + i*32 + (lane&31);
 // n = nw + j*32 + 8*(reg>>2) + 4*(lane>>5) + (reg&3)   (weights were the MFMA A operand, activations the B operand)
 template <int TM, int TN>
@@ -57,6 +69,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
     if (m >= p.M) continue;
     const int bidx = m / p.rpb;
     const int key = m - bidx * p.rpb;
+    float lna, lnc;
+    ln_row_coef(p, m, lna, lnc);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nt = nw + j * 32;
@@ -68,6 +82,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q * 4 + r];
+        if (p.ln_stat) {
+          const f32x4 cz = *reinterpret_cast<const f32x4*>(p.ln_cs + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = lna * v[r] + lnc * cz[r];
+        }
         if (p.bias) {
           const f32x4 bz = *reinterpret_cast<const f32x4*>(p.bias + nb);
 #pragma unroll
@@ -82,8 +101,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
         if (geglu) {
           f32x4 gz = {0.f, 0.f, 0.f, 0.f};
           if (p.bias) gz = *reinterpret_cast<const f32x4*>(p.bias + nb + 16);
+          f32x4 gc = {0.f, 0.f, 0.f, 0.f};
+          if (p.ln_stat) gc = *reinterpret_cast<const f32x4*>(p.ln_cs + nb + 16);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(acc[i][j][(q + 2) * 4 + r] + gz[r]);
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(lna * acc[i][j][(q + 2) * 4 + r] + lnc * gc[r] + gz[r]);
           nout = (nt >> 1) + 8 * q + 4 * fh;
         }
         if (geglu || nb < p.n_split) {
@@ -147,6 +168,9 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
   constexpr int WM = TM * 32, WN = TN * 32;
   constexpr int ROWS = WM;                         // staged rows: m (normal) -- for the transposed part rows = n, cols = m
   constexpr int COLS = GEGLU ? WN / 2 : WN;
+  // chunk swizzle (16-byte chunk index ^ row&7) needs whole groups of 8 chunks per staged row; odd widths go unswizzled
+  constexpr int SWN = (COLS % 32) == 0 ? 7 : 0;    // normal image: COLS/4 chunks per row
+  constexpr int SWT = (WM % 32) == 0 ? 7 : 0;      // transposed image: WM/4 chunks per row
   const int fr = lane & 31, fh = lane >> 5;
   // ---------------- stage 1: registers -> LDS (fp32)
   if (!transposed) {
@@ -156,6 +180,8 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       const int row = i * 32 + fr;
       const int m = mw + row;
       const int bidx = (p.ebias && m < p.M) ? m / p.rpb : 0;
+      float lna, lnc;
+      ln_row_coef(p, m, lna, lnc);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int nt = nw + j * 32;
@@ -166,17 +192,20 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q * 4 + r];
           const bool ncol_ok = nb < p.N;           // columns of the zero-padded weight rows: nothing to add, never stored
+          if (p.ln_stat && ncol_ok) v = lna * v + lnc * *reinterpret_cast<const f32x4*>(p.ln_cs + nb);
           if (p.bias && ncol_ok) v += *reinterpret_cast<const f32x4*>(p.bias + nb);
           if (p.ebias && ncol_ok) v += *reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx * p.ebias_ld + nb);
           int col = j * 32 + 8 * q + 4 * fh;
           if constexpr (GEGLU) {
             f32x4 gz = {0.f, 0.f, 0.f, 0.f};
             if (p.bias && ncol_ok) gz = *reinterpret_cast<const f32x4*>(p.bias + nb + 16);
+            f32x4 gc = {0.f, 0.f, 0.f, 0.f};
+            if (p.ln_stat && ncol_ok) gc = *reinterpret_cast<const f32x4*>(p.ln_cs + nb + 16);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(acc[i][j][(q + 2) * 4 + r] + gz[r]);
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(lna * acc[i][j][(q + 2) * 4 + r] + lnc * gc[r] + gz[r]);
             col = j * 16 + 8 * q + 4 * fh;
           }
-          *reinterpret_cast<f32x4*>(lds + row * RB + ((((col >> 2) ^ (row & 7))) << 4)) = v;
+          *reinterpret_cast<f32x4*>(lds + row * RB + ((((col >> 2) ^ (row & SWN))) << 4)) = v;
         }
       }
     }
@@ -185,6 +214,8 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int mcol = i * 32 + fr;
+      float lna, lnc;
+      ln_row_coef(p, mw + mcol, lna, lnc);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -193,11 +224,12 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q * 4 + r];
+          if (p.ln_stat && nb < p.N) v = lna * v + lnc * *reinterpret_cast<const f32x4*>(p.ln_cs + nb);
           if (p.bias && nb < p.N) v += *reinterpret_cast<const f32x4*>(p.bias + nb);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int nrow = j * 32 + 8 * q + 4 * fh + r;
-            *reinterpret_cast<float*>(lds + nrow * RB + (((mcol >> 2) ^ (nrow & 7)) << 4) + (mcol & 3) * 4) = v[r];
+            *reinterpret_cast<float*>(lds + nrow * RB + (((mcol >> 2) ^ (nrow & SWT)) << 4) + (mcol & 3) * 4) = v[r];
           }
         }
       }
@@ -208,18 +240,21 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
   if (!transposed) {
     constexpr int RB = COLS * 4;
     constexpr int LPR = COLS / 8;                  // lanes per row (8 values each)
-    constexpr int RPI = 64 / LPR;                  // rows per wave instruction
+    constexpr int ITEMS = ROWS * LPR;              // (row, 8-value piece) items, 64 per wave instruction
     const int nlim = GEGLU ? (p.N >> 1) : (p.n_split < p.N ? p.n_split : p.N);
     const int nwo = GEGLU ? (nw >> 1) : nw;
-    const int piece = lane % LPR;
-    const int n0 = nwo + piece * 8;
 #pragma unroll
-    for (int it = 0; it < ROWS / RPI; ++it) {
-      const int row = it * RPI + lane / LPR;
+    for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / LPR, piece = idx - row * LPR;
+      if (ITEMS % 64 != 0 && idx >= ITEMS) continue;
+      const int n0 = nwo + piece * 8;
       const int m = mw + row;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece) ^ (row & 7)) << 4));
-      const f32x4 b = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece + 1) ^ (row & 7)) << 4));
-      if (m >= p.M || n0 >= nlim) continue;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece) ^ (row & SWN)) << 4));
+      const f32x4 b = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece + 1) ^ (row & SWN)) << 4));
+      const bool valid = m < p.M && n0 < nlim;
+      float s1 = 0.f, s2 = 0.f;                      // row statistics of the stored values (stat_out)
+      if (valid) {
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
       const bool full = n0 + 8 <= nlim;
       if (p.R) {
@@ -245,6 +280,14 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
           }
         }
       }
+      if (p.stat_out) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < nlim) {
+            const float r = p.c_dt == DT_F16 ? (float)(half_t)v[e] : v[e];   // statistics of what the consumer will read
+            s1 += r; s2 += r * r;
+          }
+      }
       if (p.c_dt == DT_F16) {
         half_t* cp = reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n0;
         if (full && (reinterpret_cast<uintptr_t>(cp) & 15) == 0) {
@@ -266,22 +309,33 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
           for (int e = 0; e < 8; ++e) if (n0 + e < nlim) cp[e] = v[e];
         }
       }
+      }   // valid
+      if (p.stat_out) {
+        if constexpr ((LPR & (LPR - 1)) == 0 && ITEMS % 64 == 0) {   // LPR consecutive lanes share the row: butterfly first
+#pragma unroll
+          for (int o = 1; o < LPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+          if (piece == 0 && valid) { atomicAdd(p.stat_out + 2 * (size_t)m, s1); atomicAdd(p.stat_out + 2 * (size_t)m + 1, s2); }
+        } else {
+          if (valid) { atomicAdd(p.stat_out + 2 * (size_t)m, s1); atomicAdd(p.stat_out + 2 * (size_t)m + 1, s2); }
+        }
+      }
     }
   } else {
     // rows = n (Ct row n - n_split of batch b), 8 consecutive m = 8 consecutive keys when they sit in one batch entry
     constexpr int RB = WM * 4;
     constexpr int LPR = WM / 8;
-    constexpr int RPI = 64 / LPR;
-    const int piece = lane % LPR;
-    const int mbase = mw + piece * 8;
-    const int b0 = mbase / p.rpb;
-    const int key0 = mbase - b0 * p.rpb;
+    constexpr int ITEMS = WN * LPR;
 #pragma unroll
-    for (int it = 0; it < WN / RPI; ++it) {
-      const int row = it * RPI + lane / LPR;
+    for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / LPR, piece = idx - row * LPR;
+      if (ITEMS % 64 != 0 && idx >= ITEMS) continue;
+      const int mbase = mw + piece * 8;
+      const int b0 = mbase / p.rpb;
+      const int key0 = mbase - b0 * p.rpb;
       const int n = nw + row;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece) ^ (row & 7)) << 4));
-      const f32x4 b = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece + 1) ^ (row & 7)) << 4));
+      const f32x4 a = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece) ^ (row & SWT)) << 4));
+      const f32x4 b = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece + 1) ^ (row & SWT)) << 4));
       if (n >= p.N || mbase >= p.M) continue;
       const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
       const size_t o = ((size_t)b0 * p.ct_rows + (n - p.n_split)) * p.ct_ld + key0;
@@ -514,13 +568,20 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
 //        2 = measurement only: as 1 but the DMA sources never advance along k (every k-tile re-reads the block's first
 //            one from L2) -- the compute-only ceiling of the loop.  Results are wrong by construction.
 //        3 = measurement only: as 1 but NO DMA is issued inside the loop at all (ds_read + MFMA + barrier only).
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0>
+// WGM = waves along M (4: 4x2 wave grid, 8: 8x1 -- the 256x160 GEGLU tile: N = 10240 / 5120 gives 512 / 1024 tiles = whole
+// rounds of 256 CUs where 256x128 leaves the last round 44 % empty).  BN need not be a multiple of 64: the weight tile's
+// BN/8 eight-row pieces are dealt round-robin, waves below REM carry one more piece and wait on their own count.
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4>
 __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
-  constexpr int WM = BM / 4, WN = BN / 2;     // wave tile, waves arranged 4 (M) x 2 (N)
+  constexpr int WGN = 8 / WGM;
+  constexpr int WM = BM / WGM, WN = BN / WGN; // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NF = TM + TN;                 // ds_read_b128 per kk-step
-  constexpr int AJ = BM / 64, BJ = BN / 64;   // DMA pieces per wave per k-tile (8 rows each, 8 waves)
+  constexpr int BPC = BN / 8;                 // 8-row pieces of the weight tile
+  constexpr int AJ = BM / 64, BJ = (BPC + 7) / 8;   // DMA pieces per wave per k-tile (8 rows each, 8 waves)
+  constexpr int REM = BPC % 8;                // waves >= REM (when REM != 0) have no last weight piece
   constexpr int PER = AJ + BJ;
+  static_assert(BM % 64 == 0 && WM % 32 == 0 && WN % 32 == 0 && BN % 8 == 0, "bad tile");
   constexpr int KT = 64;
   constexpr int STAGE = (BM + BN) * 128;
   static_assert(NS >= 3, "counted-wait pipeline needs a ring of at least 3 slots");
@@ -530,7 +591,8 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const bool lastb = REM == 0 || wave < REM;  // this wave carries weight piece BJ-1
 
   const int tilesN = (p.N + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
@@ -544,6 +606,12 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   if ((size_t)p.N * p.K > (size_t)p.M * p.Cin) { tn = bid / tilesM; tm = bid - tn * tilesM; }
   else { tm = bid / tilesN; tn = bid - tm * tilesN; }
   const int m0 = tm * BM, n0 = tn * BN;
+  // counted DMA wait: K tiles of this wave's pieces may stay in flight
+  auto wait_tiles = [&](auto KK) {
+    constexpr int k = decltype(KK)::value;
+    if constexpr (REM == 0) wait_vmcnt<PER * k>();
+    else { if (lastb) wait_vmcnt<PER * k>(); else wait_vmcnt<(PER - 1) * k>(); }
+  };
 
   // ---- DMA geometry: piece j of this wave covers tile rows (j*8 + wave)*8 .. +7; lane -> (row, slot)
   const int lrow = lane >> 3, slot = lane & 7;
@@ -597,7 +665,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
         if constexpr (q < AJ) {
           __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(la + q * 8192), 16, 0, 0);
           if constexpr (DMODE != 2) aptr[q] += aadv[q];
-        } else {
+        } else if (q - AJ < BJ - 1 || lastb) {     // ragged weight tile: wave-uniform predicate on the last piece
           __builtin_amdgcn_global_load_lds((gptr_t)wptr[q - AJ], (lptr_t)(lb + (q - AJ) * 8192), 16, 0, 0);
           if constexpr (DMODE != 2) wptr[q - AJ] += KT;
         }
@@ -677,7 +745,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
 #pragma unroll
   for (int s = 0; s < NPRO; ++s)
     if (s < nk) { issue(s, IALL{}); tile_done(); }
-  if (NPRO <= nk) wait_vmcnt<PER * (NPRO - 1)>(); else wait_vmcnt<0>();
+  if (NPRO <= nk) wait_tiles(std::integral_constant<int, NPRO - 1>{}); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -700,7 +768,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     if constexpr (DMODE == 0) { mma(I0{}, fill, I2{}, more); if (more) tile_done(); } else mma(I0{}, fill, I3{}, false);
     if (kt + 1 < nk) {
       // own pieces of tile kt+1 landed (tiles kt+2 .. kt+NS-1 may stay in flight); own reads of tile kt complete
-      if (more) wait_vmcnt<PER * (NS - 2)>(); else wait_vmcnt<0>();
+      if (more) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
       wait_lgkmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -715,6 +783,202 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     cur = nslot;
   }
   __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring: it becomes the staging area
+  asm volatile("" ::: "memory");
+  constexpr bool FITS = 8 * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
+  if (FITS || p.act == 1) {
+    const int region = p.act == 1 ? WM * (WN / 2) * 4 : WM * WN * 4;   // GEGLU halves the staged width
+    igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * region);
+  } else {
+    igemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, fr, fh);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Warp-specialised variant: 8 compute waves + NL loader waves per workgroup.
+//
+// Measured on the pipelined kernel above (tools/igemm_ksweep.py): with the DMA pieces issued by the computing waves the
+// k-loop runs at ~1000 TFLOP/s; the same loop with NO DMA issue runs at ~1300-1440, and pointing every piece at
+// L2-resident data changes nothing -- the cost is the ISSUE of global_load_lds (~60+ cycles of the issuing wave per
+// 1-KiB piece, right between its MFMAs), not latency or bandwidth.  So the pieces move to dedicated loader waves: they
+// own the tap walk, the source pointers, the counted vmcnt waits and nothing else; the compute waves run ds_read + MFMA
+// + one barrier per k-tile.  Protocol per k-tile kt (all waves meet at the same raw s_barrier):
+//   loader : wait own pieces of tile kt+1 (vmcnt leaves tiles kt+2.. in flight) -> barrier -> issue tile kt+NS into the
+//            slot of tile kt (free: every compute wave finished reading it before the barrier)
+//   compute: kk-steps 0..2 of tile kt (fragments double buffered, counted lgkmcnt) -> lgkmcnt(0) -> barrier -> prefetch
+//            the first fragments of tile kt+1 -> kk-step 3
+template <int BM, int BN, int NS, int NL>
+__global__ __launch_bounds__(512 + 64 * NL) void igemm_ws_kernel(const IgemmParams p, const void* zeros) {
+  constexpr int WM = BM / 4, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NF = TM + TN;
+  constexpr int APC = BM / 8, BPC = BN / 8;            // 8-row DMA pieces per k-tile
+  constexpr int AJ = APC / NL, BJ = BPC / NL;          // per loader wave
+  constexpr int PER = AJ + BJ;
+  constexpr int KT = 64;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(NS >= 3 && APC % NL == 0 && BPC % NL == 0, "bad loader split");
+  static_assert(PER * (NS - 1) <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  if ((size_t)p.N * p.K > (size_t)p.M * p.Cin) { tn = bid / tilesM; tm = bid - tn * tilesM; }
+  else { tm = bid / tilesN; tn = bid - tm * tilesN; }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = p.Kpad / KT;
+
+  if (wave >= 8) {
+    // =============================================================== loader wave lw: pieces pc = j*NL + lw
+    const int lw = wave - 8;
+    const int lrow = lane >> 3, slot = lane & 7;
+    const int HWo = p.Hout * p.Wout;
+    const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+    int rb[AJ], ry[AJ], rx[AJ], rsw[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int row = (j * NL + lw) * 8 + lrow;
+      const int m = m0 + row;
+      rsw[j] = (slot ^ ((row >> 1) & 7)) * 8;
+      if (m < p.M) {
+        const int b = m / HWo;
+        const int rem = m - b * HWo;
+        const int oy = rem / p.Wout;
+        rb[j] = b; ry[j] = oy * p.stride - p.pad; rx[j] = (rem - oy * p.Wout) * p.stride - p.pad;
+      } else { rb[j] = -1; ry[j] = -(1 << 28); rx[j] = 0; }
+    }
+    const half_t* Ag = reinterpret_cast<const half_t*>(p.A);
+    const half_t* wptr[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int row = (j * NL + lw) * 8 + lrow;
+      wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * 8;
+    }
+    const half_t* aptr[AJ];
+    int aadv[AJ];
+    int s_c0 = 0, s_dy = 0, s_dx = 0;
+    auto retap = [&]() {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int iy = ry[j] + s_dy, ix = rx[j] + s_dx;
+        const bool ok = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
+        const size_t off = (((size_t)(rb[j] < 0 ? 0 : rb[j]) * p.Hin + ((ok ? iy : 0) >> p.up)) * p.Win + ((ok ? ix : 0) >> p.up)) * p.lda + rsw[j];
+        aptr[j] = ok ? Ag + off : reinterpret_cast<const half_t*>(zeros);
+        aadv[j] = ok ? KT : 0;
+      }
+    };
+    retap();
+    auto issue_tile = [&](int buf) {
+      char* la = smem + buf * STAGE + lw * 1024;
+      char* lb = la + BM * 128;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(la + j * NL * 1024), 16, 0, 0);
+        aptr[j] += aadv[j];
+      }
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(lb + j * NL * 1024), 16, 0, 0);
+        wptr[j] += KT;
+      }
+      s_c0 += KT;
+      if (s_c0 == p.Cin) {
+        s_c0 = 0;
+        if (++s_dx == p.ksize) { s_dx = 0; ++s_dy; }
+        retap();
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (s < nk) issue_tile(s);
+    if (NS <= nk) wait_vmcnt<PER * (NS - 1)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      if (kt + NS - 1 < nk) wait_vmcnt<PER * (NS - 2)>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + NS < nk) issue_tile(cur);
+      cur = cur + 1 == NS ? 0 : cur + 1;
+    }
+    __builtin_amdgcn_s_barrier();               // the compute waves' "ring is dead" barrier before the staged epilogue
+    return;
+  }
+
+  // ================================================================= compute wave
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fr = lane & 31, fh = lane >> 5;
+  unsigned basea, baseb;
+  {
+    const int ra = wm * WM + fr, rbw = wn * WN + fr;
+    basea = lds0 + ra * 128 + ((fh ^ ((ra >> 1) & 7)) << 4);
+    baseb = lds0 + BM * 128 + rbw * 128 + ((fh ^ ((rbw >> 1) & 7)) << 4);
+  }
+  half8 fA[2][TM], fB[2][TN];
+  auto ldfrag = [&](unsigned so, int kk, auto SET) {
+    constexpr int set = decltype(SET)::value;
+    const unsigned aa = (basea ^ (kk << 5)) + so, ab = (baseb ^ (kk << 5)) + so;
+    static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<decltype(I)::value * 4096>(aa); });
+    static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<decltype(J)::value * 4096>(ab); });
+  };
+  auto mma = [&](auto SET) {
+    constexpr int set = decltype(SET)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][j], fA[set][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  __builtin_amdgcn_s_barrier();                 // tile 0 landed (loaders waited for their pieces)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  ldfrag(0, 0, I0{});
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned so = cur * STAGE;
+    const int nslot = cur + 1 == NS ? 0 : cur + 1;
+    ldfrag(so, 1, I1{});
+    wait_lgkmcnt<NF>();
+    mma(I0{});
+    ldfrag(so, 2, I0{});
+    wait_lgkmcnt<NF>();
+    mma(I1{});
+    ldfrag(so, 3, I1{});
+    wait_lgkmcnt<NF>();
+    mma(I0{});
+    wait_lgkmcnt<0>();                          // own reads of tile kt complete
+    if (kt + 1 < nk) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      ldfrag(nslot * STAGE, 0, I0{});
+    }
+    mma(I1{});
+    cur = nslot;
+  }
+  __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4));
 }
@@ -741,17 +1005,30 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
 }
 
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0>
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NS * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_page);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_page);
+}
+
+template <int BM, int BN, int NS, int NL>
+static void launch_ws(const IgemmParams& p, hipStream_t s) {
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
+  const size_t lds = (size_t)NS * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ws_kernel<BM, BN, NS, NL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_ws_kernel<BM, BN, NS, NL>), dim3(tilesM * tilesN), dim3(512 + 64 * NL), lds, s, p, g_zero_page);
 }
 
 // variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
@@ -775,6 +1052,13 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     if (t128 <= 256) variant = 13;
     else if (t256 <= 256 || eff256 >= 0.8) variant = 11;
     else variant = t128 >= 400 ? 4 : 6;
+    if (p.act == 1 && p.N % 160 == 0 && variant == 11) {
+      // GEGLU projections: the 256x160 tile (8x1 waves) when it saves whole rounds of 256 CUs (N = 10240 at M = 2048: 512
+      // tiles = 2 rounds instead of 640 = 2.5 -> 3); it pays ~10 % more LDS reads per MFMA, so it must win >= 15 % of area
+      const long t160 = (long)((p.M + 255) / 256) * (p.N / 160);
+      const double cost128 = (double)((t256 + 255) / 256) * 128.0, cost160 = (double)((t160 + 255) / 256) * 160.0 * 1.12;
+      if (cost160 < cost128) variant = 19;
+    }
   }
   switch (variant) {
     case 1: launch_glds<128, 128, 3>(p, s); break;
@@ -794,6 +1078,13 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 16: launch_pipe<128, 128, 4, true, 1>(p, s); break;
     case 17: launch_pipe<256, 128, 3, true, 2>(p, s); break;    // measurement only: no k advance (WRONG results)
     case 18: launch_pipe<256, 128, 3, true, 3>(p, s); break;    // measurement only: no DMA in the loop (WRONG results)
+    case 19:                                                    // 256x160, 8x1 waves: weight rows must exist up to the tile edge
+      if (p.N % 160 != 0) return false;
+      launch_pipe<256, 160, 3, true, 0, 8>(p, s); break;
+    case 20: launch_ws<256, 128, 3, 2>(p, s); break;            // 8 compute + 2 loader waves
+    case 21: launch_ws<256, 128, 3, 4>(p, s); break;            // 8 compute + 4 loader waves
+    case 22: launch_ws<128, 128, 4, 2>(p, s); break;
+    case 23: launch_ws<128, 128, 4, 4>(p, s); break;
     default: return false;
   }
   return true;

@@ -35,6 +35,13 @@ struct IgemmParams {
   void* C; int ldc; int c_dt;           // output for columns n < n_split (after GEGLU: n/2)
   int n_split;          // columns >= n_split go to the transposed output (set = N when unused)
   void* Ct; int ct_rows; int ct_ld;     // Ct[b][n - n_split][key]  (ct_rows rows per batch, row stride ct_ld), dtype c_dt
+  // LayerNorm folded into the GEMM (reference layernorm/mod.rs:34-49 followed by nn::Linear): A holds the RAW rows x,
+  // W holds diag(gamma) W, bias holds beta W + b, and the epilogue applies  v = rstd[m]*acc - rstd[m]*mu[m]*ln_cs[n] + bias[n]
+  // with (mu, rstd) from the row sums the PRODUCER of x accumulated:  ln_stat[m] = (sum x, sum x^2).  null -> plain GEMM.
+  const float* ln_stat; const float* ln_cs; float ln_invc; float ln_eps;
+  // when set, the staged epilogue adds (sum, sum of squares) of every stored output row into stat_out[m][2] (fp32 atomics;
+  // the buffer is zeroed once per forward) -- the statistics of the LayerNorm that reads this output next
+  float* stat_out;
 };
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
@@ -142,7 +149,10 @@ void launch_from_u8_image(const unsigned char* src, void* dst, int dt, int ldd, 
 void launch_synth_fill(float* dst, size_t numel, uint64_t key, float scale, float mean, hipStream_t s);
 // canonical Linear [K][N] fp32 (burn layout) -> packed [Npad][Kpad] (dt); optional GEGLU interleave
 void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu,
-                        int n_offset, hipStream_t s);
+                        int n_offset, hipStream_t s, const float* kscale = nullptr);   // kscale[k]: LayerNorm gamma fold
+// LayerNorm fold helpers: column sums of the packed (rounded) weight rows; beta . W + bias in canonical column order
+void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s);
+void launch_beta_dot(const float* w, const float* beta, const float* bias, float* out, int K, int N, hipStream_t s);
 // canonical conv [Cout][Cin][kh][kw] fp32 -> packed [Npad][Kpad], k = (kh*kw_idx)*Cin + c
 void launch_pack_conv(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad,
                       hipStream_t s);

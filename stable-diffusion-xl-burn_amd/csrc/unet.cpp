@@ -35,7 +35,7 @@ ResBlockW load_res(WeightBuilder& wb, const std::string& p, int cin, int cout, s
   emb_off += cout;
   return r;
 }
-STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth) {
+STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln) {
   STW s;
   s.C = C; s.heads = heads;
   s.norm = wb.norm(p + ".norm");
@@ -43,6 +43,19 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
   for (int j = 0; j < depth; ++j) {
     const std::string q = p + ".blocks." + std::to_string(j);
     TBlockW t;
+    if (fuse_ln) {
+      // the three LayerNorms of TransformerBlock::forward (unet/mod.rs:885-891) are folded into the projections that
+      // consume them; their row statistics come out of the epilogue of the GEMM that produced the residual stream
+      t.qkv = wb.fused_linear_ln({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, q + ".norm1");
+      t.out1 = wb.linear(q + ".attn1.out");
+      t.q2 = wb.linear_ln(q + ".attn2.query", false, q + ".norm2");
+      t.kv2 = wb.fused_linear({q + ".attn2.key", q + ".attn2.value"});
+      t.out2 = wb.linear(q + ".attn2.out");
+      t.geglu = wb.linear_ln(q + ".mlp.geglu.proj", true, q + ".norm3");
+      t.ff = wb.linear(q + ".mlp.lin");
+      s.blocks.push_back(t);
+      continue;
+    }
     t.n1 = wb.norm(q + ".norm1");
     t.qkv = wb.fused_linear({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"});
     t.out1 = wb.linear(q + ".attn1.out");
@@ -86,6 +99,7 @@ UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src,
   SDXL_REQUIRE(cfg.n_head_channels == 64, "this engine's fused attention kernel is specialised for 64 channels per head");
   SDXL_REQUIRE(!(compute_dt == DT_F32 && stream_dt != DT_F32), "f32 compute implies an f32 residual stream");
   SDXL_REQUIRE(cfg.model_channels % 32 == 0, "GroupNorm(32) needs model_channels % 32 == 0");
+  fuse_ln_ = compute_dt == DT_F16 && stream_dt == DT_F16;
   build_weights(src, st);
 }
 UNet::~UNet() {
@@ -111,7 +125,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
       case BK_RES: b.res = load_res(wb, p, d.c_in, d.c_out, emb_names, emb_off); break;
       default:
         b.res = load_res(wb, p + ".res", d.c_in, d.c_out, emb_names, emb_off);
-        if (d.kind == BK_REST || d.kind == BK_RESTU) b.st = load_st(wb, p + ".transformer", d.c_out, d.n_head, d.depth);
+        if (d.kind == BK_REST || d.kind == BK_RESTU) b.st = load_st(wb, p + ".transformer", d.c_out, d.n_head, d.depth, fuse_ln_);
         if (d.kind == BK_RESTU || d.kind == BK_RESU) b.conv = wb.conv(p + ".upsample.conv");
     }
     return b;
@@ -119,7 +133,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
   for (size_t i = 0; i < inp.size(); ++i) inp_.push_back(load_block("input_blocks." + std::to_string(i), inp[i]));
   mid_res1_.d = mid;
   mid_res1_.res = load_res(wb, "middle_block.res1", mid.c_in, mid.c_out, emb_names, emb_off);
-  mid_res1_.st = load_st(wb, "middle_block.transformer", mid.c_out, mid.n_head, mid.depth);
+  mid_res1_.st = load_st(wb, "middle_block.transformer", mid.c_out, mid.n_head, mid.depth, fuse_ln_);
   mid_res2_.d = mid;
   mid_res2_.res = load_res(wb, "middle_block.res2", mid.c_in, mid.c_out, emb_names, emb_off);
   for (size_t i = 0; i < out.size(); ++i) out_.push_back(load_block("output_blocks." + std::to_string(i), out[i]));
@@ -211,7 +225,8 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   Act gn = ex.alloc(M, C, ex.cdt);
   run_groupnorm(ex, w.norm, x, B, HW, gn, false);
   Act t = ex.alloc(M, C, ex.sdt);
-  run_linear(ex, w.proj_in, gn, (int)M, t);
+  float* st_first = (fuse_ln_ && !w.blocks.empty()) ? ex.stat_alloc(M) : nullptr;
+  { Epi ep; ep.stat_out = st_first; run_linear(ex, w.proj_in, gn, (int)M, t, ep); }
   Act ln = ex.alloc(M, C, ex.cdt);
   Act qk = ex.alloc(M, 2 * C, ex.cdt);
   void* vt = ex.act->alloc((size_t)B * C * npad * dt_size(ex.cdt));
@@ -219,6 +234,33 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   Act q = ex.alloc(M, C, ex.cdt);
   Act gg = ex.alloc(M, 4 * C, ex.cdt);
   if (npad != HW && !ex.dry) launch_fill_zero(vt, (size_t)B * C * npad * dt_size(ex.cdt), ex.s);
+  if (fuse_ln_) {
+    // LayerNorms folded into the consuming GEMMs: every producer of the residual stream t also accumulates the row
+    // (sum, sum^2) its consumer needs, so no LayerNorm kernel runs and t is read by the projections directly
+    SDXL_REQUIRE(w.blocks.empty() || w.blocks[0].qkv.cs, "transformer weights were not LayerNorm-folded");
+    std::vector<float*> st1(w.blocks.size()), st2(w.blocks.size()), st3(w.blocks.size());
+    for (size_t j = 0; j < w.blocks.size(); ++j) {
+      st1[j] = j == 0 ? st_first : ex.stat_alloc(M);
+      st2[j] = ex.stat_alloc(M); st3[j] = ex.stat_alloc(M);
+    }
+    for (size_t j = 0; j < w.blocks.size(); ++j) {
+      const TBlockW& b = w.blocks[j];
+      Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.ln_stat = st1[j];
+      run_linear(ex, b.qkv, t, (int)M, qk, eq);
+      attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
+      Epi e1; e1.R = t; e1.stat_out = st2[j];
+      run_linear(ex, b.out1, ao, (int)M, t, e1);
+      Epi e2q; e2q.ln_stat = st2[j];
+      run_linear(ex, b.q2, t, (int)M, q, e2q);
+      attention(ex, q, Act(kv_[si][j].k, C, ex.cdt), kv_[si][j].vt, vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
+      Epi e2; e2.R = t; e2.stat_out = st3[j];
+      run_linear(ex, b.out2, ao, (int)M, t, e2);
+      Epi eg; eg.act = 1; eg.ln_stat = st3[j];
+      run_linear(ex, b.geglu, t, (int)M, gg, eg);
+      Epi ef; ef.R = t; ef.stat_out = j + 1 < w.blocks.size() ? st1[j + 1] : nullptr;
+      run_linear(ex, b.ff, gg, (int)M, t, ef);
+    }
+  } else
   for (size_t j = 0; j < w.blocks.size(); ++j) {
     const TBlockW& b = w.blocks[j];
     run_layernorm(ex, b.n1, t, (int)M, ln);
@@ -245,6 +287,9 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
 void UNet::run(Exec& ex, const float* t_dev, int t_stride) {
   const int B = pB_, H = pH_, W = pW_;
   const int mc = cfg_.model_channels, emb = 4 * mc;
+  ex.stat_base = ex.dry ? nullptr : ln_stat_;
+  ex.stat_off = 0;
+  if (!ex.dry && ln_stat_bytes_) launch_fill_zero(ln_stat_, ln_stat_bytes_, ex.s);   // folded-LayerNorm row sums
   // --- embeddings (unet/mod.rs:458-468)
   if (!ex.dry) launch_timestep_embedding(t_dev, t_stride, temb_, B, mc, ex.s);
   gemv(ex, lin1_t_, temb_, mc, g1_, emb, B, false, true);
@@ -351,9 +396,11 @@ void UNet::ensure_plan(int B, int H, int W) {
     ebias_ = (float*)act_.alloc((size_t)B * emb_total_ * sizeof(float));
     gn_partial_ = (float*)act_.alloc((size_t)B * 32 * 128 * 3 * sizeof(float));
     tconv_ = (float*)act_.alloc(8 * sizeof(float));
+    ln_stat_ = ln_stat_bytes_ ? (char*)act_.alloc(ln_stat_bytes_) : nullptr;
   };
-  // dry run for the peak, then the real arena
+  // dry run for the peak (and the size of the folded-LayerNorm statistics), then the real arena
   act_.dry = true; act_.off = 0; act_.peak = 0;
+  ln_stat_bytes_ = 0;
   persist();
   Exec ex; ex.dry = true; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_;
   const size_t m = act_.mark();
@@ -365,7 +412,8 @@ void UNet::ensure_plan(int B, int H, int W) {
   run(ex, nullptr, 0);
   if (!had_kv) kv_.clear();
   act_.reset(m);
-  const size_t peak = act_.peak;
+  ln_stat_bytes_ = ex.stat_off;
+  const size_t peak = act_.peak + round_up(ln_stat_bytes_, 256) + 256;
   act_.dry = false;
   act_.reserve(peak + 4096);
   act_.off = 0; act_.peak = 0;

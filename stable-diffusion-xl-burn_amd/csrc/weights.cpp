@@ -75,7 +75,7 @@ WeightBuilder::WeightBuilder(const std::vector<ParamSpec>& sp, WeightSource& s, 
   }
   SDXL_HIP(hipMalloc((void**)&tmp, tmp_numel * sizeof(float)));
 }
-WeightBuilder::~WeightBuilder() { if (tmp) (void)hipFree(tmp); }
+WeightBuilder::~WeightBuilder() { if (tmp) (void)hipFree(tmp); if (tmp2) (void)hipFree(tmp2); }
 
 size_t WeightBuilder::arena_bound(const std::vector<ParamSpec>& specs, int dt) {
   size_t total = 1 << 20;
@@ -85,6 +85,7 @@ size_t WeightBuilder::arena_bound(const std::vector<ParamSpec>& specs, int dt) {
       total += round_up(p.shape[0], 128) * round_up((size_t)p.shape[1] * p.shape[2] * p.shape[3], 64) * dt_size(dt) + 256;
     else total += round_up(p.numel(), 128) * sizeof(float) + 256;
     if (p.kind == PK_LINEAR_W || p.kind == PK_CONV_W) total += round_up(p.kind == PK_LINEAR_W ? p.shape[1] : p.shape[0], 128) * 4 + 256;
+    if (p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * 4 + 256;   // column sums of LayerNorm-folded projections
   }
   return total;
 }
@@ -143,6 +144,64 @@ Lin WeightBuilder::fused_linear(const std::vector<std::string>& names) {
   l.w = w; l.b = b;
   return l;
 }
+// LayerNorm(gamma, beta) followed by Linear(W, b):  LN(x) W + b = rstd (x - mu) (diag(gamma) W) + (beta W + b)
+//   = rstd * (x W') - rstd * mu * colsum(W') + b'   -- W' is packed (rounded to the compute dtype) FIRST and the column sums
+// are taken over the rounded values, so the identity holds exactly for what the MFMA multiplies.
+Lin WeightBuilder::linear_ln(const std::string& name, bool geglu, const std::string& norm) {
+  return fold_ln({name}, norm, geglu);
+}
+Lin WeightBuilder::fused_linear_ln(const std::vector<std::string>& names, const std::string& norm) {
+  return fold_ln(names, norm, false);
+}
+Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu) {
+  SDXL_REQUIRE(!geglu || names.size() == 1, "GEGLU packing applies to a single projection");
+  Lin l; l.ksize = 1;
+  int ntot = 0;
+  for (const std::string& n : names) {
+    const ParamSpec& s = spec(n + ".weight");
+    if (l.K == 0) l.K = s.shape[0];
+    SDXL_REQUIRE(l.K == s.shape[0], "fused_linear_ln: K mismatch");
+    ntot += s.shape[1];
+  }
+  l.N = ntot; l.cin = l.K;
+  const int kt = dt == DT_F16 ? 64 : 32;
+  l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
+  char* w = (char*)arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
+  float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
+  float* cs = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
+  l.w = w; l.b = b; l.cs = cs;
+  if (src.empty()) return l;
+  const size_t need = 3 * (size_t)l.Npad + 2 * (size_t)l.K;
+  if (need > tmp2_numel) {
+    if (tmp2) SDXL_HIP(hipFree(tmp2));
+    SDXL_HIP(hipMalloc((void**)&tmp2, need * sizeof(float)));
+    tmp2_numel = need;
+  }
+  float* gamma = tmp2;                 // [K]
+  float* beta = tmp2 + l.K;            // [K]
+  float* bsrc = beta + l.K;            // [Npad] canonical bias of the current projection
+  float* bfold = bsrc + l.Npad;        // [Npad] beta W + bias, canonical order
+  SDXL_REQUIRE(spec(norm + ".gamma").shape[0] == l.K, "fused_linear_ln: norm width mismatch");
+  SDXL_HIP(hipMemcpyAsync(gamma, fetch(norm + ".gamma"), l.K * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SDXL_HIP(hipMemcpyAsync(beta, fetch(norm + ".beta"), l.K * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SDXL_HIP(hipMemsetAsync(w, 0, (size_t)l.Npad * l.Kpad * dt_size(dt), st));
+  SDXL_HIP(hipMemsetAsync(b, 0, (size_t)l.Npad * sizeof(float), st));
+  int off = 0;
+  for (const std::string& n : names) {
+    const ParamSpec& s = spec(n + ".weight");
+    const int N = s.shape[1];
+    const bool hb = has(n + ".bias");
+    if (hb) SDXL_HIP(hipMemcpyAsync(bsrc, fetch(n + ".bias"), N * sizeof(float), hipMemcpyDeviceToDevice, st));
+    const float* wsrc = fetch(n + ".weight");
+    if (names.size() == 1) launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st, gamma);
+    else launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, N, 0, off, st, gamma);
+    launch_beta_dot(wsrc, beta, hb ? bsrc : nullptr, bfold, l.K, N, st);
+    launch_pack_bias(bfold, b, N, names.size() == 1 ? l.Npad : N, geglu ? 1 : 0, off, st);
+    off += N;
+  }
+  launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st);
+  return l;
+}
 Lin WeightBuilder::conv(const std::string& name) {
   const ParamSpec& s = spec(name + ".weight");
   Lin l; l.N = s.shape[0]; l.cin = s.shape[1]; l.ksize = s.shape[2];
@@ -186,6 +245,10 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.C = out.p; p.ldc = out.ld; p.c_dt = out.dt;
   p.n_split = e.n_split >= 0 ? e.n_split : w.N;
   p.Ct = e.Ct; p.ct_rows = e.ct_rows; p.ct_ld = e.ct_ld;
+  p.ln_stat = e.ln_stat; p.ln_cs = w.cs; p.ln_invc = 1.0f / (float)w.K; p.ln_eps = 1e-5f;
+  p.stat_out = e.stat_out;
+  SDXL_REQUIRE(!e.ln_stat || w.cs, "ln_stat given but the weight is not LayerNorm-folded");
+  SDXL_REQUIRE(!w.cs || e.ln_stat, "LayerNorm-folded weight used without row statistics");
   SDXL_REQUIRE(!(ex.cdt == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
   if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize);
   launch_igemm(p, ex.cdt, ex.s);

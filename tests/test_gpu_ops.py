@@ -175,7 +175,7 @@ def test_attn_decoder_mask(pkg, ctx):
 # ---------------------------------------------------------------------------------------------------------
 # every fast-path implicit-GEMM tile / pipeline variant is forced in turn over shapes that exercise: fewer k-tiles than
 # ring slots, ragged M / N tiles, GEGLU pairs, 3x3 taps with halo zero-fill, stride 2 and the fused nearest-2x gather
-IGEMM_VARIANTS = [4, 6, 1, 8, 10, 11, 12, 13, 14, 15, 16]
+IGEMM_VARIANTS = [4, 6, 1, 8, 10, 11, 12, 13, 14, 15, 16, 19, 20, 21, 22, 23]
 
 
 @pytest.fixture
@@ -190,7 +190,8 @@ def igemm_variant(pkg):
 def test_igemm_variants_linear(pkg, ctx, igemm_variant, variant):
     igemm_variant(variant)
     for (M, K, N, geglu) in [(300, 640, 320, False), (2048, 64, 128, False), (520, 128, 200, False), (257, 192, 136, False),
-                             (300, 640, 640, True), (1024, 1280, 512, True), (4096, 320, 1280, False)]:
+                             (300, 640, 640, True), (1024, 1280, 512, True), (4096, 320, 1280, False),
+                             (600, 256, 320, True), (2048, 1280, 1280, True), (520, 192, 320, False)]:
         x = seeded(M, K, seed=40)
         w = seeded(K, N, seed=41) / math.sqrt(K)
         b = 0.1 * seeded(N, seed=42)
@@ -217,7 +218,7 @@ def test_igemm_variants_conv(pkg, ctx, igemm_variant, variant):
         assert e < TOL[1], f"variant {variant} conv {(B, Cin, H, W, Cout, k, stride, pad, up)}: rel err {e}"
 
 
-@pytest.mark.parametrize("variant", [11, 13])
+@pytest.mark.parametrize("variant", [11, 13, 21, 23])
 def test_igemm_variants_unet(pkg, ctx, igemm_variant, variant):
     # residual / time-embedding / transposed-V^T epilogues of the pipelined kernels, through a whole tiny UNet
     from util import to_pkg_cfg, unet_weights
