@@ -149,13 +149,6 @@ struct Profiler {
 };
 
 struct Exec {
-  // persistent [rows][2] fp32 statistics buffers of the folded LayerNorms, handed out in execution order
-  char* stat_base = nullptr; size_t stat_off = 0;
-  float* stat_alloc(size_t rows) {
-    float* p = stat_base ? reinterpret_cast<float*>(stat_base + stat_off) : nullptr;
-    stat_off += round_up(rows * 2 * sizeof(float), 256);
-    return p;
-  }
   Profiler* prof = nullptr;
   hipStream_t s = nullptr;
   bool dry = false;
@@ -171,8 +164,8 @@ struct Exec {
 // thin launch helpers shared by unet.cpp / vae.cpp (skip the launch on dry runs)
 struct ConvGeom { int B, Hin, Win, Hout, Wout, ksize, stride, pad, up; };
 struct Epi {
-  const float* ln_stat = nullptr;   // (sum, sum^2) of the A rows: the weight is LayerNorm-folded (Lin::cs)
-  float* stat_out = nullptr;        // accumulate (sum, sum^2) of the output rows for the next folded LayerNorm
+  const float* ln_stat = nullptr;   // [M][K/64][2] partial (sum, sum^2) of the A rows: the weight is LayerNorm-folded (Lin::cs)
+  float* stat_out = nullptr;        // [M][N/64][2]: leave the partial (sum, sum^2) of the output rows for the next folded LayerNorm
   const float* ebias = nullptr; int ebias_ld = 0;
   int act = 0;
   Act R;             // residual (p == nullptr -> none)
@@ -244,7 +237,6 @@ class UNet {
   void* in_ = nullptr; float* eps_ = nullptr;
   float *temb_ = nullptr, *g1_ = nullptr, *emb_ = nullptr, *ebias_ = nullptr, *gn_partial_ = nullptr, *tconv_ = nullptr;
   bool fuse_ln_ = false;                 // f16 compute + f16 residual stream: LayerNorms are folded into the GEMMs
-  char* ln_stat_ = nullptr; size_t ln_stat_bytes_ = 0;
   bool use_graph_ = true;
   hipGraphExec_t graph_ = nullptr;
   const float* graph_t_ = nullptr; int graph_ts_ = 0; int plan_runs_ = 0;

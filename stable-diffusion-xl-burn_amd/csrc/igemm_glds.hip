@@ -49,18 +49,75 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 __device__ __forceinline__ void ln_row_coef(const IgemmParams& p, int m, float& a, float& c) {
   a = 1.f; c = 0.f;
   if (p.ln_stat && m < p.M) {
-    const float s1 = p.ln_stat[2 * (size_t)m], s2 = p.ln_stat[2 * (size_t)m + 1];
+    // ln_stat[slot][m] = (sum, sum^2) of columns [64 slot, 64 slot + 64) of row m: lanes hold consecutive rows, so every
+    // load is coalesced; fixed summation order (four slots per step, then the rest) -> bit-reproducible
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stat) + m;
+    const size_t M = (size_t)p.M;
+    float s1 = 0.f, s2 = 0.f;
+    int k = 0;
+    for (; k + 4 <= p.ln_slots; k += 4) {
+      const f32x2 v0 = st[(size_t)k * M], v1 = st[(size_t)(k + 1) * M], v2 = st[(size_t)(k + 2) * M], v3 = st[(size_t)(k + 3) * M];
+      s1 += (v0[0] + v1[0]) + (v2[0] + v3[0]);
+      s2 += (v0[1] + v1[1]) + (v2[1] + v3[1]);
+    }
+    for (; k < p.ln_slots; ++k) { const f32x2 v = st[(size_t)k * M]; s1 += v[0]; s2 += v[1]; }
     const float mu = s1 * p.ln_invc;
     const float var = fmaxf(s2 * p.ln_invc - mu * mu, 0.f);     // biased variance, eps inside the sqrt (layernorm/mod.rs:42-49)
     a = 1.0f / sqrtf(var + p.ln_eps);
     c = -a * mu;
   }
 }
+// row coefficients of the folded LayerNorm for this lane's TM output rows; called in the kernel prologue so the loads overlap
+// the first DMA tiles.  Every (row, slot) partial is requested before the first one is consumed: ONE memory round trip (a
+// slot-by-slot loop serialises ln_slots round trips -- measured +6 us on the 32 us QKV projection).
+template <int TM>
+__device__ __forceinline__ void ln_prologue(const IgemmParams& p, int mw, int fr, float (&lnA)[TM], float (&lnC)[TM]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { lnA[i] = 1.f; lnC[i] = 0.f; }
+  if (!p.ln_stat) return;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int MAXS = 24;                      // K <= 1536 (SDXL refiner); larger K takes the generic loop
+  if (p.ln_slots > MAXS) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ln_row_coef(p, mw + i * 32 + fr, lnA[i], lnC[i]);
+    return;
+  }
+  const size_t M = (size_t)p.M;
+  f32x2 v[TM][MAXS];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mw + i * 32 + fr;
+    const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stat) + (m < p.M ? m : 0);
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) v[i][k] = k < p.ln_slots ? st[(size_t)k * M] : f32x2{0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k + 4 <= MAXS; k += 4) {    // same association as ln_row_coef
+      if (k + 4 <= p.ln_slots) {
+        s1 += (v[i][k][0] + v[i][k + 1][0]) + (v[i][k + 2][0] + v[i][k + 3][0]);
+        s2 += (v[i][k][1] + v[i][k + 1][1]) + (v[i][k + 2][1] + v[i][k + 3][1]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < p.ln_slots) { s1 += v[i][k + e][0]; s2 += v[i][k + e][1]; }
+      }
+    }
+    const float mu = s1 * p.ln_invc;
+    const float var = fmaxf(s2 * p.ln_invc - mu * mu, 0.f);
+    const float a = 1.0f / sqrtf(var + p.ln_eps);
+    if (mw + i * 32 + fr < p.M) { lnA[i] = a; lnC[i] = -a * mu; }
+  }
+}
 
 // ---- shared epilogue.  acc[i][j][reg] of a wave whose tile starts at (mw, nw):  m = mw + i*32 + (lane&31);
 // n = nw + j*32 + 8*(reg>>2) + 4*(lane>>5) + (reg&3)   (weights were the MFMA A operand, activations the B operand)
 template <int TM, int TN>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int fr, int fh) {
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int fr, int fh,
+                                               const float (&lnA)[TM], const float (&lnC)[TM]) {
   const bool geglu = p.act == 1;
   const int nlim = geglu ? (p.N >> 1) : p.N;
 #pragma unroll
@@ -69,8 +126,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
     if (m >= p.M) continue;
     const int bidx = m / p.rpb;
     const int key = m - bidx * p.rpb;
-    float lna, lnc;
-    ln_row_coef(p, m, lna, lnc);
+    const float lna = lnA[i], lnc = lnC[i];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nt = nw + j * 32;
@@ -164,7 +220,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
 // `lds` = this wave's private region of WM*WN*4 bytes (the k-loop ring, dead by now; callers barrier first).
 template <int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw,
-                                                           int lane, char* lds, bool transposed) {
+                                                           int lane, char* lds, bool transposed, const float (&lnA)[TM],
+                                                           const float (&lnC)[TM]) {
   constexpr int WM = TM * 32, WN = TN * 32;
   constexpr int ROWS = WM;                         // staged rows: m (normal) -- for the transposed part rows = n, cols = m
   constexpr int COLS = GEGLU ? WN / 2 : WN;
@@ -180,8 +237,7 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       const int row = i * 32 + fr;
       const int m = mw + row;
       const int bidx = (p.ebias && m < p.M) ? m / p.rpb : 0;
-      float lna, lnc;
-      ln_row_coef(p, m, lna, lnc);
+      const float lna = lnA[i], lnc = lnC[i];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int nt = nw + j * 32;
@@ -214,8 +270,7 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int mcol = i * 32 + fr;
-      float lna, lnc;
-      ln_row_coef(p, mw + mcol, lna, lnc);
+      const float lna = lnA[i], lnc = lnC[i];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -310,13 +365,14 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
         }
       }
       }   // valid
-      if (p.stat_out) {
-        if constexpr ((LPR & (LPR - 1)) == 0 && ITEMS % 64 == 0) {   // LPR consecutive lanes share the row: butterfly first
+      if constexpr (COLS % 64 == 0) {
+        if (p.stat_out) {          // 8 consecutive lanes hold one 64-column slot of a row: butterfly, one plain store
 #pragma unroll
-          for (int o = 1; o < LPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-          if (piece == 0 && valid) { atomicAdd(p.stat_out + 2 * (size_t)m, s1); atomicAdd(p.stat_out + 2 * (size_t)m + 1, s2); }
-        } else {
-          if (valid) { atomicAdd(p.stat_out + 2 * (size_t)m, s1); atomicAdd(p.stat_out + 2 * (size_t)m + 1, s2); }
+          for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+          if ((piece & 7) == 0 && valid) {
+            float* dst = p.stat_out + ((size_t)(n0 >> 6) * p.M + m) * 2;
+            dst[0] = s1; dst[1] = s2;
+          }
         }
       }
     }
@@ -374,14 +430,14 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
 // dispatch: the staged path needs the wave's column range on one side of n_split; anything else takes the direct epilogue
 template <int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw,
-                                                      int lane, char* lds) {
+                                                      int lane, char* lds, const float (&lnA)[TM], const float (&lnC)[TM]) {
   constexpr int WN = TN * 32;
-  if (p.act == 1) { igemm_epilogue_staged_impl<TM, TN, true>(p, acc, mw, nw, lane, lds, false); return; }
+  if (p.act == 1) { igemm_epilogue_staged_impl<TM, TN, true>(p, acc, mw, nw, lane, lds, false, lnA, lnC); return; }
   const bool all_normal = nw + WN <= p.n_split || p.n_split >= p.N;
   const bool all_transposed = nw >= p.n_split;
-  if (all_normal) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, false);
-  else if (all_transposed) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, true);
-  else igemm_epilogue<TM, TN>(p, acc, mw, nw, lane & 31, lane >> 5);
+  if (all_normal) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, false, lnA, lnC);
+  else if (all_transposed) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, true, lnA, lnC);
+  else igemm_epilogue<TM, TN>(p, acc, mw, nw, lane & 31, lane >> 5, lnA, lnC);
 }
 
 template <int BM, int BN, int NS>
@@ -491,6 +547,8 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) stage(s);
+  float lnA[TM], lnC[TM];
+  ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
   int cur = 0;                 // ring slot of tile kt
   int nxt = NS - 1;            // ring slot tile kt+NS-1 goes to (= slot of tile kt-1)
   for (int kt = 0; kt < nk; ++kt) {
@@ -527,7 +585,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
   }
 
   __syncthreads();                                 // every wave is done reading the ring: it becomes the staging area
-  igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4));
+  igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -745,6 +803,8 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
 #pragma unroll
   for (int s = 0; s < NPRO; ++s)
     if (s < nk) { issue(s, IALL{}); tile_done(); }
+  float lnA[TM], lnC[TM];
+  ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
   if (NPRO <= nk) wait_tiles(std::integral_constant<int, NPRO - 1>{}); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -787,9 +847,9 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   constexpr bool FITS = 8 * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
   if (FITS || p.act == 1) {
     const int region = p.act == 1 ? WM * (WN / 2) * 4 : WM * WN * 4;   // GEGLU halves the staged width
-    igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * region);
+    igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * region, lnA, lnC);
   } else {
-    igemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, fr, fh);
+    igemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, fr, fh, lnA, lnC);
   }
 }
 
@@ -951,6 +1011,8 @@ __global__ __launch_bounds__(512 + 64 * NL) void igemm_ws_kernel(const IgemmPara
     __builtin_amdgcn_sched_barrier(0);
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  float lnA[TM], lnC[TM];
+  ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
   __builtin_amdgcn_s_barrier();                 // tile 0 landed (loaders waited for their pieces)
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -980,7 +1042,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void igemm_ws_kernel(const IgemmPara
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4));
+  igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC);
 }
 
 static const void* g_zero_page = nullptr;
@@ -1039,6 +1101,7 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
   if (p.n_split < p.N && (p.n_split & 3) != 0) return false;
   if (p.ebias && (p.ebias_ld & 3) != 0) return false;
+  if (p.stat_out && (variant == 2 || variant == 5 || variant == 19)) return false;   // wave tiles narrower / other than 64 columns
   // the DMA reads weight rows up to the tile edge: Npad is a multiple of 128 for every packed weight (pack_* kernels)
   if (variant == 0) {
     // measured on MI355X (tools/igemm_sweep.py, profiles/r01_igemm_sweep.txt).  The global->LDS path sustains ~22 B/clk/CU,

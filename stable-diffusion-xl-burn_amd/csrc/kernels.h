@@ -37,11 +37,12 @@ struct IgemmParams {
   void* Ct; int ct_rows; int ct_ld;     // Ct[b][n - n_split][key]  (ct_rows rows per batch, row stride ct_ld), dtype c_dt
   // LayerNorm folded into the GEMM (reference layernorm/mod.rs:34-49 followed by nn::Linear): A holds the RAW rows x,
   // W holds diag(gamma) W, bias holds beta W + b, and the epilogue applies  v = rstd[m]*acc - rstd[m]*mu[m]*ln_cs[n] + bias[n]
-  // with (mu, rstd) from the row sums the PRODUCER of x accumulated:  ln_stat[m] = (sum x, sum x^2).  null -> plain GEMM.
-  const float* ln_stat; const float* ln_cs; float ln_invc; float ln_eps;
-  // when set, the staged epilogue adds (sum, sum of squares) of every stored output row into stat_out[m][2] (fp32 atomics;
-  // the buffer is zeroed once per forward) -- the statistics of the LayerNorm that reads this output next
-  float* stat_out;
+  // with (mu, rstd) from the partial row sums the PRODUCER of x left behind: ln_stat[slot][m] = (sum x, sum x^2) over the
+  // 64 columns of slot, ln_slots = K/64 slots per row, summed here in slot order (deterministic).  null -> plain GEMM.
+  const float* ln_stat; int ln_slots; const float* ln_cs; float ln_invc; float ln_eps;
+  // when set, the staged epilogue stores (sum, sum of squares) of every 64-column group of the stored output rows into
+  // stat_out[n/64][m] (plain stores, every entry written once) -- the statistics of the LayerNorm that reads this output
+  float* stat_out; int stat_slots;
 };
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile

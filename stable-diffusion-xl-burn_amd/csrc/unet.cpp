@@ -225,8 +225,11 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   Act gn = ex.alloc(M, C, ex.cdt);
   run_groupnorm(ex, w.norm, x, B, HW, gn, false);
   Act t = ex.alloc(M, C, ex.sdt);
-  float* st_first = (fuse_ln_ && !w.blocks.empty()) ? ex.stat_alloc(M) : nullptr;
-  { Epi ep; ep.stat_out = st_first; run_linear(ex, w.proj_in, gn, (int)M, t, ep); }
+  // folded LayerNorms: two ping-pong [M][C/64][2] partial-sum buffers -- each is written by one GEMM and read by the next
+  float* stbuf[2] = {nullptr, nullptr};
+  if (fuse_ln_) for (int i = 0; i < 2; ++i) stbuf[i] = (float*)ex.act->alloc(M * (size_t)(C / 64) * 2 * sizeof(float));
+  int stp = 0;
+  { Epi ep; ep.stat_out = w.blocks.empty() ? nullptr : stbuf[stp]; run_linear(ex, w.proj_in, gn, (int)M, t, ep); }
   Act ln = ex.alloc(M, C, ex.cdt);
   Act qk = ex.alloc(M, 2 * C, ex.cdt);
   void* vt = ex.act->alloc((size_t)B * C * npad * dt_size(ex.cdt));
@@ -238,26 +241,24 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     // LayerNorms folded into the consuming GEMMs: every producer of the residual stream t also accumulates the row
     // (sum, sum^2) its consumer needs, so no LayerNorm kernel runs and t is read by the projections directly
     SDXL_REQUIRE(w.blocks.empty() || w.blocks[0].qkv.cs, "transformer weights were not LayerNorm-folded");
-    std::vector<float*> st1(w.blocks.size()), st2(w.blocks.size()), st3(w.blocks.size());
-    for (size_t j = 0; j < w.blocks.size(); ++j) {
-      st1[j] = j == 0 ? st_first : ex.stat_alloc(M);
-      st2[j] = ex.stat_alloc(M); st3[j] = ex.stat_alloc(M);
-    }
     for (size_t j = 0; j < w.blocks.size(); ++j) {
       const TBlockW& b = w.blocks[j];
-      Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.ln_stat = st1[j];
+      Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.ln_stat = stbuf[stp];
       run_linear(ex, b.qkv, t, (int)M, qk, eq);
       attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
-      Epi e1; e1.R = t; e1.stat_out = st2[j];
+      stp ^= 1;
+      Epi e1; e1.R = t; e1.stat_out = stbuf[stp];
       run_linear(ex, b.out1, ao, (int)M, t, e1);
-      Epi e2q; e2q.ln_stat = st2[j];
+      Epi e2q; e2q.ln_stat = stbuf[stp];
       run_linear(ex, b.q2, t, (int)M, q, e2q);
       attention(ex, q, Act(kv_[si][j].k, C, ex.cdt), kv_[si][j].vt, vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
-      Epi e2; e2.R = t; e2.stat_out = st3[j];
+      stp ^= 1;
+      Epi e2; e2.R = t; e2.stat_out = stbuf[stp];
       run_linear(ex, b.out2, ao, (int)M, t, e2);
-      Epi eg; eg.act = 1; eg.ln_stat = st3[j];
+      Epi eg; eg.act = 1; eg.ln_stat = stbuf[stp];
       run_linear(ex, b.geglu, t, (int)M, gg, eg);
-      Epi ef; ef.R = t; ef.stat_out = j + 1 < w.blocks.size() ? st1[j + 1] : nullptr;
+      stp ^= 1;
+      Epi ef; ef.R = t; ef.stat_out = j + 1 < w.blocks.size() ? stbuf[stp] : nullptr;
       run_linear(ex, b.ff, gg, (int)M, t, ef);
     }
   } else
@@ -287,9 +288,6 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
 void UNet::run(Exec& ex, const float* t_dev, int t_stride) {
   const int B = pB_, H = pH_, W = pW_;
   const int mc = cfg_.model_channels, emb = 4 * mc;
-  ex.stat_base = ex.dry ? nullptr : ln_stat_;
-  ex.stat_off = 0;
-  if (!ex.dry && ln_stat_bytes_) launch_fill_zero(ln_stat_, ln_stat_bytes_, ex.s);   // folded-LayerNorm row sums
   // --- embeddings (unet/mod.rs:458-468)
   if (!ex.dry) launch_timestep_embedding(t_dev, t_stride, temb_, B, mc, ex.s);
   gemv(ex, lin1_t_, temb_, mc, g1_, emb, B, false, true);
@@ -396,11 +394,9 @@ void UNet::ensure_plan(int B, int H, int W) {
     ebias_ = (float*)act_.alloc((size_t)B * emb_total_ * sizeof(float));
     gn_partial_ = (float*)act_.alloc((size_t)B * 32 * 128 * 3 * sizeof(float));
     tconv_ = (float*)act_.alloc(8 * sizeof(float));
-    ln_stat_ = ln_stat_bytes_ ? (char*)act_.alloc(ln_stat_bytes_) : nullptr;
   };
-  // dry run for the peak (and the size of the folded-LayerNorm statistics), then the real arena
+  // dry run for the peak, then the real arena
   act_.dry = true; act_.off = 0; act_.peak = 0;
-  ln_stat_bytes_ = 0;
   persist();
   Exec ex; ex.dry = true; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_;
   const size_t m = act_.mark();
@@ -412,8 +408,7 @@ void UNet::ensure_plan(int B, int H, int W) {
   run(ex, nullptr, 0);
   if (!had_kv) kv_.clear();
   act_.reset(m);
-  ln_stat_bytes_ = ex.stat_off;
-  const size_t peak = act_.peak + round_up(ln_stat_bytes_, 256) + 256;
+  const size_t peak = act_.peak;
   act_.dry = false;
   act_.reserve(peak + 4096);
   act_.off = 0; act_.peak = 0;

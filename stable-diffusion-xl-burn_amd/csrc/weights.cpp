@@ -245,8 +245,10 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.C = out.p; p.ldc = out.ld; p.c_dt = out.dt;
   p.n_split = e.n_split >= 0 ? e.n_split : w.N;
   p.Ct = e.Ct; p.ct_rows = e.ct_rows; p.ct_ld = e.ct_ld;
-  p.ln_stat = e.ln_stat; p.ln_cs = w.cs; p.ln_invc = 1.0f / (float)w.K; p.ln_eps = 1e-5f;
-  p.stat_out = e.stat_out;
+  p.ln_stat = e.ln_stat; p.ln_slots = w.K / 64; p.ln_cs = w.cs; p.ln_invc = 1.0f / (float)w.K; p.ln_eps = 1e-5f;
+  p.stat_out = e.stat_out; p.stat_slots = w.N / 64;
+  SDXL_REQUIRE(!e.ln_stat || w.K % 64 == 0, "LayerNorm-folded GEMM needs K % 64 == 0");
+  SDXL_REQUIRE(!e.stat_out || (w.N % 64 == 0 && (e.n_split < 0 || e.n_split >= w.N) && e.act == 0), "row statistics need a plain N % 64 == 0 output");
   SDXL_REQUIRE(!e.ln_stat || w.cs, "ln_stat given but the weight is not LayerNorm-folded");
   SDXL_REQUIRE(!w.cs || e.ln_stat, "LayerNorm-folded weight used without row statistics");
   SDXL_REQUIRE(!(ex.cdt == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
