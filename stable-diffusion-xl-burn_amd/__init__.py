@@ -354,7 +354,7 @@ def bench_igemm(ctx: "Context", B: int, H: int, W: int, Cin: int, Cout: int, ksi
                 iters: int = 20) -> float:
     """mean launch duration (ms) of the implicit-GEMM kernel alone on seeded random f16 data"""
     ms = ctypes.c_float()
-    _check(lib().sdxl_bench_igemm(ctx.h, None, B, H, W, Cin, Cout, ksize, int(geglu), iters, ctypes.byref(ms)))
+    _check(lib().sdxl_bench_igemm(ctx.h, None, B, H, W, Cin, Cout, ksize, int(geglu), iters, ctypes.byref(ms)))   # geglu: bit0 GEGLU, bit1 LN-folded input, bit2 row statistics out
     return float(ms.value)
 
 
