@@ -610,7 +610,7 @@ int sdxl_group_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* ga
   Tmp tmp;
   void* xi = tmp.get((size_t)B * HW * C * dt_size(sdt));
   void* yo = tmp.get((size_t)B * HW * C * dt_size(cdt));
-  float* part = (float*)tmp.get((size_t)B * n_group * 128 * 3 * sizeof(float));
+  float* part = (float*)tmp.get((size_t)B * n_group * (128 * 3 + 2) * sizeof(float));
   launch_nchw_to_nhwc(x, C * HW, xi, sdt, B, C, HW, C, 1.0f, s);
   GroupNormParams p{};
   p.X = xi; p.x_dt = sdt; p.ldx = C; p.Y = yo; p.y_dt = cdt; p.ldy = C; p.gamma = gamma; p.beta = beta; p.partial = part;

@@ -719,7 +719,9 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
       constexpr int q = decltype(Q)::value;
       constexpr int NM = TM * TN;                                   // MFMAs per kk-step
       constexpr int PPG = (PER + (NM > 1 ? NM - 2 : 0)) / (NM > 1 ? NM - 1 : 1);   // pieces per MFMA gap (early mode)
-      if constexpr (ph < 0 || (ph < 3 && q % 3 == ph) || (ph >= 10 && q / PPG == ph - 10)) {
+      constexpr int HALF = (PER + 1) / 2;
+      if constexpr (ph < 0 || (ph < 3 && q % 3 == ph) || (ph >= 10 && q / PPG == ph - 10) || (ph == 5 && q < HALF) ||
+                    (ph == 6 && q >= HALF)) {
         if constexpr (q < AJ) {
           __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(la + q * 8192), 16, 0, 0);
           if constexpr (DMODE != 2) aptr[q] += aadv[q];
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     basea = lds0 + ra * 128 + ((fh ^ ((ra >> 1) & 7)) << 4);
     baseb = lds0 + BM * 128 + rbw * 128 + ((fh ^ ((rbw >> 1) & 7)) << 4);
   }
-  half8 fA[2][TM], fB[2][TN];
+  half8 fA[DMODE == 4 ? 4 : 2][TM], fB[DMODE == 4 ? 4 : 2][TN];
   auto ldfrag = [&](unsigned so, int kk, auto SET) {
     constexpr int set = decltype(SET)::value;
     const unsigned aa = (basea ^ (kk << 5)) + so, ab = (baseb ^ (kk << 5)) + so;
@@ -775,6 +777,10 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ph < 3) {
       if (more) issue(buf, PH);            // wave-uniform branch around the DMA pieces only, never around MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (ph == 5 || ph == 6) {    // lookahead-2 mode: half of the next tile's pieces behind the first MFMA
+      if (more) issue(buf, PH);
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (ph == 4) {               // early mode: gap 0 pieces here, gap g pieces after MFMA g
@@ -797,6 +803,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   using I4 = std::integral_constant<int, 4>;
   using IALL = std::integral_constant<int, -1>;
+  using I5 = std::integral_constant<int, 5>; using I6 = std::integral_constant<int, 6>;
   constexpr int NPRO = DMODE == 0 ? NS - 1 : NS;   // tiles staged by the prologue
 
   // ---- prologue: tiles 0 .. NPRO-1 in flight, wait for tile 0 only
@@ -812,6 +819,38 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   ldfrag(0, 0, I0{});
   int cur = 0;                      // ring slot of tile kt
   int fill = NS - 1;                // ring slot tile kt+NS-1 goes to (the slot tile kt-1 occupied)
+  if constexpr (DMODE == 4) {
+    // lookahead-2 schedule: one fragment set per kk-step, the ds_reads of step kk+2 are issued before the MFMAs of step kk,
+    // so an LDS stall of a whole kk-step (DMA write bursts into the same LDS) does not starve the matrix pipe.  The
+    // barrier moves between steps 1 and 2 (all reads of tile kt are issued by then); behind it: the first two fragment
+    // sets of tile kt+1 and the DMA pieces of tile kt+NS (slot just freed), half behind each of the last two steps.
+    ldfrag(0, 1, I1{});
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned so = cur * STAGE;
+      const int nslot = cur + 1 == NS ? 0 : cur + 1;
+      const bool more1 = kt + NS < nk;
+      ldfrag(so, 2, I2{});
+      wait_lgkmcnt<2 * NF>();
+      mma(I0{}, cur, I3{}, false);
+      ldfrag(so, 3, I3{});
+      wait_lgkmcnt<2 * NF>();
+      mma(I1{}, cur, I3{}, false);
+      wait_lgkmcnt<0>();                        // own reads of tile kt complete
+      const bool has_next = kt + 1 < nk;        // (MFMAs stay outside the branches: hipcc would clone the accumulators)
+      if (has_next) {
+        if (kt + NS - 1 < nk) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ldfrag(nslot * STAGE, 0, I0{});
+      }
+      mma(I2{}, cur, I5{}, more1);
+      if (has_next) ldfrag(nslot * STAGE, 1, I1{});
+      mma(I3{}, cur, I6{}, more1);
+      if (more1) tile_done();
+      cur = nslot;
+    }
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned so = cur * STAGE;
     const int nslot = cur + 1 == NS ? 0 : cur + 1;
@@ -1141,6 +1180,8 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 16: launch_pipe<128, 128, 4, true, 1>(p, s); break;
     case 17: launch_pipe<256, 128, 3, true, 2>(p, s); break;    // measurement only: no k advance (WRONG results)
     case 18: launch_pipe<256, 128, 3, true, 3>(p, s); break;    // measurement only: no DMA in the loop (WRONG results)
+    case 24: launch_pipe<256, 128, 3, true, 4>(p, s); break;    // lookahead-2 fragment prefetch
+    case 25: launch_pipe<128, 128, 4, true, 4>(p, s); break;
     case 19:                                                    // 256x160, 8x1 waves: weight rows must exist up to the tile edge
       if (p.N % 160 != 0) return false;
       launch_pipe<256, 160, 3, true, 0, 8>(p, s); break;

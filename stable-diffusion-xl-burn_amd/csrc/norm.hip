@@ -76,20 +76,52 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormParams p) 
   for (int pass = 0; pass < npass; ++pass) {
     const int vc = pass * VPR + vl;
     const bool active = rl < RL && vc < NV;
+    // per-thread statistics of 8 channels over its rows: sums of (x - pivot) and (x - pivot)^2 with the pivot = the thread's
+    // first sample of that channel (shifted-data algorithm: 3 VALU per element instead of Welford's 6 + a reciprocal, and
+    // as robust -- the pivot sits within the data's own spread, so there is no E[x^2] - E[x]^2 cancellation at |mean| >> std);
+    // converted to (count, mean, M2) once at the end, merged with Chan's formula from there on
     float mean[8], m2[8], cnt = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { mean[j] = 0.f; m2[j] = 0.f; }
     if (active) {
-      for (int row = row_begin + rl; row < row_end; row += RL) {
+      float piv[8], s1[8], s2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { piv[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+      int row = row_begin + rl;
+      if (row < row_end) load8<XT>(X + (size_t)row * p.ldx + vc * 8, piv);
+      // four independent row loads in flight per thread (a one-load-at-a-time loop is latency bound at ~1 TB/s)
+      for (; row + 3 * RL < row_end; row += 4 * RL) {
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load8<XT>(X + (size_t)(row + u * RL) * p.ldx + vc * 8, v[u]);
+        cnt += 4.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = v[u][j] - piv[j];
+            s1[j] += d;
+            s2[j] = fmaf(d, d, s2[j]);
+          }
+      }
+      for (; row < row_end; row += RL) {
         float v[8];
         load8<XT>(X + (size_t)row * p.ldx + vc * 8, v);
         cnt += 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = v[j] - piv[j];
+          s1[j] += d;
+          s2[j] = fmaf(d, d, s2[j]);
+        }
+      }
+      if (cnt > 0.f) {
         const float inv = 1.f / cnt;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float d = v[j] - mean[j];
-          mean[j] += d * inv;
-          m2[j] += d * (v[j] - mean[j]);
+          const float dm = s1[j] * inv;
+          mean[j] = piv[j] + dm;
+          m2[j] = fmaxf(s2[j] - s1[j] * dm, 0.f);
         }
       }
     }
@@ -125,16 +157,35 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormParams p) 
   }
 }
 
-// finalize: one thread per (batch, group) merges the row-split partials -> (mean, rstd) at partial[b][g][0..1] of a
-// second region (stat), so the apply blocks do not each redo the merge.
-__global__ void gn_finalize_kernel(const GroupNormParams p, float* stat) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// finalize: one wavefront per (batch, group): lane s holds row-split partial s (nsplit <= 64), butterfly Chan merge
+// -> (mean, rstd) at stat[b][g][0..1], so the apply blocks do not each redo the merge.  (A single thread walking the 64
+// partials was a 10 us dependent-load chain per GroupNorm.)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GroupNormParams p, float* stat) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= p.B * p.G) return;
   const float* part = p.partial + (size_t)i * p.nsplit * 3;
   float na = 0.f, ma = 0.f, qa = 0.f;
-  for (int s = 0; s < p.nsplit; ++s) chan_merge(na, ma, qa, part[s * 3], part[s * 3 + 1], part[s * 3 + 2]);
-  stat[i * 2] = ma;
-  stat[i * 2 + 1] = 1.0f / sqrtf(qa / na + p.eps);
+  if (lane < p.nsplit) { na = part[lane * 3]; ma = part[lane * 3 + 1]; qa = part[lane * 3 + 2]; }
+  if (lane + 64 < p.nsplit) chan_merge(na, ma, qa, part[(lane + 64) * 3], part[(lane + 64) * 3 + 1], part[(lane + 64) * 3 + 2]);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float nb = __shfl_xor(na, o), mb = __shfl_xor(ma, o), qb = __shfl_xor(qa, o);
+    // symmetric merge (both partners compute the same (n, mean, M2) up to rounding of the identical expression)
+    const float n = na + nb;
+    if (n > 0.f) {
+      const float d = mb - ma;
+      const float f = nb / n;
+      const float mnew = (lane & o) ? mb + (ma - mb) * (na / n) : ma + d * f;   // each side updates from its own mean
+      qa = qa + qb + d * d * na * f;
+      ma = mnew;
+    }
+    na = n;
+  }
+  if (lane == 0) {
+    stat[i * 2] = ma;
+    stat[i * 2 + 1] = 1.0f / sqrtf(qa / na + p.eps);
+  }
 }
 
 // apply: grid (row chunks, B).  thread -> (row lane, fixed vector column): the 8 channels' (mean, rstd*gamma, beta)
@@ -164,7 +215,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
       scale[j] = stat[((size_t)b * p.G + g) * 2 + 1] * p.gamma[c];
       beta[j] = p.beta[c];
     }
-    for (int row = row0 + rl; row < row1; row += RL) {
+    int row = row0 + rl;
+    for (; row + RL < row1; row += 2 * RL) {      // two rows in flight per thread
+      float v[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) load8<XT>(X + (size_t)(row + u * RL) * p.ldx + vc * 8, v[u]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float y = (v[u][j] - mean[j]) * scale[j] + beta[j];
+          if (p.silu) y = y / (1.0f + __expf(-y));
+          v[u][j] = y;
+        }
+        store8<YT>(Y + (size_t)(row + u * RL) * p.ldy + vc * 8, v[u]);
+      }
+    }
+    for (; row < row1; row += RL) {
       float v[8];
       load8<XT>(X + (size_t)row * p.ldx + vc * 8, v);
 #pragma unroll
@@ -180,9 +247,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
 
 int groupnorm_nsplit(int B, int HW, int C) {
   (void)B; (void)C;
-  int n = HW / 64;
+  int n = HW / 32;       // >= 32 rows per block; up to 128 row splits x B blocks keep all 256 CUs streaming
   if (n < 1) n = 1;
-  if (n > 64) n = 64;
+  if (n > 128) n = 128;
   return n;
 }
 
@@ -196,9 +263,9 @@ void launch_groupnorm(const GroupNormParams& pin, hipStream_t s) {
   dim3 g1(p.nsplit, p.B);
   if (p.x_dt == DT_F16) hipLaunchKernelGGL(gn_stats_kernel<half_t>, g1, dim3(256), lds_stats, s, p);
   else hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds_stats, s, p);
-  // (mean, rstd) per (batch, group) live right after the partials: workspace is [B][G][128][3] floats, nsplit <= 64
-  float* stat = p.partial + (size_t)p.B * p.G * 64 * 3;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.G + 63) / 64), dim3(64), 0, s, p, stat);
+  // (mean, rstd) per (batch, group) live right after the partials: workspace is [B][G][128][3] + [B][G][2] floats
+  float* stat = p.partial + (size_t)p.B * p.G * 128 * 3;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.G + 3) / 4), dim3(256), 0, s, p, stat);
   // apply: aim for >= ~512 blocks, each row lane walking >= 4 rows
   int rows_per_block = (int)(((long)p.B * p.HW + 511) / 512);
   if (rows_per_block < 4 * RL) rows_per_block = 4 * RL;

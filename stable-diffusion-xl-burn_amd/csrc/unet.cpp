@@ -392,7 +392,7 @@ void UNet::ensure_plan(int B, int H, int W) {
     g1_ = (float*)act_.alloc((size_t)B * emb * sizeof(float));
     emb_ = (float*)act_.alloc((size_t)B * emb * sizeof(float));
     ebias_ = (float*)act_.alloc((size_t)B * emb_total_ * sizeof(float));
-    gn_partial_ = (float*)act_.alloc((size_t)B * 32 * 128 * 3 * sizeof(float));
+    gn_partial_ = (float*)act_.alloc((size_t)B * 32 * (128 * 3 + 2) * sizeof(float));
     tconv_ = (float*)act_.alloc(8 * sizeof(float));
   };
   // dry run for the peak, then the real arena

@@ -72,7 +72,7 @@ Vae::Vae(const VaeCfg& cfg, int compute_dt, WeightSource* dec_src, WeightSource*
     SDXL_HIP(hipStreamSynchronize(st));
     has_enc_ = true;
   }
-  SDXL_HIP(hipMalloc((void**)&gn_partial_, (size_t)8 * 32 * 128 * 3 * sizeof(float)));
+  SDXL_HIP(hipMalloc((void**)&gn_partial_, (size_t)8 * 32 * (128 * 3 + 2) * sizeof(float)));
 }
 Vae::~Vae() { if (gn_partial_) (void)hipFree(gn_partial_); }
 

@@ -175,7 +175,7 @@ def test_attn_decoder_mask(pkg, ctx):
 # ---------------------------------------------------------------------------------------------------------
 # every fast-path implicit-GEMM tile / pipeline variant is forced in turn over shapes that exercise: fewer k-tiles than
 # ring slots, ragged M / N tiles, GEGLU pairs, 3x3 taps with halo zero-fill, stride 2 and the fused nearest-2x gather
-IGEMM_VARIANTS = [4, 6, 1, 8, 10, 11, 12, 13, 14, 15, 16, 19, 20, 21, 22, 23]
+IGEMM_VARIANTS = [4, 6, 1, 8, 10, 11, 12, 13, 14, 15, 16, 19, 20, 21, 22, 23, 24, 25]
 
 
 @pytest.fixture
@@ -218,7 +218,7 @@ def test_igemm_variants_conv(pkg, ctx, igemm_variant, variant):
         assert e < TOL[1], f"variant {variant} conv {(B, Cin, H, W, Cout, k, stride, pad, up)}: rel err {e}"
 
 
-@pytest.mark.parametrize("variant", [11, 13, 21, 23])
+@pytest.mark.parametrize("variant", [11, 13, 21, 23, 24, 25])
 def test_igemm_variants_unet(pkg, ctx, igemm_variant, variant):
     # residual / time-embedding / transposed-V^T epilogues of the pipelined kernels, through a whole tiny UNet
     from util import to_pkg_cfg, unet_weights
