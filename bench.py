@@ -262,9 +262,20 @@ def main():
     ig_ms, ig_n, ig_fl = prof["igemm"]
     peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_F16_TFLOPS
     achieved = ig_fl / 1e12 / (ig_ms / 1e3) if ig_ms > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "igemm_kernel (NHWC implicit-GEMM conv3x3/1x1/linear)",
+    # HBM-side traffic of the same launches: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_step.py,
+    # summarised by tools/pmc_traffic.py (gfx950 correction applied there); null when no committed summary exists
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath) and args.dtype == "f16" and res == 1024:
+        try:
+            with open(tpath) as fh:
+                traffic = round(json.load(fh)["igemm_total"]["bytes_per_launch"])
+            traffic_src = "profiles/r01_pmc_traffic.json (bytes per implicit-GEMM launch, averaged over one UNet step)"
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "kernel": "igemm_{pipe,glds}_kernel (NHWC implicit-GEMM conv3x3/1x1/linear, direct-to-LDS f16)",
                 "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_unet_step": ig_n, "avg_launch_us": round(1e3 * ig_ms / max(ig_n, 1), 2),
                 "algorithmic_tflop_per_unet_step": round(ig_fl / 1e12, 3),
                 "class_ms_per_unet_step": {k: round(v[0], 3) for k, v in prof.items()},

@@ -20,6 +20,16 @@ for p in $PARTS; do
       done; ls $OUT;;
     ksweep) timeout 600 python tools/igemm_ksweep.py ${KSWEEP_VARIANTS:-0,11} > $OUT/ksweep.txt 2>&1; cat $OUT/ksweep.txt;;
     attn) timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "attention or geglu" > $OUT/attn_tests.log 2>&1; tail -3 $OUT/attn_tests.log; timeout 300 python tools/attn_bench.py ${ATTN_VARIANTS:-1,2} > $OUT/attn_bench.txt 2>&1; cat $OUT/attn_bench.txt;;
+    traffic) # HBM-side counters of the dominant GEMM shapes (one shape per pass; only the small summary is kept)
+      rm -f $OUT/traffic_raw.txt
+      for shp in "0 2 32 32 1280 10240 1 1 5" "0 2 32 32 1280 3840 1 0 5" "0 2 32 32 5120 1280 1 0 5" "0 2 32 32 1280 1280 1 0 5" "0 2 128 128 320 320 3 0 5"; do
+        for c in FETCH_SIZE WRITE_SIZE; do
+          rm -rf /tmp/tr; (cd /tmp && timeout 60 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/tr -o t -- python $GRAFT_REPO_ROOT/tools/igemm_one.py $shp > /tmp/tr.log 2>&1)
+          echo "== $shp $c" >> $OUT/traffic_raw.txt
+          for f in $(find /tmp/tr -name '*counter_collection*'); do python tools/pmc_parse.py $f >> $OUT/traffic_raw.txt 2>&1; done
+          tail -2 /tmp/tr.log | head -1 >> $OUT/traffic_raw.txt
+        done
+      done; cut -c1-400 $OUT/traffic_raw.txt;;
     tests) timeout 900 python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; echo "tests rc=$?" >> $OUT/tests.log; tail -3 $OUT/tests.log;;
     sweep) timeout 600 python tools/igemm_sweep.py ${SWEEP_VARIANTS:--1,0,4,6,1,8} > $OUT/igemm_sweep.txt 2>&1; tail -25 $OUT/igemm_sweep.txt;;
     prof)  SDXL_PROFILE_DUMP=$OUT/step_launches.csv timeout 600 python tools/profile_step.py > $OUT/profile_step.txt 2>&1; tail -3 $OUT/profile_step.txt;;
