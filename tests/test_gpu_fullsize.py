@@ -53,10 +53,10 @@ def test_fullsize_sample_and_decode(pkg, ctx):
                             unconditional_context_full=r(77, cfg.context_dim),
                             unconditional_channel_context=r(cfg.adm_in_channels), resolution=(1024, 1024))
     noise = r(1, 4, 128, 128)
-    lat = d.sample_latent(cond, 7.5, 250, noise)          # 1000 / 250 -> 4 CFG step pairs
-    assert pkg.step_count(250) == 4
+    assert pkg.step_count(4) == 4                        # step_size = 1000 / 4 -> t = 999, 749, 499, 249
+    lat = d.sample_latent(cond, 7.5, 4, noise)
     assert lat.shape == (1, 4, 128, 128) and torch.isfinite(lat).all()
-    lat2 = d.sample_latent(cond, 7.5, 250, noise)
+    lat2 = d.sample_latent(cond, 7.5, 4, noise)
     assert torch.equal(lat, lat2), "trajectory is not deterministic"
     ld = pkg.LatentDecoder(ctx, None, pkg.DTYPE_F16, seed=0)
     img = ld.latent_to_image(lat)
