@@ -221,7 +221,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
 template <int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw,
                                                            int lane, char* lds, bool transposed, const float (&lnA)[TM],
-                                                           const float (&lnC)[TM]) {
+                                                           const float (&lnC)[TM], const void* zeros) {
   constexpr int WM = TM * 32, WN = TN * 32;
   constexpr int ROWS = WM;                         // staged rows: m (normal) -- for the transposed part rows = n, cols = m
   constexpr int COLS = GEGLU ? WN / 2 : WN;
@@ -230,35 +230,49 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
   constexpr int SWT = (WM % 32) == 0 ? 7 : 0;      // transposed image: WM/4 chunks per row
   const int fr = lane & 31, fh = lane >> 5;
   // ---------------- stage 1: registers -> LDS (fp32)
+  // Every per-column vector (bias, gate bias, folded-LayerNorm column sums, time-embedding bias) is fetched through a
+  // pointer SELECT (a 16-byte zero page stands in for "absent"), never inside a branch: hipcc then issues the loads of a
+  // whole 32-column group back to back and waits once.  With `if (p.bias) v += *ptr` each of the 8..32 loads became its own
+  // load -> s_waitcnt vmcnt(0) -> use chain, i.e. 8..32 serial L2 round trips in every GEMM's epilogue.
+  const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
+  constexpr int NQ = GEGLU ? 2 : 4;
   if (!transposed) {
     constexpr int RB = COLS * 4;                   // bytes per staged row
+    int bidx[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int row = i * 32 + fr;
-      const int m = mw + row;
-      const int bidx = (p.ebias && m < p.M) ? m / p.rpb : 0;
-      const float lna = lnA[i], lnc = lnC[i];
+    for (int i = 0; i < TM; ++i) { const int m = mw + i * 32 + fr; bidx[i] = (p.ebias && m < p.M) ? m / p.rpb : 0; }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nt = nw + j * 32;
+    for (int j = 0; j < TN; ++j) {
+      const int nt = nw + j * 32;
+      f32x4 bz[NQ], cz[NQ], gz[NQ], gc[NQ], ez[TM][NQ];
 #pragma unroll
-        for (int q = 0; q < (GEGLU ? 2 : 4); ++q) {
-          const int nb = nt + 8 * q + 4 * fh;      // packed column of element r = 0 (bias arrays are padded to Npad)
+      for (int q = 0; q < NQ; ++q) {
+        const int nb = nt + 8 * q + 4 * fh;        // packed column of element r = 0 (bias arrays are padded to Npad)
+        const bool ok = nb < p.N;                  // columns of the zero-padded weight rows: nothing to add, never stored
+        bz[q] = *((p.bias && ok) ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
+        cz[q] = *((p.ln_stat && ok) ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
+        if constexpr (GEGLU) {
+          gz[q] = *((p.bias && ok) ? reinterpret_cast<const f32x4*>(p.bias + nb + 16) : zv);
+          gc[q] = *((p.ln_stat && ok) ? reinterpret_cast<const f32x4*>(p.ln_cs + nb + 16) : zv);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          ez[i][q] = *((p.ebias && ok) ? reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx[i] * p.ebias_ld + nb) : zv);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = i * 32 + fr;
+        const float lna = lnA[i], lnc = lnC[i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q * 4 + r];
-          const bool ncol_ok = nb < p.N;           // columns of the zero-padded weight rows: nothing to add, never stored
-          if (p.ln_stat && ncol_ok) v = lna * v + lnc * *reinterpret_cast<const f32x4*>(p.ln_cs + nb);
-          if (p.bias && ncol_ok) v += *reinterpret_cast<const f32x4*>(p.bias + nb);
-          if (p.ebias && ncol_ok) v += *reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx * p.ebias_ld + nb);
+          v = lna * v + lnc * cz[q] + bz[q] + ez[i][q];          // lna = 1, lnc = 0 without a folded LayerNorm
           int col = j * 32 + 8 * q + 4 * fh;
           if constexpr (GEGLU) {
-            f32x4 gz = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && ncol_ok) gz = *reinterpret_cast<const f32x4*>(p.bias + nb + 16);
-            f32x4 gc = {0.f, 0.f, 0.f, 0.f};
-            if (p.ln_stat && ncol_ok) gc = *reinterpret_cast<const f32x4*>(p.ln_cs + nb + 16);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(lna * acc[i][j][(q + 2) * 4 + r] + lnc * gc[r] + gz[r]);
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf2(lna * acc[i][j][(q + 2) * 4 + r] + lnc * gc[q][r] + gz[q][r]);
             col = j * 16 + 8 * q + 4 * fh;
           }
           *reinterpret_cast<f32x4*>(lds + row * RB + ((((col >> 2) ^ (row & SWN))) << 4)) = v;
@@ -268,19 +282,25 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
   } else {
     constexpr int RB = WM * 4;                     // transposed image: row = n (WN rows), col = m (WM columns)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mcol = i * 32 + fr;
-      const float lna = lnA[i], lnc = lnC[i];
+    for (int j = 0; j < TN; ++j) {
+      f32x4 bz[4], cz[4];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
+      for (int q = 0; q < 4; ++q) {
+        const int nb = nw + j * 32 + 8 * q + 4 * fh;
+        const bool ok = nb < p.N;
+        bz[q] = *((p.bias && ok) ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
+        cz[q] = *((p.ln_stat && ok) ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mcol = i * 32 + fr;
+        const float lna = lnA[i], lnc = lnC[i];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int nb = nw + j * 32 + 8 * q + 4 * fh;
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q * 4 + r];
-          if (p.ln_stat && nb < p.N) v = lna * v + lnc * *reinterpret_cast<const f32x4*>(p.ln_cs + nb);
-          if (p.bias && nb < p.N) v += *reinterpret_cast<const f32x4*>(p.bias + nb);
+          v = lna * v + lnc * cz[q] + bz[q];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int nrow = j * 32 + 8 * q + 4 * fh + r;
@@ -298,8 +318,24 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
     constexpr int ITEMS = ROWS * LPR;              // (row, 8-value piece) items, 64 per wave instruction
     const int nlim = GEGLU ? (p.N >> 1) : (p.n_split < p.N ? p.n_split : p.N);
     const int nwo = GEGLU ? (nw >> 1) : nw;
+    // residual rows (f16, whole 16-byte pieces -- the case of every UNet / VAE residual): all of this lane's pieces are
+    // requested up front through a pointer select, one wait for the lot instead of a load -> wait -> add -> store chain
+    // per piece; anything else (fp32 residual stream, ragged or unaligned pieces) takes the per-piece path below
+    constexpr int NIT = (ITEMS + 63) / 64;
+    half8 rpre[NIT];
+    bool rfast[NIT];
 #pragma unroll
-    for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / LPR, piece = idx - row * LPR;
+      const int n0 = nwo + piece * 8;
+      const int m = mw + row;
+      const half_t* rp = reinterpret_cast<const half_t*>(p.R) + (size_t)m * p.ldr + n0;
+      rfast[it] = p.R && p.r_dt == DT_F16 && idx < ITEMS && m < p.M && n0 + 8 <= nlim && (reinterpret_cast<uintptr_t>(rp) & 15) == 0;
+      rpre[it] = *(rfast[it] ? reinterpret_cast<const half8*>(rp) : reinterpret_cast<const half8*>(zeros));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
       const int idx = it * 64 + lane;
       const int row = idx / LPR, piece = idx - row * LPR;
       if (ITEMS % 64 != 0 && idx >= ITEMS) continue;
@@ -312,7 +348,10 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       if (valid) {
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
       const bool full = n0 + 8 <= nlim;
-      if (p.R) {
+      if (rfast[it]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rpre[it][e];
+      } else if (p.R) {
         if (p.r_dt == DT_F16) {
           const half_t* rp = reinterpret_cast<const half_t*>(p.R) + (size_t)m * p.ldr + n0;
           if (full && (reinterpret_cast<uintptr_t>(rp) & 15) == 0) {
@@ -430,18 +469,19 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
 // dispatch: the staged path needs the wave's column range on one side of n_split; anything else takes the direct epilogue
 template <int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw,
-                                                      int lane, char* lds, const float (&lnA)[TM], const float (&lnC)[TM]) {
+                                                      int lane, char* lds, const float (&lnA)[TM], const float (&lnC)[TM],
+                                                      const void* zeros) {
   constexpr int WN = TN * 32;
-  if (p.act == 1) { igemm_epilogue_staged_impl<TM, TN, true>(p, acc, mw, nw, lane, lds, false, lnA, lnC); return; }
+  if (p.act == 1) { igemm_epilogue_staged_impl<TM, TN, true>(p, acc, mw, nw, lane, lds, false, lnA, lnC, zeros); return; }
   const bool all_normal = nw + WN <= p.n_split || p.n_split >= p.N;
   const bool all_transposed = nw >= p.n_split;
-  if (all_normal) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, false, lnA, lnC);
-  else if (all_transposed) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, true, lnA, lnC);
+  if (all_normal) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, false, lnA, lnC, zeros);
+  else if (all_transposed) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, true, lnA, lnC, zeros);
   else igemm_epilogue<TM, TN>(p, acc, mw, nw, lane & 31, lane >> 5, lnA, lnC);
 }
 
 template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, const void* zeros) {
+__global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const IgemmParams p, const void* zeros) {   // >= 2 blocks per CU
   constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
   constexpr int AJ = BM / 32, BJ = BN / 32;   // DMA instructions per wave per k-tile (8 rows each, 4 waves)
@@ -585,7 +625,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p, co
   }
 
   __syncthreads();                                 // every wave is done reading the ring: it becomes the staging area
-  igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC);
+  igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC, zeros);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -886,7 +926,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   constexpr bool FITS = 8 * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
   if (FITS || p.act == 1) {
     const int region = p.act == 1 ? WM * (WN / 2) * 4 : WM * WN * 4;   // GEGLU halves the staged width
-    igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * region, lnA, lnC);
+    igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * region, lnA, lnC, zeros);
   } else {
     igemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, fr, fh, lnA, lnC);
   }
@@ -1081,7 +1121,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void igemm_ws_kernel(const IgemmPara
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC);
+  igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC, zeros);
 }
 
 static const void* g_zero_page = nullptr;
