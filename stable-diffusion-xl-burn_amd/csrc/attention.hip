@@ -630,9 +630,11 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
   const bool aligned = ((p.ldq | p.ldk | p.vt_ld | p.ldo) & 7) == 0 &&
                        ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
                          reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) == 0;
-  if (p.dt == DT_F16 && (g_attn_variant == 0 || g_attn_variant == 2) && g_attn_zero && aligned && !p.mask) {
+  if (p.dt == DT_F16 && (g_attn_variant == 0 || g_attn_variant == 2 || g_attn_variant == 3) && g_attn_zero && aligned && !p.mask) {
+    // 3-slot ring = 48 KiB per block -> three blocks per CU: the 640 blocks of the 64^2 level run as ONE round (a 4-slot
+    // ring admits two per CU, a second half-empty round: 147 us vs 126 us measured); variant 3 keeps the 4-slot ring for A/B
     const dim3 g1(grid.x * grid.y);
-    if (p.Nk > 128) {
+    if (g_attn_variant == 3 && p.Nk > 128) {
       constexpr int NS = 4;
       static bool set = false;
       if (!set) {
