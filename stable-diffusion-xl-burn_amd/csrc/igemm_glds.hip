@@ -933,6 +933,164 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Wide-tile variant for the GEGLU projections: block tile 256 x 320, k-tile 32.
+//
+// The global->LDS path sustains ~22 B/clk/CU whatever issues it, so the reachable MFMA rate of a tile is
+// BM*BN/(BM+BN) flop per DMA byte: 85 for 256x128, 98 for 256x160, 142 for 256x320.  A 64-deep k-tile of that tile
+// would not fit a 3-slot ring (72 KiB per slot); with KT = 32 a slot is 36 KiB and FOUR slots fit (144 KiB).  N = 10240 at
+// M = 2048 is then 8 x 32 = 256 tiles: one workgroup per CU, ONE round (256x160 needs two, 256x128 three), so the per-tile
+// fixed cost is paid once.  8 waves as 4 (M) x 2 (N), wave tile 64 x 160 = 2 x 5 MFMA tiles: 7 ds_read_b128 per 10 MFMA.
+// LDS rows are 64 bytes (32 halfs): a 1-KiB DMA piece covers 16 rows, source chunk = slot ^ ((row>>2)&3), which makes the
+// 16-lane ds_read_b128 service groups hit 16 distinct 16-byte slots of the 256-byte bank row.
+// Per k-tile: {frags kk=0 -> 10 MFMA} {frags kk=1 -> wait own pieces of tile kt+1 -> barrier -> 10 MFMA with the pieces of
+// tile kt+NS (slot just freed) issued between them}.  GEGLU epilogue only (staged through LDS in two 32-row passes).
+template <int NS>
+__global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, const void* zeros) {
+  constexpr int BM = 256, BN = 320, KT = 32;
+  constexpr int WM = 64, WN = 160, TM = 2, TN = 5, NF = TM + TN;
+  constexpr int ROWB = KT * 2;                 // 64 bytes per tile row
+  constexpr int STAGE = (BM + BN) * ROWB;      // 36864
+  constexpr int AJ = BM / 16 / 8;              // 2 pieces of 16 rows per wave
+  constexpr int BPC = BN / 16, BJ = (BPC + 7) / 8, REM = BPC % 8;   // 20 pieces: waves 0..3 carry 3, waves 4..7 carry 2
+  constexpr int PER = AJ + BJ;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool lastb = wave < REM;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int tilesM = (p.M + BM - 1) / BM;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  if ((size_t)p.N * p.K > (size_t)p.M * p.Cin) { tn = bid / tilesM; tm = bid - tn * tilesM; }
+  else { tm = bid / tilesN; tn = bid - tm * tilesN; }
+  const int m0 = tm * BM, n0 = tn * BN;
+  auto wait_tiles = [&](auto KK) {
+    constexpr int k = decltype(KK)::value;
+    if (lastb) wait_vmcnt<PER * k>(); else wait_vmcnt<(PER - 1) * k>();
+  };
+
+  // ---- DMA geometry (linear layers only: ksize 1, stride 1): piece j of this wave = tile rows (j*8 + wave)*16 .. +15
+  const int lrow = lane >> 2, slot = lane & 3;
+  const half_t* aptr[AJ];
+  int aadv[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int row = (j * 8 + wave) * 16 + lrow;
+    const int m = m0 + row;
+    const bool ok = m < p.M;
+    aptr[j] = ok ? reinterpret_cast<const half_t*>(p.A) + (size_t)m * p.lda + (slot ^ ((row >> 2) & 3)) * 8
+                 : reinterpret_cast<const half_t*>(zeros);
+    aadv[j] = ok ? KT : 0;
+  }
+  const half_t* wptr[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int row = (j * 8 + wave) * 16 + lrow;
+    wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 2) & 3)) * 8;
+  }
+  auto issue = [&](int buf, auto Q) {            // piece Q of the next tile into ring slot buf
+    constexpr int q = decltype(Q)::value;
+    char* la = smem + buf * STAGE + wave * 1024;
+    char* lb = la + BM * ROWB;
+    if constexpr (q < AJ) {
+      __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(la + q * 8192), 16, 0, 0);
+      aptr[q] += aadv[q];
+    } else if (q - AJ < BJ - 1 || lastb) {
+      __builtin_amdgcn_global_load_lds((gptr_t)wptr[q - AJ], (lptr_t)(lb + (q - AJ) * 8192), 16, 0, 0);
+      wptr[q - AJ] += KT;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+  const int nk = p.Kpad / KT;
+  const int fr = lane & 31, fh = lane >> 5;
+  unsigned basea, baseb;
+  {
+    const int ra = wm * WM + fr, rbw = wn * WN + fr;
+    basea = lds0 + ra * ROWB + ((fh ^ ((ra >> 2) & 3)) << 4);
+    baseb = lds0 + BM * ROWB + rbw * ROWB + ((fh ^ ((rbw >> 2) & 3)) << 4);
+  }
+  half8 fA[TM], fB[TN];
+  auto ldfrag = [&](unsigned so, int kk) {       // chunk(kk) = (kk*2 + fh) ^ sw = (fh ^ sw) ^ (kk << 1) -> byte offset ^ (kk << 5)
+    const unsigned aa = (basea ^ (kk << 5)) + so, ab = (baseb ^ (kk << 5)) + so;
+    static_for<TM>([&](auto I) { fA[decltype(I)::value] = lds_read128<decltype(I)::value * 32 * ROWB>(aa); });
+    static_for<TN>([&](auto J) { fB[decltype(J)::value] = lds_read128<decltype(J)::value * 32 * ROWB>(ab); });
+  };
+  // ten MFMAs of one kk-step; with DMA: the PER pieces of the next tile go behind MFMAs 0, 2, 4, 6, 8
+  auto mma = [&](int buf, bool dma) {
+    __builtin_amdgcn_s_setprio(1);
+    static_for<TM * TN>([&](auto X) {
+      constexpr int x = decltype(X)::value, i = x / TN, j = x % TN;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[j], fA[i], acc[i][j], 0, 0, 0);
+      if constexpr ((x & 1) == 0 && x / 2 < PER) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma) issue(buf, std::integral_constant<int, x / 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: the whole ring in flight, wait for tile 0 only
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (s < nk) static_for<PER>([&](auto Q) { issue(s, Q); });
+  float lnA[TM], lnC[TM];
+  ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
+  if (NS <= nk) wait_tiles(std::integral_constant<int, NS - 1>{}); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  // (zeroed only now: keeping 160 accumulator registers live across the statistics loads of ln_prologue spills)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned so = cur * STAGE;
+    ldfrag(so, 0);
+    wait_lgkmcnt<0>();
+    mma(cur, false);
+    ldfrag(so, 1);
+    wait_lgkmcnt<0>();                          // own reads of tile kt complete
+    const bool more = kt + NS < nk;
+    if (kt + 1 < nk) {
+      if (kt + NS - 1 < nk) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();             // tile kt+1 visible; slot of tile kt free for tile kt+NS
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mma(cur, more);
+    cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  __builtin_amdgcn_s_barrier();                  // ring dead -> staging area
+  asm volatile("" ::: "memory");
+  if (p.act == 1) {
+    // two passes of 32 rows: a full 64 x 80 fp32 staging region per wave would not fit next to seven others
+    char* region = smem + wave * (32 * (WN / 2) * 4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float la1[1] = {lnA[i]}, lc1[1] = {lnC[i]};
+      igemm_epilogue_staged_impl<1, TN, true>(p, *reinterpret_cast<const f32x16(*)[1][TN]>(&acc[i]), m0 + wm * WM + i * 32,
+                                              n0 + wn * WN, lane, region, false, la1, lc1, zeros);
+    }
+  }   // (the launcher only admits GEGLU projections)
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Warp-specialised variant: 8 compute waves + NL loader waves per workgroup.
 //
 // Measured on the pipelined kernel above (tools/igemm_ksweep.py): with the DMA pieces issued by the computing waves the
@@ -1172,6 +1330,19 @@ static void launch_ws(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_ws_kernel<BM, BN, NS, NL>), dim3(tilesM * tilesN), dim3(512 + 64 * NL), lds, s, p, g_zero_page);
 }
 
+static void launch_wide(const IgemmParams& p, hipStream_t s) {
+  constexpr int NS = 4;
+  const int tilesM = (p.M + 255) / 256, tilesN = (p.N + 319) / 320;
+  const size_t lds = (size_t)NS * (256 + 320) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wide_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_wide_kernel<NS>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_page);
+}
+
 // variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
 // 6 = 64x128 ring 2; 7 = 128x128 ring 4; 8 = 64x128 ring 3.  Returns false when the shape needs the generic kernel.
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
@@ -1220,6 +1391,9 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 16: launch_pipe<128, 128, 4, true, 1>(p, s); break;
     case 17: launch_pipe<256, 128, 3, true, 2>(p, s); break;    // measurement only: no k advance (WRONG results)
     case 18: launch_pipe<256, 128, 3, true, 3>(p, s); break;    // measurement only: no DMA in the loop (WRONG results)
+    case 26:                                                    // 256x320, k-tile 32: linear GEGLU projections only
+      if (p.act != 1 || p.ksize != 1 || p.stride != 1 || p.up != 0 || p.N % 320 != 0 || p.Kpad % 32 != 0) return false;
+      launch_wide(p, s); break;
     case 24: launch_pipe<256, 128, 3, true, 4>(p, s); break;    // lookahead-2 fragment prefetch
     case 25: launch_pipe<128, 128, 4, true, 4>(p, s); break;
     case 19:                                                    // 256x160, 8x1 waves: weight rows must exist up to the tile edge

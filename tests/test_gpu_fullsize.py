@@ -63,3 +63,38 @@ def test_fullsize_sample_and_decode(pkg, ctx):
     buf = img.buffer
     assert buf.dtype == torch.uint8 and buf.numel() == 1024 * 1024 * 3
     assert int(buf.max()) > int(buf.min()), "constant image"
+
+
+def test_fullsize_refiner_and_inpainting(pkg, ctx):
+    """BASELINE configs[3] / configs[4] at full size: the 4-level refiner UNet (model_channels 384, C up to 1536 -> 24
+    LayerNorm slots, context 1280) through refine_latent, and the inpainting path (u8 image -> VAE encoder -> masked
+    trajectory).  Properties: finite, deterministic, the inpainting blend keeps the reference outside the mask at t -> 0."""
+    rcfg = pkg.sdxl_refiner_config()
+    d = pkg.Diffuser(ctx, rcfg, pkg.DTYPE_F16, seed=0)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)   # noqa: E731
+    cond = pkg.Conditioning(context_open_clip=r(1, 77, rcfg.context_dim), channel_context_refiner=r(1, rcfg.adm_in_channels),
+                            unconditional_context_open_clip=r(77, rcfg.context_dim),
+                            unconditional_channel_context_refiner=r(rcfg.adm_in_channels), resolution=(1024, 1024))
+    latent, noise = r(1, 4, 128, 128), r(1, 4, 128, 128)
+    out = d.refine_latent(latent, cond, 7.5, 800, 20, noise)       # (0..200).rev().step_by(50) -> 4 refiner iterations
+    assert out.shape == latent.shape and torch.isfinite(out).all()
+    assert torch.equal(out, d.refine_latent(latent, cond, 7.5, 800, 20, noise))
+    del d
+
+    # inpainting: encode a synthetic u8 image, keep generated content only in latent rows 0..24 (README: crop rows 0..200 px)
+    ld = pkg.LatentDecoder(ctx, None, pkg.DTYPE_F16, seed=0, with_encoder=True)
+    img = (torch.rand(1, 1024, 1024, 3, device="cuda", generator=g) * 255).to(torch.uint8)
+    ref_latent = ld.image_to_latent(pkg.RawImages(img, 1024, 1024))
+    assert ref_latent.shape == (1, 4, 128, 128) and torch.isfinite(ref_latent).all()
+    cfg = pkg.sdxl_base_config()
+    db = pkg.Diffuser(ctx, cfg, pkg.DTYPE_F16, seed=0)
+    condb = pkg.Conditioning(context_full=r(1, 77, cfg.context_dim), channel_context=r(1, cfg.adm_in_channels),
+                             unconditional_context_full=r(77, cfg.context_dim),
+                             unconditional_channel_context=r(cfg.adm_in_channels), resolution=(1024, 1024))
+    iters = pkg.step_count(4)
+    mask = torch.zeros(1, 4, 128, 128, dtype=torch.bool, device="cuda")
+    mask[:, :, 0:25, :] = True
+    step_noise = torch.zeros(iters, 1, 4, 128, 128, device="cuda")     # zero re-noise: the kept region must track the reference
+    out = db.sample_latent_with_inpainting(condb, 7.5, 4, ref_latent, mask, r(1, 4, 128, 128), step_noise)
+    assert torch.isfinite(out).all()
