@@ -227,3 +227,26 @@ def test_errors_are_reported_not_fatal(pkg, ctx):
     with pytest.raises(pkg.EngineError):   # height not divisible by 4
         u.forward(torch.zeros(1, 4, 6, 8).cuda(), torch.zeros(1, dtype=torch.int32).cuda(),
                   torch.zeros(1, 3, ocfg.context_dim).cuda(), torch.zeros(1, ocfg.adm_in_channels).cuda())
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_empty_replica_receives_weight_arena(pkg, ctx, dtype):
+    """the multi-GPU replica path on one GPU: a model created `empty` (identical arena layout, no contents) must reproduce
+    the source model bit for bit once the packed arena has been copied in through the zero-copy tensor view -- exactly what
+    bench.py's RCCL broadcast does (folded-LayerNorm weights, column sums and biases all live in the arena)"""
+    ocfg = OC.tiny_config()
+    cfg = to_pkg_cfg(pkg, ocfg)
+    res = (64, 64)
+    c, _ = _cond(ocfg, 1, res)
+    noise = seeded(1, 4, 8, 8, seed=46)
+    src = pkg.Diffuser(ctx, cfg, dtype, seed=0)
+    dst = pkg.Diffuser(ctx, cfg, dtype, seed=0, empty=True)
+    a_src, a_dst = src.diffusion.weight_arena_tensor(), dst.diffusion.weight_arena_tensor()
+    base, nbytes = src.diffusion.weight_arena()
+    assert a_src.data_ptr() == base and a_src.numel() == nbytes and a_src.dtype == torch.uint8, "arena view is not zero-copy"
+    assert a_dst.numel() == a_src.numel(), "replica arena layout differs from the source's"
+    a_dst.copy_(a_src)
+    torch.cuda.synchronize()
+    ref = src.sample_latent(_pkg_cond(pkg, c, res), 7.5, 4, noise.cuda()).cpu()
+    out = dst.sample_latent(_pkg_cond(pkg, c, res), 7.5, 4, noise.cuda()).cpu()
+    assert torch.equal(out, ref)
