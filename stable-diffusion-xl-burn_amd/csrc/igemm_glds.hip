@@ -1,20 +1,24 @@
 // Fast-path implicit GEMM for gfx950: f16 operands, direct-to-LDS staging through an NS-deep ring.
 //
 // Same contract as igemm_kernel (igemm.hip) for the shapes that dominate the SDXL step (f16 activations, Cin % 64 == 0,
-// 16-byte aligned rows); everything else stays on the generic kernel.  Differences, all CDNA4-specific:
+// 16-byte aligned rows); everything else stays on the generic kernel.  What every kernel in this file shares (CDNA4-specific):
 //   * HBM/L2 -> LDS without a VGPR round trip: every wave issues `global_load_lds_dwordx4` (16 B per lane, 1 KiB per wave
 //     instruction = 8 tile rows of 128 B).  The LDS image is lane-linear, so the bank-conflict swizzle is applied to the
 //     per-lane SOURCE address (chunk ^ f(row)) and again on the fragment read; halo / tail rows fetch from a zero page.
 //     The conv gather (tap, stride, fused nearest-2x upsample) is still just a per-lane source address.
-//   * NS-deep LDS ring with COUNTED waits: tile kt+NS-1 is issued while tile kt is multiplied, `s_waitcnt vmcnt(N)` leaves
-//     NS-2 tiles in flight across the (raw) s_barrier, so HBM latency is covered even at one block per CU -- the regime of
-//     the M=2048 transformer GEMMs (160..480 tiles on 256 CUs).  One barrier per k-tile.
-//   * v_mfma_f32_32x32x16_f16, wave tile (BM/2)x(BN/2) >= 64x32: LDS read traffic stays <= 75 % of the 256 B/clk/CU budget.
-//   * operand roles swapped (weights = MFMA A operand, activations = B operand): the accumulator layout then gives each
-//     lane 4 CONSECUTIVE output columns of one row -> 8-byte packed stores, vector bias / residual loads, and GEGLU pairs
-//     (x, gate) sit in the same lane of the same accumulator tile.
+//   * NS-deep LDS ring with COUNTED `s_waitcnt vmcnt(N)` across a raw s_barrier; one barrier per k-tile.
+//   * v_mfma_f32_32x32x16_f16 with the operand roles swapped (weights = MFMA A operand, activations = B operand): the
+//     accumulator layout then gives each lane 4 CONSECUTIVE output columns of one row, and GEGLU pairs (x, gate) sit in the
+//     same lane of the same accumulator tile.
 //   * swizzle f(row) = (row>>1)&7 makes the ds_read_b128 fragment reads of 32 rows conflict-free across the four 16-lane
-//     service groups (two 128-byte tile rows share one 256-byte bank row).
+//     service groups (two 128-byte tile rows share one 256-byte bank row); measured SQ_LDS_BANK_CONFLICT = 0.
+//   * XCD-aware block -> tile mapping; epilogue staged through LDS so loads/stores are whole row segments; folded LayerNorm.
+// Kernels, in file order (selection: launch_igemm_glds at the bottom; measurements: DESIGN.md section 4.1):
+//   igemm_glds_kernel  4 waves, 2..4-slot ring, several co-resident blocks per CU       (ragged multi-round grids)
+//   igemm_pipe_kernel  8 waves, hand-ordered k-loop: counted lgkmcnt/vmcnt, register-double-buffered fragments, DMA pieces
+//                      between the MFMAs; tiles 256x128, 128x128, 256x160 (GEGLU)        (everything else -- the default)
+//   igemm_wide_kernel  256x320 tile, k-tile 32                                           (experiment, not selected)
+//   igemm_ws_kernel    8 compute + 2/4 DMA-loader waves                                  (experiment, not selected)
 #include "kernels.h"
 #include <type_traits>
 
