@@ -81,6 +81,13 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise EngineError(f"{LIB_PATH} is missing: run `python stable-diffusion-xl-burn_amd/build.py` "
                               "(hipcc --offload-arch=gfx950). There is no fallback path.")
+        # torch's ROCm wheel bundles its own libamdhip64: it must be in the process BEFORE this library is loaded, so both
+        # bind to ONE HIP runtime.  Loaded the other way round (library first, torch later) the process ends up with two
+        # runtimes and the second one reports "no ROCm-capable device" (seen with build() followed by smoke() in one process).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = ctypes.CDLL(LIB_PATH)
         l.sdxl_last_error.restype = ctypes.c_char_p
         l.sdxl_build_info.restype = ctypes.c_char_p
