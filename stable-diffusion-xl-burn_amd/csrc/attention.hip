@@ -614,6 +614,204 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// f16 variant 3: variant 2 with the two GEMMs of consecutive tiles software-pipelined inside each wave.
+//   iteration t:  [row max of S(t), rare rescale]  ->  { S(t+1) = K(t+1) Q^T  (8 MFMA)  ||  P = exp2(S(t)), row sums, fp16
+//   fragments (VALU) }  ->  O^T += V^T(t) P^T (8 MFMA).  The matrix pipe and the VALU are separate: in variant 2 a wave ran
+//   QK^T, softmax and PV strictly one after the other.  K runs one tile ahead of V, so K and V^T have separate 3-slot rings
+//   (48 KiB together, three blocks per CU): after the barrier of iteration t the wave stages {K(t+3), V(t+2)} -- both slots
+//   were last read in iteration t-1 -- and waits with vmcnt(4) for {K(t+1), V(t)} only (two iterations of prefetch).
+//   Tile indices past the end are clamped (a few redundant DMA pieces keep the counts uniform).
+//   MEASURED (profiles/r01_attention_bench.txt): slower than variant 2 -- the second score tile costs 49 VGPRs (189 vs 140),
+//   i.e. two blocks per CU instead of three (155 vs 136 us at 64^2); bounded to 168 VGPRs it spills inside the loop (181 us).
+//   Kept as forced variant 4 for the record; variant 2 is what runs.
+__global__ __launch_bounds__(256, 2) void attn_d64_v3_kernel(const AttnParams p, const void* zeros) {
+  constexpr int KV = 64, TILE = 64 * 128;
+  constexpr float THR = 8.0f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3] K tiles | [3] V^T tiles
+  char* sK = smem;
+  char* sV = smem + 3 * TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, h = lane >> 5;
+  const int nqb = (p.Nq + 127) / 128;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bh = bid / nqb, qb = bid - bh * nqb;
+  const int b = bh / p.H, hd = bh - b * p.H;
+  const int q0 = qb * 128 + wave * 32;
+  const half_t* Qg = reinterpret_cast<const half_t*>(p.Q) + (size_t)b * p.Nq * p.ldq + hd * 64;
+  const half_t* Kg = reinterpret_cast<const half_t*>(p.K) + (size_t)b * p.Nk * p.ldk + hd * 64;
+  const half_t* Vg = reinterpret_cast<const half_t*>(p.Vt) + ((size_t)b * p.H + hd) * 64 * p.vt_ld;
+  const float sc = p.scale * 1.44269504088896340736f;
+  const int nt = (p.Nk + KV - 1) / KV;
+
+  half8 qf[4];
+  {
+    const int q = q0 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      half8 v = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < p.Nq) v = *reinterpret_cast<const half8*>(Qg + (size_t)q * p.ldq + ks * 16 + h * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * sc);
+      qf[ks] = v;
+    }
+  }
+  const int lrow = lane >> 3, slot = lane & 7;
+  auto stage_k = [&](int t) {           // K tile t (clamped) -> K slot t % 3: rows [16w, 16w+16) of this wave, two pieces
+    const int tc = t < nt ? t : nt - 1;
+    char* lk = sK + (t % 3) * TILE + wave * 2048;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wave * 16 + j * 8 + lrow;
+      const int key = tc * KV + row;
+      const half_t* ks = key < p.Nk ? Kg + (size_t)key * p.ldk + (slot ^ ((row >> 1) & 7)) * 8 : reinterpret_cast<const half_t*>(zeros);
+      __builtin_amdgcn_global_load_lds((agptr_t)ks, (alptr_t)(lk + j * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_v = [&](int t) {
+    const int tc = t < nt ? t : nt - 1;
+    char* lv = sV + (t % 3) * TILE + wave * 2048;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wave * 16 + j * 8 + lrow;
+      const half_t* vs = Vg + (size_t)row * p.vt_ld + tc * KV + (slot ^ ((row ^ (row >> 3)) & 7)) * 8;
+      __builtin_amdgcn_global_load_lds((agptr_t)vs, (alptr_t)(lv + j * 1024), 16, 0, 0);
+    }
+  };
+  int koff[2], voff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = u * 32 + fr;
+    koff[u] = row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
+    voff[u] = row * 128;
+  }
+  const int vsw[2] = {(fr ^ (fr >> 3)) & 7, ((32 + fr) ^ ((32 + fr) >> 3)) & 7};
+  auto qk = [&](const char* kb, float init, f32x16 (&sv)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[u][r] = init;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const half8 kf = *reinterpret_cast<const half8*>(kb + (koff[u] ^ (ks << 5)));
+        sv[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sv[u], 0, 0, 0);
+      }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m = 0.f, l = 0.f;
+  // prologue: K(0) | {K(1), V(0)} | {K(2), V(1)}; wait for K(0) only
+  stage_k(0);
+  stage_k(1); stage_v(0);
+  stage_k(2); stage_v(1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  f32x16 sc_[2];                       // S(t) - m
+  qk(sK, 0.f, sc_);
+  for (int t = 0; t < nt; ++t) {
+    // group t = {K(t+1), V(t)} landed (group t+1 may stay in flight); everyone is done with K(t) and V(t-1)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage_k(t + 3); stage_v(t + 2);
+    if (t == nt - 1 && (p.Nk & 63) != 0) {                      // key tail (wave-uniform)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * KV + u * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= p.Nk) sc_[u][r] = -INFINITY;
+    }
+    float lmax = sc_[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) lmax = fmaxf(lmax, sc_[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lmax = fmaxf(lmax, sc_[1][r]);
+    if (t == 0 || __any(lmax > THR)) {
+      const float pm = fmaxf(lmax, __shfl_xor(lmax, 32));
+      const float delta = t == 0 ? pm : fmaxf(pm, 0.f);
+      const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+      m = t == 0 ? delta : m + delta;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc_[u][r] -= delta;
+    }
+    // ---- S(t+1) - m on the matrix pipe while the VALU turns S(t) into P
+    f32x16 sn[2];
+    qk(sK + ((t + 1) % 3) * TILE, -m, sn);                     // past the last tile: a clamped copy, never used
+    half8 pf[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        half8 hh;
+        float ls = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(sc_[u][8 * hf + e]);
+          ls += pe;
+          hh[e] = (half_t)pe;
+        }
+        l += ls;
+        pf[u * 2 + hf] = hh;
+      }
+    // ---- O^T += V^T(t) P^T
+    const char* vb = sV + (t % 3) * TILE;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int base = (s4 >> 1) * 32 + (s4 & 1) * 16;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int b1 = (base + 4 * h) * 2, b2 = b1 + 16;
+        const i32x2 v1 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b1 >> 4)) ^ vsw[dt]) << 4) + (b1 & 15));
+        const i32x2 v2 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b2 >> 4)) ^ vsw[dt]) << 4) + (b2 & 15));
+        const i32x4 vf = i32x4{v1[0], v1[1], v2[0], v2[1]};
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, vf), pf[s4], o[dt], 0, 0, 0);
+      }
+    }
+    sc_[0] = sn[0]; sc_[1] = sn[1];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // clamped look-ahead pieces still in flight
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+  __syncthreads();
+  char* ob = smem + wave * 4096;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      half4 hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hv[r] = (half_t)(o[dt][g * 4 + r] * inv);
+      *reinterpret_cast<half4*>(ob + fr * 128 + (((dt * 4 + g) ^ (fr & 7)) << 4) + 8 * h) = hv;
+    }
+  half_t* Og = reinterpret_cast<half_t*>(p.O) + (size_t)b * p.Nq * p.ldo + hd * 64;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3), piece = lane & 7;
+    const i32x4 v = *reinterpret_cast<const i32x4*>(ob + row * 128 + ((piece ^ (row & 7)) << 4));
+    const int q = q0 + row;
+    if (q < p.Nq) *reinterpret_cast<i32x4*>(Og + (size_t)q * p.ldo + piece * 8) = v;
+  }
+}
+
 static const void* g_attn_zero = nullptr;
 static int g_attn_variant = 0;   // -1: generic kernel only
 void attention_set_variant(int v) { g_attn_variant = v; }
@@ -630,11 +828,13 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
   const bool aligned = ((p.ldq | p.ldk | p.vt_ld | p.ldo) & 7) == 0 &&
                        ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
                          reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) == 0;
-  if (p.dt == DT_F16 && (g_attn_variant == 0 || g_attn_variant == 2 || g_attn_variant == 3) && g_attn_zero && aligned && !p.mask) {
+  if (p.dt == DT_F16 && (g_attn_variant == 0 || g_attn_variant == 2 || g_attn_variant == 3 || g_attn_variant == 4) && g_attn_zero && aligned && !p.mask) {
     // 3-slot ring = 48 KiB per block -> three blocks per CU: the 640 blocks of the 64^2 level run as ONE round (a 4-slot
     // ring admits two per CU, a second half-empty round: 147 us vs 126 us measured); variant 3 keeps the 4-slot ring for A/B
     const dim3 g1(grid.x * grid.y);
-    if (g_attn_variant == 3 && p.Nk > 128) {
+    if (g_attn_variant == 4) {
+      hipLaunchKernelGGL(attn_d64_v3_kernel, g1, dim3(256), 6 * 64 * 128, s, p, g_attn_zero);
+    } else if (g_attn_variant == 3 && p.Nk > 128) {
       constexpr int NS = 4;
       static bool set = false;
       if (!set) {
