@@ -206,3 +206,96 @@ def test_product_path_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+# ------------------------------------------------------------------ Embedder: tokenizers (host string code) + CLIP oracle
+_TOKDIR = REF + "/tokenizer"
+_need_assets = pytest.mark.skipif(not os.path.exists(_TOKDIR + "/clip/bpe_simple_vocab_16e6.txt"),
+                                  reason="tokenizer assets (reference checkout) not present")
+
+
+@pytest.fixture(scope="module")
+def tok(pkg):
+    import importlib
+    return importlib.import_module(pkg.__name__ + ".tokenizer")
+
+
+@_need_assets
+def test_clip_tokenizer_known_answer(tok):
+    # src/token/clip.rs:236-248 -- the reference's only expected-value test on this path
+    t = tok.ClipTokenizer(_TOKDIR)
+    text = "Hello world! <|startoftext|>asdf<|startoftext|>"
+    ids = t.encode(text, False, False)
+    assert ids == [3306, 1002, 256, 49406, 587, 10468, 49406]
+    assert t.decode(ids) == "hello world ! <|startoftext|>asdf <|startoftext|>"
+    assert (t.start_of_text_token(), t.end_of_text_token(), t.padding_token()) == (49406, 49407, 49407)
+
+
+@_need_assets
+def test_tokenizers_agree_with_hf_tokenizer_json(tok):
+    # the reference ships the HF tokenizer.json of the same vocabulary: an independent implementation to pin against
+    tokenizers = pytest.importorskip("tokenizers")
+    hf = tokenizers.Tokenizer.from_file(_TOKDIR + "/tokenizer.json")
+    clip, oc = tok.ClipTokenizer(_TOKDIR), tok.OpenClipTokenizer(_TOKDIR)
+    texts = ["a photo of an astronaut riding a horse on mars", "An elegant bright-colored bird, ultra-detailed 8k!!",
+             "  multiple   spaces\tand\nnewlines ", "it's the cat's 1234 toys", "naïve café — déjà vu", "日本語のテキスト", ""]
+    for s in texts:
+        want = hf.encode(s, add_special_tokens=False).ids
+        assert clip.encode(s, False, False) == want, s
+        assert oc.encode(s, False, False) == want, s      # same vocabulary, read from files (open_clip.rs:82-113)
+    assert oc.padding_token() == 0
+
+
+@_need_assets
+def test_tokenize_text_pads_and_truncates(tok):
+    clip, oc = tok.ClipTokenizer(_TOKDIR), tok.OpenClipTokenizer(_TOKDIR)
+    a = tok.tokenize_text("a cat", clip, 77)
+    b = tok.tokenize_text("a cat", oc, 77)
+    assert len(a) == len(b) == 77 and a[0] == b[0] == 49406
+    assert a[:4] == b[:4] and a[3] == 49407 and set(a[4:]) == {49407} and set(b[4:]) == {0}
+    long = tok.tokenize_text("cat " * 200, clip, 77)
+    assert len(long) == 77 and long[-1] != 49407        # truncation drops the eot, as the reference's loop does
+
+
+def test_bytes_to_unicode_is_a_bijection(tok):
+    bu = tok.bytes_to_unicode()
+    assert len(bu) == 256 and len({b for b, _ in bu}) == 256 and len({c for _, c in bu}) == 256
+    assert dict(bu)[ord("a")] == "a" and dict(bu)[0] == chr(256) and dict(bu)[32] == chr(256 + 32)
+
+
+def test_clip_param_counts():
+    from oracle import clip as OCL
+    n = lambda cfg: sum(p.numel for p in OCL.clip_param_specs(cfg))   # noqa: E731
+    assert abs(n(OCL.clip_l_config()) / 1e6 - 123.65) < 0.01            # CLIP ViT-L/14 text tower + projection
+    assert abs(n(OCL.open_clip_bigg_config()) / 1e6 - 694.66) < 0.01    # OpenCLIP bigG text tower + projection
+
+
+def test_clip_oracle_structure():
+    from oracle import clip as OCL
+    cfg = OCL.tiny_open_clip_config()
+    W = OM.to_torch(OC.synth_weights(OCL.clip_param_specs(cfg), 3))
+    ids = torch.zeros(2, 77, dtype=torch.int64)
+    ids[0, :5] = torch.tensor([49406, 320, 2368, 49407, 0]); ids[1, :7] = torch.tensor([49406, 5, 49407, 9, 49407, 0, 0])
+    h0 = OCL.forward_hidden(cfg, W, ids, 0)
+    assert torch.equal(h0, W["token_embedding.weight"][ids] + W["position_embedding"][None])
+    h, pooled = OCL.forward_hidden_pooled(cfg, W, ids, cfg.n_layer - 1)
+    assert torch.allclose(h, OCL.forward_hidden(cfg, W, ids, cfg.n_layer - 1), atol=1e-6)
+    assert pooled.shape == (2, cfg.embed_dim)
+    # causal: positions before a changed token are unaffected; the pooled row is the FIRST eot (argmax) of each sequence
+    ids2 = ids.clone(); ids2[1, 5] = 77
+    h2, pooled2 = OCL.forward_hidden_pooled(cfg, W, ids2, cfg.n_layer - 1)
+    assert torch.equal(h2[1, :5], h[1, :5]) and not torch.equal(h2[1, 5:], h[1, 5:])
+    assert torch.allclose(pooled2, pooled, atol=1e-6)
+
+
+def test_embedder_oracle_shapes():
+    from oracle import clip as OCL
+    c1, c2 = OCL.tiny_clip_config(), OCL.tiny_open_clip_config()
+    e = OCL.Embedder(c1, OM.to_torch(OC.synth_weights(OCL.clip_param_specs(c1), 1)),
+                     c2, OM.to_torch(OC.synth_weights(OCL.clip_param_specs(c2), 2)))
+    ids = torch.full((1, 77), 49407, dtype=torch.int64); ids[0, 0] = 49406
+    size, crop, ar = torch.tensor([[1024, 1024]]), torch.tensor([[0, 0]]), torch.tensor([1024, 1024])
+    c = e.tokens_to_conditioning(ids, ids, ids, ids, size, crop, ar)
+    assert c.context_full.shape == (1, 77, c1.n_state + c2.n_state) and c.unconditional_context_full.shape == (77, 320)
+    assert c.channel_context.shape == (1, c2.embed_dim + 6 * 256)
+    assert c.channel_context_refiner.shape == (1, c2.embed_dim + 5 * 256)
