@@ -31,6 +31,7 @@ typedef struct sdxl_ctx sdxl_ctx;
 typedef struct sdxl_unet sdxl_unet;
 typedef struct sdxl_diffuser sdxl_diffuser;
 typedef struct sdxl_vae sdxl_vae;
+typedef struct sdxl_clip sdxl_clip;
 
 enum { SDXL_OK = 0, SDXL_ERR_INVALID = 1, SDXL_ERR_RUNTIME = 2 };
 /* precision of a model instance */
@@ -59,6 +60,13 @@ typedef struct {
   int32_t n_group, enc_out_channels;
   double scale_factor;             /* LatentDecoderConfig.scale_factor (stablediffusion/mod.rs:176-179), 0.13025 */
 } sdxl_vae_config;
+
+/* CLIPConfig (src/model/clip/mod.rs:19-28); SDXL: CLIP ViT-L/14 text {49408,768,768,12,77,12,1} and OpenCLIP ViT-bigG/14
+ * text {49408,1280,1280,20,77,32,0} */
+typedef struct {
+  int32_t n_vocab, n_state, embed_dim, n_head, n_ctx, n_layer;
+  int32_t quick_gelu;
+} sdxl_clip_config;
 
 /* Conditioning<B> (src/model/stablediffusion/mod.rs:544-555): device fp32 tensors, same ranks as the reference */
 typedef struct {
@@ -158,6 +166,32 @@ int sdxl_latent_to_image(sdxl_vae* v, void* stream, const float* latent, int n, 
 int sdxl_vae_encode_image(sdxl_vae* v, void* stream, const float* image, int n, int H, int W, float* out_latent);
 /* LatentDecoder::image_to_latent (:239-255): uint8 [n,H,W,3] (device) -> latent */
 int sdxl_image_to_latent(sdxl_vae* v, void* stream, const uint8_t* image_hwc, int n, int H, int W, float* out_latent);
+
+/* ---- Embedder (stablediffusion/mod.rs:626-801): the two CLIP text encoders.  Tokenisation stays with the caller (host
+ * string code: src/token/{clip,open_clip}.rs) -- token ids cross the boundary, as in the reference's CLIP::forward_* */
+void sdxl_clip_config_clip_l(sdxl_clip_config* cfg);
+void sdxl_clip_config_open_clip_bigg(sdxl_clip_config* cfg);
+/* parameter enumeration, replaces clip/load.rs:  token_embedding.weight [n_vocab,n_state], position_embedding [n_ctx,n_state],
+ * blocks.{i}.{attn.{query,key,value,out}, attn_ln, mlp.{fc1,fc2}, mlp_ln}, layer_norm, text_projection [n_state,embed_dim] */
+int sdxl_clip_param_count(const sdxl_clip_config* cfg);
+int sdxl_clip_param_spec(const sdxl_clip_config* cfg, int index, const char** name, int* ndim, int64_t shape[4], int* kind,
+                         float* synth_scale, float* synth_mean);
+/* CLIPConfig::init + load (clip/mod.rs:30-59) */
+int sdxl_clip_create(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, const float* weights_flat, sdxl_clip** out);
+int sdxl_clip_create_synthetic(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, uint64_t seed, sdxl_clip** out);
+void sdxl_clip_destroy(sdxl_clip* c);
+/* CLIP::forward_hidden (clip/mod.rs:94-112): tokens int32 [n,seq] (device) -> hidden [n,seq,n_state] after the first
+ * hidden_idx blocks, no final LayerNorm */
+int sdxl_clip_forward_hidden(sdxl_clip* c, void* stream, const int32_t* tokens, int n, int seq, int hidden_idx, float* out_hidden);
+/* CLIP::forward_hidden_pooled (clip/mod.rs:114-151): hidden = input of block hidden_idx [n,seq,n_state];
+ * pooled [n,embed_dim] = layer_norm(x_final)[argmax(tokens)] @ text_projection */
+int sdxl_clip_forward_hidden_pooled(sdxl_clip* c, void* stream, const int32_t* tokens, int n, int seq, int hidden_idx,
+                                    float* out_hidden, float* out_pooled);
+/* conditioning_embedding (unet/mod.rs:41-57): pooled [n,E] and int32 values [n,w] (size|crop|ar, device) ->
+ * out [n, E + w*dim] = [pooled | timestep_embedding(values, dim)] */
+int sdxl_conditioning_embedding(sdxl_ctx* ctx, void* stream, const float* pooled, int n, int E, const int32_t* values, int w,
+                                int dim, float* out);
+int sdxl_clip_weight_arena(sdxl_clip* c, void** base, size_t* bytes);
 
 /* ---- multi-GPU: the packed weight arena of a model, for a one-time RCCL broadcast from rank 0 (SURVEY 2.3 C-bcast).
  * Replica ranks create the model "empty" (identical arena layout, contents undefined) and receive the bytes. */

@@ -46,6 +46,10 @@ class _VaeConfigC(ctypes.Structure):
                 ("enc_out_channels", ctypes.c_int32), ("scale_factor", ctypes.c_double)]
 
 
+class _ClipConfigC(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("n_vocab", "n_state", "embed_dim", "n_head", "n_ctx", "n_layer", "quick_gelu")]
+
+
 class _ConditioningC(ctypes.Structure):
     _fields_ = [("unconditional_context_full", _f_p), ("unconditional_context_open_clip", _f_p),
                 ("context_full", _f_p), ("context_open_clip", _f_p), ("unconditional_channel_context", _f_p),
@@ -69,6 +73,9 @@ ABI_SYMBOLS = [
     "sdxl_unet_weight_arena", "sdxl_vae_weight_arena", "sdxl_diffuser_create_empty", "sdxl_vae_create_empty",
     "sdxl_unet_profile", "sdxl_bench_igemm", "sdxl_bench_attention", "sdxl_debug_set",
     "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear",
+    "sdxl_clip_config_clip_l", "sdxl_clip_config_open_clip_bigg", "sdxl_clip_param_count", "sdxl_clip_param_spec",
+    "sdxl_clip_create", "sdxl_clip_create_synthetic", "sdxl_clip_destroy", "sdxl_clip_forward_hidden",
+    "sdxl_clip_forward_hidden_pooled", "sdxl_conditioning_embedding", "sdxl_clip_weight_arena",
 ]
 
 _lib = None
@@ -93,7 +100,7 @@ def lib() -> ctypes.CDLL:
         l.sdxl_build_info.restype = ctypes.c_char_p
         l.sdxl_diffuser_unet.restype = ctypes.c_void_p
         l.sdxl_diffuser_unet.argtypes = [ctypes.c_void_p]
-        for name in ("sdxl_ctx_destroy", "sdxl_unet_destroy", "sdxl_diffuser_destroy", "sdxl_vae_destroy"):
+        for name in ("sdxl_ctx_destroy", "sdxl_unet_destroy", "sdxl_diffuser_destroy", "sdxl_vae_destroy", "sdxl_clip_destroy"):
             getattr(l, name).restype = None
             getattr(l, name).argtypes = [ctypes.c_void_p]
         _lib = l
@@ -216,6 +223,13 @@ def vae_param_specs(cfg: VAEConfig, encoder: bool) -> List[ParamSpec]:
     l = lib()
     return _specs(lambda: l.sdxl_vae_param_count(ctypes.byref(c), int(encoder)),
                   lambda i, *a: l.sdxl_vae_param_spec(ctypes.byref(c), int(encoder), i, *a))
+
+
+def clip_param_specs(cfg: "CLIPConfig") -> List[ParamSpec]:
+    c = cfg.to_c()
+    l = lib()
+    return _specs(lambda: l.sdxl_clip_param_count(ctypes.byref(c)),
+                  lambda i, *a: l.sdxl_clip_param_spec(ctypes.byref(c), i, *a))
 
 
 def step_count(n_steps: int, step_start: int = 0, n_train: int = 1000) -> int:
@@ -341,6 +355,149 @@ class UNet:
         if getattr(self, "_owned", False) and getattr(self, "h", None) and _lib is not None:
             _lib.sdxl_unet_destroy(self.h)
             self.h = None
+
+
+@dataclass
+class CLIPConfig:
+    """reference CLIPConfig (src/model/clip/mod.rs:19-28)"""
+    n_vocab: int
+    n_state: int
+    embed_dim: int
+    n_head: int
+    n_ctx: int
+    n_layer: int
+    quick_gelu: bool
+
+    def to_c(self) -> _ClipConfigC:
+        return _ClipConfigC(self.n_vocab, self.n_state, self.embed_dim, self.n_head, self.n_ctx, self.n_layer,
+                            int(self.quick_gelu))
+
+
+def clip_l_config() -> CLIPConfig:
+    return CLIPConfig(49408, 768, 768, 12, 77, 12, True)
+
+
+def open_clip_bigg_config() -> CLIPConfig:
+    return CLIPConfig(49408, 1280, 1280, 20, 77, 32, False)
+
+
+class CLIP:
+    """reference CLIP<B> (src/model/clip/mod.rs:62-151): text transformer on the GPU, token ids in"""
+
+    def __init__(self, ctx: Context, cfg: CLIPConfig, dtype: int = DTYPE_F16, weights: Optional[np.ndarray] = None,
+                 seed: int = 0):
+        self.ctx, self.cfg, self.dtype = ctx, cfg, dtype
+        self.h = ctypes.c_void_p()
+        c = cfg.to_c()
+        if weights is None:
+            _check(lib().sdxl_clip_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), ctypes.byref(self.h)))
+        else:
+            w = np.ascontiguousarray(weights, dtype=np.float32)
+            _check(lib().sdxl_clip_create(ctx.h, ctypes.byref(c), dtype, w.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self.h)))
+
+    def max_sequence_length(self) -> int:
+        return self.cfg.n_ctx
+
+    def num_layers(self) -> int:
+        return self.cfg.n_layer
+
+    def _tokens(self, tokens):
+        torch = _torch()
+        t = torch.as_tensor(tokens)
+        if t.dim() != 2:
+            raise EngineError("tokens must be [n_batch, seq_len]")
+        if int(t.min()) < 0 or int(t.max()) >= self.cfg.n_vocab:
+            raise EngineError("token id outside the vocabulary")
+        return _dev(t.to(f"cuda:{self.ctx.device_id}"), torch.int32)
+
+    def forward_hidden(self, tokens, hidden_idx: int):
+        """CLIP::forward_hidden (:94-112) -> [n, seq, n_state]"""
+        torch = _torch()
+        t, pt = self._tokens(tokens)
+        n, seq = t.shape
+        out = torch.empty((n, seq, self.cfg.n_state), device=t.device, dtype=torch.float32)
+        _check(lib().sdxl_clip_forward_hidden(self.h, _stream(), pt, n, seq, int(hidden_idx), ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def forward_hidden_pooled(self, tokens, hidden_idx: int):
+        """CLIP::forward_hidden_pooled (:114-151) -> ([n, seq, n_state], [n, embed_dim])"""
+        torch = _torch()
+        t, pt = self._tokens(tokens)
+        n, seq = t.shape
+        hidden = torch.empty((n, seq, self.cfg.n_state), device=t.device, dtype=torch.float32)
+        pooled = torch.empty((n, self.cfg.embed_dim), device=t.device, dtype=torch.float32)
+        _check(lib().sdxl_clip_forward_hidden_pooled(self.h, _stream(), pt, n, seq, int(hidden_idx),
+                                                     ctypes.c_void_p(hidden.data_ptr()), ctypes.c_void_p(pooled.data_ptr())))
+        return hidden, pooled
+
+    def weight_arena(self) -> Tuple[int, int]:
+        base, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().sdxl_clip_weight_arena(self.h, ctypes.byref(base), ctypes.byref(n)))
+        return int(base.value or 0), int(n.value)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.sdxl_clip_destroy(self.h)
+            self.h = None
+
+
+def conditioning_embedding(ctx: Context, pooled, dim: int, size, crop, ar):
+    """reference conditioning_embedding (src/model/unet/mod.rs:41-57): [pooled | timestep_embedding(size|crop|ar)]"""
+    torch = _torch()
+    pooled, pp = _dev(pooled)
+    vals = torch.cat([torch.as_tensor(v).to(pooled.device).reshape(pooled.shape[0], -1) for v in (size, crop, ar)], dim=1)
+    vals, pv = _dev(vals, torch.int32)
+    n, E = pooled.shape
+    w = int(vals.shape[1])
+    out = torch.empty((n, E + w * dim), device=pooled.device, dtype=torch.float32)
+    _check(lib().sdxl_conditioning_embedding(ctx.h, _stream(), pp, n, E, pv, w, dim, ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
+class Embedder:
+    """reference Embedder<B> (stablediffusion/mod.rs:652-757).  The tokenizers are optional: without them (no asset files)
+    only tokens_to_conditioning is available -- which is also what a Rust caller of the C ABI uses."""
+
+    def __init__(self, ctx: Context, clip: CLIP, open_clip: CLIP, clip_tokenizer=None, open_clip_tokenizer=None):
+        self.ctx, self.clip, self.open_clip = ctx, clip, open_clip
+        self.clip_tokenizer, self.open_clip_tokenizer = clip_tokenizer, open_clip_tokenizer
+
+    def _context(self, clip_ids, open_ids, size, crop, ar):
+        """Embedder::context / unconditional_context (:697-757)"""
+        torch = _torch()
+        clip_ctx = self.clip.forward_hidden(clip_ids, self.clip.num_layers() - 1)                      # :759-770
+        open_ctx, pooled = self.open_clip.forward_hidden_pooled(open_ids, self.open_clip.num_layers() - 1)
+        n = int(torch.as_tensor(ar).shape[0])
+        if pooled.shape[0] != n:
+            raise EngineError("the reference concatenates a [1, E] pooled embedding with [n_batch, .] size embeddings: n_batch must be 1")
+        aesthetic = torch.full((n, 1), 6, dtype=torch.int32)                                           # :709,740
+        return (torch.cat([clip_ctx, open_ctx], dim=2), open_ctx,
+                conditioning_embedding(self.ctx, pooled, 256, size, crop, ar),
+                conditioning_embedding(self.ctx, pooled, 256, size, crop, aesthetic))
+
+    def tokens_to_conditioning(self, clip_ids, open_ids, uncond_clip_ids, uncond_open_ids, size, crop, ar) -> Conditioning:
+        """text_to_conditioning (:661-696) after tokenize_text: ids [1, n_ctx]; size / crop [n, 2] ints, ar [2] ints"""
+        torch = _torch()
+        size, crop, ar = torch.as_tensor(size), torch.as_tensor(crop), torch.as_tensor(ar)
+        n = int(size.shape[0])
+        bar = ar.reshape(1, -1).repeat(n, 1)
+        ucf, uco, ucc, uccr = self._context(uncond_clip_ids, uncond_open_ids, size, crop, bar)
+        cf, co, cc, ccr = self._context(clip_ids, open_ids, size, crop, bar)
+        return Conditioning(context_full=cf, channel_context=cc, unconditional_context_full=ucf.squeeze(0),
+                            unconditional_channel_context=ucc.squeeze(0), context_open_clip=co, channel_context_refiner=ccr,
+                            unconditional_context_open_clip=uco.squeeze(0), unconditional_channel_context_refiner=uccr.squeeze(0),
+                            resolution=(int(ar[0]), int(ar[1])))
+
+    def text_to_conditioning(self, text: str, size, crop, ar) -> Conditioning:
+        """Embedder::text_to_conditioning (:661-696); the unconditional prompt is "" (:703-705)"""
+        if self.clip_tokenizer is None or self.open_clip_tokenizer is None:
+            raise EngineError("Embedder was built without tokenizers (asset files not available): use tokens_to_conditioning")
+        from .tokenizer import tokenize_text
+        torch = _torch()
+        ids = lambda t, tok, m: torch.tensor([tokenize_text(t, tok, m.max_sequence_length())], dtype=torch.int32)   # noqa: E731
+        return self.tokens_to_conditioning(ids(text, self.clip_tokenizer, self.clip), ids(text, self.open_clip_tokenizer, self.open_clip),
+                                           ids("", self.clip_tokenizer, self.clip), ids("", self.open_clip_tokenizer, self.open_clip),
+                                           size, crop, ar)
 
 
 class _ArenaView:

@@ -20,7 +20,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsdxl_mi355.so")
 ARCH = "gfx950"
 SOURCES = ["igemm.hip", "igemm_glds.hip", "norm.hip", "attention.hip", "elementwise.hip", "capi.hip",
-           "specs.cpp", "weights.cpp", "unet.cpp", "vae.cpp", "sampler.cpp"]
+           "specs.cpp", "weights.cpp", "unet.cpp", "vae.cpp", "sampler.cpp", "clip.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
 

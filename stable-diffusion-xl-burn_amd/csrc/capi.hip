@@ -12,6 +12,7 @@ struct sdxl_ctx { int device = 0; hipStream_t stream = nullptr; };
 struct sdxl_unet { sdxl_ctx* ctx = nullptr; UNet* u = nullptr; bool owned = true; };
 struct sdxl_diffuser { sdxl_ctx* ctx = nullptr; Diffuser* d = nullptr; sdxl_unet view; };
 struct sdxl_vae { sdxl_ctx* ctx = nullptr; Vae* v = nullptr; };
+struct sdxl_clip { sdxl_ctx* ctx = nullptr; ClipText* c = nullptr; };
 
 namespace {
 thread_local std::string g_err;
@@ -36,6 +37,13 @@ UNetCfg to_cfg(const sdxl_unet_config* c) {
   for (int i = 0; i < c->n_levels; ++i) { u.channel_mults.push_back(c->channel_mults[i]); u.transformer_depths.push_back(c->transformer_depths[i]); }
   SDXL_REQUIRE(u.model_channels > 0 && u.n_head_channels > 0 && u.context_dim > 0 && u.adm_in_channels > 0, "bad UNet config");
   return u;
+}
+ClipCfg to_ccfg(const sdxl_clip_config* c) {
+  SDXL_REQUIRE(c != nullptr, "null config");
+  ClipCfg k;
+  k.n_vocab = c->n_vocab; k.n_state = c->n_state; k.embed_dim = c->embed_dim; k.n_head = c->n_head; k.n_ctx = c->n_ctx;
+  k.n_layer = c->n_layer; k.quick_gelu = c->quick_gelu != 0;
+  return k;
 }
 VaeCfg to_vcfg(const sdxl_vae_config* c) {
   SDXL_REQUIRE(c != nullptr, "null config");
@@ -404,6 +412,79 @@ int sdxl_attn_decoder_mask(sdxl_ctx* ctx, void* stream, int n, float* out) {
   SDXL_REQUIRE(ctx && out && n > 0, "bad argument");
   use(ctx);
   hipLaunchKernelGGL(causal_mask_kernel, dim3((n * n + 255) / 256), dim3(256), 0, pick(ctx, stream), out, n);
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------- Embedder (CLIP text encoders)
+void sdxl_clip_config_clip_l(sdxl_clip_config* c) { if (c) *c = sdxl_clip_config{49408, 768, 768, 12, 77, 12, 1}; }
+void sdxl_clip_config_open_clip_bigg(sdxl_clip_config* c) { if (c) *c = sdxl_clip_config{49408, 1280, 1280, 20, 77, 32, 0}; }
+int sdxl_clip_param_count(const sdxl_clip_config* cfg) {
+  try { return (int)clip_param_specs(to_ccfg(cfg)).size(); } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int sdxl_clip_param_spec(const sdxl_clip_config* cfg, int index, const char** name, int* ndim, int64_t shape[4], int* kind,
+                         float* sc, float* mean) {
+  API_BEGIN
+  static thread_local std::vector<ParamSpec> cache; static thread_local sdxl_clip_config key;
+  if (cache.empty() || std::memcmp(&key, cfg, sizeof(key)) != 0) { cache = clip_param_specs(to_ccfg(cfg)); key = *cfg; }
+  return spec_out(cache, index, name, ndim, shape, kind, sc, mean);
+  API_END
+}
+static int clip_create_impl(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, WeightSource& src, sdxl_clip** out) {
+  SDXL_REQUIRE(ctx && out, "bad argument");
+  use(ctx);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  sdxl_clip* h = new sdxl_clip();
+  h->ctx = ctx;
+  try { h->c = new ClipText(to_ccfg(cfg), cdt, sdt, src, ctx->stream); } catch (...) { delete h; throw; }
+  *out = h;
+  return SDXL_OK;
+}
+int sdxl_clip_create(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, const float* weights_flat, sdxl_clip** out) {
+  API_BEGIN
+  SDXL_REQUIRE(weights_flat != nullptr, "null weights");
+  const std::vector<ParamSpec> specs = clip_param_specs(to_ccfg(cfg));
+  FlatSource src(weights_flat, specs);
+  return clip_create_impl(ctx, cfg, dtype, src, out);
+  API_END
+}
+int sdxl_clip_create_synthetic(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, uint64_t seed, sdxl_clip** out) {
+  API_BEGIN
+  SyntheticSource src(seed);
+  return clip_create_impl(ctx, cfg, dtype, src, out);
+  API_END
+}
+void sdxl_clip_destroy(sdxl_clip* c) {
+  if (!c) return;
+  delete c->c;
+  delete c;
+}
+int sdxl_clip_forward_hidden(sdxl_clip* c, void* stream, const int32_t* tokens, int n, int seq, int hidden_idx, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(c && tokens && out, "null argument");
+  use(c->ctx);
+  c->c->forward_hidden(tokens, n, seq, hidden_idx, out, pick(c->ctx, stream));
+  API_END
+}
+int sdxl_clip_forward_hidden_pooled(sdxl_clip* c, void* stream, const int32_t* tokens, int n, int seq, int hidden_idx,
+                                    float* out_hidden, float* out_pooled) {
+  API_BEGIN
+  SDXL_REQUIRE(c && tokens && out_hidden && out_pooled, "null argument");
+  use(c->ctx);
+  c->c->forward_hidden_pooled(tokens, n, seq, hidden_idx, out_hidden, out_pooled, pick(c->ctx, stream));
+  API_END
+}
+int sdxl_conditioning_embedding(sdxl_ctx* ctx, void* stream, const float* pooled, int n, int E, const int32_t* values, int w,
+                                int dim, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && pooled && values && out && n > 0 && E > 0 && w > 0 && dim > 0 && dim % 2 == 0, "bad argument");
+  use(ctx);
+  launch_conditioning_embedding(pooled, E, values, w, dim, out, n, pick(ctx, stream));
+  API_END
+}
+int sdxl_clip_weight_arena(sdxl_clip* c, void** base, size_t* bytes) {
+  API_BEGIN
+  SDXL_REQUIRE(c && base && bytes, "null argument");
+  *base = c->c->weight_base(); *bytes = c->c->weight_bytes();
   API_END
 }
 

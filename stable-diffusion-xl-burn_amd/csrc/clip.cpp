@@ -1,0 +1,129 @@
+// CLIP text encoders of the SDXL Embedder on MI355X (reference CLIP<B>, clip/mod.rs:62-151; used by
+// Embedder::text_to_conditioning, stablediffusion/mod.rs:661-770).
+//
+// Token-major [B*S][C] activations like the UNet's transformer blocks, and the same building blocks: Q|K|V as one fused
+// projection whose V columns leave the GEMM epilogue already transposed (V^T [B][C][npad], keys contiguous, zero padded to
+// the attention kernel's 64-key step), the d=64 fused attention kernel with the additive causal mask, residual adds in the
+// GEMM epilogues, GELU / QuickGELU in the fc1 epilogue.  The reference's per-head swap_dims/reshape copies
+// (backend.rs:96-127) never materialise.  One call streams every weight once (CLIP-L 0.25 GB, bigG 1.4 GB in fp16) over
+// M = B*77 rows: it is weight-bandwidth / launch bound, not MFMA bound, and runs once per prompt -- outside the sampling loop.
+#include "engine.h"
+
+namespace sdxl {
+
+ClipText::ClipText(const ClipCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st)
+    : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt) {
+  SDXL_REQUIRE(!(compute_dt == DT_F32 && stream_dt != DT_F32), "f32 compute implies an f32 residual stream");
+  const std::vector<ParamSpec> specs = clip_param_specs(cfg_);
+  warena_.reserve(WeightBuilder::arena_bound(specs, cdt_));
+  WeightBuilder wb(specs, src, warena_, cdt_, st);
+  const int C = cfg_.n_state;
+  // embedding tables in the compute dtype, row-major as the reference stores them
+  void* tok = warena_.alloc((size_t)cfg_.n_vocab * C * dt_size(cdt_));
+  void* pos = warena_.alloc((size_t)cfg_.n_ctx * C * dt_size(cdt_));
+  if (!src.empty()) {
+    launch_copy_rows(wb.fetch("token_embedding.weight"), DT_F32, C, tok, cdt_, C, cfg_.n_vocab, C, st);
+    launch_copy_rows(wb.fetch("position_embedding"), DT_F32, C, pos, cdt_, C, cfg_.n_ctx, C, st);
+  }
+  tok_ = tok; pos_ = pos;
+  for (int i = 0; i < cfg_.n_layer; ++i) {
+    const std::string p = "blocks." + std::to_string(i);
+    ClipBlockW b;
+    b.attn_ln = wb.norm(p + ".attn_ln");
+    b.qkv = wb.fused_linear({p + ".attn.query", p + ".attn.key", p + ".attn.value"});
+    b.out = wb.linear(p + ".attn.out");
+    b.mlp_ln = wb.norm(p + ".mlp_ln");
+    b.fc1 = wb.linear(p + ".mlp.fc1");
+    b.fc2 = wb.linear(p + ".mlp.fc2");
+    blocks_.push_back(b);
+  }
+  final_ln_ = wb.norm("layer_norm");
+  {
+    // text_projection is a bare [n_state][embed_dim] matrix (clip/mod.rs:68,149): pack it like a bias-free Linear
+    const ParamSpec& sp = wb.spec("text_projection");
+    Lin l; l.K = sp.shape[0]; l.N = sp.shape[1]; l.ksize = 1; l.cin = l.K;
+    l.Kpad = (int)round_up(l.K, cdt_ == DT_F16 ? 64 : 32); l.Npad = (int)round_up(l.N, 128);
+    void* w = warena_.alloc((size_t)l.Npad * l.Kpad * dt_size(cdt_));
+    l.w = w; l.b = nullptr;
+    if (!src.empty()) launch_pack_linear(wb.fetch("text_projection"), w, cdt_, l.K, l.N, l.Kpad, l.Npad, 0, 0, st);
+    proj_ = l;
+  }
+  SDXL_HIP(hipStreamSynchronize(st));
+}
+
+void ClipText::block(Exec& ex, const ClipBlockW& w, const Act& x, int B, int S, const Act& ln, const Act& qk, void* vt, int npad,
+                     const Act& ao, const Act& h) {
+  // ResidualDecoderAttentionBlock::forward (clip/mod.rs:194-199), MultiHeadSelfAttention (:243-257), MLP (:296-306)
+  const int C = cfg_.n_state, M = B * S;
+  run_layernorm(ex, w.attn_ln, x, M, ln);
+  Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = S;
+  run_linear(ex, w.qkv, ln, M, qk, eq);
+  {
+    AttnParams p{};
+    p.Q = qk.p; p.ldq = qk.ld; p.K = qk.cols(C).p; p.ldk = qk.ld; p.Vt = vt; p.vt_ld = npad; p.O = ao.p; p.ldo = ao.ld;
+    p.dt = ex.cdt; p.B = B; p.H = cfg_.n_head; p.Nq = S; p.Nk = S; p.scale = 0.125f; p.mask = mask_; p.ldmask = S;
+    launch_attention_d64(p, ex.s);
+  }
+  Epi er; er.R = x;
+  run_linear(ex, w.out, ao, M, x, er);
+  run_layernorm(ex, w.mlp_ln, x, M, ln);
+  Epi ea; ea.act = cfg_.quick_gelu ? 3 : 2;
+  run_linear(ex, w.fc1, ln, M, h, ea);
+  run_linear(ex, w.fc2, h, M, x, er);
+}
+
+void ClipText::run(const int* ids, int B, int S, int n_blocks, int tap, float* hidden, float* pooled, hipStream_t s) {
+  SDXL_REQUIRE(ids && B > 0 && S > 0 && S <= cfg_.n_ctx, "CLIP: sequence longer than the position table (or empty)");
+  SDXL_REQUIRE(n_blocks >= 0 && n_blocks <= cfg_.n_layer, "CLIP: hidden_idx out of range");
+  const int C = cfg_.n_state, M = B * S;
+  const int npad = (int)round_up(S, 64);
+  const size_t e = dt_size(cdt_);
+  const size_t need = (size_t)M * C * dt_size(sdt_) + (size_t)M * C * e * 2 + (size_t)M * 2 * C * e + (size_t)B * C * npad * e +
+                      (size_t)M * 4 * C * e + (size_t)S * S * 4 + (size_t)B * (C + cfg_.embed_dim + 1) * 4 * 2 + (1 << 16);
+  if (need > act_.cap) { SDXL_HIP(hipStreamSynchronize(s)); act_.reserve(need); mask_ = nullptr; }
+  act_.off = 0;
+  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_;
+  float* mask = (float*)act_.alloc((size_t)S * S * 4);
+  if (mask != mask_ || mask_n_ != S) { launch_causal_mask(mask, S, s); mask_ = mask; mask_n_ = S; }
+  Act x = ex.alloc(M, C, sdt_);
+  Act ln = ex.alloc(M, C, cdt_);
+  Act qk = ex.alloc(M, 2 * C, cdt_);
+  void* vt = act_.alloc((size_t)B * C * npad * e);
+  Act ao = ex.alloc(M, C, cdt_);
+  Act h = ex.alloc(M, 4 * C, cdt_);
+  int* eot = (int*)act_.alloc((size_t)B * 4);
+  float* sel = (float*)act_.alloc((size_t)B * C * 4);
+  float* seln = (float*)act_.alloc((size_t)B * C * 4);
+  if (npad != S) launch_fill_zero(vt, (size_t)B * C * npad * e, s);   // keys S..npad-1 of V^T stay zero
+  launch_embed_tokens(ids, tok_, pos_, cdt_, x.p, x.dt, x.ld, B, S, C, cfg_.n_vocab, s);     // clip/mod.rs:99-105
+  for (int i = 0; i < n_blocks; ++i) {
+    if (i == tap && hidden) launch_copy_rows(x.p, x.dt, x.ld, hidden, DT_F32, C, M, C, s);    // :128-130
+    block(ex, blocks_[i], x, B, S, ln, qk, vt, npad, ao, h);
+  }
+  if (tap == n_blocks && hidden) launch_copy_rows(x.p, x.dt, x.ld, hidden, DT_F32, C, M, C, s);
+  if (pooled) {
+    // :139-149 -- the eot token has the highest id of its sequence; LayerNorm only the B selected rows
+    launch_argmax_rows(ids, eot, B, S, s);
+    launch_gather_rows(x.p, x.dt, x.ld, eot, S, sel, B, C, s);
+    run_layernorm(ex, final_ln_, Act(sel, C, DT_F32), B, Act(seln, C, DT_F32));
+    for (int b0 = 0; b0 < B; b0 += 8) {
+      GemvParams g{};
+      g.X = seln + (size_t)b0 * C; g.ldx = C; g.W = proj_.w; g.w_dt = cdt_; g.Kpad = proj_.Kpad; g.bias = nullptr;
+      g.Y = pooled + (size_t)b0 * cfg_.embed_dim; g.ldy = cfg_.embed_dim; g.Yadd = nullptr;
+      g.Bm = B - b0 < 8 ? B - b0 : 8; g.N = proj_.N; g.K = proj_.K; g.silu_in = 0; g.silu_out = 0;
+      launch_gemv(g, s);
+    }
+  }
+}
+
+void ClipText::forward_hidden(const int* ids, int B, int S, int hidden_idx, float* out, hipStream_t s) {
+  SDXL_REQUIRE(out, "null output");
+  run(ids, B, S, hidden_idx, hidden_idx, out, nullptr, s);
+}
+void ClipText::forward_hidden_pooled(const int* ids, int B, int S, int hidden_idx, float* hidden, float* pooled, hipStream_t s) {
+  SDXL_REQUIRE(hidden && pooled, "null output");
+  SDXL_REQUIRE(hidden_idx >= 0 && hidden_idx < cfg_.n_layer, "CLIP: hidden_idx out of range");
+  run(ids, B, S, cfg_.n_layer, hidden_idx, hidden, pooled, s);
+}
+
+}  // namespace sdxl

@@ -129,6 +129,26 @@ void launch_timestep_embedding(const float* t_dev, int t_stride, float* out, int
   hipLaunchKernelGGL(temb_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t_dev, t_stride, out, Bm, dim);
 }
 
+// conditioning_embedding (unet/mod.rs:41-57): out[b] = [pooled[b] | temb(vals[b][0]) | ... | temb(vals[b][w-1])]
+__global__ void cond_embedding_kernel(const float* pooled, int E, const int* vals, int w, int dim, float* out, int n) {
+  const int half = dim / 2;
+  const int ld = E + w * dim;
+  const int per = E + w * half;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * per) return;
+  const int b = i / per, c = i - b * per;
+  if (c < E) { out[(size_t)b * ld + c] = pooled[(size_t)b * E + c]; return; }
+  const int v = (c - E) / half, j = (c - E) - v * half;
+  const float coef = (float)(-9.210340371976184 / (double)half);
+  const float a = (float)vals[b * w + v] * expf((float)j * coef);
+  out[(size_t)b * ld + E + v * dim + j] = cosf(a);
+  out[(size_t)b * ld + E + v * dim + half + j] = sinf(a);
+}
+void launch_conditioning_embedding(const float* pooled, int E, const int* vals, int w, int dim, float* out, int n, hipStream_t s) {
+  const int total = n * (E + w * (dim / 2));
+  hipLaunchKernelGGL(cond_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pooled, E, vals, w, dim, out, n);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* src, int sbs, void* dst, int dt, int B, int C, int HW, int ldd, float scale) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,6 +198,61 @@ void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s) {
   hipLaunchKernelGGL(i32_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
 }
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s) { (void)hipMemsetAsync(p, 0, bytes, s); }
+
+// ---------------------------------------------------------------------------------------------------------
+// CLIP text-encoder glue (clip/mod.rs:99-105 embedding sum, :139-147 eot pooling, backend.rs attn_decoder_mask)
+__global__ void embed_tokens_kernel(const int* ids, const void* tok, const void* pos, int w_dt, void* x, int x_dt, int ldx,
+                                    size_t rows, int S, int C, int n_vocab) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const size_t r = i / C;
+  const int c = i - r * C;
+  int id = ids[r];
+  id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);   // ids are validated on the host; never read out of the table
+  st_f(x, r * ldx + c, x_dt, ld_f(tok, (size_t)id * C + c, w_dt) + ld_f(pos, (size_t)(r % S) * C + c, w_dt));
+}
+void launch_embed_tokens(const int* ids, const void* tok, const void* pos, int w_dt, void* x, int x_dt, int ldx, int B, int S,
+                         int C, int n_vocab, hipStream_t s) {
+  const size_t total = (size_t)B * S * C;
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ids, tok, pos, w_dt, x, x_dt, ldx,
+                     (size_t)B * S, S, C, n_vocab);
+}
+// one wavefront per sequence: (value, index) butterfly, ties resolved to the lower index (= first occurrence, like argmax)
+__global__ __launch_bounds__(64) void argmax_rows_kernel(const int* ids, int* out, int S) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int bv = -2147483647 - 1, bi = 0x7fffffff;
+  for (int t = lane; t < S; t += 64) {
+    const int v = ids[(size_t)b * S + t];
+    if (v > bv) { bv = v; bi = t; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int ov = __shfl_xor(bv, o), oi = __shfl_xor(bi, o);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) out[b] = bi;
+}
+void launch_argmax_rows(const int* ids, int* out, int B, int S, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(64), 0, s, ids, out, S);
+}
+__global__ void gather_rows_kernel(const void* x, int x_dt, int ldx, const int* idx, int S, float* out, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  out[i] = ld_f(x, ((size_t)b * S + idx[b]) * ldx + c, x_dt);
+}
+void launch_gather_rows(const void* x, int x_dt, int ldx, const int* idx, int S, float* out, int B, int C, hipStream_t s) {
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, x, x_dt, ldx, idx, S, out, B, C);
+}
+__global__ void causal_mask_fill_kernel(float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * n) return;
+  const int r = i / n, c = i - r * n;
+  out[i] = c > r ? -INFINITY : 0.f;
+}
+void launch_causal_mask(float* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(causal_mask_fill_kernel, dim3((n * n + 255) / 256), dim3(256), 0, s, out, n);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // CFG combine + DDIM (eta = 0) update + inpaint blend + next-UNet-input refresh, one thread per latent pixel.

@@ -47,6 +47,9 @@ struct VaeCfg {
   double scale_factor = 0.13025;
 };
 
+// mirrors CLIPConfig (clip/mod.rs:19-28)
+struct ClipCfg { int n_vocab = 49408, n_state = 0, embed_dim = 0, n_head = 0, n_ctx = 77, n_layer = 0; bool quick_gelu = false; };
+
 enum ParamKind { PK_LINEAR_W = 0, PK_CONV_W = 1, PK_BIAS = 2, PK_GAMMA = 3, PK_BETA = 4 };
 struct ParamSpec {
   std::string name;
@@ -61,6 +64,7 @@ void unet_block_plan(const UNetCfg& cfg, std::vector<BlockDesc>& inp, BlockDesc&
 std::vector<ParamSpec> unet_param_specs(const UNetCfg& cfg);
 std::vector<ParamSpec> vae_decoder_param_specs(const VaeCfg& cfg);
 std::vector<ParamSpec> vae_encoder_param_specs(const VaeCfg& cfg);
+std::vector<ParamSpec> clip_param_specs(const ClipCfg& cfg);
 uint64_t fnv1a64(const std::string& s);
 
 // ------------------------------------------------------------------------------------------ memory
@@ -285,6 +289,38 @@ class Vae {
   DeviceArena act_;
   size_t act_peak_ = 0;
   float* gn_partial_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------ CLIP text encoder (Embedder)
+struct ClipBlockW { NormW attn_ln, mlp_ln; Lin qkv, out, fc1, fc2; };
+
+// CLIP<B> of the reference (clip/mod.rs:62-151): token + position embedding, n_layer pre-LN causal transformer blocks,
+// final LayerNorm + eot pooling + text projection.  Runs once per prompt (Embedder::text_to_conditioning,
+// stablediffusion/mod.rs:661-770), so it is launch/weight-bandwidth bound: the weights are streamed once per call.
+class ClipText {
+ public:
+  ClipText(const ClipCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st);
+  const ClipCfg& cfg() const { return cfg_; }
+  // CLIP::forward_hidden (:94-112): ids int32 device [B][S] -> out fp32 device [B][S][n_state], the residual stream after
+  // the first hidden_idx blocks (no final LayerNorm)
+  void forward_hidden(const int* ids, int B, int S, int hidden_idx, float* out, hipStream_t s);
+  // CLIP::forward_hidden_pooled (:114-151): hidden = input of block hidden_idx; pooled fp32 [B][embed_dim] =
+  // LayerNorm(last)[argmax ids] . text_projection
+  void forward_hidden_pooled(const int* ids, int B, int S, int hidden_idx, float* hidden, float* pooled, hipStream_t s);
+  size_t weight_bytes() const { return warena_.off; }
+  void* weight_base() const { return warena_.base; }
+
+ private:
+  void run(const int* ids, int B, int S, int n_blocks, int tap, float* hidden, float* pooled, hipStream_t s);
+  void block(Exec& ex, const ClipBlockW& w, const Act& x, int B, int S, const Act& ln, const Act& qk, void* vt, int npad,
+             const Act& ao, const Act& h);
+  ClipCfg cfg_;
+  int cdt_, sdt_;
+  DeviceArena warena_, act_;
+  const void* tok_ = nullptr; const void* pos_ = nullptr;
+  std::vector<ClipBlockW> blocks_;
+  NormW final_ln_; Lin proj_;
+  float* mask_ = nullptr; int mask_n_ = 0;   // causal mask [S][S] (lives in act_)
 };
 
 // ------------------------------------------------------------------------------------------ sampler

@@ -250,6 +250,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
           }
         }
       }
+      if (p.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      } else if (p.act == 3) {   // QuickGELU (clip/mod.rs:309-320)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
+      }
       int nout = ncol;
       if (p.act == 1) {
         // this tile = x columns, tile j+1 = matching gate columns (pack_linear geglu interleave)

@@ -1351,6 +1351,7 @@ static void launch_wide(const IgemmParams& p, hipStream_t s) {
 // 6 = 64x128 ring 2; 7 = 128x128 ring 4; 8 = 64x128 ring 3.  Returns false when the shape needs the generic kernel.
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if (!g_zero_page) return false;
+  if (p.act > 1) return false;   // GELU / QuickGELU epilogues (CLIP MLP, once per prompt) live in the generic kernel
   if (p.a_dt != DT_F16 || (p.Cin % 64) != 0 || (p.lda % 8) != 0 || (p.Kpad % 64) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
   if (p.n_split < p.N && (p.n_split & 3) != 0) return false;

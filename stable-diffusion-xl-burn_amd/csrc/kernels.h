@@ -30,7 +30,8 @@ struct IgemmParams {
   const float* ebias;   // [B][ebias_ld] fp32 or null (ResBlock time-embedding add, unet/mod.rs:1092)
   int ebias_ld;
   int rpb;              // rows per batch element (Hout*Wout or tokens) for ebias / transposed store
-  int act;              // 0 none, 1 GEGLU: packed column pairs (x,gate) in 16-wide groups -> x*gelu_erf(gate)
+  int act;              // 0 none, 1 GEGLU: packed column pairs (x,gate) in 16-wide groups -> x*gelu_erf(gate);
+                        // 2 GELU(erf), 3 QuickGELU x*sigmoid(1.702x)  (CLIP MLP, clip/mod.rs:296-320; generic kernel only)
   const void* R; int ldr; int r_dt;     // residual added after act (same logical shape as output)
   void* C; int ldc; int c_dt;           // output for columns n < n_split (after GEGLU: n/2)
   int n_split;          // columns >= n_split go to the transposed output (set = N when unused)
@@ -119,6 +120,15 @@ void launch_nhwc_to_nchw(const void* src, int dt, int lds, float* dst, int B, in
 void launch_copy_rows(const void* src, int sdt, int lds, void* dst, int ddt, int ldd, int rows, int C, hipStream_t s);
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s);
+// CLIP text encoder (clip/mod.rs:99-105,139-147): x[b][t][:] = tok[ids[b][t]][:] + pos[t][:] (tables in dtype w_dt);
+// eot[b] = first index of max(ids[b][:]); sel[b][:] = x[b][eot[b]][:] as fp32; additive causal mask [n][n] (0 / -inf)
+void launch_embed_tokens(const int* ids, const void* tok, const void* pos, int w_dt, void* x, int x_dt, int ldx, int B, int S,
+                         int C, int n_vocab, hipStream_t s);
+void launch_argmax_rows(const int* ids, int* out, int B, int S, hipStream_t s);
+void launch_gather_rows(const void* x, int x_dt, int ldx, const int* idx, int S, float* out, int B, int C, hipStream_t s);
+void launch_causal_mask(float* out, int n, hipStream_t s);
+// conditioning_embedding (unet/mod.rs:41-57): out[n][E + w*dim] = [pooled | sinusoidal embedding of each of the w ints]
+void launch_conditioning_embedding(const float* pooled, int E, const int* vals, int w, int dim, float* out, int n, hipStream_t s);
 
 // DDIM step table entry (host f64 -> f32): stablediffusion/mod.rs:407-428
 struct StepCoef { float t; float sqrt_a; float sqrt_1ma; float sqrt_ap; float sqrt_1map; float cfg; float pad0, pad1; };

@@ -205,4 +205,27 @@ std::vector<ParamSpec> vae_encoder_param_specs(const VaeCfg& cfg) {   // autoenc
   return s.items;
 }
 
+std::vector<ParamSpec> clip_param_specs(const ClipCfg& cfg) {   // clip/mod.rs:62-69,178-184,231-238,282-290
+  SDXL_REQUIRE(cfg.n_vocab > 0 && cfg.n_state > 0 && cfg.embed_dim > 0 && cfg.n_ctx > 0 && cfg.n_layer > 0, "bad CLIP config");
+  SDXL_REQUIRE(cfg.n_head > 0 && cfg.n_state == cfg.n_head * 64, "this engine's attention kernels are specialised for 64 channels per head");
+  Spec s;
+  const int c = cfg.n_state;
+  s.add("token_embedding.weight", {cfg.n_vocab, c}, PK_LINEAR_W, (float)(kSqrt12 * 0.5), 0.f);
+  s.add("position_embedding", {cfg.n_ctx, c}, PK_LINEAR_W, (float)(kSqrt12 * 0.1), 0.f);
+  for (int i = 0; i < cfg.n_layer; ++i) {
+    const std::string p = "blocks." + std::to_string(i);
+    s.linear(p + ".attn.query", c, c);
+    s.linear(p + ".attn.key", c, c);
+    s.linear(p + ".attn.value", c, c);
+    s.linear(p + ".attn.out", c, c, true, kResGain);
+    s.norm(p + ".attn_ln", c);
+    s.linear(p + ".mlp.fc1", c, 4 * c);
+    s.linear(p + ".mlp.fc2", 4 * c, c, true, kResGain);
+    s.norm(p + ".mlp_ln", c);
+  }
+  s.norm("layer_norm", c);
+  s.add("text_projection", {c, cfg.embed_dim}, PK_LINEAR_W, Spec::wscale(c, 1.0), 0.f);
+  return s.items;
+}
+
 }  // namespace sdxl

@@ -299,3 +299,25 @@ def test_embedder_oracle_shapes():
     assert c.context_full.shape == (1, 77, c1.n_state + c2.n_state) and c.unconditional_context_full.shape == (77, 320)
     assert c.channel_context.shape == (1, c2.embed_dim + 6 * 256)
     assert c.channel_context_refiner.shape == (1, c2.embed_dim + 5 * 256)
+
+
+@pytest.mark.parametrize("which", ["tiny_clip", "tiny_open_clip", "clip_l", "open_clip_bigg"])
+def test_clip_param_specs_equal_oracle(built, which):
+    from oracle import clip as OCL
+    ocfg = {"tiny_clip": OCL.tiny_clip_config, "tiny_open_clip": OCL.tiny_open_clip_config, "clip_l": OCL.clip_l_config,
+            "open_clip_bigg": OCL.open_clip_bigg_config}[which]()
+    mine = built.clip_param_specs(built.CLIPConfig(**ocfg.__dict__))
+    ref = OCL.clip_param_specs(ocfg)
+    assert len(mine) == len(ref)
+    for a, b in zip(mine, ref):
+        assert a.name == b.name and tuple(a.shape) == tuple(b.shape) and a.kind == b.kind
+        assert np.float32(a.scale) == b.scale and np.float32(a.mean) == b.mean, a.name
+    if which == "clip_l":
+        assert built.clip_l_config() == built.CLIPConfig(**ocfg.__dict__)
+    if which == "open_clip_bigg":
+        assert built.open_clip_bigg_config() == built.CLIPConfig(**ocfg.__dict__)
+
+
+def test_bad_clip_config_is_reported(built):
+    assert built.lib().sdxl_clip_param_count(ctypes.byref(built.CLIPConfig(49408, 96, 96, 2, 77, 1, True).to_c())) == -1
+    assert b"64 channels per head" in built.lib().sdxl_last_error()
