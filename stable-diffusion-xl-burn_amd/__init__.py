@@ -462,17 +462,14 @@ class Embedder:
         self.ctx, self.clip, self.open_clip = ctx, clip, open_clip
         self.clip_tokenizer, self.open_clip_tokenizer = clip_tokenizer, open_clip_tokenizer
 
-    def _context(self, clip_ids, open_ids, size, crop, ar):
-        """Embedder::context / unconditional_context (:697-757)"""
+    def _finish(self, full, open_ctx, pooled, size, crop, ar):
+        """tail of Embedder::context / unconditional_context (:697-757): the two label vectors of one prompt"""
         torch = _torch()
-        clip_ctx = self.clip.forward_hidden(clip_ids, self.clip.num_layers() - 1)                      # :759-770
-        open_ctx, pooled = self.open_clip.forward_hidden_pooled(open_ids, self.open_clip.num_layers() - 1)
         n = int(torch.as_tensor(ar).shape[0])
         if pooled.shape[0] != n:
             raise EngineError("the reference concatenates a [1, E] pooled embedding with [n_batch, .] size embeddings: n_batch must be 1")
         aesthetic = torch.full((n, 1), 6, dtype=torch.int32)                                           # :709,740
-        return (torch.cat([clip_ctx, open_ctx], dim=2), open_ctx,
-                conditioning_embedding(self.ctx, pooled, 256, size, crop, ar),
+        return (full, open_ctx, conditioning_embedding(self.ctx, pooled, 256, size, crop, ar),
                 conditioning_embedding(self.ctx, pooled, 256, size, crop, aesthetic))
 
     def tokens_to_conditioning(self, clip_ids, open_ids, uncond_clip_ids, uncond_open_ids, size, crop, ar) -> Conditioning:
@@ -481,8 +478,14 @@ class Embedder:
         size, crop, ar = torch.as_tensor(size), torch.as_tensor(crop), torch.as_tensor(ar)
         n = int(size.shape[0])
         bar = ar.reshape(1, -1).repeat(n, 1)
-        ucf, uco, ucc, uccr = self._context(uncond_clip_ids, uncond_open_ids, size, crop, bar)
-        cf, co, cc, ccr = self._context(clip_ids, open_ids, size, crop, bar)
+        # the reference encodes "" and the prompt in two passes (:680-683); here they ride one batch-2 pass per encoder (the
+        # rows of a batch are independent -- bit-identical to separate passes, tests/test_gpu_clip.py) and are split after
+        cat = lambda a, b: torch.cat([torch.as_tensor(a).reshape(1, -1), torch.as_tensor(b).reshape(1, -1)], dim=0)   # noqa: E731
+        clip_ctx = self.clip.forward_hidden(cat(uncond_clip_ids, clip_ids), self.clip.num_layers() - 1)      # :759-770
+        open_ctx, pooled = self.open_clip.forward_hidden_pooled(cat(uncond_open_ids, open_ids), self.open_clip.num_layers() - 1)
+        full = torch.cat([clip_ctx, open_ctx], dim=2)
+        ucf, uco, ucc, uccr = self._finish(full[0:1], open_ctx[0:1], pooled[0:1], size, crop, bar)
+        cf, co, cc, ccr = self._finish(full[1:2], open_ctx[1:2], pooled[1:2], size, crop, bar)
         return Conditioning(context_full=cf, channel_context=cc, unconditional_context_full=ucf.squeeze(0),
                             unconditional_channel_context=ucc.squeeze(0), context_open_clip=co, channel_context_refiner=ccr,
                             unconditional_context_open_clip=uco.squeeze(0), unconditional_channel_context_refiner=uccr.squeeze(0),

@@ -44,14 +44,76 @@ def test_fullsize_unet_properties(pkg, ctx, base_inputs):
     assert e < 3e-2
 
 
+def _prompt_ids(seed, n_tok, pad):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.full((1, 77), pad, dtype=torch.int64)
+    ids[0, 0] = 49406
+    ids[0, 1:1 + n_tok] = torch.randint(256, 49000, (n_tok,), generator=g)
+    ids[0, 1 + n_tok] = 49407
+    return ids
+
+
+def test_fullsize_embedder(pkg, ctx):
+    """SURVEY 8f row 1 at SDXL size: CLIP ViT-L/14 text (12 blocks x 768, QuickGELU) against the CPU oracle, OpenCLIP bigG
+    (32 blocks x 1280, GELU) fp16 against this engine's strict-fp32 mode (itself oracle-checked on the tiny configs), the
+    decoder mask as a bit-exact prefix property, and the Conditioning shapes the base / refiner UNets expect."""
+    from oracle import clip as OCL, config as OC, model as OM
+    lcfg = OCL.clip_l_config()
+    W = OM.to_torch(OC.synth_weights(OCL.clip_param_specs(lcfg), 11))
+    clip_l = pkg.CLIP(ctx, pkg.clip_l_config(), pkg.DTYPE_F16, seed=11)
+    ids = _prompt_ids(1, 12, 49407)
+    out = clip_l.forward_hidden(ids, lcfg.n_layer - 1)
+    e = rel_err(out, OCL.forward_hidden(lcfg, W, ids, lcfg.n_layer - 1))
+    print(f"CLIP-L f16 vs fp32 oracle rel err {e:.3e}")
+    assert e < 3e-2
+    del W
+
+    ids_o = _prompt_ids(1, 12, 0)
+    bigg = pkg.CLIP(ctx, pkg.open_clip_bigg_config(), pkg.DTYPE_F16, seed=12)
+    h16, p16 = bigg.forward_hidden_pooled(ids_o, 31)
+    assert h16.shape == (1, 77, 1280) and p16.shape == (1, 1280) and torch.isfinite(h16).all() and torch.isfinite(p16).all()
+    ids2 = ids_o.clone(); ids2[0, 40] = 777
+    h2, p2 = bigg.forward_hidden_pooled(ids2, 31)
+    assert torch.equal(h2[0, :40], h16[0, :40]) and not torch.equal(h2[0, 40:], h16[0, 40:])
+    assert torch.equal(p2, p16)                           # pooled row = first eot (index 13), upstream of the edit
+    ref = pkg.CLIP(ctx, pkg.open_clip_bigg_config(), pkg.DTYPE_F32, seed=12)
+    h32, p32 = ref.forward_hidden_pooled(ids_o, 31)
+    eh, ep = rel_err(h16, h32), rel_err(p16, p32)
+    print(f"OpenCLIP bigG f16 vs strict-f32 engine: hidden {eh:.3e} pooled {ep:.3e}")
+    assert eh < 3e-2 and ep < 3e-2
+    del ref
+
+    emb = pkg.Embedder(ctx, clip_l, bigg)
+    un_c = torch.full((1, 77), 49407, dtype=torch.int64); un_c[0, 0] = 49406
+    un_o = torch.zeros((1, 77), dtype=torch.int64); un_o[0, 0], un_o[0, 1] = 49406, 49407
+    size, crop, ar = torch.tensor([[1024, 1024]]), torch.tensor([[0, 0]]), torch.tensor([1024, 1024])
+    cond = emb.tokens_to_conditioning(ids, ids_o, un_c, un_o, size, crop, ar)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    cond = emb.tokens_to_conditioning(ids, ids_o, un_c, un_o, size, crop, ar)
+    t1.record(); torch.cuda.synchronize()
+    print(f"Embedder (2 prompts x (CLIP-L + bigG), f16): {t0.elapsed_time(t1):.2f} ms")
+    base, refiner = pkg.sdxl_base_config(), pkg.sdxl_refiner_config()
+    assert cond.context_full.shape == (1, 77, base.context_dim) and cond.unconditional_context_full.shape == (77, base.context_dim)
+    assert cond.channel_context.shape == (1, base.adm_in_channels) and cond.unconditional_channel_context.shape == (base.adm_in_channels,)
+    assert cond.context_open_clip.shape == (1, 77, refiner.context_dim)
+    assert cond.channel_context_refiner.shape == (1, refiner.adm_in_channels)
+    assert torch.equal(cond.context_full[..., 768:], cond.context_open_clip)
+
+
 def test_fullsize_sample_and_decode(pkg, ctx):
+    """text ids -> Embedder -> Diffuser::sample_latent -> LatentDecoder::latent_to_image, everything at SDXL size"""
     cfg = pkg.sdxl_base_config()
+    emb = pkg.Embedder(ctx, pkg.CLIP(ctx, pkg.clip_l_config(), pkg.DTYPE_F16, seed=11),
+                       pkg.CLIP(ctx, pkg.open_clip_bigg_config(), pkg.DTYPE_F16, seed=12))
+    un_c = torch.full((1, 77), 49407, dtype=torch.int64); un_c[0, 0] = 49406
+    un_o = torch.zeros((1, 77), dtype=torch.int64); un_o[0, 0], un_o[0, 1] = 49406, 49407
+    cond = emb.tokens_to_conditioning(_prompt_ids(1, 12, 49407), _prompt_ids(1, 12, 0), un_c, un_o,
+                                      torch.tensor([[1024, 1024]]), torch.tensor([[0, 0]]), torch.tensor([1024, 1024]))
+    del emb
     d = pkg.Diffuser(ctx, cfg, pkg.DTYPE_F16, seed=0)
     g = torch.Generator(device="cuda").manual_seed(7)
     r = lambda *s: torch.randn(*s, device="cuda", generator=g)   # noqa: E731
-    cond = pkg.Conditioning(context_full=r(1, 77, cfg.context_dim), channel_context=r(1, cfg.adm_in_channels),
-                            unconditional_context_full=r(77, cfg.context_dim),
-                            unconditional_channel_context=r(cfg.adm_in_channels), resolution=(1024, 1024))
     noise = r(1, 4, 128, 128)
     assert pkg.step_count(4) == 4                        # step_size = 1000 / 4 -> t = 999, 749, 499, 249
     lat = d.sample_latent(cond, 7.5, 4, noise)
