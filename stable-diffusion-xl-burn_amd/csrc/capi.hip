@@ -124,6 +124,7 @@ int sdxl_debug_set(const char* key, int value) {
   SDXL_REQUIRE(key != nullptr, "null key");
   if (std::strcmp(key, "igemm_variant") == 0) igemm_set_variant(value);
   else if (std::strcmp(key, "attn_variant") == 0) attention_set_variant(value);
+  else if (std::strcmp(key, "no_cfg") == 0) g_debug_no_cfg = value != 0;
   else throw Error(std::string("unknown debug key ") + key);
   API_END
 }

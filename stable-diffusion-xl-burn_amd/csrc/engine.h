@@ -337,6 +337,8 @@ struct Conditioning {
   int n = 1, n_ctx = 77, height = 1024, width = 1024;
 };
 
+extern bool g_debug_no_cfg;   // sdxl_debug_set("no_cfg"): base model without the unconditional branch (measurement only)
+
 class Diffuser {
  public:
   Diffuser(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, const float* alphas_host, int n_train,

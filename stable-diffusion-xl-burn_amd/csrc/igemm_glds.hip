@@ -686,6 +686,13 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   static_assert(BM % 64 == 0 && WM % 32 == 0 && WN % 32 == 0 && BN % 8 == 0, "bad tile");
   constexpr int KT = 64;
   constexpr int STAGE = (BM + BN) * 128;
+  // measurement-only modes (results wrong by construction): 5 = schedule of mode 0 WITHOUT ds_reads / MFMAs (DMA-only
+  // ceiling), 6 = 5 with every DMA piece reading 1 KiB CONTIGUOUS (operands as if pre-tiled [rows/8][K/64][8][64]),
+  // 7 = mode 0 (full compute) with the contiguous sources of 6
+  constexpr bool SCHED0 = DMODE == 0 || DMODE >= 5;
+  constexpr bool NOMMA = DMODE == 5 || DMODE == 6;
+  constexpr bool CONTIG = DMODE == 6 || DMODE == 7;
+  constexpr int WADV = CONTIG ? 512 : KT;
   static_assert(NS >= 3, "counted-wait pipeline needs a ring of at least 3 slots");
   static_assert(BM * 128 + (TN - 1) * 4096 < 65536, "fragment offsets must fit the ds_read immediate");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -753,6 +760,13 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     }
   };
   retap();
+  if constexpr (CONTIG) {
+    const int nkc = p.Kpad / KT;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) { aptr[j] = Ag + (size_t)((m0 >> 3) + j * 8 + wave) * nkc * 512 + lane * 8; aadv[j] = 512; }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)((n0 >> 3) + j * 8 + wave) * nkc * 512 + lane * 8;
+  }
   // pieces q of one k-tile: q < AJ -> activation piece q, else weight piece q - AJ.  PH selects the pieces with q % 3 == PH
   // (PH < 0: all of them); the tap walk advances once per k-tile, after the last piece (tile_done).
   auto issue = [&](int buf, auto PH) {
@@ -771,13 +785,13 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
           if constexpr (DMODE != 2) aptr[q] += aadv[q];
         } else if (q - AJ < BJ - 1 || lastb) {     // ragged weight tile: wave-uniform predicate on the last piece
           __builtin_amdgcn_global_load_lds((gptr_t)wptr[q - AJ], (lptr_t)(lb + (q - AJ) * 8192), 16, 0, 0);
-          if constexpr (DMODE != 2) wptr[q - AJ] += KT;
+          if constexpr (DMODE != 2) wptr[q - AJ] += WADV;
         }
       }
     });
   };
   auto tile_done = [&]() {
-    if constexpr (DMODE == 2) return;
+    if constexpr (DMODE == 2 || CONTIG) return;
     s_c0 += KT;
     if (s_c0 == p.Cin) {
       s_c0 = 0;
@@ -809,6 +823,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   auto ldfrag = [&](unsigned so, int kk, auto SET) {
     constexpr int set = decltype(SET)::value;
     const unsigned aa = (basea ^ (kk << 5)) + so, ab = (baseb ^ (kk << 5)) + so;
+    if constexpr (NOMMA) return;
     static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<decltype(I)::value * 4096>(aa); });
     static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<decltype(J)::value * 4096>(ab); });
   };
@@ -817,7 +832,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     constexpr int set = decltype(SET)::value;
     constexpr int ph = decltype(PH)::value;
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][0], fA[set][0], acc[0][0], 0, 0, 0);
+    if constexpr (!NOMMA) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][0], fA[set][0], acc[0][0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ph < 3) {
       if (more) issue(buf, PH);            // wave-uniform branch around the DMA pieces only, never around MFMAs
@@ -833,7 +848,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     }
     static_for<TM * TN - 1>([&](auto X) {
       constexpr int x = decltype(X)::value + 1, i = x / TN, j = x % TN;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][j], fA[set][i], acc[i][j], 0, 0, 0);
+      if constexpr (!NOMMA) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][j], fA[set][i], acc[i][j], 0, 0, 0);
       if constexpr (ph == 4 && x < TM * TN - 1) {
         __builtin_amdgcn_sched_barrier(0);
         if (more) issue(buf, std::integral_constant<int, 10 + x>{});
@@ -848,7 +863,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   using I4 = std::integral_constant<int, 4>;
   using IALL = std::integral_constant<int, -1>;
   using I5 = std::integral_constant<int, 5>; using I6 = std::integral_constant<int, 6>;
-  constexpr int NPRO = DMODE == 0 ? NS - 1 : NS;   // tiles staged by the prologue
+  constexpr int NPRO = SCHED0 ? NS - 1 : NS;   // tiles staged by the prologue
 
   // ---- prologue: tiles 0 .. NPRO-1 in flight, wait for tile 0 only
 #pragma unroll
@@ -902,13 +917,13 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     const bool more1 = DMODE == 3 ? false : kt + NS < nk;   // tile kt+NS exists: DMODE 1 stages it after this k-tile's barrier
     ldfrag(so, 1, I1{});
     wait_lgkmcnt<NF>();
-    if constexpr (DMODE == 0) mma(I0{}, fill, I0{}, more); else mma(I0{}, fill, I3{}, false);
+    if constexpr (SCHED0) mma(I0{}, fill, I0{}, more); else mma(I0{}, fill, I3{}, false);
     ldfrag(so, 2, I0{});
     wait_lgkmcnt<NF>();
-    if constexpr (DMODE == 0) mma(I1{}, fill, I1{}, more); else mma(I1{}, fill, I3{}, false);
+    if constexpr (SCHED0) mma(I1{}, fill, I1{}, more); else mma(I1{}, fill, I3{}, false);
     ldfrag(so, 3, I1{});
     wait_lgkmcnt<NF>();
-    if constexpr (DMODE == 0) { mma(I0{}, fill, I2{}, more); if (more) tile_done(); } else mma(I0{}, fill, I3{}, false);
+    if constexpr (SCHED0) { mma(I0{}, fill, I2{}, more); if (more) tile_done(); } else mma(I0{}, fill, I3{}, false);
     if (kt + 1 < nk) {
       // own pieces of tile kt+1 landed (tiles kt+2 .. kt+NS-1 may stay in flight); own reads of tile kt complete
       if (more) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
@@ -920,7 +935,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
     } else {
       wait_lgkmcnt<0>();
     }
-    if constexpr (DMODE == 0) mma(I1{}, fill, I3{}, false);
+    if constexpr (SCHED0) mma(I1{}, fill, I3{}, false);
     else { mma(I1{}, cur, I4{}, more1); if (more1) tile_done(); }
     fill = cur;
     cur = nslot;
@@ -1370,6 +1385,11 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     if (t128 <= 256) variant = 13;
     else if (t256 <= 256 || eff256 >= 0.8) variant = 11;
     else variant = t128 >= 400 ? 4 : 6;
+    if (p.act == 1 && p.N % 160 == 0 && variant != 11) {
+      // single-prompt (M = 1024) GEGLU: 256x160 gives exactly one round of 256 tiles where 128x128 needs 2.5
+      const long t160 = (long)((p.M + 255) / 256) * (p.N / 160);
+      if (t160 <= 256 && t160 * 160 * 2 >= t128 * 128) variant = 19;
+    }
     if (p.act == 1 && p.N % 160 == 0 && variant == 11) {
       // GEGLU projections: the 256x160 tile (8x1 waves) when it saves whole rounds of 256 CUs (N = 10240 at M = 2048: 512
       // tiles = 2 rounds instead of 640 = 2.5 -> 3); it pays ~10 % more LDS reads per MFMA, so it must win >= 15 % of area
@@ -1400,6 +1420,12 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
       if (p.act != 1 || p.ksize != 1 || p.stride != 1 || p.up != 0 || p.N % 320 != 0 || p.Kpad % 32 != 0) return false;
       launch_wide(p, s); break;
     case 24: launch_pipe<256, 128, 3, true, 4>(p, s); break;    // lookahead-2 fragment prefetch
+    case 27: launch_pipe<256, 128, 3, true, 5>(p, s); break;    // measurement only: DMA-only / contiguous-source modes
+    case 28: launch_pipe<256, 128, 3, true, 6>(p, s); break;
+    case 29: launch_pipe<256, 128, 3, true, 7>(p, s); break;
+    case 30: launch_pipe<128, 128, 4, true, 5>(p, s); break;
+    case 31: launch_pipe<128, 128, 4, true, 6>(p, s); break;
+    case 32: launch_pipe<128, 128, 4, true, 7>(p, s); break;
     case 25: launch_pipe<128, 128, 4, true, 4>(p, s); break;
     case 19:                                                    // 256x160, 8x1 waves: weight rows must exist up to the tile edge
       if (p.N % 160 != 0) return false;

@@ -38,12 +38,15 @@ Diffuser::~Diffuser() {
     if (p) (void)hipFree(p);
 }
 
+bool g_debug_no_cfg = false;
+
 void Diffuser::diffuse(float* latent, const Conditioning& c, int step_start, int n_steps, double cfg_scale,
                        const float* reference, const unsigned char* mask, const float* step_noise, hipStream_t s) {
   // diffuse_latent :390-432 / diffuse_latent_with_inpainting :434-483
   UNet& u = *unet_;
   const UNetCfg& uc = u.cfg();
-  const int n = c.n, B = is_refiner_ ? n : 2 * n;
+  const bool single = is_refiner_ || g_debug_no_cfg;   // debug knob: conditional branch only (concurrency experiments)
+  const int n = c.n, B = single ? n : 2 * n;
   SDXL_REQUIRE(n >= 1 && B <= 8, "batch out of range");
   const int h = c.height / 8, w = c.width / 8, HW = h * w;
   const int ctx_dim = uc.context_dim, adm = uc.adm_in_channels;
@@ -53,7 +56,7 @@ void Diffuser::diffuse(float* latent, const Conditioning& c, int step_start, int
   const float* y = is_refiner_ ? c.channel_context_refiner : c.channel_context;
   const float* uy = is_refiner_ ? c.unconditional_channel_context_refiner : c.unconditional_channel_context;
   SDXL_REQUIRE(ctx && y, "conditioning tensors missing");
-  SDXL_REQUIRE(is_refiner_ || (uctx && uy), "unconditional conditioning tensors missing");
+  SDXL_REQUIRE(single || (uctx && uy), "unconditional conditioning tensors missing");
   const size_t ctx_elems = (size_t)c.n_ctx * ctx_dim;
   if ((size_t)B * ctx_elems > ctx_cap_) {
     if (ctx_buf_) SDXL_HIP(hipFree(ctx_buf_));
@@ -67,7 +70,7 @@ void Diffuser::diffuse(float* latent, const Conditioning& c, int step_start, int
   }
   SDXL_HIP(hipMemcpyAsync(ctx_buf_, ctx, (size_t)n * ctx_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
   SDXL_HIP(hipMemcpyAsync(y_buf_, y, (size_t)n * adm * sizeof(float), hipMemcpyDeviceToDevice, s));
-  if (!is_refiner_)
+  if (!single)
     for (int i = 0; i < n; ++i) {   // unconditional_context.unsqueeze().repeat(0, n_batch) :535-536
       SDXL_HIP(hipMemcpyAsync(ctx_buf_ + (size_t)(n + i) * ctx_elems, uctx, ctx_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
       SDXL_HIP(hipMemcpyAsync(y_buf_ + (size_t)(n + i) * adm, uy, adm * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -106,9 +109,9 @@ void Diffuser::diffuse(float* latent, const Conditioning& c, int step_start, int
   p.latent = latent;
   p.eps = u.eps_out(); p.eps_dt = DT_F32; p.eps_ld = uc.out_channels;
   p.table = table_; p.step_idx = step_idx_;
-  p.n = n; p.HW = HW; p.use_cfg = is_refiner_ ? 0 : 1;
+  p.n = n; p.HW = HW; p.use_cfg = single ? 0 : 1;
   p.ref = reference; p.mask = mask; p.step_noise = step_noise; p.n_steps_total = iters;
-  p.unet_in = unet_in; p.in_dt = u.compute_dt(); p.in_ld = uc.in_channels; p.in_rep = is_refiner_ ? 1 : 2;
+  p.unet_in = unet_in; p.in_dt = u.compute_dt(); p.in_ld = uc.in_channels; p.in_rep = single ? 1 : 2;
   p.t_out = t_dev_;
   launch_ddim_step(p, 0, s);
 

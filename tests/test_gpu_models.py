@@ -218,6 +218,28 @@ def test_host_weights_equal_synthetic(pkg, ctx):
     assert torch.equal(oa, ob)
 
 
+def test_reference_npy_tree_loads_into_the_engine(pkg, ctx, tmp_path):
+    # the reference's params/ tree (python/save.py format) -> importer -> sdxl_unet_create == synthetic weights of the same seed
+    import importlib
+    imp = importlib.import_module(pkg.__name__ + ".importer")
+    ocfg = OC.tiny_config()
+    specs = OC.unet_param_specs(ocfg)
+    root = str(tmp_path / "diffuser_base")
+    imp.export_tree(specs, OC.synth_weights(specs, 0), root, "unet")
+    kind = {"Conv": 0, "Res": 1, "Down": 2, "ResT": 3, "ResTU": 4, "ResU": 5}
+    inp, mid, out = OC.unet_block_plan(ocfg)
+    blocks = lambda bl: [(kind[b["kind"]], b.get("depth", 0), b.get("n_head", 0)) for b in bl]   # noqa: E731
+    imp.export_unet_structure(root, ocfg.model_channels, blocks(inp), blocks(out), mid["depth"], mid["n_head"])
+    cfg, flat = imp.load_unet(pkg, root)
+    x = torch.from_numpy(OC.arb_tensor(1, 4, 8, 8)).cuda()
+    t = torch.tensor([7], dtype=torch.int32).cuda()
+    c = torch.from_numpy(OC.arb_tensor(1, 5, ocfg.context_dim)).cuda()
+    y = torch.from_numpy(OC.arb_tensor(1, ocfg.adm_in_channels)).cuda()
+    a = pkg.UNet(ctx, cfg, 1, weights=flat).forward(x, t, c, y)
+    b = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), 1, seed=0).forward(x, t, c, y)
+    assert torch.equal(a, b)
+
+
 def test_errors_are_reported_not_fatal(pkg, ctx):
     bad = pkg.UNetConfig(128, 48, [1, 2, 4], 64, [0, 1, 2], 128)     # 48 % 64 != 0 -> reference asserts (unet/mod.rs:73-76)
     with pytest.raises(pkg.EngineError):
