@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--split-cfg", action="store_true",
+                    help="run the CFG pair as two concurrent batch-1 chains (measured -2.6 %% step time; off by default so "
+                         "the timed launches are the ones the roofline object and the rocprofv3 summary describe)")
     args = ap.parse_args()
 
     import torch
@@ -218,6 +221,8 @@ def main():
     t_bcast = time.time() - t0
     if args.no_graph:
         diffuser.diffusion.set_graph(False)
+    if args.split_cfg:
+        pkg.debug_set("split_cfg", 1)
     diffuser.enable_step_timing(True)
 
     res = args.res
@@ -296,7 +301,7 @@ def main():
                                    f"batch 1 prompt/GPU + VAE decode to u8 (BASELINE configs[1])",
                        "precision": args.dtype, "weights": "synthetic seeded (random-init SDXL-base architecture)",
                        "parallelism": f"replica x{world}, 1 prompt per GPU, weights broadcast once over RCCL",
-                       "hipgraph": not args.no_graph},
+                       "hipgraph": not args.no_graph, "split_cfg": bool(args.split_cfg)},
             "images_per_sec_per_gpu": round(value / world, 4),
             "unet_step_ms_p50": None if p50 is None else round(p50, 3),
             "tflop_per_image": round(tflop_image, 1),

@@ -125,6 +125,8 @@ int sdxl_debug_set(const char* key, int value) {
   if (std::strcmp(key, "igemm_variant") == 0) igemm_set_variant(value);
   else if (std::strcmp(key, "attn_variant") == 0) attention_set_variant(value);
   else if (std::strcmp(key, "no_cfg") == 0) g_debug_no_cfg = value != 0;
+  else if (std::strcmp(key, "split_cfg") == 0) g_split_cfg = value != 0;
+  else if (std::strcmp(key, "split_offset") == 0) g_split_offset = value;
   else throw Error(std::string("unknown debug key ") + key);
   API_END
 }

@@ -160,6 +160,10 @@ struct Exec {
   int sdt = DT_F16;      // residual-stream dtype
   DeviceArena* act = nullptr;
   float* gn_partial = nullptr;
+  const float* ebias = nullptr;   // [nb][emb_total] per-ResBlock time-embedding biases of this run's batch entries
+  int b0 = 0;                      // first batch entry of this run (split-CFG chains address the K/V caches with it)
+  hipEvent_t fork_ev = nullptr;    // split-CFG: recorded on s after the fork_after-th GEMM launch of chain 0 -- the second
+  int fork_after = 0, launches = 0; // chain starts there, so the two chains run out of phase (GEMMs of one under the attention of the other)
   Act alloc(size_t rows, int C, int dt) {
     return Act(act->alloc(rows * (size_t)C * dt_size(dt)), C, dt);
   }
@@ -216,7 +220,7 @@ class UNet {
  private:
   void build_weights(WeightSource& src, hipStream_t st);
   void ensure_plan(int B, int H, int W);
-  void run(Exec& ex, const float* t_dev, int t_stride);
+  void run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb);
   void res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, int H, int W, const Act& out);
   void spatial_transformer(Exec& ex, const STW& w, int st_index, const Act& x, int B, int H, int W);
 
@@ -242,6 +246,11 @@ class UNet {
   float *temb_ = nullptr, *g1_ = nullptr, *emb_ = nullptr, *ebias_ = nullptr, *gn_partial_ = nullptr, *tconv_ = nullptr;
   bool fuse_ln_ = false;                 // f16 compute + f16 residual stream: LayerNorms are folded into the GEMMs
   bool use_graph_ = true;
+  // split-CFG mode: the two entries of a batch-2 forward run as two independent batch-1 chains on two streams (fork / join
+  // by events, captured into the same graph); the second chain has its own scratch arena
+  bool plan_split_ = false; int graph_off_ = 0;
+  hipStream_t s2_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  DeviceArena act2_;
   hipGraphExec_t graph_ = nullptr;
   const float* graph_t_ = nullptr; int graph_ts_ = 0; int plan_runs_ = 0;
 };
@@ -337,6 +346,8 @@ struct Conditioning {
   int n = 1, n_ctx = 77, height = 1024, width = 1024;
 };
 
+extern int g_split_offset;    // GEMM launches of chain 0 before chain 1 is released (sdxl_debug_set("split_offset"))
+extern bool g_split_cfg;      // sdxl_debug_set("split_cfg"): run the CFG pair as two concurrent batch-1 chains (UNet::forward, B == 2)
 extern bool g_debug_no_cfg;   // sdxl_debug_set("no_cfg"): base model without the unconditional branch (measurement only)
 
 class Diffuser {

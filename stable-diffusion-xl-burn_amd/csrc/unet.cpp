@@ -104,6 +104,9 @@ UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src,
 }
 UNet::~UNet() {
   if (graph_) (void)hipGraphExecDestroy(graph_);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
+  if (s2_) (void)hipStreamDestroy(s2_);
 }
 
 void UNet::build_weights(WeightSource& src, hipStream_t st) {
@@ -204,7 +207,7 @@ void UNet::res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, int H, i
   Act gn1 = ex.alloc(M, w.cin, ex.cdt);
   run_groupnorm(ex, w.norm_in, x, B, H * W, gn1, true);
   Act h = ex.alloc(M, w.cout, ex.cdt);
-  Epi e1; e1.ebias = ebias_ + w.emb_off; e1.ebias_ld = emb_total_;
+  Epi e1; e1.ebias = ex.ebias + w.emb_off; e1.ebias_ld = emb_total_;
   run_conv(ex, w.conv_in, gn1, w.cin, g3, h, e1);
   Act gn2 = ex.alloc(M, w.cout, ex.cdt);
   run_groupnorm(ex, w.norm_out, h, B, H * W, gn2, true);
@@ -222,6 +225,9 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   const size_t M = (size_t)B * HW;
   SDXL_REQUIRE(C == w.heads * 64, "head dim must be 64");
   const int npad = (int)round_up(HW, 64);
+  // cross-attention caches of this run's batch entries (dry runs carry null caches)
+  auto kv_k = [&](int s_, size_t j) { char* k = (char*)kv_[s_][j].k; return (void*)(k ? k + (size_t)ex.b0 * n_ctx_ * C * dt_size(ex.cdt) : k); };
+  auto kv_vt = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].vt; return (const void*)(v ? v + (size_t)ex.b0 * C * vt_ld_ctx_ * dt_size(ex.cdt) : v); };
   Act gn = ex.alloc(M, C, ex.cdt);
   run_groupnorm(ex, w.norm, x, B, HW, gn, false);
   Act t = ex.alloc(M, C, ex.sdt);
@@ -251,7 +257,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       run_linear(ex, b.out1, ao, (int)M, t, e1);
       Epi e2q; e2q.ln_stat = stbuf[stp];
       run_linear(ex, b.q2, t, (int)M, q, e2q);
-      attention(ex, q, Act(kv_[si][j].k, C, ex.cdt), kv_[si][j].vt, vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
+      attention(ex, q, Act(kv_k(si, j), C, ex.cdt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
       stp ^= 1;
       Epi e2; e2.R = t; e2.stat_out = stbuf[stp];
       run_linear(ex, b.out2, ao, (int)M, t, e2);
@@ -272,7 +278,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_linear(ex, b.out1, ao, (int)M, t, er);
     run_layernorm(ex, b.n2, t, (int)M, ln);
     run_linear(ex, b.q2, ln, (int)M, q);
-    attention(ex, q, Act(kv_[si][j].k, C, ex.cdt), kv_[si][j].vt, vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
+    attention(ex, q, Act(kv_k(si, j), C, ex.cdt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
     run_linear(ex, b.out2, ao, (int)M, t, er);
     run_layernorm(ex, b.n3, t, (int)M, ln);
     Epi eg; eg.act = 1;
@@ -285,14 +291,24 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
 }
 
 // ------------------------------------------------------------------------------------------ forward
-void UNet::run(Exec& ex, const float* t_dev, int t_stride) {
-  const int B = pB_, H = pH_, W = pW_;
+void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
+  // batch entries [b0, b0 + nb) of the plan: every per-entry buffer is addressed through these views
+  const int B = nb, H = pH_, W = pW_;
   const int mc = cfg_.model_channels, emb = 4 * mc;
+  float* temb = temb_ + (size_t)b0 * mc;
+  float* g1 = g1_ + (size_t)b0 * emb;
+  float* embv = emb_ + (size_t)b0 * emb;
+  float* ebias = ebias_ + (size_t)b0 * emb_total_;
+  const float* label_emb = label_emb_ ? label_emb_ + (size_t)b0 * emb : nullptr;
+  void* in = (char*)in_ + (size_t)b0 * H * W * cfg_.in_channels * dt_size(cdt_);
+  float* eps = eps_ + (size_t)b0 * H * W * cfg_.out_channels;
+  ex.ebias = ebias; ex.b0 = b0;
+  ex.gn_partial = gn_partial_ + (size_t)b0 * 32 * (128 * 3 + 2);
   // --- embeddings (unet/mod.rs:458-468)
-  if (!ex.dry) launch_timestep_embedding(t_dev, t_stride, temb_, B, mc, ex.s);
-  gemv(ex, lin1_t_, temb_, mc, g1_, emb, B, false, true);
-  gemv(ex, lin2_t_, g1_, emb, emb_, emb, B, false, false, label_emb_);
-  gemv(ex, embcat_, emb_, emb, ebias_, emb_total_, B, true, false);
+  if (!ex.dry) launch_timestep_embedding(t_dev + (size_t)b0 * t_stride, t_stride, temb, B, mc, ex.s);
+  gemv(ex, lin1_t_, temb, mc, g1, emb, B, false, true);
+  gemv(ex, lin2_t_, g1, emb, embv, emb, B, false, false, label_emb);
+  gemv(ex, embcat_, embv, emb, ebias, emb_total_, B, true, false);
 
   // --- geometry of the skip / concat buffers
   const int n_in = (int)inp_.size(), n_out = (int)out_.size();
@@ -315,7 +331,7 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride) {
     cat[j] = ex.alloc((size_t)B * hs_h[i] * hs_w[i], out_[j].d.c_in, ex.sdt);
   }
   // --- input blocks (:474-477)
-  Act cur(in_, cfg_.in_channels, ex.cdt);
+  Act cur(in, cfg_.in_channels, ex.cdt);
   int h = H, w = W, cur_c = cfg_.in_channels;
   int si = 0;
   for (int i = 0; i < n_in; ++i) {
@@ -370,13 +386,17 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride) {
     const size_t mk = ex.act->mark();
     Act gn = ex.alloc((size_t)B * H * W, mc, ex.cdt);
     run_groupnorm(ex, norm_out_, last, B, H * W, gn, true);
-    run_conv(ex, conv_out_, gn, mc, ConvGeom{B, H, W, H, W, 3, 1, 1, 0}, Act(eps_, cfg_.out_channels, DT_F32));
+    run_conv(ex, conv_out_, gn, mc, ConvGeom{B, H, W, H, W, 3, 1, 1, 0}, Act(eps, cfg_.out_channels, DT_F32));
     ex.act->reset(mk);
   }
 }
 
+bool g_split_cfg = false;
+int g_split_offset = 0;
+
 void UNet::ensure_plan(int B, int H, int W) {
-  if (B == pB_ && H == pH_ && W == pW_) return;
+  const bool split = g_split_cfg && B == 2;
+  if (B == pB_ && H == pH_ && W == pW_ && split == plan_split_) return;
   SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
   const int div = 1 << (cfg_.channel_mults.size() - 1);
   SDXL_REQUIRE(H >= div && W >= div && H % div == 0 && W % div == 0,
@@ -405,7 +425,22 @@ void UNet::ensure_plan(int B, int H, int W) {
     kv_.assign(st_list_.size(), std::vector<KV>());
     for (size_t i = 0; i < st_list_.size(); ++i) kv_[i].assign(st_list_[i]->blocks.size(), KV());
   }
-  run(ex, nullptr, 0);
+  run(ex, nullptr, 0, 0, B);
+  if (split) {   // scratch peak of one batch-1 chain -> the second chain's own arena
+    act2_.dry = true; act2_.off = 0; act2_.peak = 0;
+    Exec e2; e2.dry = true; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_;
+    run(e2, nullptr, 0, 1, 1);
+    const size_t peak2 = act2_.peak;
+    act2_.dry = false;
+    act2_.reserve(peak2 + 4096);
+    act2_.off = 0; act2_.peak = 0;
+    if (!s2_) {
+      SDXL_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+      SDXL_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+      SDXL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
+  }
+  plan_split_ = split;
   if (!had_kv) kv_.clear();
   act_.reset(m);
   const size_t peak = act_.peak;
@@ -422,24 +457,39 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
   SDXL_REQUIRE(ctx_B_ == B && !kv_.empty(), "set_context must be called with the same batch before forward");
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_;
   const size_t m = act_.mark();
-  if (use_graph_ && graph_ && (graph_t_ != t_dev || graph_ts_ != t_stride)) {
+  // one batched chain, or (split-CFG) entry 0 on s and entry 1 on the side stream between a fork and a join event
+  auto go = [&]() {
+    if (!plan_split_) { run(ex, t_dev, t_stride, 0, B); return; }
+    Exec e2; e2.s = s2_; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_;
+    act2_.off = 0;
+    ex.fork_ev = ev_fork_; ex.fork_after = g_split_offset; ex.launches = 0;
+    if (ex.fork_after <= 0) SDXL_HIP(hipEventRecord(ev_fork_, s));
+    run(ex, t_dev, t_stride, 0, 1);
+    if (ex.fork_after > 0 && ex.launches < ex.fork_after) SDXL_HIP(hipEventRecord(ev_fork_, s));   // offset beyond the chain
+    ex.fork_ev = nullptr;
+    SDXL_HIP(hipStreamWaitEvent(s2_, ev_fork_, 0));
+    run(e2, t_dev, t_stride, 1, 1);
+    SDXL_HIP(hipEventRecord(ev_join_, s2_));
+    SDXL_HIP(hipStreamWaitEvent(s, ev_join_, 0));
+  };
+  if (use_graph_ && graph_ && (graph_t_ != t_dev || graph_ts_ != t_stride || graph_off_ != g_split_offset)) {
     (void)hipGraphExecDestroy(graph_); graph_ = nullptr;
   }
   if (use_graph_ && !graph_ && plan_runs_ >= 1) {
     // capture the whole forward (~1.3k launches) once; replay costs one launch per forward
     hipGraph_t g = nullptr;
     SDXL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-    try { run(ex, t_dev, t_stride); } catch (...) { (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); act_.reset(m); throw; }
+    try { go(); } catch (...) { (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); act_.reset(m); throw; }
     SDXL_HIP(hipStreamEndCapture(s, &g));
     SDXL_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
     SDXL_HIP(hipGraphDestroy(g));
-    graph_t_ = t_dev; graph_ts_ = t_stride;
+    graph_t_ = t_dev; graph_ts_ = t_stride; graph_off_ = g_split_offset;
     act_.reset(m);
   }
   if (use_graph_ && graph_) {
     SDXL_HIP(hipGraphLaunch(graph_, s));
   } else {
-    run(ex, t_dev, t_stride);
+    go();
     act_.reset(m);
   }
   ++plan_runs_;
@@ -455,7 +505,7 @@ void UNet::profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[P
   Profiler prof;
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.prof = &prof;
   const size_t m = act_.mark();
-  run(ex, tconv_, 1);
+  run(ex, tconv_, 1, 0, B);   // always the batched chain: per-launch events need one stream
   act_.reset(m);
   prof.collect(ms, launches, flops);
 }

@@ -255,6 +255,7 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize);
   launch_igemm(p, ex.cdt, ex.s);
   if (ex.prof) ex.prof->end(ex.s);
+  if (ex.fork_ev && ++ex.launches == ex.fork_after) SDXL_HIP(hipEventRecord(ex.fork_ev, ex.s));
 }
 void run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e) {
   ConvGeom g{1, M, 1, M, 1, 1, 1, 0, 0};

@@ -76,6 +76,31 @@ def test_unet_forward(pkg, ctx, dtype, which):
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_split_cfg_chains_equal_batched_pair(pkg, ctx, dtype):
+    # sdxl_debug_set("split_cfg"): the two entries of a batch-2 forward as two concurrent batch-1 chains (fork / join inside
+    # the captured graph, second chain released after `split_offset` GEMMs) -- same bits as the batched pair, eager and replayed
+    ocfg = OC.tiny_config()
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    x = torch.from_numpy(OC.arb_tensor(2, 4, 16, 16)).cuda()
+    context = torch.from_numpy(OC.arb_tensor(2, 5, ocfg.context_dim)).cuda()
+    y = torch.from_numpy(OC.arb_tensor(2, ocfg.adm_in_channels)).cuda()
+    t = torch.tensor([999, 1], dtype=torch.int32).cuda()
+    ref = u.forward(x, t, context, y)
+    try:
+        for off in (0, 3, 10000):
+            pkg.debug_set("split_cfg", 1)
+            pkg.debug_set("split_offset", off)
+            outs = [u.forward(x, t, context, y) for _ in range(3)]      # eager, capture, replay
+            assert all(torch.equal(o, ref) for o in outs), off
+        one = u.forward(x[:1], t[:1], context[:1], y[:1])                # batch 1 is untouched by the knob
+        assert torch.equal(one[0], ref[0])
+    finally:
+        pkg.debug_set("split_cfg", 0)
+        pkg.debug_set("split_offset", 0)
+    assert torch.equal(u.forward(x, t, context, y), ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 def test_unet_forward_batch_independence(pkg, ctx, dtype):
     # the engine batches the CFG pair; per-sample results must not depend on what else is in the batch
     ocfg = OC.tiny_config()
