@@ -615,6 +615,190 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// f16 variant "key split" (variant 6): variant 2 for grids that leave most SIMDs with ONE wave.
+//   Self-attention at 32^2 (Nq = Nk = 1024, 40 batch-heads) is 320 blocks of 128 queries = 1280 waves on 1024 SIMDs: a wave
+//   alone on its SIMD runs QK^T (MFMA), softmax (VALU, the longer part) and PV (MFMA) strictly in turn, and the SIMDs that
+//   carry two waves set the kernel time while the others idle half of it.  Here a block is 64 queries and its four waves are
+//   {query sub-tile} x {key half}: every wave takes 32 queries and the 32 keys of its parity out of each 64-key tile, with
+//   its own (m, l, O) -- half the work per wave, twice the waves (2.5 per SIMD: softmax of one under the MFMAs of another,
+//   worst SIMD 3 half-units instead of 2 whole ones).  The ring, the DMA pieces and the barriers are variant 2's.  At the end
+//   the odd-half waves park (m, l, O) in the dead ring and the even-half waves merge:  O = O0 2^(m0-m) + O1 2^(m1-m).
+//   Needs Nk % 64 == 0 (no key tail inside a half) -- the launcher sends everything else to variant 2.
+__global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p, const void* zeros) {
+  constexpr int KV = 64, TILE = 64 * 128, NS = 3;
+  constexpr float THR = 8.0f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][K tile | V^T tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qs = wave & 1, kp = wave >> 1;
+  const int fr = lane & 31, h = lane >> 5;
+  const int nqb = (p.Nq + 63) / 64;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bh = bid / nqb, qb = bid - bh * nqb;
+  const int b = bh / p.H, hd = bh - b * p.H;
+  const int q0 = qb * 64 + qs * 32;
+  const half_t* Qg = reinterpret_cast<const half_t*>(p.Q) + (size_t)b * p.Nq * p.ldq + hd * 64;
+  const half_t* Kg = reinterpret_cast<const half_t*>(p.K) + (size_t)b * p.Nk * p.ldk + hd * 64;
+  const half_t* Vg = reinterpret_cast<const half_t*>(p.Vt) + ((size_t)b * p.H + hd) * 64 * p.vt_ld;
+  const float sc = p.scale * 1.44269504088896340736f;
+
+  half8 qf[4];
+  {
+    const int q = q0 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      half8 v = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < p.Nq) v = *reinterpret_cast<const half8*>(Qg + (size_t)q * p.ldq + ks * 16 + h * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * sc);
+      qf[ks] = v;
+    }
+  }
+  // DMA geometry (as variant 2): wave w stages tile rows [16w, 16w+16) of K and of V^T, two 1-KiB pieces each
+  const int lrow = lane >> 3, slot = lane & 7;
+  auto stage = [&](int t, int buf) {
+    const int k0 = t * KV;
+    char* lk = smem + buf * 2 * TILE + wave * 2048;
+    char* lv = lk + TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wave * 16 + j * 8 + lrow;
+      const half_t* ksrc = Kg + (size_t)(k0 + row) * p.ldk + (slot ^ ((row >> 1) & 7)) * 8;
+      __builtin_amdgcn_global_load_lds((agptr_t)ksrc, (alptr_t)(lk + j * 1024), 16, 0, 0);
+      const half_t* vs = Vg + (size_t)row * p.vt_ld + k0 + (slot ^ ((row ^ (row >> 3)) & 7)) * 8;
+      __builtin_amdgcn_global_load_lds((agptr_t)vs, (alptr_t)(lv + j * 1024), 16, 0, 0);
+    }
+  };
+  // fragment byte offsets inside a tile: K rows kp*32 + fr; V^T rows dt*32 + fr, keys of this wave's half
+  const int krow = kp * 32 + fr;
+  const int koff = krow * 128 + ((h ^ ((krow >> 1) & 7)) << 4);   // chunk of k-step ks: ^ (ks << 5)
+  const int voff[2] = {fr * 128, (32 + fr) * 128};
+  const int vsw[2] = {(fr ^ (fr >> 3)) & 7, ((32 + fr) ^ ((32 + fr) >> 3)) & 7};
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m = 0.f, l = 0.f;
+  const int nt = p.Nk / KV;
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nt) stage(s0, s0);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + NS - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + NS - 1 < nt) stage(t + NS - 1, cur == 0 ? NS - 1 : cur - 1);
+    const char* kb = smem + cur * 2 * TILE;
+    const char* vb = kb + TILE;
+    // ---- S^T - m for this wave's 32 keys
+    f32x16 sv;
+    const float init = t == 0 ? 0.f : -m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = init;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8 kf = *reinterpret_cast<const half8*>(kb + (koff ^ (ks << 5)));
+      sv = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sv, 0, 0, 0);
+    }
+    float lmax = sv[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) lmax = fmaxf(lmax, sv[r]);
+    if (t == 0 || __any(lmax > THR)) {
+      const float pm = fmaxf(lmax, __shfl_xor(lmax, 32));
+      const float delta = t == 0 ? pm : fmaxf(pm, 0.f);
+      const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+      m = t == 0 ? delta : m + delta;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] -= delta;
+    }
+    // ---- P = exp2(S - m): k-step hf holds registers 8*hf .. 8*hf+7
+    half8 pf[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      half8 hh;
+      float ls = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(sv[8 * hf + e]);
+        ls += pe;
+        hh[e] = (half_t)pe;
+      }
+      l += ls;
+      pf[hf] = hh;
+    }
+    // ---- O^T += V^T P^T: k-step hf covers keys kp*32 + 16*hf + {4h..4h+3, 8+4h..8+4h+3}
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int base = kp * 32 + hf * 16;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int b1 = (base + 4 * h) * 2, b2 = b1 + 16;
+        const i32x2 v1 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b1 >> 4)) ^ vsw[dt]) << 4) + (b1 & 15));
+        const i32x2 v2 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b2 >> 4)) ^ vsw[dt]) << 4) + (b2 & 15));
+        const i32x4 vf = i32x4{v1[0], v1[1], v2[0], v2[1]};
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, vf), pf[hf], o[dt], 0, 0, 0);
+      }
+    }
+    cur = cur == NS - 1 ? 0 : cur + 1;
+  }
+  l += __shfl_xor(l, 32);
+  // ---- merge the two key halves of each query sub-tile through the dead ring: [qs][34][64 lanes] floats at smem + 0
+  __syncthreads();
+  float* mb = reinterpret_cast<float*>(smem) + qs * (34 * 64) + lane;
+  if (kp == 1) {
+    mb[0] = m; mb[64] = l;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mb[(2 + dt * 16 + r) * 64] = o[dt][r];
+  }
+  __syncthreads();
+  if (kp == 1) return;
+  {
+    const float m1 = mb[0], l1 = mb[64];
+    const float mm = fmaxf(m, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+    l = l * a0 + l1 * a1;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = o[dt][r] * a0 + mb[(2 + dt * 16 + r) * 64] * a1;
+  }
+  const float inv = 1.0f / l;
+  char* ob = smem + 24576 + qs * 4096;          // behind the merge buffers (2 x 8704 B)
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      half4 hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hv[r] = (half_t)(o[dt][g * 4 + r] * inv);
+      *reinterpret_cast<half4*>(ob + fr * 128 + (((dt * 4 + g) ^ (fr & 7)) << 4) + 8 * h) = hv;
+    }
+  half_t* Og = reinterpret_cast<half_t*>(p.O) + (size_t)b * p.Nq * p.ldo + hd * 64;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3), piece = lane & 7;
+    const i32x4 v = *reinterpret_cast<const i32x4*>(ob + row * 128 + ((piece ^ (row & 7)) << 4));
+    const int q = q0 + row;
+    if (q < p.Nq) *reinterpret_cast<i32x4*>(Og + (size_t)q * p.ldo + piece * 8) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // f16 variant 3: variant 2 with the two GEMMs of consecutive tiles software-pipelined inside each wave.
 //   iteration t:  [row max of S(t), rare rescale]  ->  { S(t+1) = K(t+1) Q^T  (8 MFMA)  ||  P = exp2(S(t)), row sums, fp16
 //   fragments (VALU) }  ->  O^T += V^T(t) P^T (8 MFMA).  The matrix pipe and the VALU are separate: in variant 2 a wave ran
@@ -828,10 +1012,17 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
   const bool aligned = ((p.ldq | p.ldk | p.vt_ld | p.ldo) & 7) == 0 &&
                        ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
                          reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) == 0;
-  if (p.dt == DT_F16 && (g_attn_variant == 0 || g_attn_variant == 2 || g_attn_variant == 3 || g_attn_variant == 4) && g_attn_zero && aligned && !p.mask) {
+  if (p.dt == DT_F16 && (g_attn_variant == 0 || (g_attn_variant >= 2 && g_attn_variant <= 6)) && g_attn_zero && aligned && !p.mask) {
     // 3-slot ring = 48 KiB per block -> three blocks per CU: the 640 blocks of the 64^2 level run as ONE round (a 4-slot
     // ring admits two per CU, a second half-empty round: 147 us vs 126 us measured); variant 3 keeps the 4-slot ring for A/B
     const dim3 g1(grid.x * grid.y);
+    // key-split kernel (64-query blocks, waves = query sub-tile x key half): where 128-query blocks leave fewer than two
+    // waves per SIMD (self-attention at 32^2: 320 blocks on 256 CUs) and the keys are whole 64-key tiles
+    const bool ks_ok = (p.Nk % 64) == 0 && p.Nk >= 128;
+    if (ks_ok && (g_attn_variant == 6 || (g_attn_variant == 0 && g1.x < 512))) {
+      hipLaunchKernelGGL(attn_d64_ks_kernel, dim3(((p.Nq + 63) / 64) * p.B * p.H), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
+      return;
+    }
     if (g_attn_variant == 4) {
       hipLaunchKernelGGL(attn_d64_v3_kernel, g1, dim3(256), 6 * 64 * 128, s, p, g_attn_zero);
     } else if (g_attn_variant == 3 && p.Nk > 128) {

@@ -87,7 +87,7 @@ struct AttnParams {
 };
 void launch_attention_d64(const AttnParams& p, hipStream_t s);
 void attention_init();                 // zero page for the DMA-staged f16 kernel (once per process)
-void attention_set_variant(int v);     // -1: generic kernel only, 0: auto, 1: DMA-staged 16x16x32 kernel, 2: 32x32x16 deferred-max kernel
+void attention_set_variant(int v);     // -1: generic kernel only, 0: auto, 1: DMA-staged 16x16x32 kernel, 2: 32x32x16 deferred-max kernel, 6: key-split kernel
 
 // row softmax for the unfused attention path (VAE mid block, d=512, 1 head): P[r][:] = softmax(S[r][:]*scale + mask)
 // S fp32 [rows][lds] (scores from igemm), P in dtype p_dt [rows][ldp]; columns n..npad-1 of P are zero filled.

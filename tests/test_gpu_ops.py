@@ -136,7 +136,7 @@ def test_qkv_attention(pkg, ctx, dtype, B, Nq, Nk, C, heads, masked):
     assert rel_err(out, ref) < (1e-4 if dtype == 0 else 6e-3)
 
 
-@pytest.mark.parametrize("dtype,variant", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 4)])
+@pytest.mark.parametrize("dtype,variant", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 4), (1, 6)])
 def test_qkv_attention_online_softmax_rescale(pkg, ctx, dtype, variant):
     # keys far above the rest in LATE tiles force the running-max rescale branch (guide rule 26): for the deferred-max
     # f16 kernel both the "exceeds the threshold" path (spikes) and the "stays below it" path (all other tiles) run
@@ -154,9 +154,9 @@ def test_qkv_attention_online_softmax_rescale(pkg, ctx, dtype, variant):
     assert rel_err(out, ref) < (1e-4 if dtype == 0 else 6e-3)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [1, 2, 4, 6])     # 6 = key-split kernel (64-query blocks, waves = query sub-tile x key half)
 @pytest.mark.parametrize("B,Nq,Nk,C,heads", [(2, 256, 256, 128, 2), (2, 300, 77, 640, 10), (1, 1024, 1024, 1280, 20),
-                                             (1, 130, 200, 64, 1), (2, 64, 1, 64, 1)])
+                                             (1, 130, 200, 64, 1), (2, 64, 1, 64, 1), (2, 100, 128, 128, 2), (1, 33, 192, 64, 1)])
 def test_qkv_attention_f16_variants(pkg, ctx, variant, B, Nq, Nk, C, heads):
     q, k, v = seeded(B, Nq, C, seed=16), seeded(B, Nk, C, seed=17), seeded(B, Nk, C, seed=18)
     ref = OM.qkv_attention(q, k, v, None, heads)
