@@ -503,6 +503,11 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p,
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = 0.f, l = 0.f;
+  // -m as a live 16-register accumulator image: the first MFMA of every score tile takes it as its C operand directly
+  // (rebuilding it cost 16 v_mov per tile); it changes only in the rare rescale branch
+  f32x16 minit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
   const int nt = (p.Nk + KV - 1) / KV;
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
@@ -519,17 +524,12 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p,
     const char* vb = kb + TILE;
     // ---- S^T - m
     f32x16 sv[2];
-    const float init = t == 0 ? 0.f : -m;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sv[u][r] = init;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const half8 kf = *reinterpret_cast<const half8*>(kb + (koff[u] ^ (ks << 5)));
-        sv[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sv[u], 0, 0, 0);
+        sv[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? minit : sv[u], 0, 0, 0);
       }
     if (t == nt - 1 && (p.Nk & 63) != 0) {                      // key tail (wave-uniform branch)
 #pragma unroll
@@ -548,6 +548,8 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p,
       const float delta = t == 0 ? pm : fmaxf(pm, 0.f);         // never lower the reference
       const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
       m = t == 0 ? delta : m + delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) minit[r] = -m;
       l *= alpha;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -685,6 +687,9 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = 0.f, l = 0.f;
+  f32x16 minit;                                 // -m, the C operand of every score tile's first MFMA (see variant 2)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
   const int nt = p.Nk / KV;
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
@@ -700,13 +705,10 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
     const char* vb = kb + TILE;
     // ---- S^T - m for this wave's 32 keys
     f32x16 sv;
-    const float init = t == 0 ? 0.f : -m;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sv[r] = init;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const half8 kf = *reinterpret_cast<const half8*>(kb + (koff ^ (ks << 5)));
-      sv = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sv, 0, 0, 0);
+      sv = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? minit : sv, 0, 0, 0);
     }
     float lmax = sv[0];
 #pragma unroll
@@ -716,6 +718,8 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
       const float delta = t == 0 ? pm : fmaxf(pm, 0.f);
       const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
       m = t == 0 ? delta : m + delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) minit[r] = -m;
       l *= alpha;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
