@@ -1021,9 +1021,11 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
     // ring admits two per CU, a second half-empty round: 147 us vs 126 us measured); variant 3 keeps the 4-slot ring for A/B
     const dim3 g1(grid.x * grid.y);
     // key-split kernel (64-query blocks, waves = query sub-tile x key half): where 128-query blocks leave fewer than two
-    // waves per SIMD (self-attention at 32^2: 320 blocks on 256 CUs) and the keys are whole 64-key tiles
+    // waves per SIMD (self-attention at 32^2: 160 blocks per batch entry) and the keys are whole 64-key tiles.
+    // The choice must not depend on the batch size: a batch entry has to come out bit-identical whether it runs alone or
+    // next to others (tests/test_gpu_fullsize.py, split-CFG chains), so it is made on one batch entry's grid (query blocks x heads).
     const bool ks_ok = (p.Nk % 64) == 0 && p.Nk >= 128;
-    if (ks_ok && (g_attn_variant == 6 || (g_attn_variant == 0 && g1.x < 512))) {
+    if (ks_ok && (g_attn_variant == 6 || (g_attn_variant == 0 && (int)grid.x * p.H < 256))) {
       hipLaunchKernelGGL(attn_d64_ks_kernel, dim3(((p.Nq + 63) / 64) * p.B * p.H), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
       return;
     }
