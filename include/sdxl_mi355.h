@@ -211,7 +211,11 @@ int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, 
                      float* avg_ms);
 /* times the fused attention kernel alone (head dim 64, f16) on seeded random data: B*H heads, Nq queries, Nk keys */
 int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int Nk, int iters, float* avg_ms);
-/* benchmarking / debugging knobs ("igemm_variant": -1 generic kernel only, 0 auto, 1..3 forced fast-path tile) */
+/* benchmarking / debugging knobs.  "igemm_variant": -1 generic kernel only, 0 auto, > 0 forced fast-path tile / pipeline
+ * (list in csrc/igemm_glds.hip); "attn_variant": -1 generic, 0 auto, 1/2/4/6 forced f16 kernels (csrc/attention.hip);
+ * "split_cfg": 1 = a batch-2 UNet::forward runs its two entries as two concurrent batch-1 chains (bit-identical results);
+ * "split_offset": GEMM launches of the first chain before the second is released; "no_cfg": base model without the
+ * unconditional branch (measurement only -- NOT the reference's semantics) */
 int sdxl_debug_set(const char* key, int value);
 
 /* ---- single-op entry points used by the parity tests (same kernels the models run) */

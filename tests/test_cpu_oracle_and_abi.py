@@ -321,3 +321,26 @@ def test_clip_param_specs_equal_oracle(built, which):
 def test_bad_clip_config_is_reported(built):
     assert built.lib().sdxl_clip_param_count(ctypes.byref(built.CLIPConfig(49408, 96, 96, 2, 77, 1, True).to_c())) == -1
     assert b"64 channels per head" in built.lib().sdxl_last_error()
+
+
+def test_header_is_plain_c_and_links(built, tmp_path):
+    # the boundary is a C ABI: the header must compile as C99 (no C++-isms, no torch types) and a C program must link
+    # against the library and call the host-only entry points
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "sdxl_mi355.h"\n'
+                   'int main(void) { sdxl_unet_config c; sdxl_clip_config k; sdxl_vae_config v;\n'
+                   '  sdxl_unet_config_base(&c); sdxl_clip_config_open_clip_bigg(&k); sdxl_vae_config_default(&v);\n'
+                   '  if (sdxl_unet_param_count(&c) <= 0 || sdxl_clip_param_count(&k) != 517) return 2;\n'
+                   '  return sdxl_step_count(30, 0, 1000) == 31 ? 0 : 1; }\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(built.LIB_PATH)
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                        "-o", str(exe), "-L", libdir, "-lsdxl_mi355", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
