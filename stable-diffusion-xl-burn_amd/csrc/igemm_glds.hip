@@ -484,8 +484,8 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, cons
   else igemm_epilogue<TM, TN>(p, acc, mw, nw, lane & 31, lane >> 5, lnA, lnC);
 }
 
-template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const IgemmParams p, const void* zeros) {   // >= 2 blocks per CU
+template <int BM, int BN, int NS, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams p, const void* zeros) {   // >= MINB blocks per CU
   constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
   constexpr int AJ = BM / 32, BJ = BN / 32;   // DMA instructions per wave per k-tile (8 rows each, 4 waves)
@@ -1310,17 +1310,17 @@ void igemm_glds_init() {
   g_zero_page = z;
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int MINB = 2>
 static void launch_glds(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NS * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, NS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, NS, MINB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
+  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
 }
 
 template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4>
@@ -1407,6 +1407,7 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 6: launch_glds<64, 128, 2>(p, s); break;
     case 7: launch_glds<128, 128, 4>(p, s); break;
     case 8: launch_glds<64, 128, 3>(p, s); break;
+    case 33: launch_glds<256, 128, 3, 1>(p, s); break;   // experiment: 4 waves, wave tile 128x64 (6 fragment reads per 8 MFMAs)
     case 10: launch_pipe<256, 128, 3, false>(p, s); break;   // 8-wave pipelined kernels
     case 11: launch_pipe<256, 128, 3, true>(p, s); break;
     case 12: launch_pipe<128, 128, 4, false>(p, s); break;
