@@ -673,17 +673,17 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
 // WGM = waves along M (4: 4x2 wave grid, 8: 8x1 -- the 256x160 GEGLU tile: N = 10240 / 5120 gives 512 / 1024 tiles = whole
 // rounds of 256 CUs where 256x128 leaves the last round 44 % empty).  BN need not be a multiple of 64: the weight tile's
 // BN/8 eight-row pieces are dealt round-robin, waves below REM carry one more piece and wait on their own count.
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4>
-__global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
-  constexpr int WGN = 8 / WGM;
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
+  constexpr int WGN = NW / WGM;               // NW waves per workgroup (8, or 4 with twice the wave tile)
   constexpr int WM = BM / WGM, WN = BN / WGN; // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NF = TM + TN;                 // ds_read_b128 per kk-step
   constexpr int BPC = BN / 8;                 // 8-row pieces of the weight tile
-  constexpr int AJ = BM / 64, BJ = (BPC + 7) / 8;   // DMA pieces per wave per k-tile (8 rows each, 8 waves)
-  constexpr int REM = BPC % 8;                // waves >= REM (when REM != 0) have no last weight piece
+  constexpr int AJ = BM / (8 * NW), BJ = (BPC + NW - 1) / NW;   // DMA pieces per wave per k-tile (8 rows each, NW waves)
+  constexpr int REM = BPC % NW;               // waves >= REM (when REM != 0) have no last weight piece
   constexpr int PER = AJ + BJ;
-  static_assert(BM % 64 == 0 && WM % 32 == 0 && WN % 32 == 0 && BN % 8 == 0, "bad tile");
+  static_assert(BM % (8 * NW) == 0 && WM % 32 == 0 && WN % 32 == 0 && BN % 8 == 0, "bad tile");
   constexpr int KT = 64;
   constexpr int STAGE = (BM + BN) * 128;
   // measurement-only modes (results wrong by construction): 5 = schedule of mode 0 WITHOUT ds_reads / MFMAs (DMA-only
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   int rb[AJ], ry[AJ], rx[AJ], rsw[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int row = (j * 8 + wave) * 8 + lrow;
+    const int row = (j * NW + wave) * 8 + lrow;
     const int m = m0 + row;
     rsw[j] = (slot ^ ((row >> 1) & 7)) * 8;
     if (m < p.M) {
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   const half_t* wptr[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    const int row = (j * 8 + wave) * 8 + lrow;
+    const int row = (j * NW + wave) * 8 + lrow;
     wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * 8;
   }
   const half_t* aptr[AJ];
@@ -763,9 +763,9 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   if constexpr (CONTIG) {
     const int nkc = p.Kpad / KT;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) { aptr[j] = Ag + (size_t)((m0 >> 3) + j * 8 + wave) * nkc * 512 + lane * 8; aadv[j] = 512; }
+    for (int j = 0; j < AJ; ++j) { aptr[j] = Ag + (size_t)((m0 >> 3) + j * NW + wave) * nkc * 512 + lane * 8; aadv[j] = 512; }
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)((n0 >> 3) + j * 8 + wave) * nkc * 512 + lane * 8;
+    for (int j = 0; j < BJ; ++j) wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)((n0 >> 3) + j * NW + wave) * nkc * 512 + lane * 8;
   }
   // pieces q of one k-tile: q < AJ -> activation piece q, else weight piece q - AJ.  PH selects the pieces with q % 3 == PH
   // (PH < 0: all of them); the tap walk advances once per k-tile, after the last piece (tile_done).
@@ -781,10 +781,10 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
       if constexpr (ph < 0 || (ph < 3 && q % 3 == ph) || (ph >= 10 && q / PPG == ph - 10) || (ph == 5 && q < HALF) ||
                     (ph == 6 && q >= HALF)) {
         if constexpr (q < AJ) {
-          __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(la + q * 8192), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(la + q * (NW * 1024)), 16, 0, 0);
           if constexpr (DMODE != 2) aptr[q] += aadv[q];
         } else if (q - AJ < BJ - 1 || lastb) {     // ragged weight tile: wave-uniform predicate on the last piece
-          __builtin_amdgcn_global_load_lds((gptr_t)wptr[q - AJ], (lptr_t)(lb + (q - AJ) * 8192), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)wptr[q - AJ], (lptr_t)(lb + (q - AJ) * (NW * 1024)), 16, 0, 0);
           if constexpr (DMODE != 2) wptr[q - AJ] += WADV;
         }
       }
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p, co
   }
   __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring: it becomes the staging area
   asm volatile("" ::: "memory");
-  constexpr bool FITS = 8 * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
+  constexpr bool FITS = NW * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
   if (FITS || p.act == 1) {
     const int region = p.act == 1 ? WM * (WN / 2) * 4 : WM * WN * 4;   // GEGLU halves the staged width
     igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * region, lnA, lnC, zeros);
@@ -1323,17 +1323,17 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
 }
 
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4>
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NS * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_page);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW>), dim3(tilesM * tilesN), dim3(64 * NW), lds, s, p, g_zero_page);
 }
 
 template <int BM, int BN, int NS, int NL>
@@ -1407,7 +1407,8 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 6: launch_glds<64, 128, 2>(p, s); break;
     case 7: launch_glds<128, 128, 4>(p, s); break;
     case 8: launch_glds<64, 128, 3>(p, s); break;
-    case 33: launch_glds<256, 128, 3, 1>(p, s); break;   // experiment: 4 waves, wave tile 128x64 (6 fragment reads per 8 MFMAs)
+    case 33: launch_glds<256, 128, 3, 1>(p, s); break;
+    case 34: launch_pipe<256, 128, 3, true, 0, 2, 4>(p, s); break;   // experiment: the hand-ordered loop on 4 waves x (128x64)   // experiment: 4 waves, wave tile 128x64 (6 fragment reads per 8 MFMAs)
     case 10: launch_pipe<256, 128, 3, false>(p, s); break;   // 8-wave pipelined kernels
     case 11: launch_pipe<256, 128, 3, true>(p, s); break;
     case 12: launch_pipe<128, 128, 4, false>(p, s); break;
