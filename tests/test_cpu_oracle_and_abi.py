@@ -344,3 +344,47 @@ def test_header_is_plain_c_and_links(built, tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr)
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_clip_oracle_matches_hf_clip_text_model(act):
+    # an independent implementation of the same architecture: HF transformers' CLIPTextModelWithProjection (the model the
+    # reference's python/clip.py dumps its CLIP-L weights FROM).  Same random weights through oracle/clip.py must give the
+    # same penultimate hidden state and the same pooled, projected embedding.
+    transformers = pytest.importorskip("transformers")
+    from oracle import clip as OCL
+    ocfg = OCL.CLIPConfig(49408, 128, 96, 2, 77, 3, act == "quick_gelu")
+    hcfg = transformers.CLIPTextConfig(vocab_size=ocfg.n_vocab, hidden_size=ocfg.n_state, intermediate_size=4 * ocfg.n_state,
+                                       num_hidden_layers=ocfg.n_layer, num_attention_heads=ocfg.n_head,
+                                       max_position_embeddings=ocfg.n_ctx, hidden_act=act, projection_dim=ocfg.embed_dim,
+                                       eos_token_id=2)      # legacy eos id: pooled row = argmax(input_ids), as the reference
+    torch.manual_seed(0)
+    hf = transformers.CLIPTextModelWithProjection(hcfg).eval()
+    sd = {k: v.detach().float() for k, v in hf.state_dict().items()}
+    for k in list(sd):                                       # default init is near-degenerate (std 0.02): widen it
+        if k.endswith("weight") and sd[k].dim() == 2 and "embedding" not in k:
+            sd[k] = sd[k] * 8
+    sd = {k: v + (0.05 * torch.randn(v.shape, generator=torch.Generator().manual_seed(len(k))) if k.endswith("bias") else 0) for k, v in sd.items()}
+    hf.load_state_dict(sd)
+    W = {"token_embedding.weight": sd["text_model.embeddings.token_embedding.weight"],
+         "position_embedding": sd["text_model.embeddings.position_embedding.weight"],
+         "layer_norm.gamma": sd["text_model.final_layer_norm.weight"], "layer_norm.beta": sd["text_model.final_layer_norm.bias"],
+         "text_projection": sd["text_projection.weight"].t().contiguous()}          # save_tensor(text_projection) is [C, E]
+    for i in range(ocfg.n_layer):
+        h, o = f"text_model.encoder.layers.{i}.", f"blocks.{i}."
+        for a, b in (("self_attn.q_proj", "attn.query"), ("self_attn.k_proj", "attn.key"), ("self_attn.v_proj", "attn.value"),
+                     ("self_attn.out_proj", "attn.out"), ("mlp.fc1", "mlp.fc1"), ("mlp.fc2", "mlp.fc2")):
+            W[o + b + ".weight"] = sd[h + a + ".weight"].t().contiguous()           # save_linear transposes (save.py:23)
+            W[o + b + ".bias"] = sd[h + a + ".bias"]
+        for a, b in (("layer_norm1", "attn_ln"), ("layer_norm2", "mlp_ln")):
+            W[o + b + ".gamma"], W[o + b + ".beta"] = sd[h + a + ".weight"], sd[h + a + ".bias"]
+    assert set(W) == {p.name for p in OCL.clip_param_specs(ocfg)}
+    ids = torch.randint(1, 49000, (2, 77), generator=torch.Generator().manual_seed(1))
+    ids[:, 0] = 49406; ids[0, 5] = 49407; ids[0, 6:] = 49407; ids[1, 20] = 49407; ids[1, 21:] = 0
+    with torch.no_grad():
+        out = hf(input_ids=ids, output_hidden_states=True)
+    hid, pooled = OCL.forward_hidden_pooled(ocfg, W, ids, ocfg.n_layer - 1)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())   # noqa: E731
+    assert rel(hid, out.hidden_states[-2]) < 5e-5                   # penultimate layer, no final LayerNorm
+    assert rel(pooled, out.text_embeds) < 5e-5
+    assert rel(OCL.forward_hidden(ocfg, W, ids, ocfg.n_layer), out.hidden_states[-1]) < 5e-5     # fp32 round-off of two different op orders
