@@ -72,19 +72,38 @@ void ClipText::block(Exec& ex, const ClipBlockW& w, const Act& x, int B, int S, 
   run_linear(ex, w.fc2, h, M, x, er);
 }
 
+ClipText::~ClipText() {
+  if (graph_) (void)hipGraphExecDestroy(graph_);
+}
+
 void ClipText::run(const int* ids, int B, int S, int n_blocks, int tap, float* hidden, float* pooled, hipStream_t s) {
   SDXL_REQUIRE(ids && B > 0 && S > 0 && S <= cfg_.n_ctx, "CLIP: sequence longer than the position table (or empty)");
   SDXL_REQUIRE(n_blocks >= 0 && n_blocks <= cfg_.n_layer, "CLIP: hidden_idx out of range");
-  const int C = cfg_.n_state, M = B * S;
+  const int C = cfg_.n_state, M = B * S, E = cfg_.embed_dim;
   const int npad = (int)round_up(S, 64);
   const size_t e = dt_size(cdt_);
-  const size_t need = (size_t)M * C * dt_size(sdt_) + (size_t)M * C * e * 2 + (size_t)M * 2 * C * e + (size_t)B * C * npad * e +
-                      (size_t)M * 4 * C * e + (size_t)S * S * 4 + (size_t)B * (C + cfg_.embed_dim + 1) * 4 * 2 + (1 << 16);
-  if (need > act_.cap) { SDXL_HIP(hipStreamSynchronize(s)); act_.reserve(need); mask_ = nullptr; }
+  const size_t need = (size_t)M * 4 + (size_t)M * C * 4 + (size_t)B * E * 4 +                          // ids, hidden, pooled (stable I/O)
+                      (size_t)M * C * dt_size(sdt_) + (size_t)M * C * e * 2 + (size_t)M * 2 * C * e + (size_t)B * C * npad * e +
+                      (size_t)M * 4 * C * e + (size_t)S * S * 4 + (size_t)B * (C + 1) * 4 * 2 + (1 << 16);
+  // one call = ~9 launches per block, all tiny (M = B*77 rows): after the first (eager) call of a shape the whole pass is a
+  // captured hipGraph over stable internal buffers -- ids are copied in, results copied out
+  const long key[6] = {B, S, n_blocks, tap, hidden != nullptr, pooled != nullptr};
+  bool same = graph_ != nullptr;
+  for (int i = 0; i < 6; ++i) same = same && key[i] == key_[i];
+  if (need > act_.cap) { SDXL_HIP(hipStreamSynchronize(s)); act_.reserve(need); same = false; }
+  if (!same) {
+    if (graph_) { (void)hipGraphExecDestroy(graph_); graph_ = nullptr; }
+    bool eq = true;
+    for (int i = 0; i < 6; ++i) eq = eq && key[i] == key_[i];
+    if (!eq) runs_ = 0;
+    for (int i = 0; i < 6; ++i) key_[i] = key[i];
+  }
   act_.off = 0;
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_;
+  int* ids_buf = (int*)act_.alloc((size_t)M * 4);
+  float* hid_buf = (float*)act_.alloc((size_t)M * C * 4);
+  float* pool_buf = (float*)act_.alloc((size_t)B * E * 4);
   float* mask = (float*)act_.alloc((size_t)S * S * 4);
-  if (mask != mask_ || mask_n_ != S) { launch_causal_mask(mask, S, s); mask_ = mask; mask_n_ = S; }
   Act x = ex.alloc(M, C, sdt_);
   Act ln = ex.alloc(M, C, cdt_);
   Act qk = ex.alloc(M, 2 * C, cdt_);
@@ -94,26 +113,44 @@ void ClipText::run(const int* ids, int B, int S, int n_blocks, int tap, float* h
   int* eot = (int*)act_.alloc((size_t)B * 4);
   float* sel = (float*)act_.alloc((size_t)B * C * 4);
   float* seln = (float*)act_.alloc((size_t)B * C * 4);
-  if (npad != S) launch_fill_zero(vt, (size_t)B * C * npad * e, s);   // keys S..npad-1 of V^T stay zero
-  launch_embed_tokens(ids, tok_, pos_, cdt_, x.p, x.dt, x.ld, B, S, C, cfg_.n_vocab, s);     // clip/mod.rs:99-105
-  for (int i = 0; i < n_blocks; ++i) {
-    if (i == tap && hidden) launch_copy_rows(x.p, x.dt, x.ld, hidden, DT_F32, C, M, C, s);    // :128-130
-    block(ex, blocks_[i], x, B, S, ln, qk, vt, npad, ao, h);
-  }
-  if (tap == n_blocks && hidden) launch_copy_rows(x.p, x.dt, x.ld, hidden, DT_F32, C, M, C, s);
-  if (pooled) {
-    // :139-149 -- the eot token has the highest id of its sequence; LayerNorm only the B selected rows
-    launch_argmax_rows(ids, eot, B, S, s);
-    launch_gather_rows(x.p, x.dt, x.ld, eot, S, sel, B, C, s);
-    run_layernorm(ex, final_ln_, Act(sel, C, DT_F32), B, Act(seln, C, DT_F32));
-    for (int b0 = 0; b0 < B; b0 += 8) {
-      GemvParams g{};
-      g.X = seln + (size_t)b0 * C; g.ldx = C; g.W = proj_.w; g.w_dt = cdt_; g.Kpad = proj_.Kpad; g.bias = nullptr;
-      g.Y = pooled + (size_t)b0 * cfg_.embed_dim; g.ldy = cfg_.embed_dim; g.Yadd = nullptr;
-      g.Bm = B - b0 < 8 ? B - b0 : 8; g.N = proj_.N; g.K = proj_.K; g.silu_in = 0; g.silu_out = 0;
-      launch_gemv(g, s);
+  mask_ = mask;
+  auto body = [&]() {
+    launch_causal_mask(mask, S, s);
+    if (npad != S) launch_fill_zero(vt, (size_t)B * C * npad * e, s);   // keys S..npad-1 of V^T stay zero
+    launch_embed_tokens(ids_buf, tok_, pos_, cdt_, x.p, x.dt, x.ld, B, S, C, cfg_.n_vocab, s);   // clip/mod.rs:99-105
+    for (int i = 0; i < n_blocks; ++i) {
+      if (i == tap && hidden) launch_copy_rows(x.p, x.dt, x.ld, hid_buf, DT_F32, C, M, C, s);    // :128-130
+      block(ex, blocks_[i], x, B, S, ln, qk, vt, npad, ao, h);
     }
+    if (tap == n_blocks && hidden) launch_copy_rows(x.p, x.dt, x.ld, hid_buf, DT_F32, C, M, C, s);
+    if (pooled) {
+      // :139-149 -- the eot token has the highest id of its sequence; LayerNorm only the B selected rows
+      launch_argmax_rows(ids_buf, eot, B, S, s);
+      launch_gather_rows(x.p, x.dt, x.ld, eot, S, sel, B, C, s);
+      run_layernorm(ex, final_ln_, Act(sel, C, DT_F32), B, Act(seln, C, DT_F32));
+      for (int b0 = 0; b0 < B; b0 += 8) {
+        GemvParams g{};
+        g.X = seln + (size_t)b0 * C; g.ldx = C; g.W = proj_.w; g.w_dt = cdt_; g.Kpad = proj_.Kpad; g.bias = nullptr;
+        g.Y = pool_buf + (size_t)b0 * E; g.ldy = E; g.Yadd = nullptr;
+        g.Bm = B - b0 < 8 ? B - b0 : 8; g.N = proj_.N; g.K = proj_.K; g.silu_in = 0; g.silu_out = 0;
+        launch_gemv(g, s);
+      }
+    }
+  };
+  SDXL_HIP(hipMemcpyAsync(ids_buf, ids, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
+  if (use_graph_ && !graph_ && runs_ >= 1) {
+    hipGraph_t g = nullptr;
+    SDXL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    try { body(); } catch (...) { (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); throw; }
+    SDXL_HIP(hipStreamEndCapture(s, &g));
+    SDXL_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
+    SDXL_HIP(hipGraphDestroy(g));
   }
+  if (use_graph_ && graph_) SDXL_HIP(hipGraphLaunch(graph_, s));
+  else body();
+  ++runs_;
+  if (hidden) SDXL_HIP(hipMemcpyAsync(hidden, hid_buf, (size_t)M * C * 4, hipMemcpyDeviceToDevice, s));
+  if (pooled) SDXL_HIP(hipMemcpyAsync(pooled, pool_buf, (size_t)B * E * 4, hipMemcpyDeviceToDevice, s));
 }
 
 void ClipText::forward_hidden(const int* ids, int B, int S, int hidden_idx, float* out, hipStream_t s) {

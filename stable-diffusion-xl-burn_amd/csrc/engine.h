@@ -309,6 +309,8 @@ struct ClipBlockW { NormW attn_ln, mlp_ln; Lin qkv, out, fc1, fc2; };
 class ClipText {
  public:
   ClipText(const ClipCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st);
+  ~ClipText();
+  void set_use_graph(bool g) { use_graph_ = g; }
   const ClipCfg& cfg() const { return cfg_; }
   // CLIP::forward_hidden (:94-112): ids int32 device [B][S] -> out fp32 device [B][S][n_state], the residual stream after
   // the first hidden_idx blocks (no final LayerNorm)
@@ -329,7 +331,8 @@ class ClipText {
   const void* tok_ = nullptr; const void* pos_ = nullptr;
   std::vector<ClipBlockW> blocks_;
   NormW final_ln_; Lin proj_;
-  float* mask_ = nullptr; int mask_n_ = 0;   // causal mask [S][S] (lives in act_)
+  float* mask_ = nullptr;                    // causal mask [S][S] (lives in act_)
+  hipGraphExec_t graph_ = nullptr; long key_[6] = {0, 0, 0, 0, 0, 0}; int runs_ = 0; bool use_graph_ = true;
 };
 
 // ------------------------------------------------------------------------------------------ sampler

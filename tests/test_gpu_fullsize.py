@@ -87,12 +87,15 @@ def test_fullsize_embedder(pkg, ctx):
     un_c = torch.full((1, 77), 49407, dtype=torch.int64); un_c[0, 0] = 49406
     un_o = torch.zeros((1, 77), dtype=torch.int64); un_o[0, 0], un_o[0, 1] = 49406, 49407
     size, crop, ar = torch.tensor([[1024, 1024]]), torch.tensor([[0, 0]]), torch.tensor([1024, 1024])
-    cond = emb.tokens_to_conditioning(ids, ids_o, un_c, un_o, size, crop, ar)
+    first = emb.tokens_to_conditioning(ids, ids_o, un_c, un_o, size, crop, ar)        # eager
+    cond = emb.tokens_to_conditioning(ids, ids_o, un_c, un_o, size, crop, ar)         # captures the hipGraphs
+    assert torch.equal(first.context_full, cond.context_full) and torch.equal(first.channel_context, cond.channel_context)
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
     cond = emb.tokens_to_conditioning(ids, ids_o, un_c, un_o, size, crop, ar)
     t1.record(); torch.cuda.synchronize()
-    print(f"Embedder (2 prompts x (CLIP-L + bigG), f16): {t0.elapsed_time(t1):.2f} ms")
+    print(f"Embedder (2 prompts x (CLIP-L + bigG), f16, graph replay): {t0.elapsed_time(t1):.2f} ms")
+    assert torch.equal(first.context_full, cond.context_full) and torch.equal(first.channel_context_refiner, cond.channel_context_refiner)
     base, refiner = pkg.sdxl_base_config(), pkg.sdxl_refiner_config()
     assert cond.context_full.shape == (1, 77, base.context_dim) and cond.unconditional_context_full.shape == (77, base.context_dim)
     assert cond.channel_context.shape == (1, base.adm_in_channels) and cond.unconditional_channel_context.shape == (base.adm_in_channels,)
