@@ -4,7 +4,9 @@ Follows /root/reference/src/model/clip/mod.rs (CLIP::forward_hidden :94-112, for
 ResidualDecoderAttentionBlock::forward :194-199, MultiHeadSelfAttention::forward :243-257, MLP::forward :296-306,
 QuickGELU :309-320) and the Embedder in /root/reference/src/model/stablediffusion/mod.rs:626-801.  fp32 torch-CPU
 functional ops; the attention is the crate's own generic `qkv_attention` (oracle.model.qkv_attention).
-PARITY UNPINNED by the reference (no expected values exist for this path either); the tokenizer KAT is the one pin.
+PARITY UNPINNED by the reference (no expected values exist for this path either; its one #[test] is the tokenizer KAT).
+Pinned instead against an independent implementation of the same architecture: HF transformers' CLIPTextModelWithProjection
+(the model python/clip.py dumps CLIP-L from) on shared random weights -- tests/test_cpu_oracle_and_abi.py.
 """
 from __future__ import annotations
 
