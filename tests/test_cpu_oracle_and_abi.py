@@ -388,3 +388,19 @@ def test_clip_oracle_matches_hf_clip_text_model(act):
     assert rel(hid, out.hidden_states[-2]) < 5e-5                   # penultimate layer, no final LayerNorm
     assert rel(pooled, out.text_embeds) < 5e-5
     assert rel(OCL.forward_hidden(ocfg, W, ids, ocfg.n_layer), out.hidden_states[-1]) < 5e-5     # fp32 round-off of two different op orders
+
+
+def test_c_host_example_builds(built, tmp_path):
+    # examples/text_to_image.c: tokens -> Embedder -> sample_latent -> latent_to_image in plain C over the ABI (run on the GPU
+    # box by hand: 828 ms per 1024^2 image, no Python / torch in the process); here: it compiles and links
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no gcc / HIP headers")
+    libdir = os.path.dirname(built.LIB_PATH)
+    r = subprocess.run([gcc, "-std=gnu99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                        "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "examples", "text_to_image.c"), "-L", libdir, "-lsdxl_mi355",
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{libdir}", "-o", str(tmp_path / "t2i")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
