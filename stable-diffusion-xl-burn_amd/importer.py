@@ -7,9 +7,10 @@ open_clip}` and reads it back with src/model/**/load.rs: one file per tensor, a 
 maps that tree onto the C ABI's flat fp32 buffer (`sdxl_*_param_spec()` order), so `UNet(ctx, cfg, weights=load_unet(...))`
 replaces `load_unet(path, device)`; the packing into MFMA layouts stays on the GPU.  Host-side file I/O only: no GPU needed.
 
-`.mpk` (burn NamedMpkFileRecorder, HalfPrecisionSettings) is NOT read here: its field layout is defined by burn 0.13's record
-derive, whose source is not available on this box, so a reader could not be validated; convert with the
-reference's own `bin/convert` in the other direction or dump `.npy` once with python/dump.py.
+`.mpk` (burn NamedMpkFileRecorder, HalfPrecisionSettings): a FIRST reader is at the bottom of this file (read_mpk / mpk_flat).
+Its field layout is defined by burn 0.13's record derive, whose source is not available on this box, and no
+record file exists here, so that reader is UNVALIDATED against real data -- it is written tolerantly around the points that
+could not be checked, and its tests only pin self-consistency.  The `.npy` path above is the checked one.
 """
 from __future__ import annotations
 
@@ -224,3 +225,104 @@ def load_clip(pkg, root: str, quick_gelu: bool):
 def load_alphas_cumprod(params_root: str) -> np.ndarray:
     """params/alphas_cumprod.npy (python/dump.py:33-35; stablediffusion/load.rs:56-60)"""
     return read_tensor(os.path.join(params_root, "alphas_cumprod.npy")).astype(np.float64)
+
+
+# ------------------------------------------------------------------------------------------------ burn `.mpk` records
+# UNVALIDATED against a real file: no `.mpk` exists on this box and burn 0.13's sources are not available (SURVEY section 5).
+# The reader below follows the record layout burn documents for `NamedMpkFileRecorder<HalfPrecisionSettings>` as far as it is
+# known here, and is written to tolerate the points that could not be checked:
+#   file        = rmp_serde "named" MessagePack of BurnRecord { metadata: {...}, item: <module record> }
+#   module      = map of its struct fields by name; Vec<Module> = array; enum module = { "<Variant>": record } (externally tagged);
+#                 Option::None = nil; non-parameter fields (usize, f64, ...) = constant records (nil / empty) -- ignored
+#   Param<T>    = { id: str, param: <tensor record> };  tensor record = { value: [...], shape: [...] }, possibly wrapped once
+#                 more ({ data: {...} }); f16 elements arrive as their 16 raw bits (the `half` crate's serde form) or as floats
+# Field names are the reference's struct fields, which is what the spec names of the C ABI already are; the enum variant level
+# (UNetBlocks::{Conv, Res, ...}, unet/mod.rs:509-516) and PaddedConv2d's inner `conv` are skipped when walking a name.
+def _mpk_tensor(node, where: str) -> np.ndarray:
+    for _ in range(3):                                   # { id, param: ... } / { data: ... } wrappers
+        if isinstance(node, dict) and "value" not in node:
+            inner = node.get("param", node.get("data"))
+            if inner is None:
+                break
+            node = inner
+    if not (isinstance(node, dict) and "value" in node and "shape" in node):
+        raise ImportError_(f"{where}: not a tensor record (keys {list(node) if isinstance(node, dict) else type(node).__name__})")
+    shape = [int(v) for v in node["shape"]]
+    val = node["value"]
+    if isinstance(val, (bytes, bytearray)):
+        arr = np.frombuffer(val, dtype=np.float16).astype(np.float32)
+    else:
+        arr = np.asarray(val)
+        arr = arr.astype(np.uint16).view(np.float16).astype(np.float32) if arr.dtype.kind in "iu" else arr.astype(np.float32)
+    if arr.size != int(np.prod(shape)):
+        raise ImportError_(f"{where}: {arr.size} values for shape {shape}")
+    return arr.reshape(shape)
+
+
+def _mpk_descend(node, key: str, where: str):
+    while True:
+        if isinstance(node, (list, tuple)):
+            if not key.isdigit() or int(key) >= len(node):
+                raise ImportError_(f"{where}: index {key!r} into an array of {len(node)}")
+            return node[int(key)]
+        if not isinstance(node, dict):
+            raise ImportError_(f"{where}: cannot take field {key!r} of {type(node).__name__}")
+        if key in node:
+            return node[key]
+        if len(node) == 1 and next(iter(node))[:1].isupper():     # enum variant wrapper
+            node = next(iter(node.values()))
+            continue
+        if "conv" in node and key in ("weight", "bias"):           # PaddedConv2d { conv: Conv2d, ... }
+            node = node["conv"]
+            continue
+        raise ImportError_(f"{where}: no field {key!r} (have {sorted(node)[:12]})")
+
+
+def read_mpk(path: str):
+    """the `item` tree of a burn NamedMpk record file (see the layout note above)"""
+    import msgpack
+    with open(path, "rb") as fh:
+        rec = msgpack.unpackb(fh.read(), raw=False, strict_map_key=False)
+    if not (isinstance(rec, dict) and "item" in rec):
+        raise ImportError_(f"{path}: not a burn record (top-level keys {list(rec) if isinstance(rec, dict) else type(rec).__name__})")
+    return rec["item"]
+
+
+def mpk_flat(specs, item, prefix: str = "", optional: Sequence[str] = ()) -> np.ndarray:
+    """spec entries looked up by field path under `prefix` (e.g. 'diffusion' for a Diffuser record, 'autoencoder' for a
+    LatentDecoder record, 'clip' / 'open_clip' for an Embedder record), concatenated in spec order"""
+    root = item
+    for k in [p for p in prefix.split(".") if p]:
+        root = _mpk_descend(root, k, prefix)
+    parts = []
+    for p in specs:
+        node, ok = root, True
+        try:
+            for k in p.name.split("."):
+                node = _mpk_descend(node, k, p.name)
+        except ImportError_:
+            ok = False
+        if (not ok or node is None) and p.name in optional:
+            parts.append(np.zeros(int(np.prod(p.shape)), dtype=np.float32))
+            continue
+        if not ok or node is None:
+            raise ImportError_(f"{p.name}: missing in the record")
+        t = _mpk_tensor(node, p.name)
+        if tuple(t.shape) != tuple(p.shape):
+            raise ImportError_(f"{p.name}: record has shape {tuple(t.shape)}, expected {tuple(p.shape)}")
+        parts.append(t.reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+def write_mpk(path: str, item) -> None:
+    """writes `item` in the layout read_mpk expects (tests; f16 values as raw 16-bit integers)"""
+    import msgpack
+    with open(path, "wb") as fh:
+        fh.write(msgpack.packb({"metadata": {"float": "f16", "int": "i32", "format": "burn_core::record::file::NamedMpkFileRecorder",
+                                             "version": "0.13.0", "settings": "HalfPrecisionSettings"}, "item": item}))
+
+
+def mpk_param(arr, pid: str = "0", as_bytes: bool = False) -> dict:
+    a = np.asarray(arr, dtype=np.float32).astype(np.float16)
+    val = a.tobytes() if as_bytes else a.reshape(-1).view(np.uint16).tolist()
+    return {"id": pid, "param": {"value": val, "shape": list(a.shape)}}

@@ -117,3 +117,76 @@ def test_alphas_cumprod_file(imp, tmp_path):
     imp.write_tensor(a, str(tmp_path / "alphas_cumprod.npy"))
     got = imp.load_alphas_cumprod(str(tmp_path))
     assert got.dtype == np.float64 and np.array_equal(got.astype(np.float32), a)
+
+
+# ---- burn .mpk records: the reader is UNVALIDATED against a real file (none on this box); these tests only pin that it reads
+# the layout documented in importer.py, including the enum-variant level, PaddedConv2d's inner conv and Option::None
+def test_mpk_record_round_trip(pkg, imp, tmp_path):
+    ocfg = OC.tiny_config()
+    specs = OC.unet_param_specs(ocfg)
+    W = OC.synth_weights(specs, 8)
+    item = {"n_steps": None, "alpha_cumulative_products": imp.mpk_param(OC.alphas_cumprod()), "is_refiner": None, "diffusion": {}}
+    inp, mid, out = OC.unet_block_plan(ocfg)
+    variant = {"input_blocks": [b["kind"] for b in inp], "output_blocks": [b["kind"] for b in out]}
+    for p in specs:
+        keys = p.name.split(".")
+        node = item["diffusion"]
+        i = 0
+        while i < len(keys) - 1:
+            k = keys[i]
+            if keys[i + 1].isdigit():                       # Vec<Module>
+                lst = node.setdefault(k, [])
+                idx = int(keys[i + 1])
+                while len(lst) <= idx:
+                    lst.append(None)
+                if lst[idx] is None:
+                    lst[idx] = {variant[k][idx]: {}} if k in variant else {}
+                node = lst[idx][variant[k][idx]] if k in variant else lst[idx]
+                i += 2
+            else:
+                node = node.setdefault(k, {})
+                i += 1
+        node[keys[-1]] = imp.mpk_param(W[p.name], pid=p.name, as_bytes=W[p.name].size > 4096)   # big tensors as raw f16 bytes (speed)
+    path = str(tmp_path / "diffuser.mpk")
+    imp.write_mpk(path, item)
+    tree = imp.read_mpk(path)
+    flat = imp.mpk_flat(pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg)), tree, "diffusion")
+    want = pkg.flatten_weights(pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg)),
+                               {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in W.items()})
+    assert np.array_equal(flat, want)                      # the record holds f16: equal to the f16-rounded weights
+    a = imp._mpk_tensor(tree["alpha_cumulative_products"], "alphas")
+    assert a.shape == (1000,) and abs(float(a[0]) - float(OC.alphas_cumprod()[0])) < 1e-3
+    with pytest.raises(imp.ImportError_, match="missing in the record"):
+        imp.mpk_flat(pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg)), tree, "alpha_cumulative_products")
+
+
+def test_mpk_padded_conv_and_optional(pkg, imp, tmp_path):
+    from oracle import clip as OCL
+    ocfg = OCL.tiny_clip_config()
+    specs = OCL.clip_param_specs(ocfg)
+    W = OC.synth_weights(specs, 9)
+    clip = {"blocks": [{} for _ in range(ocfg.n_layer)]}
+    for p in specs:
+        if p.name == "text_projection":
+            clip["text_projection"] = None                 # Option::None (the CLIP-L record has no projection)
+            continue
+        keys = p.name.split(".")
+        node = clip
+        i = 0
+        while i < len(keys) - 1:
+            if keys[i + 1].isdigit():
+                node = node[keys[i]][int(keys[i + 1])]; i += 2
+            else:
+                node = node.setdefault(keys[i], {}); i += 1
+        # tensor record wrapped once more in { data: ... }: tolerated
+        node[keys[-1]] = {"id": "x", "param": {"data": imp.mpk_param(W[p.name])["param"]}}
+    path = str(tmp_path / "embedder.mpk")
+    imp.write_mpk(path, {"clip": clip, "clip_tokenizer": None})
+    flat = imp.mpk_flat(pkg.clip_param_specs(pkg.CLIPConfig(**ocfg.__dict__)), imp.read_mpk(path), "clip", optional=("text_projection",))
+    W16 = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in W.items()}
+    W16["text_projection"] = np.zeros_like(W16["text_projection"])
+    assert np.array_equal(flat, pkg.flatten_weights(pkg.clip_param_specs(pkg.CLIPConfig(**ocfg.__dict__)), W16))
+    # PaddedConv2d { conv: Conv2d { weight, bias }, ... }: the inner level is skipped
+    node = {"downsampler": {"conv": {"weight": imp.mpk_param(np.ones((2, 2, 3, 3))), "bias": None}, "kernel_size": None}}
+    t = imp._mpk_tensor(imp._mpk_descend(imp._mpk_descend(node, "downsampler", "x"), "weight", "x"), "x")
+    assert t.shape == (2, 2, 3, 3)
