@@ -404,3 +404,36 @@ def test_c_host_example_builds(built, tmp_path):
                         "-L/opt/rocm/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{libdir}", "-o", str(tmp_path / "t2i")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+@_need_assets
+def test_tokenizers_agree_with_hf_on_random_text(tok):
+    # 300 seeded pseudo-random strings (words, digits, punctuation runs, accents, CJK, emoji, odd spacing) through both
+    # tokenizers and the HF tokenizer.json the reference ships
+    tokenizers = pytest.importorskip("tokenizers")
+    import random
+    hf = tokenizers.Tokenizer.from_file(_TOKDIR + "/tokenizer.json")
+    clip, oc = tok.ClipTokenizer(_TOKDIR), tok.OpenClipTokenizer(_TOKDIR)
+    rng = random.Random(1234)
+    words = ["a", "photo", "of", "an", "astronaut", "riding", "horse", "Mars", "ultra-detailed", "8k", "it's", "they'll", "we've",
+             "I'm", "don't", "café", "naïve", "über", "日本語", "猫", "🙂", "🚀", "1234", "3.14", "...", "!!!", "?!", "(", ")", "#tag", "@me",
+             "under_score", "CamelCase", "x" * 30, "$9.99", "50%", "a/b", "c\\d", "é", "Ω"]
+    # (special-token literals are left out on purpose: the reference's regex -- like OpenAI's original -- lets a preceding
+    # punctuation run swallow "<|", e.g. "-<|startoftext|>" -> "-<|", "startoftext", "|>", whereas HF extracts added tokens
+    # before pre-tokenisation; tokenizer.py follows the reference, and the KAT above covers the special tokens)
+    seps = [" ", "  ", "\t", "\n", " , ", "-", ""]
+    for _ in range(300):
+        s = "".join(rng.choice(words) + rng.choice(seps) for _ in range(rng.randint(1, 12)))
+        want = hf.encode(s, add_special_tokens=False).ids
+        assert clip.encode(s, False, False) == want, repr(s)
+        assert oc.encode(s, False, False) == want, repr(s)
+
+
+@_need_assets
+def test_special_token_literal_follows_the_reference_regex(tok):
+    # src/token/clip.rs:110: the alternation is tried left to right at each position, so a punctuation run that starts
+    # BEFORE "<|startoftext|>" takes the "<|" with it (OpenAI's original behaves the same; HF's added-token pass does not)
+    t = tok.ClipTokenizer(_TOKDIR)
+    assert t.encode("a <|startoftext|>", False, False) == [320, 49406]
+    ids = t.encode("-<|startoftext|>", False, False)
+    assert 49406 not in ids and t.decode(ids).replace(" ", "") == "-<|startoftext|>"
