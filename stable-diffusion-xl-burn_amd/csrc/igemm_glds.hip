@@ -673,7 +673,7 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
 // WGM = waves along M (4: 4x2 wave grid, 8: 8x1 -- the 256x160 GEGLU tile: N = 10240 / 5120 gives 512 / 1024 tiles = whole
 // rounds of 256 CUs where 256x128 leaves the last round 44 % empty).  BN need not be a multiple of 64: the weight tile's
 // BN/8 eight-row pieces are dealt round-robin, waves below REM carry one more piece and wait on their own count.
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8>
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
   constexpr int WGN = NW / WGM;               // NW waves per workgroup (8, or 4 with twice the wave tile)
   constexpr int WM = BM / WGM, WN = BN / WGN; // wave tile
@@ -878,7 +878,65 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   ldfrag(0, 0, I0{});
   int cur = 0;                      // ring slot of tile kt
   int fill = NS - 1;                // ring slot tile kt+NS-1 goes to (the slot tile kt-1 occupied)
-  if constexpr (DMODE == 4) {
+  if constexpr (UNR) {
+    // The schedule of DMODE 0 with the k-loop unrolled by the ring depth: ring slots become compile-time constants, so every
+    // fragment read is {one of 16 loop-invariant lane addresses} + immediate and the DMA destinations fold into M0
+    // constants -- the rolled loop re-derives them with ~25 VALU / SALU instructions per k-tile, and instruction issue (not
+    // LDS or DMA bandwidth) is what fills this kernel's SIMDs.  ds_read immediates are 16 bit: slots
+    // beyond 64 KiB go through a second address set (+ 65536).
+    static_assert(DMODE == 0, "unrolled ring: production schedule only");
+    // wave tiles of up to 4 MFMA tiles per operand: two address sets (+0, +64 KiB); wider ones (256x160: 5): one set per slot
+    constexpr bool PERSLOT = TM > 4 || TN > 4;
+    constexpr int NSET = PERSLOT ? NS : 2;
+    unsigned fa[NSET][4], fb[NSET][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int q = 0; q < NSET; ++q) {
+        fa[q][kk] = (basea ^ (kk << 5)) + (PERSLOT ? q * STAGE : q * 65536u);
+        fb[q][kk] = (baseb ^ (kk << 5)) + (PERSLOT ? q * STAGE : q * 65536u);
+      }
+    auto ldf = [&](auto SO, auto KK, auto SET) {
+      constexpr unsigned so = decltype(SO)::value;
+      constexpr int kk = decltype(KK)::value, set = decltype(SET)::value;
+      constexpr int hi = PERSLOT ? (int)(so / STAGE) : (so >= 65536u ? 1 : 0);
+      constexpr unsigned lo = PERSLOT ? 0u : so - hi * 65536u;
+      static_assert(lo + (TM - 1) * 4096 < 65536u && lo + (TN - 1) * 4096 < 65536u, "fragment immediate out of range");
+      static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<lo + decltype(I)::value * 4096>(fa[hi][kk]); });
+      static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<lo + decltype(J)::value * 4096>(fb[hi][kk]); });
+    };
+    auto ktile = [&](int kt, auto CUR) {
+      constexpr int c = decltype(CUR)::value;
+      constexpr int nslot = (c + 1) % NS, fl = (c + NS - 1) % NS;
+      using SO = std::integral_constant<unsigned, (unsigned)c * STAGE>;
+      using SN = std::integral_constant<unsigned, (unsigned)nslot * STAGE>;
+      const bool more = kt + NS - 1 < nk;
+      ldf(SO{}, I1{}, I1{});
+      wait_lgkmcnt<NF>();
+      mma(I0{}, fl, I0{}, more);
+      ldf(SO{}, I2{}, I0{});
+      wait_lgkmcnt<NF>();
+      mma(I1{}, fl, I1{}, more);
+      ldf(SO{}, I3{}, I1{});
+      wait_lgkmcnt<NF>();
+      mma(I0{}, fl, I2{}, more);
+      if (more) tile_done();
+      if (kt + 1 < nk) {
+        if (more) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ldf(SN{}, I0{}, I0{});
+      } else {
+        wait_lgkmcnt<0>();
+      }
+      mma(I1{}, fl, I3{}, false);
+    };
+    int kt = 0;
+    for (; kt + NS <= nk; kt += NS) static_for<NS>([&](auto S) { ktile(kt + decltype(S)::value, S); });
+    static_for<NS - 1>([&](auto S) { if (kt + decltype(S)::value < nk) ktile(kt + decltype(S)::value, S); });
+  } else if constexpr (DMODE == 4) {
     // lookahead-2 schedule: one fragment set per kk-step, the ds_reads of step kk+2 are issued before the MFMAs of step kk,
     // so an LDS stall of a whole kk-step (DMA write bursts into the same LDS) does not starve the matrix pipe.  The
     // barrier moves between steps 1 and 2 (all reads of tile kt are issued by then); behind it: the first two fragment
@@ -1323,17 +1381,17 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
 }
 
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8>
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NS * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW>), dim3(tilesM * tilesN), dim3(64 * NW), lds, s, p, g_zero_page);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR>), dim3(tilesM * tilesN), dim3(64 * NW), lds, s, p, g_zero_page);
 }
 
 template <int BM, int BN, int NS, int NL>
@@ -1364,6 +1422,9 @@ static void launch_wide(const IgemmParams& p, hipStream_t s) {
 
 // variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
 // 6 = 64x128 ring 2; 7 = 128x128 ring 4; 8 = 64x128 ring 3.  Returns false when the shape needs the generic kernel.
+static bool g_igemm_unrolled = true;
+void igemm_set_unrolled(int v) { g_igemm_unrolled = v != 0; }
+
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if (!g_zero_page) return false;
   if (p.act > 1) return false;   // GELU / QuickGELU epilogues (CLIP MLP, once per prompt) live in the generic kernel
@@ -1371,8 +1432,9 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
   if (p.n_split < p.N && (p.n_split & 3) != 0) return false;
   if (p.ebias && (p.ebias_ld & 3) != 0) return false;
-  if (p.stat_out && (variant == 2 || variant == 5 || variant == 19)) return false;   // wave tiles narrower / other than 64 columns
+  if (p.stat_out && (variant == 2 || variant == 5 || variant == 19 || variant == 38)) return false;   // wave tiles narrower / other than 64 columns
   // the DMA reads weight rows up to the tile edge: Npad is a multiple of 128 for every packed weight (pack_* kernels)
+  const bool was_auto = variant == 0;
   if (variant == 0) {
     // measured on MI355X (tools/igemm_sweep.py, profiles/r01_igemm_sweep.txt).  The global->LDS path sustains ~22 B/clk/CU,
     // so the MFMA rate of a tile is ~ BM*BN/(BM+BN) flop per DMA byte: 256x128 (8 waves, pipelined) beats 128x128 wherever
@@ -1398,6 +1460,11 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
       if (cost160 < cost128) variant = 19;
     }
   }
+  if (was_auto && g_igemm_unrolled) {
+    // the pipelined kernels with the k-loop unrolled by the ring depth (fewer instructions per MFMA, no s_setprio): measured
+    // 4..12 % faster on every shape of the step (tools/igemm_ksweep.py 11,35,37); sdxl_debug_set("igemm_unrolled", 0) = A/B
+    if (variant == 11) variant = 35; else if (variant == 13) variant = 36; else if (variant == 19) variant = 38;
+  }
   switch (variant) {
     case 1: launch_glds<128, 128, 3>(p, s); break;
     case 2: launch_glds<128, 64, 4>(p, s); break;
@@ -1408,7 +1475,13 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 7: launch_glds<128, 128, 4>(p, s); break;
     case 8: launch_glds<64, 128, 3>(p, s); break;
     case 33: launch_glds<256, 128, 3, 1>(p, s); break;
-    case 34: launch_pipe<256, 128, 3, true, 0, 2, 4>(p, s); break;   // experiment: the hand-ordered loop on 4 waves x (128x64)   // experiment: 4 waves, wave tile 128x64 (6 fragment reads per 8 MFMAs)
+    case 34: launch_pipe<256, 128, 3, true, 0, 2, 4>(p, s); break;   // experiment: the hand-ordered loop on 4 waves x (128x64)
+    case 35: launch_pipe<256, 128, 3, false, 0, 4, 8, true>(p, s); break;   // unrolled ring (slots as immediates), no s_setprio
+    case 36: launch_pipe<128, 128, 4, false, 0, 4, 8, true>(p, s); break;
+    case 37: launch_pipe<256, 128, 3, true, 0, 4, 8, true>(p, s); break;    // the same with s_setprio
+    case 38:                                                    // 256x160 GEGLU tile, unrolled ring
+      if (p.N % 160 != 0) return false;
+      launch_pipe<256, 160, 3, false, 0, 8, 8, true>(p, s); break;   // experiment: 4 waves, wave tile 128x64 (6 fragment reads per 8 MFMAs)
     case 10: launch_pipe<256, 128, 3, false>(p, s); break;   // 8-wave pipelined kernels
     case 11: launch_pipe<256, 128, 3, true>(p, s); break;
     case 12: launch_pipe<128, 128, 4, false>(p, s); break;

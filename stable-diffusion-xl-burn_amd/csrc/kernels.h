@@ -47,6 +47,7 @@ struct IgemmParams {
 };
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
+void igemm_set_unrolled(int v);   // auto selection: pipelined kernels with the k-loop unrolled by the ring depth (default on)
 void igemm_glds_init();          // allocates the zero page the DMA fast path reads halo pixels from (call once per process)
 
 // ---------------------------------------------------------------------------------------------------------

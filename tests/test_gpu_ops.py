@@ -175,7 +175,7 @@ def test_attn_decoder_mask(pkg, ctx):
 # ---------------------------------------------------------------------------------------------------------
 # every fast-path implicit-GEMM tile / pipeline variant is forced in turn over shapes that exercise: fewer k-tiles than
 # ring slots, ragged M / N tiles, GEGLU pairs, 3x3 taps with halo zero-fill, stride 2 and the fused nearest-2x gather
-IGEMM_VARIANTS = [4, 6, 1, 8, 10, 11, 12, 13, 14, 15, 16, 19, 20, 21, 22, 23, 24, 25, 26, 33, 34]
+IGEMM_VARIANTS = [4, 6, 1, 8, 10, 11, 12, 13, 14, 15, 16, 19, 20, 21, 22, 23, 24, 25, 26, 33, 34, 35, 36, 37, 38]
 
 
 @pytest.fixture
