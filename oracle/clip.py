@@ -17,8 +17,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .config import KIND_BETA, KIND_BIAS, KIND_GAMMA, KIND_LINEAR_W, ParamSpec, _SQRT12, _wscale
-from .model import attn_decoder_mask, conditioning_embedding, layer_norm, linear, qkv_attention
+from .config import DEFAULT_EPS, KIND_BETA, KIND_BIAS, KIND_EPS, KIND_GAMMA, KIND_LINEAR_W, ParamSpec, _SQRT12, _wscale
+from .model import attn_decoder_mask, conditioning_embedding, linear, ln, qkv_attention
 from .pipeline import Conditioning
 
 Tensor = torch.Tensor
@@ -64,6 +64,7 @@ def clip_param_specs(cfg: CLIPConfig) -> List[ParamSpec]:
     def norm(name, c):
         s.append(ParamSpec(name + ".gamma", (c,), KIND_GAMMA, np.float32(_SQRT12 * 0.02), np.float32(1)))
         s.append(ParamSpec(name + ".beta", (c,), KIND_BETA, np.float32(_SQRT12 * 0.02), np.float32(0)))
+        s.append(ParamSpec(name + ".eps", (1,), KIND_EPS, np.float32(0), np.float32(DEFAULT_EPS)))   # layernorm/load.rs:17
 
     c = cfg.n_state
     s.append(ParamSpec("token_embedding.weight", (cfg.n_vocab, c), KIND_LINEAR_W, np.float32(_SQRT12 * 0.5), np.float32(0)))
@@ -85,10 +86,10 @@ def clip_param_specs(cfg: CLIPConfig) -> List[ParamSpec]:
 
 def _block(x: Tensor, mask: Tensor, W, p: str, cfg: CLIPConfig) -> Tensor:
     """ResidualDecoderAttentionBlock::forward (:194-199)"""
-    h = layer_norm(x, W[p + ".attn_ln.gamma"], W[p + ".attn_ln.beta"])
+    h = ln(x, W, p + ".attn_ln")
     q, k, v = linear(h, W, p + ".attn.query"), linear(h, W, p + ".attn.key"), linear(h, W, p + ".attn.value")
     x = x + linear(qkv_attention(q, k, v, mask, cfg.n_head), W, p + ".attn.out")            # :243-257
-    h = linear(layer_norm(x, W[p + ".mlp_ln.gamma"], W[p + ".mlp_ln.beta"]), W, p + ".mlp.fc1")
+    h = linear(ln(x, W, p + ".mlp_ln"), W, p + ".mlp.fc1")
     h = h * torch.sigmoid(h * 1.702) if cfg.quick_gelu else F.gelu(h)                        # :296-320
     return x + linear(h, W, p + ".mlp.fc2")
 
@@ -117,7 +118,7 @@ def forward_hidden_pooled(cfg: CLIPConfig, W, tokens: Tensor, hidden_idx: int) -
             h_out = x.clone()
         x = _block(x, mask, W, f"blocks.{i}", cfg)
     eot = tokens.long().argmax(dim=1)           # eot_token is the highest id of each sequence (:139-140)
-    normed = layer_norm(x, W["layer_norm.gamma"], W["layer_norm.beta"])
+    normed = ln(x, W, "layer_norm")
     o = normed[torch.arange(tokens.shape[0]), eot]
     return h_out, o @ W["text_projection"]
 

@@ -86,6 +86,8 @@ KIND_CONV_W = 1     # [out, in, kh, kw]
 KIND_BIAS = 2
 KIND_GAMMA = 3
 KIND_BETA = 4
+KIND_EPS = 5        # [1] scalar: the norm's eps
+DEFAULT_EPS = 1e-5  # GroupNormConfig / LayerNormConfig default (groupnorm/mod.rs:13-14, layernorm/mod.rs:12-13)
 
 
 @dataclass
@@ -127,6 +129,9 @@ class _Spec:
     def norm(self, name, c):
         self.items.append(ParamSpec(name + ".gamma", (c,), KIND_GAMMA, np.float32(_SQRT12 * 0.02), np.float32(1)))
         self.items.append(ParamSpec(name + ".beta", (c,), KIND_BETA, np.float32(_SQRT12 * 0.02), np.float32(0)))
+        # per-module eps, read per norm by the reference's .npy loaders (groupnorm/load.rs:19, layernorm/load.rs:17);
+        # synthetic value = the Config default 1e-5 exactly (scale 0)
+        self.items.append(ParamSpec(name + ".eps", (1,), KIND_EPS, np.float32(0), np.float32(DEFAULT_EPS)))
 
 
 RES_GAIN = 0.5  # residual-branch output layers: keeps the residual stream's variance moderate

@@ -52,6 +52,21 @@ def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = EPS) -> Tens
     return layernorm_fn(x, eps) * gamma + beta
 
 
+def _eps(W, p: str) -> float:
+    """per-norm eps: the reference's .npy loaders read it per module (groupnorm/load.rs:19, layernorm/load.rs:17);
+    the parameter enumeration carries it as `<norm>.eps` (default 1e-5 = the Config default the .mpk path gets)."""
+    e = W.get(p + ".eps")
+    return EPS if e is None else float(e.reshape(-1)[0])
+
+
+def gn(x: Tensor, W, p: str, n_group: int = 32) -> Tensor:
+    return group_norm(x, W[p + ".gamma"], W[p + ".beta"], n_group, _eps(W, p))
+
+
+def ln(x: Tensor, W, p: str) -> Tensor:
+    return layer_norm(x, W[p + ".gamma"], W[p + ".beta"], _eps(W, p))
+
+
 def linear(x: Tensor, W: Dict[str, Tensor], name: str) -> Tensor:
     """burn nn::Linear: y = x @ W[d_in,d_out] (+ b)."""
     y = x @ W[name + ".weight"]
@@ -111,10 +126,10 @@ def conditioning_embedding(pooled: Tensor, dim: int, size: Tensor, crop: Tensor,
 
 def res_block(x: Tensor, emb: Tensor, W, p: str) -> Tensor:
     """ResBlock::forward src/model/unet/mod.rs:1082-1106."""
-    h = conv2d(silu(group_norm(x, W[p + ".norm_in.gamma"], W[p + ".norm_in.beta"])), W, p + ".conv_in", padding=1)
+    h = conv2d(silu(gn(x, W, p + ".norm_in")), W, p + ".conv_in", padding=1)
     e = linear(silu(emb), W, p + ".lin_embed")
     h = h + e[:, :, None, None]
-    h = conv2d(silu(group_norm(h, W[p + ".norm_out.gamma"], W[p + ".norm_out.beta"])), W, p + ".conv_out", padding=1)
+    h = conv2d(silu(gn(h, W, p + ".norm_out")), W, p + ".conv_out", padding=1)
     if (p + ".skip_connection.weight") in W:
         return conv2d(x, W, p + ".skip_connection") + h
     return x + h
@@ -138,9 +153,9 @@ def geglu(x: Tensor, W, p: str) -> Tensor:
 
 def transformer_block(x: Tensor, context: Tensor, W, p: str, n_head: int) -> Tensor:
     """TransformerBlock::forward src/model/unet/mod.rs:885-891."""
-    x = x + multi_head_attention(layer_norm(x, W[p + ".norm1.gamma"], W[p + ".norm1.beta"]), None, W, p + ".attn1", n_head)
-    x = x + multi_head_attention(layer_norm(x, W[p + ".norm2.gamma"], W[p + ".norm2.beta"]), context, W, p + ".attn2", n_head)
-    h = layer_norm(x, W[p + ".norm3.gamma"], W[p + ".norm3.beta"])
+    x = x + multi_head_attention(ln(x, W, p + ".norm1"), None, W, p + ".attn1", n_head)
+    x = x + multi_head_attention(ln(x, W, p + ".norm2"), context, W, p + ".attn2", n_head)
+    h = ln(x, W, p + ".norm3")
     return x + linear(geglu(h, W, p + ".mlp.geglu"), W, p + ".mlp.lin")   # MLP::forward :915-918
 
 
@@ -148,7 +163,7 @@ def spatial_transformer(x: Tensor, context: Tensor, W, p: str, n_head: int, dept
     """SpatialTransformer::forward src/model/unet/mod.rs:820-845."""
     b, c, h, w = x.shape
     x_in = x
-    t = group_norm(x, W[p + ".norm.gamma"], W[p + ".norm.beta"]).reshape(b, c, h * w).transpose(1, 2)
+    t = gn(x, W, p + ".norm").reshape(b, c, h * w).transpose(1, 2)
     t = linear(t, W, p + ".proj_in")
     for j in range(depth):
         t = transformer_block(t, context, W, f"{p}.blocks.{j}", n_head)
@@ -189,7 +204,7 @@ def unet_forward(cfg: UNetConfig, W, x: Tensor, timesteps: Tensor, context: Tens
     for i, b in enumerate(out):
         x = torch.cat([x, saved.pop()], dim=1)                                      # :484
         x = _unet_block(x, emb, context, W, f"output_blocks.{i}", b)
-    x = silu(group_norm(x, W["norm_out.gamma"], W["norm_out.beta"]))
+    x = silu(gn(x, W, "norm_out"))
     return conv2d(x, W, "conv_out", padding=1)
 
 
@@ -197,8 +212,8 @@ def unet_forward(cfg: UNetConfig, W, x: Tensor, timesteps: Tensor, context: Tens
 
 def vae_resnet_block(x: Tensor, W, p: str) -> Tensor:
     """ResnetBlock::forward src/model/autoencoder/mod.rs:500-516."""
-    h = conv2d(silu(group_norm(x, W[p + ".norm1.gamma"], W[p + ".norm1.beta"])), W, p + ".conv1", padding=1)
-    h = conv2d(silu(group_norm(h, W[p + ".norm2.gamma"], W[p + ".norm2.beta"])), W, p + ".conv2", padding=1)
+    h = conv2d(silu(gn(x, W, p + ".norm1")), W, p + ".conv1", padding=1)
+    h = conv2d(silu(gn(h, W, p + ".norm2")), W, p + ".conv2", padding=1)
     if (p + ".nin_shortcut.weight") in W:
         return conv2d(x, W, p + ".nin_shortcut") + h
     return x + h
@@ -207,7 +222,7 @@ def vae_resnet_block(x: Tensor, W, p: str) -> Tensor:
 def vae_attn_block(x: Tensor, W, p: str) -> Tensor:
     """ConvSelfAttentionBlock::forward src/model/autoencoder/mod.rs:550-586 (1 head, 1x1-conv q/k/v)."""
     b, c, hh, ww = x.shape
-    h = group_norm(x, W[p + ".norm.gamma"], W[p + ".norm.beta"])
+    h = gn(x, W, p + ".norm")
     q = conv2d(h, W, p + ".q").reshape(b, c, hh * ww).transpose(1, 2)
     k = conv2d(h, W, p + ".k").reshape(b, c, hh * ww).transpose(1, 2)
     v = conv2d(h, W, p + ".v").reshape(b, c, hh * ww).transpose(1, 2)
@@ -233,7 +248,7 @@ def vae_decoder_forward(cfg: VAEConfig, W, x: Tensor) -> Tensor:
             x = vae_resnet_block(x, W, f"{p}.{r}")
         if i != n - 1:
             x = conv2d(upsample_nearest2x(x), W, p + ".upsampler", padding=1)
-    x = silu(group_norm(x, W["decoder.norm_out.gamma"], W["decoder.norm_out.beta"]))
+    x = silu(gn(x, W, "decoder.norm_out"))
     return conv2d(x, W, "decoder.conv_out", padding=1)
 
 
@@ -266,7 +281,7 @@ def vae_encoder_forward(cfg: VAEConfig, W, x: Tensor) -> Tensor:
         if i != n - 1:
             x = padded_conv2d_s2(x, W, p + ".downsampler")
     x = vae_mid(x, W, "encoder.mid")
-    x = silu(group_norm(x, W["encoder.norm_out.gamma"], W["encoder.norm_out.beta"]))
+    x = silu(gn(x, W, "encoder.norm_out"))
     return conv2d(x, W, "encoder.conv_out", padding=1)
 
 

@@ -51,6 +51,11 @@ VaeCfg to_vcfg(const sdxl_vae_config* c) {
   VaeCfg v; v.enc.clear(); v.dec.clear();
   for (int i = 0; i < c->n_blocks; ++i) { v.enc.push_back({c->enc_in[i], c->enc_out[i]}); v.dec.push_back({c->dec_in[i], c->dec_out[i]}); }
   v.n_group = c->n_group; v.enc_out = c->enc_out_channels; v.scale_factor = c->scale_factor;
+  SDXL_REQUIRE(v.n_group >= 1 && v.n_group <= 256, "n_group out of range (1..256)");
+  for (int i = 0; i < c->n_blocks; ++i)
+    for (int ch : {c->enc_in[i], c->enc_out[i], c->dec_in[i], c->dec_out[i]})
+      SDXL_REQUIRE(ch > 0 && ch % v.n_group == 0 && ch % 8 == 0,
+                   "The number of channels must be divisible by the number of groups (and by 8)");   // groupnorm/mod.rs:19-24
   return v;
 }
 void dtypes(int dtype, int& cdt, int& sdt) {

@@ -50,7 +50,7 @@ struct VaeCfg {
 // mirrors CLIPConfig (clip/mod.rs:19-28)
 struct ClipCfg { int n_vocab = 49408, n_state = 0, embed_dim = 0, n_head = 0, n_ctx = 77, n_layer = 0; bool quick_gelu = false; };
 
-enum ParamKind { PK_LINEAR_W = 0, PK_CONV_W = 1, PK_BIAS = 2, PK_GAMMA = 3, PK_BETA = 4 };
+enum ParamKind { PK_LINEAR_W = 0, PK_CONV_W = 1, PK_BIAS = 2, PK_GAMMA = 3, PK_BETA = 4, PK_EPS = 5 };
 struct ParamSpec {
   std::string name;
   std::vector<int> shape;
@@ -106,8 +106,11 @@ struct Lin {        // packed dense weight: [Npad][Kpad] compute dtype + fp32 bi
   // LayerNorm folded in (linear_ln / fused_linear_ln): w = diag(gamma) W, b = beta W + bias, cs = column sums of the
   // packed rows; the GEMM then takes the RAW rows plus their (sum, sum^2) statistics -- see IgemmParams::ln_stat
   const float* cs = nullptr;
+  const float* ln_eps = nullptr;   // device scalar: eps of the folded LayerNorm
 };
-struct NormW { const float* gamma = nullptr; const float* beta = nullptr; int C = 0; };
+// eps lives in the weight arena (device scalar, read by the kernels): replicas that receive the arena by broadcast need no
+// host-side copy, and a checkpoint's per-norm eps (groupnorm/load.rs:19, layernorm/load.rs:17) travels with the weights
+struct NormW { const float* gamma = nullptr; const float* beta = nullptr; const float* eps = nullptr; int C = 0; };
 
 struct WeightBuilder {
   const std::vector<ParamSpec>& specs;
@@ -297,7 +300,7 @@ class Vae {
   std::vector<EncBlk> e_blocks_;
   DeviceArena act_;
   size_t act_peak_ = 0;
-  float* gn_partial_ = nullptr;
+  float* gn_workspace(Exec& ex, int n);
 };
 
 // ------------------------------------------------------------------------------------------ CLIP text encoder (Embedder)

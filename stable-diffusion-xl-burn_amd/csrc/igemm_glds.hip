@@ -68,7 +68,7 @@ __device__ __forceinline__ void ln_row_coef(const IgemmParams& p, int m, float& 
     for (; k < p.ln_slots; ++k) { const f32x2 v = st[(size_t)k * M]; s1 += v[0]; s2 += v[1]; }
     const float mu = s1 * p.ln_invc;
     const float var = fmaxf(s2 * p.ln_invc - mu * mu, 0.f);     // biased variance, eps inside the sqrt (layernorm/mod.rs:42-49)
-    a = 1.0f / sqrtf(var + p.ln_eps);
+    a = 1.0f / sqrtf(var + (p.ln_eps_ptr ? *p.ln_eps_ptr : p.ln_eps));
     c = -a * mu;
   }
 }
@@ -112,7 +112,7 @@ __device__ __forceinline__ void ln_prologue(const IgemmParams& p, int mw, int fr
     }
     const float mu = s1 * p.ln_invc;
     const float var = fmaxf(s2 * p.ln_invc - mu * mu, 0.f);
-    const float a = 1.0f / sqrtf(var + p.ln_eps);
+    const float a = 1.0f / sqrtf(var + (p.ln_eps_ptr ? *p.ln_eps_ptr : p.ln_eps));
     if (mw + i * 32 + fr < p.M) { lnA[i] = a; lnC[i] = -a * mu; }
   }
 }

@@ -41,6 +41,7 @@ struct IgemmParams {
   // with (mu, rstd) from the partial row sums the PRODUCER of x left behind: ln_stat[slot][m] = (sum x, sum x^2) over the
   // 64 columns of slot, ln_slots = K/64 slots per row, summed here in slot order (deterministic).  null -> plain GEMM.
   const float* ln_stat; int ln_slots; const float* ln_cs; float ln_invc; float ln_eps;
+  const float* ln_eps_ptr;   // optional device scalar overriding ln_eps
   // when set, the staged epilogue stores (sum, sum of squares) of every 64-column group of the stored output rows into
   // stat_out[n/64][m] (plain stores, every entry written once) -- the statistics of the LayerNorm that reads this output
   float* stat_out; int stat_slots;
@@ -59,6 +60,7 @@ struct GroupNormParams {
   float* partial;      // workspace: [B][32][nsplit][3] (count, mean, M2)
   int B, HW, C, G;
   float eps;
+  const float* eps_ptr; // optional device scalar overriding eps (per-norm eps stored with the weights)
   int silu;            // fuse x*sigmoid(x) after the affine
   int nsplit;          // filled by the launcher helper
 };
@@ -71,6 +73,7 @@ struct LayerNormParams {
   void* Y; int y_dt; int ldy;
   const float* gamma; const float* beta;
   int rows, C; float eps;
+  const float* eps_ptr;   // optional device scalar overriding eps
 };
 void launch_layernorm(const LayerNormParams& p, hipStream_t s);
 

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GroupNormParams 
   }
   if (lane == 0) {
     stat[i * 2] = ma;
-    stat[i * 2 + 1] = 1.0f / sqrtf(qa / na + p.eps);
+    stat[i * 2 + 1] = 1.0f / sqrtf(qa / na + (p.eps_ptr ? *p.eps_ptr : p.eps));
   }
 }
 
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-  const float rstd = 1.0f / sqrtf(sq / (float)p.C + p.eps);
+  const float rstd = 1.0f / sqrtf(sq / (float)p.C + (p.eps_ptr ? *p.eps_ptr : p.eps));
   for (int vc = lane; vc < NV; vc += 64) {
     float v[8];
     load8<XT>(x + vc * 8, v);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void layernorm_cached_kernel(const LayerNormPa
     }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-  const float rstd = 1.0f / sqrtf(sq / (float)p.C + p.eps);
+  const float rstd = 1.0f / sqrtf(sq / (float)p.C + (p.eps_ptr ? *p.eps_ptr : p.eps));
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int vc = lane + 64 * i;

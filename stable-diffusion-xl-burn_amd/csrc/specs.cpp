@@ -36,6 +36,9 @@ struct Spec {
   void norm(const std::string& n, int c) {
     add(n + ".gamma", {c}, PK_GAMMA, (float)(kSqrt12 * 0.02), 1.f);
     add(n + ".beta", {c}, PK_BETA, (float)(kSqrt12 * 0.02), 0.f);
+    // per-module eps: the reference's .npy loaders read it per norm (groupnorm/load.rs:19, layernorm/load.rs:17);
+    // synthetic value = the Config default 1e-5 exactly (scale 0)
+    add(n + ".eps", {1}, PK_EPS, 0.f, 1e-5f);
   }
 };
 

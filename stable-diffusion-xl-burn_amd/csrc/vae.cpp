@@ -72,9 +72,8 @@ Vae::Vae(const VaeCfg& cfg, int compute_dt, WeightSource* dec_src, WeightSource*
     SDXL_HIP(hipStreamSynchronize(st));
     has_enc_ = true;
   }
-  SDXL_HIP(hipMalloc((void**)&gn_partial_, (size_t)8 * 32 * (128 * 3 + 2) * sizeof(float)));
 }
-Vae::~Vae() { if (gn_partial_) (void)hipFree(gn_partial_); }
+Vae::~Vae() {}
 
 void Vae::res_block(Exec& ex, const VaeResW& w, const Act& x, int B, int H, int W, const Act& out) {
   // ResnetBlock::forward autoencoder/mod.rs:500-516
@@ -215,10 +214,16 @@ void Vae::run_encode(Exec& ex, const Act& in, int n, int H, int W, const Act& ou
   run_conv(ex, quant_, e8, cfg_.enc_out, ConvGeom{n, h, w, h, w, 1, 1, 0, 0}, out);
 }
 
+// GroupNorm workspace of launch_groupnorm: [n][G][128][3] partials + [n][G][2] (mean, rstd), sized per call from the arena
+// (a fixed allocation silently overflowed for n * n_group > 256)
+float* Vae::gn_workspace(Exec& ex, int n) {
+  return (float*)ex.act->alloc((size_t)n * cfg_.n_group * (128 * 3 + 2) * sizeof(float));
+}
+
 // two-pass execution: dry run sizes the arena, then the real run
 #define VAE_RUN(...)                                                                   \
   do {                                                                                 \
-    Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = cdt_; ex.act = &act_; ex.gn_partial = gn_partial_; \
+    Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = cdt_; ex.act = &act_;                  \
     act_.dry = true; act_.off = 0; act_.peak = 0; ex.dry = true;                       \
     __VA_ARGS__;                                                                       \
     const size_t peak = act_.peak;                                                     \
@@ -232,6 +237,7 @@ const float* Vae::decode(const float* latent, int n, int h, int w, hipStream_t s
   SDXL_REQUIRE(has_dec_, "this Vae was created without decoder weights");
   float* img = nullptr;
   VAE_RUN({
+    ex.gn_partial = gn_workspace(ex, n);
     Act in = ex.alloc((size_t)n * h * w, 4, cdt_);
     Act out = ex.alloc((size_t)n * h * w * 64, 3, DT_F32);
     img = (float*)out.p;
@@ -252,6 +258,7 @@ void Vae::latent_to_image(const float* latent, int n, int h, int w, unsigned cha
 void Vae::encode_nchw(const float* img, int n, int H, int W, float* latent_out, hipStream_t s) {
   SDXL_REQUIRE(has_enc_, "this Vae was created without encoder weights");
   VAE_RUN({
+    ex.gn_partial = gn_workspace(ex, n);
     Act in = ex.alloc((size_t)n * H * W, 3, cdt_);
     Act out = ex.alloc((size_t)n * (H / 8) * (W / 8), cfg_.enc_out, DT_F32);
     if (!ex.dry) launch_nchw_to_nhwc(img, 3 * H * W, in.p, cdt_, n, 3, H * W, 3, 1.0f, s);
@@ -263,6 +270,7 @@ void Vae::encode_nchw(const float* img, int n, int H, int W, float* latent_out, 
 void Vae::image_to_latent(const unsigned char* img_hwc, int n, int H, int W, float* latent_out, hipStream_t s) {
   SDXL_REQUIRE(has_enc_, "this Vae was created without encoder weights");
   VAE_RUN({
+    ex.gn_partial = gn_workspace(ex, n);
     Act in = ex.alloc((size_t)n * H * W, 3, cdt_);
     Act out = ex.alloc((size_t)n * (H / 8) * (W / 8), cfg_.enc_out, DT_F32);
     if (!ex.dry) launch_from_u8_image(img_hwc, in.p, cdt_, 3, (size_t)n * H * W, s);

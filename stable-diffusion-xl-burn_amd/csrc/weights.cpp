@@ -169,8 +169,10 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
   char* w = (char*)arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   float* cs = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
-  l.w = w; l.b = b; l.cs = cs;
+  float* leps = (float*)arena.alloc(sizeof(float));
+  l.w = w; l.b = b; l.cs = cs; l.ln_eps = leps;
   if (src.empty()) return l;
+  SDXL_HIP(hipMemcpyAsync(leps, fetch(norm + ".eps"), sizeof(float), hipMemcpyDeviceToDevice, st));
   const size_t need = 3 * (size_t)l.Npad + 2 * (size_t)l.K;
   if (need > tmp2_numel) {
     if (tmp2) SDXL_HIP(hipFree(tmp2));
@@ -221,10 +223,12 @@ NormW WeightBuilder::norm(const std::string& name) {
   NormW n; n.C = s.shape[0];
   float* g = (float*)arena.alloc((size_t)n.C * sizeof(float));
   float* b = (float*)arena.alloc((size_t)n.C * sizeof(float));
-  n.gamma = g; n.beta = b;
+  float* e = (float*)arena.alloc(sizeof(float));
+  n.gamma = g; n.beta = b; n.eps = e;
   if (src.empty()) return n;
   SDXL_HIP(hipMemcpyAsync(g, fetch(name + ".gamma"), n.C * sizeof(float), hipMemcpyDeviceToDevice, st));
   SDXL_HIP(hipMemcpyAsync(b, fetch(name + ".beta"), n.C * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SDXL_HIP(hipMemcpyAsync(e, fetch(name + ".eps"), sizeof(float), hipMemcpyDeviceToDevice, st));
   return n;
 }
 
@@ -245,7 +249,7 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.C = out.p; p.ldc = out.ld; p.c_dt = out.dt;
   p.n_split = e.n_split >= 0 ? e.n_split : w.N;
   p.Ct = e.Ct; p.ct_rows = e.ct_rows; p.ct_ld = e.ct_ld;
-  p.ln_stat = e.ln_stat; p.ln_slots = w.K / 64; p.ln_cs = w.cs; p.ln_invc = 1.0f / (float)w.K; p.ln_eps = 1e-5f;
+  p.ln_stat = e.ln_stat; p.ln_slots = w.K / 64; p.ln_cs = w.cs; p.ln_invc = 1.0f / (float)w.K; p.ln_eps = 1e-5f; p.ln_eps_ptr = w.ln_eps;
   p.stat_out = e.stat_out; p.stat_slots = w.N / 64;
   SDXL_REQUIRE(!e.ln_stat || w.K % 64 == 0, "LayerNorm-folded GEMM needs K % 64 == 0");
   SDXL_REQUIRE(!e.stat_out || (w.N % 64 == 0 && (e.n_split < 0 || e.n_split >= w.N) && e.act == 0), "row statistics need a plain N % 64 == 0 output");
@@ -265,11 +269,12 @@ void run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, con
 }
 void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups) {
   if (ex.dry) return;
+  SDXL_REQUIRE(groups >= 1 && groups <= 256 && n.C % groups == 0, "The number of channels must be divisible by the number of groups");
   GroupNormParams p{};
   p.X = x.p; p.x_dt = x.dt; p.ldx = x.ld;
   p.Y = y.p; p.y_dt = y.dt; p.ldy = y.ld;
   p.gamma = n.gamma; p.beta = n.beta; p.partial = ex.gn_partial;
-  p.B = B; p.HW = HW; p.C = n.C; p.G = groups; p.eps = 1e-5f; p.silu = silu ? 1 : 0;
+  p.B = B; p.HW = HW; p.C = n.C; p.G = groups; p.eps = 1e-5f; p.eps_ptr = n.eps; p.silu = silu ? 1 : 0;
   if (ex.prof) ex.prof->begin(Profiler::GROUPNORM, 0.0, ex.s);
   launch_groupnorm(p, ex.s);
   if (ex.prof) ex.prof->end(ex.s);
@@ -278,7 +283,7 @@ void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& 
   if (ex.dry) return;
   LayerNormParams p{};
   p.X = x.p; p.x_dt = x.dt; p.ldx = x.ld; p.Y = y.p; p.y_dt = y.dt; p.ldy = y.ld;
-  p.gamma = n.gamma; p.beta = n.beta; p.rows = rows; p.C = n.C; p.eps = 1e-5f;
+  p.gamma = n.gamma; p.beta = n.beta; p.rows = rows; p.C = n.C; p.eps = 1e-5f; p.eps_ptr = n.eps;
   if (ex.prof) ex.prof->begin(Profiler::LAYERNORM, 0.0, ex.s);
   launch_layernorm(p, ex.s);
   if (ex.prof) ex.prof->end(ex.s);

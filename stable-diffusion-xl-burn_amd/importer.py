@@ -24,6 +24,9 @@ class ImportError_(RuntimeError):
     pass
 
 
+DEFAULT_EPS = 1e-5   # GroupNormConfig / LayerNormConfig default
+
+
 # ------------------------------------------------------------------------------------------------ one tensor <-> one file
 def read_tensor(path: str, shape: Optional[Sequence[int]] = None) -> np.ndarray:
     """`[dims..., values...]` float32 -> ndarray.  With `shape` the header must match it exactly; without, the rank is
@@ -302,6 +305,11 @@ def mpk_flat(specs, item, prefix: str = "", optional: Sequence[str] = ()) -> np.
                 node = _mpk_descend(node, k, p.name)
         except ImportError_:
             ok = False
+        if p.name.endswith(".eps"):
+            # module constants (eps, n_group, ...) are not tensors of a burn record: the loaded module keeps what its
+            # Config::init set, i.e. the 1e-5 default (groupnorm/mod.rs:13-14, layernorm/mod.rs:12-13); a numeric field is honoured
+            parts.append(np.asarray([float(node) if ok and isinstance(node, (int, float)) else DEFAULT_EPS], dtype=np.float32))
+            continue
         if (not ok or node is None) and p.name in optional:
             parts.append(np.zeros(int(np.prod(p.shape)), dtype=np.float32))
             continue

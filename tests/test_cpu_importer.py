@@ -146,13 +146,17 @@ def test_mpk_record_round_trip(pkg, imp, tmp_path):
             else:
                 node = node.setdefault(k, {})
                 i += 1
+        if keys[-1] == "eps":
+            node["eps"] = None                              # module constant: not a tensor of the record
+            continue
         node[keys[-1]] = imp.mpk_param(W[p.name], pid=p.name, as_bytes=W[p.name].size > 4096)   # big tensors as raw f16 bytes (speed)
     path = str(tmp_path / "diffuser.mpk")
     imp.write_mpk(path, item)
     tree = imp.read_mpk(path)
     flat = imp.mpk_flat(pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg)), tree, "diffusion")
     want = pkg.flatten_weights(pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg)),
-                               {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in W.items()})
+                               {k: (np.asarray(v, np.float32) if k.endswith(".eps") else
+                                    np.asarray(v, np.float32).astype(np.float16).astype(np.float32)) for k, v in W.items()})
     assert np.array_equal(flat, want)                      # the record holds f16: equal to the f16-rounded weights
     a = imp._mpk_tensor(tree["alpha_cumulative_products"], "alphas")
     assert a.shape == (1000,) and abs(float(a[0]) - float(OC.alphas_cumprod()[0])) < 1e-3
@@ -178,15 +182,42 @@ def test_mpk_padded_conv_and_optional(pkg, imp, tmp_path):
                 node = node[keys[i]][int(keys[i + 1])]; i += 2
             else:
                 node = node.setdefault(keys[i], {}); i += 1
+        if keys[-1] == "eps":
+            continue                                       # module constant: absent from the record -> Config default
         # tensor record wrapped once more in { data: ... }: tolerated
         node[keys[-1]] = {"id": "x", "param": {"data": imp.mpk_param(W[p.name])["param"]}}
     path = str(tmp_path / "embedder.mpk")
     imp.write_mpk(path, {"clip": clip, "clip_tokenizer": None})
     flat = imp.mpk_flat(pkg.clip_param_specs(pkg.CLIPConfig(**ocfg.__dict__)), imp.read_mpk(path), "clip", optional=("text_projection",))
-    W16 = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in W.items()}
+    W16 = {k: (np.asarray(v, np.float32) if k.endswith(".eps") else np.asarray(v, np.float32).astype(np.float16).astype(np.float32))
+           for k, v in W.items()}
     W16["text_projection"] = np.zeros_like(W16["text_projection"])
     assert np.array_equal(flat, pkg.flatten_weights(pkg.clip_param_specs(pkg.CLIPConfig(**ocfg.__dict__)), W16))
     # PaddedConv2d { conv: Conv2d { weight, bias }, ... }: the inner level is skipped
     node = {"downsampler": {"conv": {"weight": imp.mpk_param(np.ones((2, 2, 3, 3))), "bias": None}, "kernel_size": None}}
     t = imp._mpk_tensor(imp._mpk_descend(imp._mpk_descend(node, "downsampler", "x"), "weight", "x"), "x")
     assert t.shape == (2, 2, 3, 3)
+
+
+def test_per_norm_eps_travels_through_the_npy_tree(pkg, imp, tmp_path):
+    # the reference reads eps per norm (groupnorm/load.rs:19, layernorm/load.rs:17; written by save.py:31,39): a dump whose
+    # norms carry eps = 1e-6 must reach the flat buffer in the `.eps` slots, everything else untouched
+    ocfg = OC.tiny_config()
+    specs = OC.unet_param_specs(ocfg)
+    W = OC.synth_weights(specs, 3)
+    assert all(float(W[p.name][0]) == np.float32(1e-5) for p in specs if p.name.endswith(".eps"))     # synthetic default
+    changed = [p.name for p in specs if p.name.endswith(".eps") and (".transformer.norm" in p.name or p.name == "norm_out.eps")]
+    assert changed
+    for n in changed:
+        W[n] = np.asarray([1e-6], dtype=np.float32)
+    root = str(tmp_path / "diffuser_base")
+    pspecs = pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg))
+    imp.export_tree(pspecs, W, root, "unet")
+    assert imp.read_scalar(os.path.join(root, "norm_out", "eps.npy")) == float(np.float32(1e-6))
+    flat = imp.load_flat(pspecs, root, "unet")
+    assert np.array_equal(flat, pkg.flatten_weights(pspecs, W))
+    off = 0
+    for p in pspecs:
+        if p.name.endswith(".eps"):
+            assert flat[off] == np.float32(1e-6 if p.name in changed else 1e-5), p.name
+        off += int(np.prod(p.shape))

@@ -335,7 +335,7 @@ def test_header_is_plain_c_and_links(built, tmp_path):
     src.write_text('#include "sdxl_mi355.h"\n'
                    'int main(void) { sdxl_unet_config c; sdxl_clip_config k; sdxl_vae_config v;\n'
                    '  sdxl_unet_config_base(&c); sdxl_clip_config_open_clip_bigg(&k); sdxl_vae_config_default(&v);\n'
-                   '  if (sdxl_unet_param_count(&c) <= 0 || sdxl_clip_param_count(&k) != 517) return 2;\n'
+                   '  if (sdxl_unet_param_count(&c) <= 0 || sdxl_clip_param_count(&k) != 582) return 2;\n'
                    '  return sdxl_step_count(30, 0, 1000) == 31 ? 0 : 1; }\n')
     exe = tmp_path / "abi"
     libdir = os.path.dirname(built.LIB_PATH)
@@ -378,6 +378,8 @@ def test_clip_oracle_matches_hf_clip_text_model(act):
             W[o + b + ".bias"] = sd[h + a + ".bias"]
         for a, b in (("layer_norm1", "attn_ln"), ("layer_norm2", "mlp_ln")):
             W[o + b + ".gamma"], W[o + b + ".beta"] = sd[h + a + ".weight"], sd[h + a + ".bias"]
+    for n in [k[:-6] for k in W if k.endswith(".gamma")]:
+        W[n + ".eps"] = torch.tensor([hcfg.layer_norm_eps])                         # save_layer_norm writes eps per norm (save.py:31)
     assert set(W) == {p.name for p in OCL.clip_param_specs(ocfg)}
     ids = torch.randint(1, 49000, (2, 77), generator=torch.Generator().manual_seed(1))
     ids[:, 0] = 49406; ids[0, 5] = 49407; ids[0, 6:] = 49407; ids[1, 20] = 49407; ids[1, 21:] = 0

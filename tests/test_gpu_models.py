@@ -76,6 +76,30 @@ def test_unet_forward(pkg, ctx, dtype, which):
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_unet_forward_per_norm_eps(pkg, ctx, dtype):
+    # eps is a per-module value in the reference's dumps (groupnorm/load.rs:19, layernorm/load.rs:17), not a global 1e-5:
+    # low-variance inputs make the difference visible.  Every GroupNorm / LayerNorm (stand-alone kernels AND the folded
+    # LayerNorm of the f16 mode) must honour the value that travels with the weights.
+    ocfg = OC.tiny_config()
+    W = unet_weights(ocfg)
+    for k in W:
+        if k.endswith(".eps"):
+            W[k] = torch.tensor([3e-2 if ("norm1" in k or "norm_in" in k) else 1e-3 if "norm3" in k else 1e-6])
+    x = torch.from_numpy(OC.arb_tensor(2, 4, 16, 16)) * 0.05          # small activations: eps matters
+    context = torch.from_numpy(OC.arb_tensor(2, 5, ocfg.context_dim))
+    y = torch.from_numpy(OC.arb_tensor(2, ocfg.adm_in_channels))
+    t = torch.tensor([999, 1], dtype=torch.int32)
+    ref = OM.unet_forward(ocfg, W, x, t.long(), context, y)
+    W0 = {k: (torch.tensor([1e-5]) if k.endswith(".eps") else v) for k, v in W.items()}
+    assert rel_err(OM.unet_forward(ocfg, W0, x, t.long(), context, y), ref) > 10 * FWD_TOL[dtype], "eps change is invisible"
+    specs = pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg))
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, weights=pkg.flatten_weights(specs, {k: v.numpy() for k, v in W.items()}))
+    e = rel_err(u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu(), ref)
+    print(f"unet_forward per-norm eps dtype={dtype}: rel err {e:.3e}")
+    assert e < FWD_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 def test_split_cfg_chains_equal_batched_pair(pkg, ctx, dtype):
     # sdxl_debug_set("split_cfg"): the two entries of a batch-2 forward as two concurrent batch-1 chains (fork / join inside
     # the captured graph, second chain released after `split_offset` GEMMs) -- same bits as the batched pair, eager and replayed
