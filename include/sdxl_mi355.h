@@ -151,6 +151,10 @@ int sdxl_step_count(int n_steps, int step_start, int n_train_steps);
 /* per-iteration GPU milliseconds of the last trajectory (enable first); returns the number written */
 int sdxl_diffuser_enable_step_timing(sdxl_diffuser* d, int enabled);
 int sdxl_diffuser_step_times(sdxl_diffuser* d, float* out_ms, int capacity);
+/* parity instrumentation: after DDIM iteration i (< capacity_steps) of every following trajectory the latent [n,4,h/8,w/8]
+ * is copied to trace_dev + i * numel (device buffer owned by the caller); NULL / 0 switches it off.  These are the
+ * per-step latents `diffuse_latent` rebinds at stablediffusion/mod.rs:424-428. */
+int sdxl_diffuser_set_trace(sdxl_diffuser* d, float* trace_dev, int capacity_steps);
 
 /* ---- LatentDecoder / Autoencoder (stablediffusion/mod.rs:193-267, autoencoder/mod.rs:46-70) */
 int sdxl_vae_create(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, const float* decoder_weights_flat,
@@ -232,6 +236,12 @@ int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
 /* burn nn::Linear: y = x[M,K] @ W[K,N] + b; geglu!=0 returns x_half * gelu_erf(gate_half) (unet/mod.rs:942-956) */
 int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight, const float* bias, int M, int K, int N,
                 int geglu, int dtype, float* out);
+/* LayerNorm::forward (layernorm/mod.rs:34-49) followed by nn::Linear, as TransformerBlock::forward pairs them
+ * (unet/mod.rs:885-891): y = LN(x[M,K]; gamma, beta, eps) @ W[K,N] + b (bias may be NULL), optional GEGLU.  Runs the path
+ * the UNet runs in that dtype: SDXL_DTYPE_F16 = LayerNorm folded into the GEMM (row statistics from the producer's
+ * epilogue), otherwise the stand-alone LayerNorm kernel.  K % 64 == 0. */
+int sdxl_layer_norm_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, float eps,
+                           const float* weight, const float* bias, int M, int K, int N, int geglu, int dtype, float* out);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,9 @@ oracle's 1-2 minutes (and 10 GB of fp32 weights) on the GPU box:
   fullsize_config1.npz   BASELINE configs[0]: SDXL-base, 512x512 (latent 64x64), n_steps=4 (t = 999, 749, 499, 249),
                          CFG 1.0 (both branches evaluated, stablediffusion/mod.rs:523-540), per-step latents + final
                          latent + decode_latent + u8 image (src/bin/sample/main.rs:239-278)
+  fullsize_config2.npz   BASELINE configs[1] (the configuration bench.py times): 1024x1024, n_steps=30 -> 31 iterations,
+                         CFG 7.5; final latent + 9 of the 31 per-step latents (~25 minutes of oracle time on 8 cores;
+                         not part of the default set: `python -m oracle.make_golden_fullsize config2`)
   fullsize_unet1024.npz  one UNet::forward at 1024x1024 (latent 128x128), unet/mod.rs:450-492
   fullsize_decode1024.npz one LatentDecoder::latent_to_image at 1024x1024: stride-5 subsample of the fp32 image and of
                          the u8 image (the full fp32 image is 12 MB) + four dense 64x64 crops
@@ -45,6 +48,31 @@ def config1_inputs(cfg):
     return dict(noise=seeded(1, 4, 64, 64, seed=101), ctx=seeded(1, 77, cfg.context_dim, seed=102),
                 uctx=seeded(77, cfg.context_dim, seed=103), y=seeded(1, cfg.adm_in_channels, seed=104),
                 uy=seeded(cfg.adm_in_channels, seed=105))
+
+
+def config2_inputs(cfg):
+    """BASELINE configs[1] (the benchmarked one): 1024x1024, n_steps=30 -> 31 iterations, CFG 7.5 (seeds shared with the tests)"""
+    return dict(noise=seeded(1, 4, 128, 128, seed=131), ctx=seeded(1, 77, cfg.context_dim, seed=132),
+                uctx=seeded(77, cfg.context_dim, seed=133), y=seeded(1, cfg.adm_in_channels, seed=134),
+                uy=seeded(cfg.adm_in_channels, seed=135))
+
+
+CONFIG2_KEEP = (0, 1, 2, 5, 10, 15, 20, 25, 30)   # trajectory steps stored in the fixture (each 256 KB)
+
+
+def run_config2(cfg, W):
+    i = config2_inputs(cfg)
+    cond = OP.Conditioning(i["uctx"], None, i["ctx"], None, i["uy"], None, i["y"], None, (1024, 1024))
+    trace = []
+    t0 = time.time()
+    lat = OP.Diffuser(cfg, W, OC.alphas_cumprod()).sample_latent(cond, 7.5, 30, i["noise"], trace)
+    dt = time.time() - t0
+    amax = np.array([float(t.abs().max()) for t in trace])
+    print(f"[golden] config 2: 31-step sample_latent {dt:.1f} s, |latent|max per step {np.array2string(amax, precision=2)}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "fullsize_config2.npz"), steps=np.array(CONFIG2_KEEP),
+                        traj=np.stack([trace[k].numpy() for k in CONFIG2_KEEP]), latent=lat.numpy(), absmax=amax,
+                        in_checksum=checksum(*i.values()), oracle_seconds=np.array([dt]),
+                        oracle_threads=np.array([torch.get_num_threads()]))
 
 
 def unet1024_inputs(cfg):
@@ -119,12 +147,14 @@ def main():
     v, Wv = vae_weights()
     if "decode1024" in what:
         run_decode1024(v, Wv)
-    if what & {"config1", "unet1024"}:
+    if what & {"config1", "unet1024", "config2"}:
         cfg, W = base_weights()
         if "unet1024" in what:
             run_unet1024(cfg, W)
         if "config1" in what:
             run_config1(cfg, W, v, Wv)
+        if "config2" in what:
+            run_config2(cfg, W)
 
 
 if __name__ == "__main__":

@@ -67,12 +67,12 @@ ABI_SYMBOLS = [
     "sdxl_qkv_attention", "sdxl_attn_decoder_mask",
     "sdxl_diffuser_create", "sdxl_diffuser_create_synthetic", "sdxl_diffuser_destroy", "sdxl_diffuser_unet",
     "sdxl_sample_latent", "sdxl_sample_latent_with_inpainting", "sdxl_refine_latent", "sdxl_step_count",
-    "sdxl_diffuser_enable_step_timing", "sdxl_diffuser_step_times",
+    "sdxl_diffuser_enable_step_timing", "sdxl_diffuser_step_times", "sdxl_diffuser_set_trace",
     "sdxl_vae_create", "sdxl_vae_create_synthetic", "sdxl_vae_destroy", "sdxl_vae_decode_latent",
     "sdxl_latent_to_image", "sdxl_vae_encode_image", "sdxl_image_to_latent",
     "sdxl_unet_weight_arena", "sdxl_vae_weight_arena", "sdxl_diffuser_create_empty", "sdxl_vae_create_empty",
     "sdxl_unet_profile", "sdxl_bench_igemm", "sdxl_bench_attention", "sdxl_debug_set",
-    "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear",
+    "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear", "sdxl_layer_norm_linear",
     "sdxl_clip_config_clip_l", "sdxl_clip_config_open_clip_bigg", "sdxl_clip_param_count", "sdxl_clip_param_spec",
     "sdxl_clip_create", "sdxl_clip_create_synthetic", "sdxl_clip_destroy", "sdxl_clip_forward_hidden",
     "sdxl_clip_forward_hidden_pooled", "sdxl_conditioning_embedding", "sdxl_clip_weight_arena",
@@ -604,6 +604,16 @@ class Diffuser:
     def enable_step_timing(self, enabled: bool = True):
         _check(lib().sdxl_diffuser_enable_step_timing(self.h, int(enabled)))
 
+    def set_trace(self, trace=None):
+        """trace: float32 device tensor [steps, n, 4, h, w] that receives the latent after every DDIM iteration of the
+        following trajectories (None switches it off).  The tensor must stay alive while tracing is on."""
+        self._trace = trace
+        if trace is None:
+            _check(lib().sdxl_diffuser_set_trace(self.h, None, 0))
+        else:
+            assert trace.is_cuda and trace.dtype == _torch().float32 and trace.is_contiguous()
+            _check(lib().sdxl_diffuser_set_trace(self.h, ctypes.c_void_p(trace.data_ptr()), int(trace.shape[0])))
+
     def step_times_ms(self) -> List[float]:
         buf = (ctypes.c_float * 1024)()
         n = lib().sdxl_diffuser_step_times(self.h, buf, 1024)
@@ -781,4 +791,25 @@ def linear(ctx: Context, x, weight, bias, geglu: bool = False, dtype: int = DTYP
     M = int(x.numel() // K)
     out = torch.empty(tuple(x.shape[:-1]) + ((N // 2) if geglu else N,), device=x.device, dtype=torch.float32)
     _check(lib().sdxl_linear(ctx.h, _stream(), px, pw, pb, M, K, N, int(geglu), dtype, ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
+def layer_norm_linear(ctx: Context, x, gamma, beta, weight, bias, eps: float = 1e-5, geglu: bool = False,
+                      dtype: int = DTYPE_F16):
+    """LayerNorm::forward (layernorm/mod.rs:34-49) then nn::Linear, as TransformerBlock::forward pairs them
+    (unet/mod.rs:885-891).  DTYPE_F16 runs the LayerNorm FOLDED into the GEMM (the UNet's f16 path), the other dtypes the
+    stand-alone LayerNorm kernel."""
+    torch = _torch()
+    x, px = _dev(x)
+    gamma, pg = _dev(gamma)
+    beta, pbeta = _dev(beta)
+    weight, pw = _dev(weight)
+    pb = None
+    if bias is not None:
+        bias, pb = _dev(bias)
+    K, N = weight.shape
+    M = int(x.numel() // K)
+    out = torch.empty(tuple(x.shape[:-1]) + ((N // 2) if geglu else N,), device=x.device, dtype=torch.float32)
+    _check(lib().sdxl_layer_norm_linear(ctx.h, _stream(), px, pg, pbeta, ctypes.c_float(eps), pw, pb, M, K, N, int(geglu),
+                                       dtype, ctypes.c_void_p(out.data_ptr())))
     return out

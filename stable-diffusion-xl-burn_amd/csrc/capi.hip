@@ -609,6 +609,13 @@ int sdxl_diffuser_enable_step_timing(sdxl_diffuser* d, int enabled) {
   d->d->time_steps = enabled != 0;
   API_END
 }
+int sdxl_diffuser_set_trace(sdxl_diffuser* d, float* trace_dev, int capacity_steps) {
+  API_BEGIN
+  SDXL_REQUIRE(d && (trace_dev || capacity_steps == 0) && capacity_steps >= 0, "bad argument");
+  d->d->trace = capacity_steps > 0 ? trace_dev : nullptr;
+  d->d->trace_cap = capacity_steps;
+  API_END
+}
 int sdxl_diffuser_step_times(sdxl_diffuser* d, float* out_ms, int capacity) {
   if (!d || !out_ms) return -1;
   const int n = (int)d->d->step_ms.size() < capacity ? (int)d->d->step_ms.size() : capacity;
@@ -777,6 +784,70 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
   Epi e; e.act = geglu ? 1 : 0;
   run_linear(ex, l, Act(xi, K, sdt), M, Act(out, geglu ? N / 2 : N, DT_F32), e);
+  SDXL_HIP(hipStreamSynchronize(s));
+  API_END
+}
+int sdxl_layer_norm_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, float eps,
+                           const float* weight, const float* bias, int M, int K, int N, int geglu, int dtype, float* out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && x && gamma && beta && weight && out, "null argument");
+  SDXL_REQUIRE(!geglu || (N % 32 == 0), "GEGLU width must be a multiple of 32");
+  SDXL_REQUIRE(K % 64 == 0, "LayerNorm width must be a multiple of 64");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  // the model's own builder does the packing / folding: a five-entry parameter list over a device-side flat buffer
+  std::vector<ParamSpec> specs(5);
+  specs[0].name = "lin.weight"; specs[0].shape = {K, N}; specs[0].kind = PK_LINEAR_W;
+  specs[1].name = "lin.bias"; specs[1].shape = {N}; specs[1].kind = PK_BIAS;
+  specs[2].name = "norm.gamma"; specs[2].shape = {K}; specs[2].kind = PK_GAMMA;
+  specs[3].name = "norm.beta"; specs[3].shape = {K}; specs[3].kind = PK_BETA;
+  specs[4].name = "norm.eps"; specs[4].shape = {1}; specs[4].kind = PK_EPS;
+  Tmp tmp;
+  const size_t nflat = (size_t)K * N + N + 2 * (size_t)K + 1;
+  float* flat = (float*)tmp.get(nflat * sizeof(float));
+  SDXL_HIP(hipMemcpyAsync(flat, weight, (size_t)K * N * sizeof(float), hipMemcpyDefault, s));
+  if (bias) SDXL_HIP(hipMemcpyAsync(flat + (size_t)K * N, bias, (size_t)N * sizeof(float), hipMemcpyDefault, s));
+  else SDXL_HIP(hipMemsetAsync(flat + (size_t)K * N, 0, (size_t)N * sizeof(float), s));
+  SDXL_HIP(hipMemcpyAsync(flat + (size_t)K * N + N, gamma, (size_t)K * sizeof(float), hipMemcpyDefault, s));
+  SDXL_HIP(hipMemcpyAsync(flat + (size_t)K * N + N + K, beta, (size_t)K * sizeof(float), hipMemcpyDefault, s));
+  SDXL_HIP(hipMemcpyAsync(flat + (size_t)K * N + N + 2 * (size_t)K, &eps, sizeof(float), hipMemcpyHostToDevice, s));
+  SDXL_HIP(hipStreamSynchronize(s));
+  FlatSource src(flat, specs);
+  DeviceArena arena;
+  arena.reserve(WeightBuilder::arena_bound(specs, cdt) + ((size_t)round_up(K, 128) * K * 2 + (1 << 16)));
+  WeightBuilder wb(specs, src, arena, cdt, s);
+  Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
+  const Act o(out, geglu ? N / 2 : N, DT_F32);
+  void* xi = tmp.get((size_t)M * K * dt_size(sdt));
+  if (cdt == DT_F16 && sdt == DT_F16) {
+    // f16 mode of the UNet: the residual stream leaves its producer GEMM with per-64-column (mean, M2) statistics and the
+    // consumer applies the LayerNorm in its epilogue.  The producer here is x * I (exact), so xi = fp16(x).
+    const Lin l = wb.linear_ln("lin", geglu != 0, "norm");
+    Lin id; id.N = K; id.K = K; id.cin = K; id.ksize = 1; id.Kpad = K; id.Npad = (int)round_up(K, 128);
+    void* ip = arena.alloc((size_t)id.Npad * id.Kpad * 2);
+    float* eye = (float*)tmp.get((size_t)K * K * sizeof(float));
+    SDXL_HIP(hipMemsetAsync(eye, 0, (size_t)K * K * sizeof(float), s));
+    const float one = 1.0f;
+    SDXL_HIP(hipMemcpy2DAsync(eye, (size_t)(K + 1) * sizeof(float), &one, 0, sizeof(float), K, hipMemcpyHostToDevice, s));
+    launch_pack_linear(eye, ip, DT_F16, K, K, id.Kpad, id.Npad, 0, 0, s);
+    id.w = ip; id.b = nullptr;
+    void* x16 = tmp.get((size_t)M * K * 2);
+    launch_copy_rows(x, DT_F32, K, x16, DT_F16, K, M, K, s);
+    float* stat = (float*)tmp.get((size_t)M * (K / 64) * 2 * sizeof(float));
+    Epi ep; ep.stat_out = stat;
+    run_linear(ex, id, Act(x16, K, DT_F16), M, Act(xi, K, DT_F16), ep);
+    Epi e; e.act = geglu ? 1 : 0; e.ln_stat = stat;
+    run_linear(ex, l, Act(xi, K, DT_F16), M, o, e);
+  } else {
+    const NormW n = wb.norm("norm");
+    const Lin l = wb.linear("lin", geglu != 0);
+    launch_copy_rows(x, DT_F32, K, xi, sdt, K, M, K, s);
+    void* ln = tmp.get((size_t)M * K * dt_size(cdt));
+    run_layernorm(ex, n, Act(xi, K, sdt), M, Act(ln, K, cdt));
+    Epi e; e.act = geglu ? 1 : 0;
+    run_linear(ex, l, Act(ln, K, cdt), M, o, e);
+  }
   SDXL_HIP(hipStreamSynchronize(s));
   API_END
 }

@@ -104,7 +104,7 @@ struct Lin {        // packed dense weight: [Npad][Kpad] compute dtype + fp32 bi
   const void* w = nullptr; const float* b = nullptr;
   int N = 0, K = 0, Kpad = 0, Npad = 0, ksize = 1, cin = 0;
   // LayerNorm folded in (linear_ln / fused_linear_ln): w = diag(gamma) W, b = beta W + bias, cs = column sums of the
-  // packed rows; the GEMM then takes the RAW rows plus their (sum, sum^2) statistics -- see IgemmParams::ln_stat
+  // packed rows; the GEMM then takes the RAW rows plus their per-64-column (mean, M2) statistics -- see IgemmParams::ln_stat
   const float* cs = nullptr;
   const float* ln_eps = nullptr;   // device scalar: eps of the folded LayerNorm
 };
@@ -175,8 +175,8 @@ struct Exec {
 // thin launch helpers shared by unet.cpp / vae.cpp (skip the launch on dry runs)
 struct ConvGeom { int B, Hin, Win, Hout, Wout, ksize, stride, pad, up; };
 struct Epi {
-  const float* ln_stat = nullptr;   // [M][K/64][2] partial (sum, sum^2) of the A rows: the weight is LayerNorm-folded (Lin::cs)
-  float* stat_out = nullptr;        // [M][N/64][2]: leave the partial (sum, sum^2) of the output rows for the next folded LayerNorm
+  const float* ln_stat = nullptr;   // [K/64][M][2] per-slot (mean, M2) of the A rows: the weight is LayerNorm-folded (Lin::cs)
+  float* stat_out = nullptr;        // [N/64][M][2]: leave the per-slot (mean, M2) of the output rows for the next folded LayerNorm
   const float* ebias = nullptr; int ebias_ld = 0;
   int act = 0;
   Act R;             // residual (p == nullptr -> none)
@@ -374,6 +374,9 @@ class Diffuser {
   static std::vector<int> step_schedule(int n_steps, int step_start, int n_train);
   std::vector<float> step_ms;   // per-iteration GPU time of the last trajectory (hipEvent), for "UNet step ms p50"
   bool time_steps = false;
+  // parity instrumentation: after DDIM iteration i the latent [n,4,h,w] is copied to trace + i * numel (device, caller-owned)
+  // for i < trace_cap -- the per-step latents the oracle's `trace` lists hold (drift reports, tests)
+  float* trace = nullptr; int trace_cap = 0;
 
  private:
   void diffuse(float* latent, const Conditioning& c, int step_start, int n_steps, double cfg_scale, const float* reference,

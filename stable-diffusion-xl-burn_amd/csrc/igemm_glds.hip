@@ -58,16 +58,24 @@ __device__ __forceinline__ void ln_row_coef(const IgemmParams& p, int m, float& 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stat) + m;
     const size_t M = (size_t)p.M;
-    float s1 = 0.f, s2 = 0.f;
+    // pass 1: mean of the slot means (equal counts); pass 2: Chan merge  M2 = sum M2_k + 64 sum (mean_k - mu)^2
+    float s1 = 0.f;
     int k = 0;
     for (; k + 4 <= p.ln_slots; k += 4) {
       const f32x2 v0 = st[(size_t)k * M], v1 = st[(size_t)(k + 1) * M], v2 = st[(size_t)(k + 2) * M], v3 = st[(size_t)(k + 3) * M];
       s1 += (v0[0] + v1[0]) + (v2[0] + v3[0]);
-      s2 += (v0[1] + v1[1]) + (v2[1] + v3[1]);
     }
-    for (; k < p.ln_slots; ++k) { const f32x2 v = st[(size_t)k * M]; s1 += v[0]; s2 += v[1]; }
-    const float mu = s1 * p.ln_invc;
-    const float var = fmaxf(s2 * p.ln_invc - mu * mu, 0.f);     // biased variance, eps inside the sqrt (layernorm/mod.rs:42-49)
+    for (; k < p.ln_slots; ++k) s1 += st[(size_t)k * M][0];
+    const float mu = s1 / (float)p.ln_slots;
+    float s2 = 0.f, sd = 0.f;
+    for (k = 0; k + 4 <= p.ln_slots; k += 4) {
+      const f32x2 v0 = st[(size_t)k * M], v1 = st[(size_t)(k + 1) * M], v2 = st[(size_t)(k + 2) * M], v3 = st[(size_t)(k + 3) * M];
+      const float d0 = v0[0] - mu, d1 = v1[0] - mu, d2 = v2[0] - mu, d3 = v3[0] - mu;
+      s2 += (v0[1] + v1[1]) + (v2[1] + v3[1]);
+      sd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    for (; k < p.ln_slots; ++k) { const f32x2 v = st[(size_t)k * M]; const float d = v[0] - mu; s2 += v[1]; sd += d * d; }
+    const float var = (s2 + 64.f * sd) * p.ln_invc;             // biased variance, eps inside the sqrt (layernorm/mod.rs:42-49)
     a = 1.0f / sqrtf(var + (p.ln_eps_ptr ? *p.ln_eps_ptr : p.ln_eps));
     c = -a * mu;
   }
@@ -98,20 +106,32 @@ __device__ __forceinline__ void ln_prologue(const IgemmParams& p, int mw, int fr
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f;
 #pragma unroll
     for (int k = 0; k + 4 <= MAXS; k += 4) {    // same association as ln_row_coef
       if (k + 4 <= p.ln_slots) {
         s1 += (v[i][k][0] + v[i][k + 1][0]) + (v[i][k + 2][0] + v[i][k + 3][0]);
-        s2 += (v[i][k][1] + v[i][k + 1][1]) + (v[i][k + 2][1] + v[i][k + 3][1]);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (k + e < p.ln_slots) { s1 += v[i][k + e][0]; s2 += v[i][k + e][1]; }
+          if (k + e < p.ln_slots) s1 += v[i][k + e][0];
       }
     }
-    const float mu = s1 * p.ln_invc;
-    const float var = fmaxf(s2 * p.ln_invc - mu * mu, 0.f);
+    const float mu = s1 / (float)p.ln_slots;
+    float s2 = 0.f, sd = 0.f;
+#pragma unroll
+    for (int k = 0; k + 4 <= MAXS; k += 4) {
+      if (k + 4 <= p.ln_slots) {
+        const float d0 = v[i][k][0] - mu, d1 = v[i][k + 1][0] - mu, d2 = v[i][k + 2][0] - mu, d3 = v[i][k + 3][0] - mu;
+        s2 += (v[i][k][1] + v[i][k + 1][1]) + (v[i][k + 2][1] + v[i][k + 3][1]);
+        sd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < p.ln_slots) { const float d = v[i][k + e][0] - mu; s2 += v[i][k + e][1]; sd += d * d; }
+      }
+    }
+    const float var = (s2 + 64.f * sd) * p.ln_invc;
     const float a = 1.0f / sqrtf(var + (p.ln_eps_ptr ? *p.ln_eps_ptr : p.ln_eps));
     if (mw + i * 32 + fr < p.M) { lnA[i] = a; lnC[i] = -a * mu; }
   }
@@ -348,7 +368,7 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       const f32x4 a = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece) ^ (row & SWN)) << 4));
       const f32x4 b = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece + 1) ^ (row & SWN)) << 4));
       const bool valid = m < p.M && n0 < nlim;
-      float s1 = 0.f, s2 = 0.f;                      // row statistics of the stored values (stat_out)
+      float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // the stored (rounded) values: what the consumer will read
       if (valid) {
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
       const bool full = n0 + 8 <= nlim;
@@ -380,11 +400,7 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       }
       if (p.stat_out) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n0 + e < nlim) {
-            const float r = p.c_dt == DT_F16 ? (float)(half_t)v[e] : v[e];   // statistics of what the consumer will read
-            s1 += r; s2 += r * r;
-          }
+        for (int e = 0; e < 8; ++e) rr[e] = p.c_dt == DT_F16 ? (float)(half_t)v[e] : v[e];
       }
       if (p.c_dt == DT_F16) {
         half_t* cp = reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n0;
@@ -409,12 +425,20 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       }
       }   // valid
       if constexpr (COLS % 64 == 0) {
-        if (p.stat_out) {          // 8 consecutive lanes hold one 64-column slot of a row: butterfly, one plain store
+        if (p.stat_out) {
+          // 8 consecutive lanes hold one 64-column slot of a row.  Shifted sums around a pivot inside the data (the slot's
+          // first value) -> (mean, M2) of the slot, never sum x^2 - (sum x)^2: rows with |mean| >> sigma (outlier channels of
+          // the residual stream) keep their variance.  The consumer Chan-merges the K/64 slots (ln_prologue).
+          const float piv = __shfl(rr[0], lane & ~7);
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = rr[e] - piv; s1 += d; s2 = fmaf(d, d, s2); }
 #pragma unroll
           for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
           if ((piece & 7) == 0 && valid) {
             float* dst = p.stat_out + ((size_t)(n0 >> 6) * p.M + m) * 2;
-            dst[0] = s1; dst[1] = s2;
+            dst[0] = piv + s1 * (1.0f / 64.0f);
+            dst[1] = fmaxf(s2 - s1 * s1 * (1.0f / 64.0f), 0.f);
           }
         }
       }

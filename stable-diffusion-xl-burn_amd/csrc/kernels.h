@@ -38,11 +38,11 @@ struct IgemmParams {
   void* Ct; int ct_rows; int ct_ld;     // Ct[b][n - n_split][key]  (ct_rows rows per batch, row stride ct_ld), dtype c_dt
   // LayerNorm folded into the GEMM (reference layernorm/mod.rs:34-49 followed by nn::Linear): A holds the RAW rows x,
   // W holds diag(gamma) W, bias holds beta W + b, and the epilogue applies  v = rstd[m]*acc - rstd[m]*mu[m]*ln_cs[n] + bias[n]
-  // with (mu, rstd) from the partial row sums the PRODUCER of x left behind: ln_stat[slot][m] = (sum x, sum x^2) over the
+  // with (mu, rstd) from the partial row sums the PRODUCER of x left behind: ln_stat[slot][m] = (mean, M2 = sum (x - mean)^2) over the
   // 64 columns of slot, ln_slots = K/64 slots per row, summed here in slot order (deterministic).  null -> plain GEMM.
   const float* ln_stat; int ln_slots; const float* ln_cs; float ln_invc; float ln_eps;
   const float* ln_eps_ptr;   // optional device scalar overriding ln_eps
-  // when set, the staged epilogue stores (sum, sum of squares) of every 64-column group of the stored output rows into
+  // when set, the staged epilogue stores (mean, M2) -- shifted sums, no sum x^2 - (sum x)^2 -- of every 64-column group of the stored output rows into
   // stat_out[n/64][m] (plain stores, every entry written once) -- the statistics of the LayerNorm that reads this output
   float* stat_out; int stat_slots;
 };

@@ -124,6 +124,8 @@ void Diffuser::diffuse(float* latent, const Conditioning& c, int step_start, int
   for (int i = 0; i < iters; ++i) {
     u.forward(B, h, w, t_dev_, 0, s);     // one timestep shared by every batch entry (:416)
     launch_ddim_step(p, 1, s);
+    if (trace && i < trace_cap)
+      SDXL_HIP(hipMemcpyAsync(trace + (size_t)i * n * 4 * HW, latent, (size_t)n * 4 * HW * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (time_steps) SDXL_HIP(hipEventRecord(ev[i + 1], s));
   }
   if (time_steps) {

@@ -1,12 +1,10 @@
 """Full-size (BASELINE configs[1]) properties of the hot path: SDXL-base architecture, 1024x1024 (latent 128x128), CFG pair.
 
-The CPU oracle needs ~20 s per full-size UNet::forward and 10 GB of fp32 weights, so at this size the HIP path is held to
-size-independent properties instead (the oracle comparisons run on the tiny architectures in test_gpu_models.py):
+Accuracy against the oracle at this size lives in test_gpu_baseline_parity.py (committed oracle fixtures for config 1, one
+1024^2 UNet::forward, one 1024^2 decode and the 31-step config-2 trajectory); here the HIP path is held to size-independent
+properties:
   * batch independence: the CFG pair is one batch-2 forward; entry i must equal a separate batch-1 forward bit for bit;
   * determinism: eager run, hipGraph capture and replay give identical bits;
-  * two independent code paths agree: DTYPE_F16 folds every LayerNorm into the consuming GEMM (statistics from the
-    producer's epilogue, fp16 residual stream) while DTYPE_F16_F32RES runs the stand-alone LayerNorm kernel on an fp32
-    residual stream -- same weights, different kernels, results within the fp16-operand tolerance;
   * the sampler stays finite over a short CFG trajectory and the decoder returns a full-range u8 image.
 """
 import pytest
@@ -36,12 +34,7 @@ def test_fullsize_unet_properties(pkg, ctx, base_inputs):
     for i in range(2):
         one = u.forward(x[i:i + 1].cuda(), t[i:i + 1].cuda(), ctxt[i:i + 1].cuda(), y[i:i + 1].cuda()).cpu()
         assert torch.equal(one[0], outs[0][i]), f"batch entry {i} depends on its batch neighbour"
-    # second code path: stand-alone LayerNorm kernels + fp32 residual stream
-    u2 = pkg.UNet(ctx, cfg, pkg.DTYPE_F16_F32RES, seed=0)
-    ref = u2.forward(x.cuda(), t.cuda(), ctxt.cuda(), y.cuda()).cpu()
-    e = rel_err(outs[0], ref)
-    print(f"full-size UNet::forward: folded-LN f16 vs LayerNorm-kernel f16/f32-residual rel err {e:.3e}")
-    assert e < 3e-2
+    # (accuracy at this size is held against the ORACLE in test_gpu_baseline_parity.py::test_unet_forward_1024_matches_oracle)
 
 
 def _prompt_ids(seed, n_tok, pad):
@@ -76,12 +69,13 @@ def test_fullsize_embedder(pkg, ctx):
     h2, p2 = bigg.forward_hidden_pooled(ids2, 31)
     assert torch.equal(h2[0, :40], h16[0, :40]) and not torch.equal(h2[0, 40:], h16[0, 40:])
     assert torch.equal(p2, p16)                           # pooled row = first eot (index 13), upstream of the edit
-    ref = pkg.CLIP(ctx, pkg.open_clip_bigg_config(), pkg.DTYPE_F32, seed=12)
-    h32, p32 = ref.forward_hidden_pooled(ids_o, 31)
+    ocfg = OCL.open_clip_bigg_config()
+    Wo = OM.to_torch(OC.synth_weights(OCL.clip_param_specs(ocfg), 12))
+    h32, p32 = OCL.forward_hidden_pooled(ocfg, Wo, ids_o, 31)
     eh, ep = rel_err(h16, h32), rel_err(p16, p32)
-    print(f"OpenCLIP bigG f16 vs strict-f32 engine: hidden {eh:.3e} pooled {ep:.3e}")
+    print(f"OpenCLIP bigG f16 vs fp32 oracle: hidden {eh:.3e} pooled {ep:.3e}")
     assert eh < 3e-2 and ep < 3e-2
-    del ref
+    del Wo
 
     emb = pkg.Embedder(ctx, clip_l, bigg)
     un_c = torch.full((1, 77), 49407, dtype=torch.int64); un_c[0, 0] = 49406

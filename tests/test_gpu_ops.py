@@ -59,6 +59,43 @@ def test_layer_norm(pkg, ctx, dtype, rows, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N,geglu", [(300, 640, 640, False), (77, 1280, 3840, False), (256, 640, 5120, True),
+                                         (130, 64, 128, False), (64, 2048, 256, False)])
+def test_layer_norm_linear(pkg, ctx, dtype, M, K, N, geglu):
+    # LayerNorm -> Linear as TransformerBlock::forward pairs them (unet/mod.rs:885-891).  dtype 1 (f16) runs the FOLDED path:
+    # statistics from the producer's epilogue, rstd/mean applied in the consumer's epilogue (K = 2048: > 24 slots, generic loop)
+    x = seeded(M, K, seed=4) * 2.0 + 0.3
+    gamma, beta = 1 + 0.1 * seeded(K, seed=5), 0.1 * seeded(K, seed=6)
+    w = seeded(K, N, seed=8) / math.sqrt(K)
+    b = 0.1 * seeded(N, seed=9)
+    eps = 1e-3
+    h = OM.layer_norm(x.half().float() if dtype == 1 else x, gamma, beta, eps) @ w + b
+    ref = h[:, :N // 2] * torch.nn.functional.gelu(h[:, N // 2:]) if geglu else h
+    out = pkg.layer_norm_linear(ctx, x.cuda(), gamma.cuda(), beta.cuda(), w.cuda(), b.cuda(), eps, geglu, dtype)
+    e = rel_err(out, ref)
+    print(f"layer_norm_linear M={M} K={K} N={N} geglu={geglu} dtype={dtype}: rel err {e:.3e}")
+    assert e < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layer_norm_linear_large_mean(pkg, ctx, dtype):
+    # rows with |mean| >> sigma (outlier channels of a real residual stream): a (sum, sum^2) variance loses every digit here
+    # (40^2 = 1600 against sigma^2 = 0.0025 in fp32); the folded path carries shifted per-slot (mean, M2) + a Chan merge.
+    # Inputs are fp16-representable so the f16 path and the oracle see the same rows.  Row 0: zero variance (rstd = eps^-1/2).
+    M, K, N = 192, 1280, 1280
+    x = (40.0 + 0.05 * seeded(M, K, seed=14)).half().float()
+    x[0] = 7.0
+    x[1] = (-300.0 + 0.5 * seeded(K, seed=15)).half().float()
+    gamma, beta = 1 + 0.1 * seeded(K, seed=5), 0.1 * seeded(K, seed=6)
+    w = seeded(K, N, seed=8) / math.sqrt(K)
+    ref = OM.layer_norm(x, gamma, beta, 1e-5) @ w
+    out = pkg.layer_norm_linear(ctx, x.cuda(), gamma.cuda(), beta.cuda(), w.cuda(), None, 1e-5, False, dtype)
+    e = rel_err(out, ref)
+    print(f"layer_norm_linear large-mean dtype={dtype}: rel err {e:.3e}")
+    assert e < (1e-3 if dtype == 0 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K,N", [(1, 64, 64), (77, 128, 192), (130, 20, 8), (256, 320, 1280), (1000, 640, 100),
                                    (64, 2816, 1280), (4096, 64, 64)])
 def test_linear(pkg, ctx, dtype, M, K, N):
