@@ -317,7 +317,7 @@ def main():
     if args.no_graph:
         diffuser.diffusion.set_graph(False)
     if args.split_cfg:
-        pkg.debug_set("split_cfg", 1)
+        diffuser.diffusion.set_split_cfg(True)
     diffuser.enable_step_timing(True)
 
     lat = res // 8

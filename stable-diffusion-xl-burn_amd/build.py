@@ -32,13 +32,19 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def _flags() -> list:
+    # SDXL_MEASURE=1 (or `build.py --measure`): also build the A/B partners, dead-end variants and measurement-only modes of
+    # the GEMM / attention kernels plus the semantics-changing debug knobs; the default (release) library has none of them
+    return FLAGS + (["-DSDXL_MEASURE"] if os.environ.get("SDXL_MEASURE") == "1" else [])
+
+
 def _deps_hash(src: str) -> str:
     h = hashlib.sha256()
     for f in [src] + [os.path.join(CSRC, x) for x in ("kernels.h", "engine.h")] + \
             [os.path.join(HERE, "..", "include", "sdxl_mi355.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(_flags()).encode())
     return h.hexdigest()
 
 
@@ -49,7 +55,7 @@ def _compile(name: str, force: bool) -> str:
     want = _deps_hash(src)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj
-    cmd = [_hipcc()] + FLAGS + (["-x", "hip"] if name.endswith(".hip") else []) + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + _flags() + (["-x", "hip"] if name.endswith(".hip") else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {name}:\n{r.stdout}\n{r.stderr}")
@@ -75,4 +81,6 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
+    if "--measure" in sys.argv:
+        os.environ["SDXL_MEASURE"] = "1"
     build(force="--force" in sys.argv)

@@ -14,6 +14,8 @@
 // next tile's global loads issued before the MFMAs, one barrier per tile.  fp32 running max / sum / accumulators.
 // T = _Float16 uses v_mfma_f32_16x16x32_f16, T = float uses v_mfma_f32_16x16x4_f32 (strict-parity mode).
 #include "kernels.h"
+#include <atomic>
+#include <stdexcept>
 
 namespace sdxl {
 
@@ -802,6 +804,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
   }
 }
 
+#ifdef SDXL_MEASURE   // lost its A/B (see the MEASURED note below): built only by `build.py --measure`
 // ---------------------------------------------------------------------------------------------------------
 // f16 variant 3: variant 2 with the two GEMMs of consecutive tiles software-pipelined inside each wave.
 //   iteration t:  [row max of S(t), rare rescale]  ->  { S(t+1) = K(t+1) Q^T  (8 MFMA)  ||  P = exp2(S(t)), row sums, fp16
@@ -1000,18 +1003,31 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v3_kernel(const AttnParams p,
   }
 }
 
-static const void* g_attn_zero = nullptr;
-static int g_attn_variant = 0;   // -1: generic kernel only
+#endif  // SDXL_MEASURE
+
+// per-DEVICE zero page (key-tail / padded rows of the DMA-staged kernels) and dynamic-LDS attribute flags
+constexpr int kMaxDev = 64;
+static const void* g_attn_zeros[kMaxDev] = {};
+static std::atomic<int> g_attn_variant{0};   // test hook (sdxl_debug_set "attn_variant"): -1 generic kernel only, 0 auto
 void attention_set_variant(int v) { g_attn_variant = v; }
+static int attn_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDev) throw std::runtime_error("attention: no current HIP device");
+  return d;
+}
 void attention_init() {
-  if (g_attn_zero) return;
+  const int d = attn_device();
+  if (g_attn_zeros[d]) return;
   void* z = nullptr;
-  if (hipMalloc(&z, 4096) != hipSuccess) return;
-  (void)hipMemset(z, 0, 4096);
-  g_attn_zero = z;
+  if (hipMalloc(&z, 4096) != hipSuccess || hipMemset(z, 0, 4096) != hipSuccess)
+    throw std::runtime_error("attention: cannot allocate the zero page");
+  g_attn_zeros[d] = z;
 }
 
 void launch_attention_d64(const AttnParams& p, hipStream_t s) {
+  const int dev = attn_device();
+  const void* g_attn_zero = g_attn_zeros[dev];
+  const int g_attn_variant = sdxl::g_attn_variant.load();
   dim3 grid((p.Nq + 127) / 128, p.B * p.H);
   const bool aligned = ((p.ldq | p.ldk | p.vt_ld | p.ldo) & 7) == 0 &&
                        ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
@@ -1029,20 +1045,24 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
       hipLaunchKernelGGL(attn_d64_ks_kernel, dim3(((p.Nq + 63) / 64) * p.B * p.H), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
       return;
     }
+#ifdef SDXL_MEASURE
     if (g_attn_variant == 4) {
       hipLaunchKernelGGL(attn_d64_v3_kernel, g1, dim3(256), 6 * 64 * 128, s, p, g_attn_zero);
-    } else if (g_attn_variant == 3 && p.Nk > 128) {
+      return;
+    }
+    if (g_attn_variant == 3 && p.Nk > 128) {
       constexpr int NS = 4;
-      static bool set = false;
-      if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_d64_v2_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  NS * 2 * 64 * 128);
-        set = true;
+      static bool set[kMaxDev] = {};
+      if (!set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_d64_v2_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                NS * 2 * 64 * 128) != hipSuccess) throw std::runtime_error("attention: hipFuncSetAttribute failed");
+        set[dev] = true;
       }
       hipLaunchKernelGGL(attn_d64_v2_kernel<NS>, g1, dim3(256), NS * 2 * 64 * 128, s, p, g_attn_zero);
-    } else {
-      hipLaunchKernelGGL(attn_d64_v2_kernel<3>, g1, dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
+      return;
     }
+#endif
+    hipLaunchKernelGGL(attn_d64_v2_kernel<3>, g1, dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
     return;
   }
   if (p.dt == DT_F16 && g_attn_variant >= 0 && g_attn_zero && aligned) {
@@ -1054,11 +1074,11 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
     hipLaunchKernelGGL(attn_d64_kernel<half_t>, grid, dim3(256), lds, s, p);
   } else {
     const size_t lds = 4 * 64 * 256;
-    static bool set = false;
-    if (!set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_d64_kernel<float>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      set = true;
+    static bool set[kMaxDev] = {};
+    if (!set[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_d64_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess) throw std::runtime_error("attention: hipFuncSetAttribute failed");
+      set[dev] = true;
     }
     hipLaunchKernelGGL(attn_d64_kernel<float>, grid, dim3(256), lds, s, p);
   }

@@ -106,7 +106,13 @@ __global__ void causal_mask_kernel(float* out, int n) {
 extern "C" {
 
 const char* sdxl_last_error(void) { return g_err.c_str(); }
-const char* sdxl_build_info(void) { return "sdxl_mi355 engine, HIP kernels for gfx950 (CDNA4, wave64, MFMA 16x16x32 f16 / 16x16x4 f32)"; }
+const char* sdxl_build_info(void) {
+#ifdef SDXL_MEASURE
+  return "sdxl_mi355 engine, HIP kernels for gfx950 (CDNA4, wave64, MFMA 32x32x16 f16 / 32x32x2 f32) [measure build: A/B variants + debug knobs]";
+#else
+  return "sdxl_mi355 engine, HIP kernels for gfx950 (CDNA4, wave64, MFMA 32x32x16 f16 / 32x32x2 f32)";
+#endif
+}
 
 int sdxl_ctx_create(int device_id, sdxl_ctx** out) {
   API_BEGIN
@@ -129,10 +135,10 @@ int sdxl_debug_set(const char* key, int value) {
   SDXL_REQUIRE(key != nullptr, "null key");
   if (std::strcmp(key, "igemm_variant") == 0) igemm_set_variant(value);
   else if (std::strcmp(key, "attn_variant") == 0) attention_set_variant(value);
+#ifdef SDXL_MEASURE
   else if (std::strcmp(key, "igemm_unrolled") == 0) igemm_set_unrolled(value);
   else if (std::strcmp(key, "no_cfg") == 0) g_debug_no_cfg = value != 0;
-  else if (std::strcmp(key, "split_cfg") == 0) g_split_cfg = value != 0;
-  else if (std::strcmp(key, "split_offset") == 0) g_split_offset = value;
+#endif
   else throw Error(std::string("unknown debug key ") + key);
   API_END
 }
@@ -342,6 +348,12 @@ int sdxl_unet_set_graph(sdxl_unet* u, int enabled) {
   API_BEGIN
   SDXL_REQUIRE(u != nullptr, "null argument");
   u->u->set_use_graph(enabled != 0);
+  API_END
+}
+int sdxl_unet_set_split_cfg(sdxl_unet* u, int enabled, int release_offset) {
+  API_BEGIN
+  SDXL_REQUIRE(u != nullptr && release_offset >= 0, "bad argument");
+  u->u->set_split_cfg(enabled != 0, release_offset);
   API_END
 }
 int sdxl_unet_weight_arena(sdxl_unet* u, void** base, size_t* bytes) {
@@ -827,9 +839,12 @@ int sdxl_layer_norm_linear(sdxl_ctx* ctx, void* stream, const float* x, const fl
     Lin id; id.N = K; id.K = K; id.cin = K; id.ksize = 1; id.Kpad = K; id.Npad = (int)round_up(K, 128);
     void* ip = arena.alloc((size_t)id.Npad * id.Kpad * 2);
     float* eye = (float*)tmp.get((size_t)K * K * sizeof(float));
-    SDXL_HIP(hipMemsetAsync(eye, 0, (size_t)K * K * sizeof(float), s));
-    const float one = 1.0f;
-    SDXL_HIP(hipMemcpy2DAsync(eye, (size_t)(K + 1) * sizeof(float), &one, 0, sizeof(float), K, hipMemcpyHostToDevice, s));
+    {
+      std::vector<float> h((size_t)K * K, 0.f);
+      for (int k = 0; k < K; ++k) h[(size_t)k * K + k] = 1.0f;
+      SDXL_HIP(hipMemcpyAsync(eye, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, s));
+      SDXL_HIP(hipStreamSynchronize(s));
+    }
     launch_pack_linear(eye, ip, DT_F16, K, K, id.Kpad, id.Npad, 0, 0, s);
     id.w = ip; id.b = nullptr;
     void* x16 = tmp.get((size_t)M * K * 2);

@@ -214,6 +214,9 @@ class UNet {
   float* eps_out() { return eps_; }
   int compute_dt() const { return cdt_; }
   void set_use_graph(bool g) { use_graph_ = g; }
+  // per-handle option: run the two entries of a batch-2 forward (the CFG pair) as two concurrent batch-1 chains on two
+  // streams, the second released after `release_offset` GEMM launches of the first; bit-identical results
+  void set_split_cfg(bool on, int release_offset) { split_cfg_ = on; split_offset_ = release_offset; }
   // one eager forward of the current plan/context with hipEvents around every launch, summed per kernel class
   void profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[Profiler::NCLS], double flops[Profiler::NCLS],
                hipStream_t s);
@@ -251,6 +254,7 @@ class UNet {
   bool use_graph_ = true;
   // split-CFG mode: the two entries of a batch-2 forward run as two independent batch-1 chains on two streams (fork / join
   // by events, captured into the same graph); the second chain has its own scratch arena
+  bool split_cfg_ = false; int split_offset_ = 0;
   bool plan_split_ = false; int graph_off_ = 0;
   hipStream_t s2_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena act2_;
@@ -352,9 +356,10 @@ struct Conditioning {
   int n = 1, n_ctx = 77, height = 1024, width = 1024;
 };
 
-extern int g_split_offset;    // GEMM launches of chain 0 before chain 1 is released (sdxl_debug_set("split_offset"))
-extern bool g_split_cfg;      // sdxl_debug_set("split_cfg"): run the CFG pair as two concurrent batch-1 chains (UNet::forward, B == 2)
-extern bool g_debug_no_cfg;   // sdxl_debug_set("no_cfg"): base model without the unconditional branch (measurement only)
+#ifdef SDXL_MEASURE
+extern bool g_debug_no_cfg;   // sdxl_debug_set("no_cfg"): base model without the unconditional branch (changes the semantics:
+                              // measurement builds only)
+#endif
 
 class Diffuser {
  public:

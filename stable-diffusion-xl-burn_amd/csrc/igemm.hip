@@ -17,6 +17,7 @@
 //   * fused epilogue: bias, per-batch time-embedding bias, GEGLU (x*gelu_erf(gate) on interleaved column
 //     pairs), residual add, dtype conversion, and an optional transposed store (V^T for the attention kernel).
 #include "kernels.h"
+#include <atomic>
 #include <stdexcept>
 #include <hip/hip_fp16.h>
 
@@ -341,13 +342,16 @@ static void launch_tiles(const IgemmParams& p, hipStream_t s) {
 }
 
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s);   // igemm_glds.hip
-static int g_igemm_variant = 0;   // -1: generic kernel only; 0: auto; >0: forced fast-path tile
-void igemm_set_variant(int v) { g_igemm_variant = v; }
+bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s);             // igemm_glds.hip (strict-fp32 mode)
+static std::atomic<int> g_igemm_variant_a{0};   // test hook (sdxl_debug_set "igemm_variant"): -1 generic kernel only, 0 auto, >0 forced tile
+void igemm_set_variant(int v) { g_igemm_variant_a = v; }
 
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return;
+  const int g_igemm_variant = g_igemm_variant_a.load();
   if (compute_dt == DT_F16 && g_igemm_variant >= 0 && launch_igemm_glds(p, g_igemm_variant, s)) return;
   if (compute_dt == DT_F16 && g_igemm_variant > 0 && launch_igemm_glds(p, 0, s)) return;   // forced tile refused the shape
+  if (compute_dt == DT_F32 && g_igemm_variant >= 0 && launch_igemm_f32_pipe(p, s)) return;
   if (p.ln_stat || p.stat_out)
     throw std::runtime_error("LayerNorm-folded GEMM (ln_stat / stat_out) needs the f16 direct-to-LDS kernels");
   if (compute_dt == DT_F16) {

@@ -20,6 +20,7 @@
 //   igemm_wide_kernel  256x320 tile, k-tile 32                                           (experiment, not selected)
 //   igemm_ws_kernel    8 compute + 2/4 DMA-loader waves                                  (experiment, not selected)
 #include "kernels.h"
+#include <stdexcept>
 #include <type_traits>
 
 namespace sdxl {
@@ -678,11 +679,32 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     f(std::integral_constant<int, N - 1>{});
   }
 }
-template <int OFF> __device__ __forceinline__ half8 lds_read128(unsigned addr) {
-  half8 v;
+template <int OFF, typename F = half8> __device__ __forceinline__ F lds_read128(unsigned addr) {
+  F v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
+// one 32x32 MFMA tile step over the 16-byte fragments of a kk-step.  f16: 8 halfs per lane = one v_mfma_f32_32x32x16_f16.
+// f32 (strict mode): 4 floats per lane = four v_mfma_f32_32x32x2_f32, MFMA e taking element e of every lane -- lanes 0..31
+// hold k-chunk 2kk, lanes 32..63 chunk 2kk+1, so MFMA e contracts k = 8kk + e and 8kk + 4 + e: a permutation of the k order
+// that A and B share (bit-for-bit an fp32 fma chain per output, at the 157 TFLOP/s f32 MFMA rate).
+template <typename T> struct PipeElem;
+template <> struct PipeElem<half_t> {
+  typedef half8 frag;
+  static __device__ __forceinline__ f32x16 mma(const half8& w, const half8& a, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, c, 0, 0, 0);
+  }
+};
+template <> struct PipeElem<float> {
+  typedef f32x4 frag;
+  static __device__ __forceinline__ f32x16 mma(const f32x4& w, const f32x4& a, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], a[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], a[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], a[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], a[3], c, 0, 0, 0);
+    return c;
+  }
+};
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -697,8 +719,11 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
 // WGM = waves along M (4: 4x2 wave grid, 8: 8x1 -- the 256x160 GEGLU tile: N = 10240 / 5120 gives 512 / 1024 tiles = whole
 // rounds of 256 CUs where 256x128 leaves the last round 44 % empty).  BN need not be a multiple of 64: the weight tile's
 // BN/8 eight-row pieces are dealt round-robin, waves below REM carry one more piece and wait on their own count.
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false>
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
+  typedef typename PipeElem<T>::frag frag_t;
+  constexpr int CE = 16 / (int)sizeof(T);     // elements per 16-byte chunk: 8 (f16) or 4 (f32, strict mode)
+  static_assert(sizeof(T) == 2 || DMODE == 0, "measurement modes exist for the f16 kernel only");
   constexpr int WGN = NW / WGM;               // NW waves per workgroup (8, or 4 with twice the wave tile)
   constexpr int WM = BM / WGM, WN = BN / WGN; // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -708,7 +733,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   constexpr int REM = BPC % NW;               // waves >= REM (when REM != 0) have no last weight piece
   constexpr int PER = AJ + BJ;
   static_assert(BM % (8 * NW) == 0 && WM % 32 == 0 && WN % 32 == 0 && BN % 8 == 0, "bad tile");
-  constexpr int KT = 64;
+  constexpr int KT = 8 * CE;                  // elements per k-tile = one 128-byte row (64 f16 / 32 f32)
   constexpr int STAGE = (BM + BN) * 128;
   // measurement-only modes (results wrong by construction): 5 = schedule of mode 0 WITHOUT ds_reads / MFMAs (DMA-only
   // ceiling), 6 = 5 with every DMA piece reading 1 KiB CONTIGUOUS (operands as if pre-tiled [rows/8][K/64][8][64]),
@@ -755,7 +780,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   for (int j = 0; j < AJ; ++j) {
     const int row = (j * NW + wave) * 8 + lrow;
     const int m = m0 + row;
-    rsw[j] = (slot ^ ((row >> 1) & 7)) * 8;
+    rsw[j] = (slot ^ ((row >> 1) & 7)) * CE;
     if (m < p.M) {
       const int b = m / HWo;
       const int rem = m - b * HWo;
@@ -763,14 +788,14 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       rb[j] = b; ry[j] = oy * p.stride - p.pad; rx[j] = (rem - oy * p.Wout) * p.stride - p.pad;
     } else { rb[j] = -1; ry[j] = -(1 << 28); rx[j] = 0; }
   }
-  const half_t* Ag = reinterpret_cast<const half_t*>(p.A);
-  const half_t* wptr[BJ];
+  const T* Ag = reinterpret_cast<const T*>(p.A);
+  const T* wptr[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int row = (j * NW + wave) * 8 + lrow;
-    wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * 8;
+    wptr[j] = reinterpret_cast<const T*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * CE;
   }
-  const half_t* aptr[AJ];
+  const T* aptr[AJ];
   int aadv[AJ];
   int s_c0 = 0, s_dy = 0, s_dx = 0;
   auto retap = [&]() {
@@ -779,7 +804,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       const int iy = ry[j] + s_dy, ix = rx[j] + s_dx;
       const bool ok = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
       const size_t off = (((size_t)(rb[j] < 0 ? 0 : rb[j]) * p.Hin + ((ok ? iy : 0) >> p.up)) * p.Win + ((ok ? ix : 0) >> p.up)) * p.lda + rsw[j];
-      aptr[j] = ok ? Ag + off : reinterpret_cast<const half_t*>(zeros);
+      aptr[j] = ok ? Ag + off : reinterpret_cast<const T*>(zeros);
       aadv[j] = ok ? KT : 0;
     }
   };
@@ -789,7 +814,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
 #pragma unroll
     for (int j = 0; j < AJ; ++j) { aptr[j] = Ag + (size_t)((m0 >> 3) + j * NW + wave) * nkc * 512 + lane * 8; aadv[j] = 512; }
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) wptr[j] = reinterpret_cast<const half_t*>(p.W) + (size_t)((n0 >> 3) + j * NW + wave) * nkc * 512 + lane * 8;
+    for (int j = 0; j < BJ; ++j) wptr[j] = reinterpret_cast<const T*>(p.W) + (size_t)((n0 >> 3) + j * NW + wave) * nkc * 512 + lane * 8;
   }
   // pieces q of one k-tile: q < AJ -> activation piece q, else weight piece q - AJ.  PH selects the pieces with q % 3 == PH
   // (PH < 0: all of them); the tap walk advances once per k-tile, after the last piece (tile_done).
@@ -843,20 +868,20 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     basea = lds0 + ra * 128 + ((fh ^ ((ra >> 1) & 7)) << 4);
     baseb = lds0 + BM * 128 + rbw * 128 + ((fh ^ ((rbw >> 1) & 7)) << 4);
   }
-  half8 fA[DMODE == 4 ? 4 : 2][TM], fB[DMODE == 4 ? 4 : 2][TN];
+  frag_t fA[DMODE == 4 ? 4 : 2][TM], fB[DMODE == 4 ? 4 : 2][TN];
   auto ldfrag = [&](unsigned so, int kk, auto SET) {
     constexpr int set = decltype(SET)::value;
     const unsigned aa = (basea ^ (kk << 5)) + so, ab = (baseb ^ (kk << 5)) + so;
     if constexpr (NOMMA) return;
-    static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<decltype(I)::value * 4096>(aa); });
-    static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<decltype(J)::value * 4096>(ab); });
+    static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<decltype(I)::value * 4096, frag_t>(aa); });
+    static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<decltype(J)::value * 4096, frag_t>(ab); });
   };
   // MFMAs of one kk-step from fragment set SET; DMA pieces PH (or none, PH = 3) are issued between them
   auto mma = [&](auto SET, int buf, auto PH, bool more) {
     constexpr int set = decltype(SET)::value;
     constexpr int ph = decltype(PH)::value;
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-    if constexpr (!NOMMA) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][0], fA[set][0], acc[0][0], 0, 0, 0);
+    if constexpr (!NOMMA) acc[0][0] = PipeElem<T>::mma(fB[set][0], fA[set][0], acc[0][0]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ph < 3) {
       if (more) issue(buf, PH);            // wave-uniform branch around the DMA pieces only, never around MFMAs
@@ -872,7 +897,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     }
     static_for<TM * TN - 1>([&](auto X) {
       constexpr int x = decltype(X)::value + 1, i = x / TN, j = x % TN;
-      if constexpr (!NOMMA) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][j], fA[set][i], acc[i][j], 0, 0, 0);
+      if constexpr (!NOMMA) acc[i][j] = PipeElem<T>::mma(fB[set][j], fA[set][i], acc[i][j]);
       if constexpr (ph == 4 && x < TM * TN - 1) {
         __builtin_amdgcn_sched_barrier(0);
         if (more) issue(buf, std::integral_constant<int, 10 + x>{});
@@ -926,8 +951,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       constexpr int hi = PERSLOT ? (int)(so / STAGE) : (so >= 65536u ? 1 : 0);
       constexpr unsigned lo = PERSLOT ? 0u : so - hi * 65536u;
       static_assert(lo + (TM - 1) * 4096 < 65536u && lo + (TN - 1) * 4096 < 65536u, "fragment immediate out of range");
-      static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<lo + decltype(I)::value * 4096>(fa[hi][kk]); });
-      static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<lo + decltype(J)::value * 4096>(fb[hi][kk]); });
+      static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<lo + decltype(I)::value * 4096, frag_t>(fa[hi][kk]); });
+      static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<lo + decltype(J)::value * 4096, frag_t>(fb[hi][kk]); });
     };
     auto ktile = [&](int kt, auto CUR) {
       constexpr int c = decltype(CUR)::value;
@@ -1033,6 +1058,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   }
 }
 
+#ifdef SDXL_MEASURE   // experiments that lost their A/B: built only by `build.py --measure`
 // ---------------------------------------------------------------------------------------------------------
 // Wide-tile variant for the GEGLU projections: block tile 256 x 320, k-tile 32.
 //
@@ -1383,66 +1409,75 @@ __global__ __launch_bounds__(512 + 64 * NL) void igemm_ws_kernel(const IgemmPara
   igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC, zeros);
 }
 
-static const void* g_zero_page = nullptr;
+#endif  // SDXL_MEASURE
+
+// Per-DEVICE state: the zero page the DMA reads halo / tail rows from lives on the device that launches, and the
+// dynamic-LDS attribute (up to 147 KiB) is set once per (kernel, device).  A second sdxl_ctx on another GPU of the same
+// process gets its own.
+constexpr int kMaxDev = 64;
+static const void* g_zero_pages[kMaxDev] = {};
+static int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDev) throw std::runtime_error("igemm: no current HIP device");
+  return d;
+}
 void igemm_glds_init() {
-  if (g_zero_page) return;
+  const int d = current_device();
+  if (g_zero_pages[d]) return;
   void* z = nullptr;
-  if (hipMalloc(&z, 4096) != hipSuccess) return;
-  (void)hipMemset(z, 0, 4096);
-  g_zero_page = z;
+  if (hipMalloc(&z, 4096) != hipSuccess || hipMemset(z, 0, 4096) != hipSuccess)
+    throw std::runtime_error("igemm: cannot allocate the zero page");
+  g_zero_pages[d] = z;
+}
+template <typename K> static void set_lds_attr(K kernel, size_t lds, bool (&done)[kMaxDev], int dev) {
+  if (done[dev]) return;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    throw std::runtime_error("igemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  done[dev] = true;
 }
 
 template <int BM, int BN, int NS, int MINB = 2>
 static void launch_glds(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NS * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, NS, MINB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_page);
+  static bool attr_set[kMaxDev] = {};
+  const int dev = current_device();
+  set_lds_attr(&igemm_glds_kernel<BM, BN, NS, MINB>, lds, attr_set, dev);
+  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_pages[dev]);
 }
 
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false>
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NS * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR>), dim3(tilesM * tilesN), dim3(64 * NW), lds, s, p, g_zero_page);
+  static bool attr_set[kMaxDev] = {};
+  const int dev = current_device();
+  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T>, lds, attr_set, dev);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T>), dim3(tilesM * tilesN), dim3(64 * NW), lds, s, p, g_zero_pages[dev]);
 }
 
+#ifdef SDXL_MEASURE
 template <int BM, int BN, int NS, int NL>
 static void launch_ws(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NS * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ws_kernel<BM, BN, NS, NL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((igemm_ws_kernel<BM, BN, NS, NL>), dim3(tilesM * tilesN), dim3(512 + 64 * NL), lds, s, p, g_zero_page);
+  static bool attr_set[kMaxDev] = {};
+  const int dev = current_device();
+  set_lds_attr(&igemm_ws_kernel<BM, BN, NS, NL>, lds, attr_set, dev);
+  hipLaunchKernelGGL((igemm_ws_kernel<BM, BN, NS, NL>), dim3(tilesM * tilesN), dim3(512 + 64 * NL), lds, s, p, g_zero_pages[dev]);
 }
 
 static void launch_wide(const IgemmParams& p, hipStream_t s) {
   constexpr int NS = 4;
   const int tilesM = (p.M + 255) / 256, tilesN = (p.N + 319) / 320;
   const size_t lds = (size_t)NS * (256 + 320) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wide_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((igemm_wide_kernel<NS>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_page);
+  static bool attr_set[kMaxDev] = {};
+  const int dev = current_device();
+  set_lds_attr(&igemm_wide_kernel<NS>, lds, attr_set, dev);
+  hipLaunchKernelGGL((igemm_wide_kernel<NS>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_pages[dev]);
 }
+
+#endif  // SDXL_MEASURE
 
 // variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
 // 6 = 64x128 ring 2; 7 = 128x128 ring 4; 8 = 64x128 ring 3.  Returns false when the shape needs the generic kernel.
@@ -1450,7 +1485,7 @@ static bool g_igemm_unrolled = true;
 void igemm_set_unrolled(int v) { g_igemm_unrolled = v != 0; }
 
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
-  if (!g_zero_page) return false;
+  if (!g_zero_pages[current_device()]) return false;
   if (p.act > 1) return false;   // GELU / QuickGELU epilogues (CLIP MLP, once per prompt) live in the generic kernel
   if (p.a_dt != DT_F16 || (p.Cin % 64) != 0 || (p.lda % 8) != 0 || (p.Kpad % 64) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
@@ -1468,45 +1503,50 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
     const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-    if (t128 <= 256) variant = 13;
-    else if (t256 <= 256 || eff256 >= 0.8) variant = 11;
+    if (t128 <= 256) variant = 36;
+    else if (t256 <= 256 || eff256 >= 0.8) variant = 35;
     else variant = t128 >= 400 ? 4 : 6;
-    if (p.act == 1 && p.N % 160 == 0 && variant != 11) {
+    if (p.act == 1 && p.N % 160 == 0 && variant != 35) {
       // single-prompt (M = 1024) GEGLU: 256x160 gives exactly one round of 256 tiles where 128x128 needs 2.5
       const long t160 = (long)((p.M + 255) / 256) * (p.N / 160);
-      if (t160 <= 256 && t160 * 160 * 2 >= t128 * 128) variant = 19;
+      if (t160 <= 256 && t160 * 160 * 2 >= t128 * 128) variant = 38;
     }
-    if (p.act == 1 && p.N % 160 == 0 && variant == 11) {
+    if (p.act == 1 && p.N % 160 == 0 && variant == 35) {
       // GEGLU projections: the 256x160 tile (8x1 waves) when it saves whole rounds of 256 CUs (N = 10240 at M = 2048: 512
       // tiles = 2 rounds instead of 640 = 2.5 -> 3); it pays ~10 % more LDS reads per MFMA, so it must win >= 15 % of area
       const long t160 = (long)((p.M + 255) / 256) * (p.N / 160);
       const double cost128 = (double)((t256 + 255) / 256) * 128.0, cost160 = (double)((t160 + 255) / 256) * 160.0 * 1.12;
-      if (cost160 < cost128) variant = 19;
+      if (cost160 < cost128) variant = 38;
     }
   }
-  if (was_auto && g_igemm_unrolled) {
-    // the pipelined kernels with the k-loop unrolled by the ring depth (fewer instructions per MFMA, no s_setprio): measured
-    // 4..12 % faster on every shape of the step (tools/igemm_ksweep.py 11,35,37); sdxl_debug_set("igemm_unrolled", 0) = A/B
-    if (variant == 11) variant = 35; else if (variant == 13) variant = 36; else if (variant == 19) variant = 38;
+#ifdef SDXL_MEASURE
+  if (was_auto && !g_igemm_unrolled) {   // A/B against the rolled loops (profiles/r01_igemm_unrolled_ab.txt)
+    if (variant == 35) variant = 11; else if (variant == 36) variant = 13; else if (variant == 38) variant = 19;
   }
+#else
+  (void)was_auto;
+#endif
   switch (variant) {
+    // ---- production kernels (what the auto selection launches)
+    case 4: launch_glds<128, 128, 2>(p, s); break;                          // 4 waves, 2-3 co-resident blocks: ragged multi-round grids
+    case 6: launch_glds<64, 128, 2>(p, s); break;
+    case 35: launch_pipe<256, 128, 3, false, 0, 4, 8, true>(p, s); break;   // 8 waves, hand-ordered k-loop unrolled by the ring depth
+    case 36: launch_pipe<128, 128, 4, false, 0, 4, 8, true>(p, s); break;
+    case 38:                                                                // 256x160 GEGLU tile (8x1 waves)
+      if (p.N % 160 != 0) return false;
+      launch_pipe<256, 160, 3, false, 0, 8, 8, true>(p, s); break;
+#ifdef SDXL_MEASURE
+    // ---- A/B partners and experiments (build.py --measure): rolled loops, other rings, loader waves, measurement modes
     case 1: launch_glds<128, 128, 3>(p, s); break;
     case 2: launch_glds<128, 64, 4>(p, s); break;
     case 3: launch_glds<64, 128, 4>(p, s); break;
-    case 4: launch_glds<128, 128, 2>(p, s); break;
     case 5: launch_glds<128, 64, 2>(p, s); break;
-    case 6: launch_glds<64, 128, 2>(p, s); break;
     case 7: launch_glds<128, 128, 4>(p, s); break;
     case 8: launch_glds<64, 128, 3>(p, s); break;
     case 33: launch_glds<256, 128, 3, 1>(p, s); break;
-    case 34: launch_pipe<256, 128, 3, true, 0, 2, 4>(p, s); break;   // experiment: the hand-ordered loop on 4 waves x (128x64)
-    case 35: launch_pipe<256, 128, 3, false, 0, 4, 8, true>(p, s); break;   // unrolled ring (slots as immediates), no s_setprio
-    case 36: launch_pipe<128, 128, 4, false, 0, 4, 8, true>(p, s); break;
-    case 37: launch_pipe<256, 128, 3, true, 0, 4, 8, true>(p, s); break;    // the same with s_setprio
-    case 38:                                                    // 256x160 GEGLU tile, unrolled ring
-      if (p.N % 160 != 0) return false;
-      launch_pipe<256, 160, 3, false, 0, 8, 8, true>(p, s); break;   // experiment: 4 waves, wave tile 128x64 (6 fragment reads per 8 MFMAs)
-    case 10: launch_pipe<256, 128, 3, false>(p, s); break;   // 8-wave pipelined kernels
+    case 34: launch_pipe<256, 128, 3, true, 0, 2, 4>(p, s); break;   // the hand-ordered loop on 4 waves x (128x64)
+    case 37: launch_pipe<256, 128, 3, true, 0, 4, 8, true>(p, s); break;    // unrolled ring with s_setprio
+    case 10: launch_pipe<256, 128, 3, false>(p, s); break;   // rolled 8-wave pipelined kernels
     case 11: launch_pipe<256, 128, 3, true>(p, s); break;
     case 12: launch_pipe<128, 128, 4, false>(p, s); break;
     case 13: launch_pipe<128, 128, 4, true>(p, s); break;
@@ -1526,15 +1566,36 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 31: launch_pipe<128, 128, 4, true, 6>(p, s); break;
     case 32: launch_pipe<128, 128, 4, true, 7>(p, s); break;
     case 25: launch_pipe<128, 128, 4, true, 4>(p, s); break;
-    case 19:                                                    // 256x160, 8x1 waves: weight rows must exist up to the tile edge
+    case 19:                                                    // 256x160, 8x1 waves, rolled
       if (p.N % 160 != 0) return false;
       launch_pipe<256, 160, 3, true, 0, 8>(p, s); break;
     case 20: launch_ws<256, 128, 3, 2>(p, s); break;            // 8 compute + 2 loader waves
     case 21: launch_ws<256, 128, 3, 4>(p, s); break;            // 8 compute + 4 loader waves
     case 22: launch_ws<128, 128, 4, 2>(p, s); break;
     case 23: launch_ws<128, 128, 4, 4>(p, s); break;
+#endif
     default: return false;
   }
+  return true;
+}
+
+// Strict-fp32 mode on the same direct-to-LDS pipeline (the VAE at the reference's precision, sample/main.rs:121,273, and the
+// parity configuration of the UNet): fp32 operands staged as 128-byte rows of 32 k-values, four v_mfma_f32_32x32x2_f32 per
+// fragment pair.  The f32 MFMA runs at 1/16 of the f16 rate, so these launches are matrix-pipe bound and the tile choice
+// only has to keep the rounds of 256 CUs full.  Returns false for shapes the generic kernel must take.
+bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s) {
+  if (!g_zero_pages[current_device()]) return false;
+  if (p.act > 1 || p.ln_stat || p.stat_out) return false;
+  if (p.a_dt != DT_F32 || (p.Cin % 32) != 0 || (p.lda % 4) != 0 || (p.Kpad % 32) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
+  if (p.n_split < p.N && (p.n_split & 3) != 0) return false;
+  if (p.ebias && (p.ebias_ld & 3) != 0) return false;
+  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+  const double eff128 = (double)t128 / (double)(((t128 + 255) / 256) * 256);
+  const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+  if (eff256 >= eff128) launch_pipe<256, 128, 3, false, 0, 4, 8, true, float>(p, s);
+  else launch_pipe<128, 128, 4, false, 0, 4, 8, true, float>(p, s);
   return true;
 }
 

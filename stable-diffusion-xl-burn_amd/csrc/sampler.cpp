@@ -38,7 +38,11 @@ Diffuser::~Diffuser() {
     if (p) (void)hipFree(p);
 }
 
+#ifdef SDXL_MEASURE
 bool g_debug_no_cfg = false;
+#else
+static constexpr bool g_debug_no_cfg = false;
+#endif
 
 void Diffuser::diffuse(float* latent, const Conditioning& c, int step_start, int n_steps, double cfg_scale,
                        const float* reference, const unsigned char* mask, const float* step_noise, hipStream_t s) {

@@ -90,6 +90,7 @@ void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, 
   p.dt = ex.cdt; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
   if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0);
   launch_attention_d64(p, ex.s);
+  SDXL_HIP(hipGetLastError());
   if (ex.prof) ex.prof->end(ex.s);
 }
 }  // namespace
@@ -391,11 +392,8 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
   }
 }
 
-bool g_split_cfg = false;
-int g_split_offset = 0;
-
 void UNet::ensure_plan(int B, int H, int W) {
-  const bool split = g_split_cfg && B == 2;
+  const bool split = split_cfg_ && B == 2;
   if (B == pB_ && H == pH_ && W == pW_ && split == plan_split_) return;
   SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
   const int div = 1 << (cfg_.channel_mults.size() - 1);
@@ -462,7 +460,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     if (!plan_split_) { run(ex, t_dev, t_stride, 0, B); return; }
     Exec e2; e2.s = s2_; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_;
     act2_.off = 0;
-    ex.fork_ev = ev_fork_; ex.fork_after = g_split_offset; ex.launches = 0;
+    ex.fork_ev = ev_fork_; ex.fork_after = split_offset_; ex.launches = 0;
     if (ex.fork_after <= 0) SDXL_HIP(hipEventRecord(ev_fork_, s));
     run(ex, t_dev, t_stride, 0, 1);
     if (ex.fork_after > 0 && ex.launches < ex.fork_after) SDXL_HIP(hipEventRecord(ev_fork_, s));   // offset beyond the chain
@@ -472,7 +470,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     SDXL_HIP(hipEventRecord(ev_join_, s2_));
     SDXL_HIP(hipStreamWaitEvent(s, ev_join_, 0));
   };
-  if (use_graph_ && graph_ && (graph_t_ != t_dev || graph_ts_ != t_stride || graph_off_ != g_split_offset)) {
+  if (use_graph_ && graph_ && (graph_t_ != t_dev || graph_ts_ != t_stride || graph_off_ != split_offset_)) {
     (void)hipGraphExecDestroy(graph_); graph_ = nullptr;
   }
   if (use_graph_ && !graph_ && plan_runs_ >= 1) {
@@ -483,7 +481,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     SDXL_HIP(hipStreamEndCapture(s, &g));
     SDXL_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
     SDXL_HIP(hipGraphDestroy(g));
-    graph_t_ = t_dev; graph_ts_ = t_stride; graph_off_ = g_split_offset;
+    graph_t_ = t_dev; graph_ts_ = t_stride; graph_off_ = split_offset_;
     act_.reset(m);
   }
   if (use_graph_ && graph_) {

@@ -258,6 +258,7 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   SDXL_REQUIRE(!(ex.cdt == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
   if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize);
   launch_igemm(p, ex.cdt, ex.s);
+  SDXL_HIP(hipGetLastError());     // a refused launch (bad grid / LDS attribute) must not pass silently
   if (ex.prof) ex.prof->end(ex.s);
   if (ex.fork_ev && ++ex.launches == ex.fork_after) SDXL_HIP(hipEventRecord(ex.fork_ev, ex.s));
 }
@@ -277,6 +278,7 @@ void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const 
   p.B = B; p.HW = HW; p.C = n.C; p.G = groups; p.eps = 1e-5f; p.eps_ptr = n.eps; p.silu = silu ? 1 : 0;
   if (ex.prof) ex.prof->begin(Profiler::GROUPNORM, 0.0, ex.s);
   launch_groupnorm(p, ex.s);
+  SDXL_HIP(hipGetLastError());
   if (ex.prof) ex.prof->end(ex.s);
 }
 void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y) {

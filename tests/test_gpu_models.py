@@ -101,7 +101,7 @@ def test_unet_forward_per_norm_eps(pkg, ctx, dtype):
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
 def test_split_cfg_chains_equal_batched_pair(pkg, ctx, dtype):
-    # sdxl_debug_set("split_cfg"): the two entries of a batch-2 forward as two concurrent batch-1 chains (fork / join inside
+    # sdxl_unet_set_split_cfg (per handle): the two entries of a batch-2 forward as two concurrent batch-1 chains (fork / join inside
     # the captured graph, second chain released after `split_offset` GEMMs) -- same bits as the batched pair, eager and replayed
     ocfg = OC.tiny_config()
     u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
@@ -112,15 +112,13 @@ def test_split_cfg_chains_equal_batched_pair(pkg, ctx, dtype):
     ref = u.forward(x, t, context, y)
     try:
         for off in (0, 3, 10000):
-            pkg.debug_set("split_cfg", 1)
-            pkg.debug_set("split_offset", off)
+            u.set_split_cfg(True, off)
             outs = [u.forward(x, t, context, y) for _ in range(3)]      # eager, capture, replay
             assert all(torch.equal(o, ref) for o in outs), off
-        one = u.forward(x[:1], t[:1], context[:1], y[:1])                # batch 1 is untouched by the knob
+        one = u.forward(x[:1], t[:1], context[:1], y[:1])                # batch 1 is untouched by the option
         assert torch.equal(one[0], ref[0])
     finally:
-        pkg.debug_set("split_cfg", 0)
-        pkg.debug_set("split_offset", 0)
+        u.set_split_cfg(False)
     assert torch.equal(u.forward(x, t, context, y), ref)
 
 

@@ -18,8 +18,7 @@ d = pkg.Diffuser(ctx, cfg, pkg.DTYPE_F16, seed=0)
 res = {}
 OFFS = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
 for mode, off in [(0, 0)] + [(1, o) for o in OFFS]:
-    pkg.debug_set("split_cfg", mode)
-    pkg.debug_set("split_offset", off)
+    d.diffusion.set_split_cfg(bool(mode), off)
     out = d.sample_latent(cond, 7.5, STEPS, noise)
     best = 1e9
     for _ in range(2):
