@@ -209,6 +209,22 @@ int sdxl_diffuser_create_empty(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int d
                                int n_train_steps, sdxl_diffuser** out);
 int sdxl_vae_create_empty(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, int with_encoder, sdxl_vae** out);
 
+/* ---- one-time weight broadcast over RCCL / xGMI (the reference is single-device, sample/main.rs:131).
+ * One process per GPU.  Rank 0 calls sdxl_comm_unique_id and ships the 128 bytes to the other ranks by any host channel;
+ * every rank then creates its communicator and the replicas (created with sdxl_*_create_empty: identical arena layout)
+ * receive rank `root`'s packed weights.  Schedule: scatter of world equal pieces over the root's links + in-place all-gather
+ * + a small tail broadcast (sdxl_bcast_plan describes it; no collective runs inside the sampling loop). */
+typedef struct sdxl_comm sdxl_comm;
+int sdxl_comm_unique_id(void* id_out_128);
+int sdxl_comm_create(int device_id, int rank, int world, const void* id_128, sdxl_comm** out);
+void sdxl_comm_destroy(sdxl_comm* c);
+int sdxl_bcast_buffer(sdxl_comm* c, void* stream, void* base_dev, size_t bytes, int root);
+int sdxl_unet_bcast_weights(sdxl_comm* c, sdxl_unet* u, int root);
+int sdxl_vae_bcast_weights(sdxl_comm* c, sdxl_vae* v, int root);
+int sdxl_clip_bcast_weights(sdxl_comm* c, sdxl_clip* k, int root);
+/* the schedule as data: this rank's piece [piece_off, +piece_len) and the common tail [tail_off, +tail_len) of `bytes` */
+int sdxl_bcast_plan(size_t bytes, int world, int rank, size_t* piece_off, size_t* piece_len, size_t* tail_off, size_t* tail_len);
+
 /* ---- measurement: one eager UNet forward of the current plan/context with hipEvents around every launch, summed per
  * kernel class (index: 0 implicit-GEMM conv/linear, 1 fused attention, 2 GroupNorm, 3 LayerNorm, 4 other); arrays of 5 */
 int sdxl_unet_profile(sdxl_unet* u, void* stream, int B, int H, int W, float class_ms[5], int class_launches[5],

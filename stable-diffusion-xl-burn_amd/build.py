@@ -20,7 +20,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsdxl_mi355.so")
 ARCH = "gfx950"
 SOURCES = ["igemm.hip", "igemm_glds.hip", "norm.hip", "attention.hip", "elementwise.hip", "capi.hip",
-           "specs.cpp", "weights.cpp", "unet.cpp", "vae.cpp", "sampler.cpp", "clip.cpp"]
+           "specs.cpp", "weights.cpp", "unet.cpp", "vae.cpp", "sampler.cpp", "clip.cpp", "comm.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
 
@@ -71,7 +71,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs = list(ex.map(lambda n: _compile(n, force), SOURCES))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -85,6 +85,14 @@ struct Tmp {   // scoped device scratch for the single-op entry points
   ~Tmp() { for (void* p : ptrs) (void)hipFree(p); }
   void* get(size_t bytes) { void* p = nullptr; SDXL_HIP(hipMalloc(&p, bytes ? bytes : 16)); ptrs.push_back(p); return p; }
 };
+// the single-op entry points run the same kernel selection as the models, split-K included (f16 compute only)
+void give_splitk_ws(Exec& ex, Tmp& tmp, int batch, int rows_per_entry, int n, hipStream_t s) {
+  if (ex.cdt != DT_F16) return;
+  ex.splitk_ws_bytes = igemm_splitk_ws_bytes(batch, rows_per_entry, n);
+  ex.splitk_ws = (float*)tmp.get(ex.splitk_ws_bytes);
+  ex.splitk_cnt = (unsigned*)tmp.get(kSplitkCounters * sizeof(unsigned));
+  SDXL_HIP(hipMemsetAsync(ex.splitk_cnt, 0, kSplitkCounters * sizeof(unsigned), s));
+}
 
 __global__ void transpose_pad_kernel(const float* src, int lds_, int rows, int C, void* dst, int dt, int ldd) {
   // dst[c][r] = src[r][c]   (dst rows of ldd elements, caller zero-fills the padding)
@@ -170,6 +178,7 @@ int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, 
   launch_copy_rows(xsrc, DT_F32, Cin, xi, DT_F16, Cin, (int)M, Cin, s);
   l.w = wp; l.b = bp;
   Exec ex; ex.s = s; ex.cdt = DT_F16; ex.sdt = DT_F16;
+  give_splitk_ws(ex, tmp, B, H * W, Cout, s);
   const bool ln_in = (geglu & 2) != 0, st_out = (geglu & 4) != 0, cold = (geglu & 8) != 0;
   geglu &= 1;
   // cold mode: rotate through enough copies of the weight (> 256 MB Infinity Cache) that every launch streams it from HBM,
@@ -706,6 +715,21 @@ int sdxl_vae_weight_arena(sdxl_vae* v, void** base, size_t* bytes) {
   API_END
 }
 
+// ---------------------------------------------------------------------------------------------- weight broadcast (comm.cpp)
+void sdxl_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }
+int sdxl_unet_bcast_weights(sdxl_comm* comm, sdxl_unet* u, int root) {
+  if (!comm || !u) return fail(SDXL_ERR_RUNTIME, "null argument");
+  return sdxl_bcast_buffer(comm, nullptr, u->u->weight_base(), u->u->weight_bytes(), root);
+}
+int sdxl_vae_bcast_weights(sdxl_comm* comm, sdxl_vae* v, int root) {
+  if (!comm || !v) return fail(SDXL_ERR_RUNTIME, "null argument");
+  return sdxl_bcast_buffer(comm, nullptr, v->v->weight_base(), v->v->weight_bytes(), root);
+}
+int sdxl_clip_bcast_weights(sdxl_comm* comm, sdxl_clip* c, int root) {
+  if (!comm || !c) return fail(SDXL_ERR_RUNTIME, "null argument");
+  return sdxl_bcast_buffer(comm, nullptr, c->c->weight_base(), c->c->weight_bytes(), root);
+}
+
 // ---------------------------------------------------------------------------------------------- single ops
 int sdxl_group_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, int B, int C, int HW,
                     int n_group, float eps, int silu, int dtype, float* out) {
@@ -719,7 +743,7 @@ int sdxl_group_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* ga
   Tmp tmp;
   void* xi = tmp.get((size_t)B * HW * C * dt_size(sdt));
   void* yo = tmp.get((size_t)B * HW * C * dt_size(cdt));
-  float* part = (float*)tmp.get((size_t)B * n_group * (128 * 3 + 2) * sizeof(float));
+  float* part = (float*)tmp.get(groupnorm_workspace_floats(B, n_group) * sizeof(float));
   launch_nchw_to_nhwc(x, C * HW, xi, sdt, B, C, HW, C, 1.0f, s);
   GroupNormParams p{};
   p.X = xi; p.x_dt = sdt; p.ldx = C; p.Y = yo; p.y_dt = cdt; p.ldy = C; p.gamma = gamma; p.beta = beta; p.partial = part;
@@ -770,6 +794,7 @@ int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   l.w = wp; l.b = bp;
   launch_nchw_to_nhwc(x, Cin * H * W, xi, sdt, B, Cin, H * W, Cin, 1.0f, s);
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
+  give_splitk_ws(ex, tmp, B, Ho * Wo, Cout, s);
   run_conv(ex, l, Act(xi, Cin, sdt), Cin, ConvGeom{B, H, W, Ho, Wo, ksize, stride, pad, upsample ? 1 : 0}, Act(yo, Cout, DT_F32));
   launch_nhwc_to_nchw(yo, DT_F32, Cout, out, B, Cout, Ho * Wo, 1.0f, s);
   SDXL_HIP(hipStreamSynchronize(s));
@@ -794,6 +819,7 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   l.w = wp; l.b = bp;
   launch_copy_rows(x, DT_F32, K, xi, sdt, K, M, K, s);
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
+  give_splitk_ws(ex, tmp, 1, M, N, s);
   Epi e; e.act = geglu ? 1 : 0;
   run_linear(ex, l, Act(xi, K, sdt), M, Act(out, geglu ? N / 2 : N, DT_F32), e);
   SDXL_HIP(hipStreamSynchronize(s));

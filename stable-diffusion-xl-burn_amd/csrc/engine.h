@@ -163,6 +163,7 @@ struct Exec {
   int sdt = DT_F16;      // residual-stream dtype
   DeviceArena* act = nullptr;
   float* gn_partial = nullptr;
+  float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0; unsigned* splitk_cnt = nullptr;   // igemm split-K workspace (optional)
   const float* ebias = nullptr;   // [nb][emb_total] per-ResBlock time-embedding biases of this run's batch entries
   int b0 = 0;                      // first batch entry of this run (split-CFG chains address the K/V caches with it)
   hipEvent_t fork_ev = nullptr;    // split-CFG: recorded on s after the fork_after-th GEMM launch of chain 0 -- the second
@@ -250,6 +251,8 @@ class UNet {
   DeviceArena act_;
   void* in_ = nullptr; float* eps_ = nullptr;
   float *temb_ = nullptr, *g1_ = nullptr, *emb_ = nullptr, *ebias_ = nullptr, *gn_partial_ = nullptr, *tconv_ = nullptr;
+  // split-K workspaces of the implicit GEMM (slabs + arrival counters), one per concurrent chain
+  float* skws_[2] = {nullptr, nullptr}; unsigned* skcnt_[2] = {nullptr, nullptr}; size_t skws_bytes_ = 0;
   bool fuse_ln_ = false;                 // f16 compute + f16 residual stream: LayerNorms are folded into the GEMMs
   bool use_graph_ = true;
   // split-CFG mode: the two entries of a batch-2 forward run as two independent batch-1 chains on two streams (fork / join

@@ -760,6 +760,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // split-K (grid = tiles x SK): consecutive remapped ids = the SK k-slices of one tile, so a tile's slices share an XCD
+  // (its L2 then serves the partial slabs to the reducing workgroup at the same-XCD rate; placement is speed only)
+  const int SK = p.splitk > 1 ? p.splitk : 1;
+  const int slice = SK > 1 ? bid % SK : 0;
+  if (SK > 1) bid /= SK;
+  const int tile_id = bid;
   int tm, tn;
   if ((size_t)p.N * p.K > (size_t)p.M * p.Cin) { tn = bid / tilesM; tm = bid - tn * tilesM; }
   else { tm = bid / tilesN; tn = bid - tm * tilesN; }
@@ -795,15 +801,25 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     const int row = (j * NW + wave) * 8 + lrow;
     wptr[j] = reinterpret_cast<const T*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * CE;
   }
+  // this workgroup's k-tiles [kbeg, kbeg + nk) of the Kpad / KT of the contraction (split-K: slice `slice` of SK)
+  const int nk_all = p.Kpad / KT;
+  const int kbeg = SK > 1 ? (int)((long)slice * nk_all / SK) : 0;
+  const int nk = SK > 1 ? (int)((long)(slice + 1) * nk_all / SK) - kbeg : nk_all;
   const T* aptr[AJ];
   int aadv[AJ];
   int s_c0 = 0, s_dy = 0, s_dx = 0;
+  if (kbeg > 0) {   // start the tap walk inside the contraction
+    const int e0 = kbeg * KT, tap = e0 / p.Cin;
+    s_c0 = e0 - tap * p.Cin; s_dy = tap / p.ksize; s_dx = tap - s_dy * p.ksize;
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) wptr[j] += e0;
+  }
   auto retap = [&]() {
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int iy = ry[j] + s_dy, ix = rx[j] + s_dx;
       const bool ok = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
-      const size_t off = (((size_t)(rb[j] < 0 ? 0 : rb[j]) * p.Hin + ((ok ? iy : 0) >> p.up)) * p.Win + ((ok ? ix : 0) >> p.up)) * p.lda + rsw[j];
+      const size_t off = (((size_t)(rb[j] < 0 ? 0 : rb[j]) * p.Hin + ((ok ? iy : 0) >> p.up)) * p.Win + ((ok ? ix : 0) >> p.up)) * p.lda + rsw[j] + s_c0;
       aptr[j] = ok ? Ag + off : reinterpret_cast<const T*>(zeros);
       aadv[j] = ok ? KT : 0;
     }
@@ -857,7 +873,6 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.Kpad / KT;
   const int fr = lane & 31, fh = lane >> 5;
   // per-lane fragment address inside a stage: A rows wm*WM + i*32 + fr (i -> +4096 B immediate), B rows likewise behind
   // the A tile.  sw(row) = (row>>1)&7 is the same for rows 32 apart, so one base per operand; step kk flips chunk bits
@@ -1049,6 +1064,52 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   }
   __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring: it becomes the staging area
   asm volatile("" ::: "memory");
+  if constexpr (BN == 128 && DMODE == 0) {
+    if (SK > 1) {
+      // ---- split-K combine inside the launch.  Every slice parks its fp32 accumulators in its slab (register order: 16-byte
+      // stores, lane-contiguous), then ONE agent-scope release + ticket; the workgroup that draws the last ticket acquires
+      // once and sums the SK slabs in slice order 0..SK-1 -- its own included, so the result does not depend on which slice
+      // arrived last (bit-reproducible) -- and runs the normal epilogue.  Correct for any placement of the slices
+      // (cdna_hip_programming.md section 6 guideline 16: plain stores -> vmcnt(0) -> barrier -> lane-0 release -> asm vmcnt(0)
+      // -> relaxed agent ticket; consumer: acquire once -> barrier -> plain loads).  The last arriver re-arms the counter.
+      constexpr int NV = TM * TN * 4;                                    // f32x4 vectors per lane
+      f32x4* slab = reinterpret_cast<f32x4*>(p.splitk_ws) + ((size_t)tile_id * SK + slice) * (size_t)(NW * NV * 64);
+      static_for<TM * TN>([&](auto X) {
+        constexpr int x = decltype(X)::value, i = x / TN, j = x % TN;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          slab[(size_t)((wave * NV + x * 4 + q) * 64 + lane)] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+      });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      volatile int* flag = reinterpret_cast<volatile int*>(smem + NS * STAGE - 16);   // inside the one LDS array, beyond the staging regions
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (unsigned)(SK - 1);
+        if (last) {
+          __hip_atomic_store(p.splitk_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *flag = last;
+      }
+      __syncthreads();
+      if (!*flag) return;
+      const f32x4* s0 = reinterpret_cast<const f32x4*>(p.splitk_ws) + (size_t)tile_id * SK * (size_t)(NW * NV * 64);
+      static_for<TM * TN>([&](auto X) {
+        constexpr int x = decltype(X)::value, i = x / TN, j = x % TN;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 sum = s0[(size_t)((wave * NV + x * 4 + q) * 64 + lane)];
+          for (int sl = 1; sl < SK; ++sl) sum += s0[(size_t)sl * (NW * NV * 64) + (size_t)((wave * NV + x * 4 + q) * 64 + lane)];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] = sum[r];
+        }
+      });
+      __syncthreads();          // every wave has read the flag before the staging regions are written
+    }
+  }
   constexpr bool FITS = NW * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
   if (FITS || p.act == 1) {
     const int region = p.act == 1 ? WM * (WN / 2) * 4 : WM * WN * 4;   // GEGLU halves the staged width
@@ -1453,7 +1514,11 @@ static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   static bool attr_set[kMaxDev] = {};
   const int dev = current_device();
   set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T>, lds, attr_set, dev);
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T>), dim3(tilesM * tilesN), dim3(64 * NW), lds, s, p, g_zero_pages[dev]);
+  const int sk = (BN == 128 && DMODE == 0 && p.splitk > 1) ? p.splitk : 1;
+  if (sk > 1 && (size_t)tilesM * tilesN * sk * BM * BN * 4 > p.splitk_ws_bytes) throw std::runtime_error("igemm: split-K workspace too small");
+  IgemmParams q = p;
+  q.splitk = sk;
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
 }
 
 #ifdef SDXL_MEASURE
@@ -1484,6 +1549,21 @@ static void launch_wide(const IgemmParams& p, hipStream_t s) {
 static bool g_igemm_unrolled = true;
 void igemm_set_unrolled(int v) { g_igemm_unrolled = v != 0; }
 
+// Split-K rule.  It depends on ONE batch entry's shape (rows per entry, N, K) only -- never on the batch size -- so an entry
+// comes out bit-identical whether it runs alone or next to others (the CFG pair as one batch-2 forward, split-CFG chains).
+int igemm_splitk_slices(const IgemmParams& p) {
+  if (!p.splitk_ws || !p.splitk_cnt) return 1;
+  if (p.act != 0 || p.n_split < p.N || p.ln_stat) return 1;
+  const int nk = p.Kpad / 64;
+  if (p.rpb <= 0 || p.rpb > 1024 || p.N > 1280 || nk < 36) return 1;
+  return 3;
+}
+size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max) {
+  const long rows = (long)batch * (rows_per_entry < 1024 ? rows_per_entry : 1024);
+  if (n_max > 1280) n_max = 1280;          // wider outputs never split (igemm_splitk_slices)
+  return (size_t)((rows + 255) / 256) * (size_t)((n_max + 127) / 128) * 3 * 256 * 128 * 4;
+}
+
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if (!g_zero_pages[current_device()]) return false;
   if (p.act > 1) return false;   // GELU / QuickGELU epilogues (CLIP MLP, once per prompt) live in the generic kernel
@@ -1494,6 +1574,15 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if (p.stat_out && (variant == 2 || variant == 5 || variant == 19 || variant == 38)) return false;   // wave tiles narrower / other than 64 columns
   // the DMA reads weight rows up to the tile edge: Npad is a multiple of 128 for every packed weight (pack_* kernels)
   const bool was_auto = variant == 0;
+  IgemmParams psk = p;
+  psk.splitk = 1;
+  if (variant == 0 && igemm_splitk_slices(p) > 1) {
+    // long contractions over a small output (FF-out and the 32^2 convs of the CFG pair: M = 2048, N = 1280 is 80 tiles of
+    // 256x128 on 256 CUs): three k-slices per tile fill the chip with the tile shape that moves the fewest bytes per flop
+    psk.splitk = igemm_splitk_slices(p);
+    launch_pipe<256, 128, 3, false, 0, 4, 8, true>(psk, s);
+    return true;
+  }
   if (variant == 0) {
     // measured on MI355X (tools/igemm_sweep.py, profiles/r01_igemm_sweep.txt).  The global->LDS path sustains ~22 B/clk/CU,
     // so the MFMA rate of a tile is ~ BM*BN/(BM+BN) flop per DMA byte: 256x128 (8 waves, pipelined) beats 128x128 wherever
@@ -1528,51 +1617,51 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
 #endif
   switch (variant) {
     // ---- production kernels (what the auto selection launches)
-    case 4: launch_glds<128, 128, 2>(p, s); break;                          // 4 waves, 2-3 co-resident blocks: ragged multi-round grids
-    case 6: launch_glds<64, 128, 2>(p, s); break;
-    case 35: launch_pipe<256, 128, 3, false, 0, 4, 8, true>(p, s); break;   // 8 waves, hand-ordered k-loop unrolled by the ring depth
-    case 36: launch_pipe<128, 128, 4, false, 0, 4, 8, true>(p, s); break;
+    case 4: launch_glds<128, 128, 2>(psk, s); break;                          // 4 waves, 2-3 co-resident blocks: ragged multi-round grids
+    case 6: launch_glds<64, 128, 2>(psk, s); break;
+    case 35: launch_pipe<256, 128, 3, false, 0, 4, 8, true>(psk, s); break;   // 8 waves, hand-ordered k-loop unrolled by the ring depth
+    case 36: launch_pipe<128, 128, 4, false, 0, 4, 8, true>(psk, s); break;
     case 38:                                                                // 256x160 GEGLU tile (8x1 waves)
       if (p.N % 160 != 0) return false;
-      launch_pipe<256, 160, 3, false, 0, 8, 8, true>(p, s); break;
+      launch_pipe<256, 160, 3, false, 0, 8, 8, true>(psk, s); break;
 #ifdef SDXL_MEASURE
     // ---- A/B partners and experiments (build.py --measure): rolled loops, other rings, loader waves, measurement modes
-    case 1: launch_glds<128, 128, 3>(p, s); break;
-    case 2: launch_glds<128, 64, 4>(p, s); break;
-    case 3: launch_glds<64, 128, 4>(p, s); break;
-    case 5: launch_glds<128, 64, 2>(p, s); break;
-    case 7: launch_glds<128, 128, 4>(p, s); break;
-    case 8: launch_glds<64, 128, 3>(p, s); break;
-    case 33: launch_glds<256, 128, 3, 1>(p, s); break;
-    case 34: launch_pipe<256, 128, 3, true, 0, 2, 4>(p, s); break;   // the hand-ordered loop on 4 waves x (128x64)
-    case 37: launch_pipe<256, 128, 3, true, 0, 4, 8, true>(p, s); break;    // unrolled ring with s_setprio
-    case 10: launch_pipe<256, 128, 3, false>(p, s); break;   // rolled 8-wave pipelined kernels
-    case 11: launch_pipe<256, 128, 3, true>(p, s); break;
-    case 12: launch_pipe<128, 128, 4, false>(p, s); break;
-    case 13: launch_pipe<128, 128, 4, true>(p, s); break;
-    case 14: launch_pipe<128, 128, 3, true>(p, s); break;
-    case 15: launch_pipe<256, 128, 3, true, 1>(p, s); break;    // early DMA issue (after the barrier)
-    case 16: launch_pipe<128, 128, 4, true, 1>(p, s); break;
-    case 17: launch_pipe<256, 128, 3, true, 2>(p, s); break;    // measurement only: no k advance (WRONG results)
-    case 18: launch_pipe<256, 128, 3, true, 3>(p, s); break;    // measurement only: no DMA in the loop (WRONG results)
+    case 1: launch_glds<128, 128, 3>(psk, s); break;
+    case 2: launch_glds<128, 64, 4>(psk, s); break;
+    case 3: launch_glds<64, 128, 4>(psk, s); break;
+    case 5: launch_glds<128, 64, 2>(psk, s); break;
+    case 7: launch_glds<128, 128, 4>(psk, s); break;
+    case 8: launch_glds<64, 128, 3>(psk, s); break;
+    case 33: launch_glds<256, 128, 3, 1>(psk, s); break;
+    case 34: launch_pipe<256, 128, 3, true, 0, 2, 4>(psk, s); break;   // the hand-ordered loop on 4 waves x (128x64)
+    case 37: launch_pipe<256, 128, 3, true, 0, 4, 8, true>(psk, s); break;    // unrolled ring with s_setprio
+    case 10: launch_pipe<256, 128, 3, false>(psk, s); break;   // rolled 8-wave pipelined kernels
+    case 11: launch_pipe<256, 128, 3, true>(psk, s); break;
+    case 12: launch_pipe<128, 128, 4, false>(psk, s); break;
+    case 13: launch_pipe<128, 128, 4, true>(psk, s); break;
+    case 14: launch_pipe<128, 128, 3, true>(psk, s); break;
+    case 15: launch_pipe<256, 128, 3, true, 1>(psk, s); break;    // early DMA issue (after the barrier)
+    case 16: launch_pipe<128, 128, 4, true, 1>(psk, s); break;
+    case 17: launch_pipe<256, 128, 3, true, 2>(psk, s); break;    // measurement only: no k advance (WRONG results)
+    case 18: launch_pipe<256, 128, 3, true, 3>(psk, s); break;    // measurement only: no DMA in the loop (WRONG results)
     case 26:                                                    // 256x320, k-tile 32: linear GEGLU projections only
       if (p.act != 1 || p.ksize != 1 || p.stride != 1 || p.up != 0 || p.N % 320 != 0 || p.Kpad % 32 != 0) return false;
-      launch_wide(p, s); break;
-    case 24: launch_pipe<256, 128, 3, true, 4>(p, s); break;    // lookahead-2 fragment prefetch
-    case 27: launch_pipe<256, 128, 3, true, 5>(p, s); break;    // measurement only: DMA-only / contiguous-source modes
-    case 28: launch_pipe<256, 128, 3, true, 6>(p, s); break;
-    case 29: launch_pipe<256, 128, 3, true, 7>(p, s); break;
-    case 30: launch_pipe<128, 128, 4, true, 5>(p, s); break;
-    case 31: launch_pipe<128, 128, 4, true, 6>(p, s); break;
-    case 32: launch_pipe<128, 128, 4, true, 7>(p, s); break;
-    case 25: launch_pipe<128, 128, 4, true, 4>(p, s); break;
+      launch_wide(psk, s); break;
+    case 24: launch_pipe<256, 128, 3, true, 4>(psk, s); break;    // lookahead-2 fragment prefetch
+    case 27: launch_pipe<256, 128, 3, true, 5>(psk, s); break;    // measurement only: DMA-only / contiguous-source modes
+    case 28: launch_pipe<256, 128, 3, true, 6>(psk, s); break;
+    case 29: launch_pipe<256, 128, 3, true, 7>(psk, s); break;
+    case 30: launch_pipe<128, 128, 4, true, 5>(psk, s); break;
+    case 31: launch_pipe<128, 128, 4, true, 6>(psk, s); break;
+    case 32: launch_pipe<128, 128, 4, true, 7>(psk, s); break;
+    case 25: launch_pipe<128, 128, 4, true, 4>(psk, s); break;
     case 19:                                                    // 256x160, 8x1 waves, rolled
       if (p.N % 160 != 0) return false;
-      launch_pipe<256, 160, 3, true, 0, 8>(p, s); break;
-    case 20: launch_ws<256, 128, 3, 2>(p, s); break;            // 8 compute + 2 loader waves
-    case 21: launch_ws<256, 128, 3, 4>(p, s); break;            // 8 compute + 4 loader waves
-    case 22: launch_ws<128, 128, 4, 2>(p, s); break;
-    case 23: launch_ws<128, 128, 4, 4>(p, s); break;
+      launch_pipe<256, 160, 3, true, 0, 8>(psk, s); break;
+    case 20: launch_ws<256, 128, 3, 2>(psk, s); break;            // 8 compute + 2 loader waves
+    case 21: launch_ws<256, 128, 3, 4>(psk, s); break;            // 8 compute + 4 loader waves
+    case 22: launch_ws<128, 128, 4, 2>(psk, s); break;
+    case 23: launch_ws<128, 128, 4, 4>(psk, s); break;
 #endif
     default: return false;
   }
@@ -1594,8 +1683,10 @@ bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s) {
   const long t256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   const double eff128 = (double)t128 / (double)(((t128 + 255) / 256) * 256);
   const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-  if (eff256 >= eff128) launch_pipe<256, 128, 3, false, 0, 4, 8, true, float>(p, s);
-  else launch_pipe<128, 128, 4, false, 0, 4, 8, true, float>(p, s);
+  IgemmParams q = p;
+  q.splitk = 1;
+  if (eff256 >= eff128) launch_pipe<256, 128, 3, false, 0, 4, 8, true, float>(q, s);
+  else launch_pipe<128, 128, 4, false, 0, 4, 8, true, float>(q, s);
   return true;
 }
 

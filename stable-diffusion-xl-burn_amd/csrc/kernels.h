@@ -45,7 +45,13 @@ struct IgemmParams {
   // when set, the staged epilogue stores (mean, M2) -- shifted sums, no sum x^2 - (sum x)^2 -- of every 64-column group of the stored output rows into
   // stat_out[n/64][m] (plain stores, every entry written once) -- the statistics of the LayerNorm that reads this output
   float* stat_out; int stat_slots;
+  // split-K workspace (optional): fp32 partial slabs [tile][slice][256 x 128] + one arrival counter per tile (zero between
+  // launches: the last-arriving slice re-arms it).  splitk is filled by the launcher (igemm_splitk_slices); 0 / 1 = off.
+  float* splitk_ws; size_t splitk_ws_bytes; unsigned* splitk_cnt; int splitk;
 };
+int igemm_splitk_slices(const IgemmParams& p);                       // 1 or 3: depends on one batch entry's shape only
+size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max);   // slab bytes a plan must provide
+constexpr int kSplitkCounters = 4096;                                // arrival counters a plan must provide (zeroed once)
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
 void igemm_set_unrolled(int v);   // auto selection: pipelined kernels with the k-loop unrolled by the ring depth (default on)
@@ -57,7 +63,7 @@ struct GroupNormParams {
   const void* X; int x_dt; int ldx;    // [B][HW] rows, C channels
   void* Y; int y_dt; int ldy;
   const float* gamma; const float* beta;
-  float* partial;      // workspace: [B][32][nsplit][3] (count, mean, M2)
+  float* partial;      // workspace: groupnorm_workspace_floats(B, G) floats
   int B, HW, C, G;
   float eps;
   const float* eps_ptr; // optional device scalar overriding eps (per-norm eps stored with the weights)
@@ -65,6 +71,10 @@ struct GroupNormParams {
   int nsplit;          // filled by the launcher helper
 };
 int  groupnorm_nsplit(int B, int HW, int C);
+// workspace of launch_groupnorm for B batch entries (a run over entries [b0, b0+nb) of a larger plan may use the slice at
+// b0 * groupnorm_workspace_floats(1, G)): per (entry, group) kGnMaxSplit row-split partials (count, mean, M2) + (mean, rstd)
+constexpr int kGnMaxSplit = 512;
+static inline size_t groupnorm_workspace_floats(int B, int G) { return (size_t)B * G * (kGnMaxSplit * 3 + 2); }
 void launch_groupnorm(const GroupNormParams& p, hipStream_t s);
 
 // LayerNorm over the last dim -- reference layernorm/mod.rs:34-49

@@ -166,8 +166,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GroupNormParams 
   if (i >= p.B * p.G) return;
   const float* part = p.partial + (size_t)i * p.nsplit * 3;
   float na = 0.f, ma = 0.f, qa = 0.f;
-  if (lane < p.nsplit) { na = part[lane * 3]; ma = part[lane * 3 + 1]; qa = part[lane * 3 + 2]; }
-  if (lane + 64 < p.nsplit) chan_merge(na, ma, qa, part[(lane + 64) * 3], part[(lane + 64) * 3 + 1], part[(lane + 64) * 3 + 2]);
+  for (int s = lane; s < p.nsplit; s += 64) chan_merge(na, ma, qa, part[s * 3], part[s * 3 + 1], part[s * 3 + 2]);
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const float nb = __shfl_xor(na, o), mb = __shfl_xor(ma, o), qb = __shfl_xor(qa, o);
@@ -247,9 +246,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
 
 int groupnorm_nsplit(int B, int HW, int C) {
   (void)B; (void)C;
-  int n = HW / 32;       // >= 32 rows per block; up to 128 row splits x B blocks keep all 256 CUs streaming
-  if (n < 1) n = 1;
-  if (n > 128) n = 128;
+  int n = HW / 32;       // >= 32 rows per block; up to 512 row splits x B blocks = several workgroups per CU: the statistics
+  if (n < 1) n = 1;      // pass is a pure stream (one 256-thread block per CU left it latency bound at ~1.5 TB/s)
+  if (n > kGnMaxSplit) n = kGnMaxSplit;
   return n;
 }
 
@@ -264,7 +263,7 @@ void launch_groupnorm(const GroupNormParams& pin, hipStream_t s) {
   if (p.x_dt == DT_F16) hipLaunchKernelGGL(gn_stats_kernel<half_t>, g1, dim3(256), lds_stats, s, p);
   else hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds_stats, s, p);
   // (mean, rstd) per (batch, group) live right after the partials: workspace is [B][G][128][3] + [B][G][2] floats
-  float* stat = p.partial + (size_t)p.B * p.G * 128 * 3;
+  float* stat = p.partial + (size_t)p.B * p.G * kGnMaxSplit * 3;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.G + 3) / 4), dim3(256), 0, s, p, stat);
   // apply: aim for >= ~512 blocks, each row lane walking >= 4 rows
   int rows_per_block = (int)(((long)p.B * p.HW + 511) / 512);

@@ -254,18 +254,18 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       run_linear(ex, b.qkv, t, (int)M, qk, eq);
       attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
       stp ^= 1;
-      Epi e1; e1.R = t; e1.stat_out = stbuf[stp];
+      Epi e1; e1.R = t; e1.stat_out = stbuf[stp]; e1.rpb = HW;
       run_linear(ex, b.out1, ao, (int)M, t, e1);
-      Epi e2q; e2q.ln_stat = stbuf[stp];
+      Epi e2q; e2q.ln_stat = stbuf[stp]; e2q.rpb = HW;
       run_linear(ex, b.q2, t, (int)M, q, e2q);
       attention(ex, q, Act(kv_k(si, j), C, ex.cdt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
       stp ^= 1;
-      Epi e2; e2.R = t; e2.stat_out = stbuf[stp];
+      Epi e2; e2.R = t; e2.stat_out = stbuf[stp]; e2.rpb = HW;
       run_linear(ex, b.out2, ao, (int)M, t, e2);
-      Epi eg; eg.act = 1; eg.ln_stat = stbuf[stp];
+      Epi eg; eg.act = 1; eg.ln_stat = stbuf[stp]; eg.rpb = HW;
       run_linear(ex, b.geglu, t, (int)M, gg, eg);
       stp ^= 1;
-      Epi ef; ef.R = t; ef.stat_out = j + 1 < w.blocks.size() ? stbuf[stp] : nullptr;
+      Epi ef; ef.R = t; ef.stat_out = j + 1 < w.blocks.size() ? stbuf[stp] : nullptr; ef.rpb = HW;
       run_linear(ex, b.ff, gg, (int)M, t, ef);
     }
   } else
@@ -275,7 +275,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW;
     run_linear(ex, b.qkv, ln, (int)M, qk, eq);
     attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
-    Epi er; er.R = t;
+    Epi er; er.R = t; er.rpb = HW;
     run_linear(ex, b.out1, ao, (int)M, t, er);
     run_layernorm(ex, b.n2, t, (int)M, ln);
     run_linear(ex, b.q2, ln, (int)M, q);
@@ -286,7 +286,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_linear(ex, b.geglu, ln, (int)M, gg, eg);
     run_linear(ex, b.ff, gg, (int)M, t, er);
   }
-  Epi eo; eo.R = x;
+  Epi eo; eo.R = x; eo.rpb = HW;
   run_linear(ex, w.proj_out, t, (int)M, x, eo);
   ex.act->reset(mk);
 }
@@ -304,7 +304,7 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
   void* in = (char*)in_ + (size_t)b0 * H * W * cfg_.in_channels * dt_size(cdt_);
   float* eps = eps_ + (size_t)b0 * H * W * cfg_.out_channels;
   ex.ebias = ebias; ex.b0 = b0;
-  ex.gn_partial = gn_partial_ + (size_t)b0 * 32 * (128 * 3 + 2);
+  ex.gn_partial = gn_partial_ + (size_t)b0 * groupnorm_workspace_floats(1, 32);
   // --- embeddings (unet/mod.rs:458-468)
   if (!ex.dry) launch_timestep_embedding(t_dev + (size_t)b0 * t_stride, t_stride, temb, B, mc, ex.s);
   gemv(ex, lin1_t_, temb, mc, g1, emb, B, false, true);
@@ -410,8 +410,15 @@ void UNet::ensure_plan(int B, int H, int W) {
     g1_ = (float*)act_.alloc((size_t)B * emb * sizeof(float));
     emb_ = (float*)act_.alloc((size_t)B * emb * sizeof(float));
     ebias_ = (float*)act_.alloc((size_t)B * emb_total_ * sizeof(float));
-    gn_partial_ = (float*)act_.alloc((size_t)B * 32 * (128 * 3 + 2) * sizeof(float));
+    gn_partial_ = (float*)act_.alloc(groupnorm_workspace_floats(B, 32) * sizeof(float));
     tconv_ = (float*)act_.alloc(8 * sizeof(float));
+    if (cdt_ == DT_F16) {   // split-K slabs + counters: chain 0 (and the second split-CFG chain)
+      skws_bytes_ = igemm_splitk_ws_bytes(B, 1024, 1280);
+      for (int c = 0; c < 2; ++c) {
+        skws_[c] = (float*)act_.alloc(skws_bytes_);
+        skcnt_[c] = (unsigned*)act_.alloc(kSplitkCounters * sizeof(unsigned));
+      }
+    }
   };
   // dry run for the peak, then the real arena
   act_.dry = true; act_.off = 0; act_.peak = 0;
@@ -446,6 +453,7 @@ void UNet::ensure_plan(int B, int H, int W) {
   act_.reserve(peak + 4096);
   act_.off = 0; act_.peak = 0;
   persist();
+  if (skcnt_[0]) for (int c = 0; c < 2; ++c) SDXL_HIP(hipMemset(skcnt_[c], 0, kSplitkCounters * sizeof(unsigned)));   // armed once
 }
 
 void* UNet::unet_in(int B, int H, int W) { ensure_plan(B, H, W); return in_; }
@@ -454,11 +462,13 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
   ensure_plan(B, H, W);
   SDXL_REQUIRE(ctx_B_ == B && !kv_.empty(), "set_context must be called with the same batch before forward");
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_;
+  ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
   const size_t m = act_.mark();
   // one batched chain, or (split-CFG) entry 0 on s and entry 1 on the side stream between a fork and a join event
   auto go = [&]() {
     if (!plan_split_) { run(ex, t_dev, t_stride, 0, B); return; }
     Exec e2; e2.s = s2_; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_;
+    e2.splitk_ws = skws_[1]; e2.splitk_ws_bytes = skws_bytes_; e2.splitk_cnt = skcnt_[1];
     act2_.off = 0;
     ex.fork_ev = ev_fork_; ex.fork_after = split_offset_; ex.launches = 0;
     if (ex.fork_after <= 0) SDXL_HIP(hipEventRecord(ev_fork_, s));
@@ -502,6 +512,7 @@ void UNet::profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[P
   SDXL_HIP(hipStreamSynchronize(s));
   Profiler prof;
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.prof = &prof;
+  ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
   const size_t m = act_.mark();
   run(ex, tconv_, 1, 0, B);   // always the batched chain: per-launch events need one stream
   act_.reset(m);

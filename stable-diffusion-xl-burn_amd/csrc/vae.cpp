@@ -217,7 +217,7 @@ void Vae::run_encode(Exec& ex, const Act& in, int n, int H, int W, const Act& ou
 // GroupNorm workspace of launch_groupnorm: [n][G][128][3] partials + [n][G][2] (mean, rstd), sized per call from the arena
 // (a fixed allocation silently overflowed for n * n_group > 256)
 float* Vae::gn_workspace(Exec& ex, int n) {
-  return (float*)ex.act->alloc((size_t)n * cfg_.n_group * (128 * 3 + 2) * sizeof(float));
+  return (float*)ex.act->alloc(groupnorm_workspace_floats(n, cfg_.n_group) * sizeof(float));
 }
 
 // two-pass execution: dry run sizes the arena, then the real run

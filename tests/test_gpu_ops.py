@@ -209,6 +209,33 @@ def test_attn_decoder_mask(pkg, ctx):
     assert torch.equal(pkg.attn_decoder_mask(ctx, 77).cpu(), OM.attn_decoder_mask(77))
 
 
+@pytest.mark.parametrize("M,K,N", [(1024, 5120, 1280), (300, 2560, 200), (1000, 2304, 640), (64, 2816, 1280), (1, 2560, 64)])
+def test_linear_split_k(pkg, ctx, M, K, N):
+    # long contraction over a small output (rows <= 1024, N <= 1280, K >= 2304): three k-slices per 256x128 tile, combined inside
+    # the launch by the last-arriving slice in slice order -> bit-reproducible, and the arrival counters re-arm themselves
+    x = seeded(M, K, seed=7)
+    w = seeded(K, N, seed=8) / math.sqrt(K)
+    b = 0.1 * seeded(N, seed=9)
+    ref = x @ w + b
+    outs = [pkg.linear(ctx, x.cuda(), w.cuda(), b.cuda(), False, 1) for _ in range(3)]
+    assert rel_err(outs[0], ref) < TOL[1]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "split-K result is not bit-reproducible"
+
+
+def test_conv_split_k_matches_batch_entries(pkg, ctx):
+    # 3x3 conv at 32x32 (K = 9 * 320 = 2880): the slices start inside the tap walk; the split depends on ONE batch entry's
+    # shape only, so a batch of two equals two separate launches bit for bit
+    x = seeded(2, 320, 32, 32, seed=43)
+    w = seeded(320, 320, 3, 3, seed=44) / math.sqrt(320 * 9)
+    b = 0.1 * seeded(320, seed=45)
+    ref = F.conv2d(x, w, b, padding=1)
+    both = pkg.conv2d(ctx, x.cuda(), w.cuda(), b.cuda(), 1, 1, False, 1)
+    assert rel_err(both, ref) < TOL[1]
+    for i in range(2):
+        one = pkg.conv2d(ctx, x[i:i + 1].cuda(), w.cuda(), b.cuda(), 1, 1, False, 1)
+        assert torch.equal(one[0], both[i])
+
+
 # ---------------------------------------------------------------------------------------------------------
 # every fast-path implicit-GEMM tile / pipeline variant is forced in turn over shapes that exercise: fewer k-tiles than
 # ring slots, ragged M / N tiles, GEGLU pairs, 3x3 taps with halo zero-fill, stride 2 and the fused nearest-2x gather
