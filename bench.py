@@ -56,13 +56,50 @@ def init_dist(backend: str):
 
 
 def broadcast_arena(arena_u8, src: int = 0, chunk_bytes: int = 1 << 30):
-    """one-time weight broadcast (RCCL over xGMI on GPUs, gloo in the CPU tests), in <=1 GiB pieces"""
+    """fallback one-time weight broadcast through torch.distributed (RCCL on GPUs, gloo in the CPU tests), in <=1 GiB
+    pieces -- used when the library's own communicator (make_comm / Comm.bcast_*) cannot be created"""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
     n = arena_u8.numel()
     for o in range(0, n, chunk_bytes):
         dist.broadcast(arena_u8[o:min(n, o + chunk_bytes)], src=src)
+
+
+def scatter_allgather_arena(arena_u8, plan_fn, src: int = 0):
+    """the LIBRARY's broadcast schedule (csrc/comm.cpp: scatter of `world` equal pieces from the root, in-place all-gather,
+    small tail broadcast) executed over torch.distributed point-to-point / collective calls.  plan_fn(nbytes, world, rank)
+    is the library's sdxl_bcast_plan.  The engine runs the same plan over RCCL inside sdxl_*_bcast_weights; this host-side
+    twin exists so that world-size-2 gloo tests push a real weight-arena byte image through the same offsets."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    rank, world, n = dist.get_rank(), dist.get_world_size(), arena_u8.numel()
+    poff, plen, toff, tlen = plan_fn(n, world, rank)
+    if plen > 0:
+        if rank == src:
+            reqs = [dist.isend(arena_u8[plan_fn(n, world, r)[0]:plan_fn(n, world, r)[0] + plen], dst=r) for r in range(world) if r != src]
+            for q in reqs:
+                q.wait()
+        else:
+            dist.recv(arena_u8[poff:poff + plen], src=src)
+        pieces = [torch.empty(plen, dtype=arena_u8.dtype, device=arena_u8.device) for _ in range(world)]
+        dist.all_gather(pieces, arena_u8[poff:poff + plen].clone())
+        for r in range(world):
+            o = plan_fn(n, world, r)[0]
+            arena_u8[o:o + plen] = pieces[r]
+    if tlen > 0:
+        dist.broadcast(arena_u8[toff:toff + tlen], src=src)
+
+
+def make_comm(pkg, local_rank: int):
+    """the engine's own RCCL communicator: rank 0 draws the unique id, the existing torch.distributed group ships it"""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [pkg.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return pkg.Comm(local_rank, rank, world, box[0])
 
 
 def max_over_ranks(seconds: float, device) -> float:
@@ -309,11 +346,22 @@ def main():
     ctx.synchronize()
     t_build = time.time() - t0
     t0 = time.time()
+    bcast_path = None
     if world > 1:
-        broadcast_arena(diffuser.diffusion.weight_arena_tensor())
-        broadcast_arena(decoder.weight_arena_tensor())
-        if refiner is not None:
-            broadcast_arena(refiner.diffusion.weight_arena_tensor())
+        try:       # the library's schedule (scatter over the root's xGMI links + in-place all-gather) on its own communicator
+            comm = make_comm(pkg, local_rank)
+            comm.bcast_unet(diffuser.diffusion)
+            comm.bcast_vae(decoder)
+            if refiner is not None:
+                comm.bcast_unet(refiner.diffusion)
+            bcast_path = "sdxl_*_bcast_weights (library RCCL communicator: scatter + all-gather)"
+        except Exception as e:   # never lose a scaling run to the communicator: torch.distributed's RCCL broadcast instead
+            print(f"[bench] library broadcast unavailable ({e}); falling back to torch.distributed.broadcast", file=sys.stderr, flush=True)
+            broadcast_arena(diffuser.diffusion.weight_arena_tensor())
+            broadcast_arena(decoder.weight_arena_tensor())
+            if refiner is not None:
+                broadcast_arena(refiner.diffusion.weight_arena_tensor())
+            bcast_path = "torch.distributed.broadcast (fallback)"
         torch.cuda.synchronize()
     t_bcast = time.time() - t0
     if args.no_graph:
@@ -468,7 +516,7 @@ def main():
             "vae_dtype": args.vae_dtype, "decode_ms": round(decode_ms, 2),
             "tflop_per_image": round(tflop_image, 1),
             "outputs_finite": finite,
-            "setup_s": {"build_weights": round(t_build, 2), "broadcast": round(t_bcast, 2)},
+            "setup_s": {"build_weights": round(t_build, 2), "broadcast": round(t_bcast, 2), "broadcast_path": bcast_path},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": load_parity(),

@@ -76,6 +76,8 @@ ABI_SYMBOLS = [
     "sdxl_clip_config_clip_l", "sdxl_clip_config_open_clip_bigg", "sdxl_clip_param_count", "sdxl_clip_param_spec",
     "sdxl_clip_create", "sdxl_clip_create_synthetic", "sdxl_clip_destroy", "sdxl_clip_forward_hidden",
     "sdxl_clip_forward_hidden_pooled", "sdxl_conditioning_embedding", "sdxl_clip_weight_arena",
+    "sdxl_comm_unique_id", "sdxl_comm_create", "sdxl_comm_destroy", "sdxl_bcast_buffer", "sdxl_unet_bcast_weights",
+    "sdxl_vae_bcast_weights", "sdxl_clip_bcast_weights", "sdxl_bcast_plan",
 ]
 
 _lib = None
@@ -100,7 +102,8 @@ def lib() -> ctypes.CDLL:
         l.sdxl_build_info.restype = ctypes.c_char_p
         l.sdxl_diffuser_unet.restype = ctypes.c_void_p
         l.sdxl_diffuser_unet.argtypes = [ctypes.c_void_p]
-        for name in ("sdxl_ctx_destroy", "sdxl_unet_destroy", "sdxl_diffuser_destroy", "sdxl_vae_destroy", "sdxl_clip_destroy"):
+        for name in ("sdxl_ctx_destroy", "sdxl_unet_destroy", "sdxl_diffuser_destroy", "sdxl_vae_destroy", "sdxl_clip_destroy",
+                     "sdxl_comm_destroy"):
             getattr(l, name).restype = None
             getattr(l, name).argtypes = [ctypes.c_void_p]
         _lib = l
@@ -817,3 +820,47 @@ def layer_norm_linear(ctx: Context, x, gamma, beta, weight, bias, eps: float = 1
     _check(lib().sdxl_layer_norm_linear(ctx.h, _stream(), px, pg, pbeta, ctypes.c_float(eps), pw, pb, M, K, N, int(geglu),
                                        dtype, ctypes.c_void_p(out.data_ptr())))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- multi-GPU
+def bcast_plan(nbytes: int, world: int, rank: int) -> Tuple[int, int, int, int]:
+    """(piece_off, piece_len, tail_off, tail_len) of the library's weight-broadcast schedule for this rank: the root scatters
+    `world` equal 256-byte-aligned pieces over its links, an in-place all-gather completes them, the tail is a small
+    broadcast (csrc/comm.cpp).  Host-only: works without a GPU."""
+    v = [ctypes.c_size_t() for _ in range(4)]
+    _check(lib().sdxl_bcast_plan(ctypes.c_size_t(nbytes), world, rank, *[ctypes.byref(x) for x in v]))
+    return tuple(int(x.value) for x in v)
+
+
+class Comm:
+    """RCCL communicator of the engine (one process per GPU).  `unique_id()` on rank 0 -> ship the 128 bytes to every rank
+    over any host channel (here: the caller's torch.distributed group) -> Comm(device, rank, world, id)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (ctypes.c_char * 128)()
+        _check(lib().sdxl_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, device_id: int, rank: int, world: int, uid: bytes):
+        assert len(uid) == 128
+        self.h = ctypes.c_void_p()
+        self.rank, self.world = rank, world
+        _check(lib().sdxl_comm_create(device_id, rank, world, ctypes.c_char_p(uid), ctypes.byref(self.h)))
+
+    def bcast_unet(self, unet: "UNet", root: int = 0):
+        _check(lib().sdxl_unet_bcast_weights(self.h, unet.h, root))
+
+    def bcast_vae(self, vae: "LatentDecoder", root: int = 0):
+        _check(lib().sdxl_vae_bcast_weights(self.h, vae.h, root))
+
+    def bcast_clip(self, clip: "CLIP", root: int = 0):
+        _check(lib().sdxl_clip_bcast_weights(self.h, clip.h, root))
+
+    def bcast_buffer(self, tensor, root: int = 0):
+        _check(lib().sdxl_bcast_buffer(self.h, None, ctypes.c_void_p(tensor.data_ptr()), ctypes.c_size_t(tensor.numel() * tensor.element_size()), root))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.sdxl_comm_destroy(self.h)
+            self.h = None

@@ -1,5 +1,6 @@
-"""world_size-2 gloo test (CPU) of bench.py's multi-GPU orchestration: one-time weight-arena broadcast from rank 0,
-independent prompt sharding (no collective in the loop), max-over-ranks timing and whole-job aggregation."""
+"""world_size-2 gloo test (CPU) of the multi-GPU orchestration: the library's weight-broadcast schedule (sdxl_bcast_plan:
+scatter + all-gather + tail, csrc/comm.cpp) executed over gloo on a real parameter byte image, the torch.distributed fallback
+broadcast, independent prompt sharding (no collective in the loop), max-over-ranks timing and whole-job aggregation."""
 import os
 import socket
 import sys
@@ -31,6 +32,20 @@ def _worker(rank, world, port, q):
     arena = (torch.arange(n, dtype=torch.int64) % 251).to(torch.uint8) if rank == 0 else torch.full((n,), 7, dtype=torch.uint8)
     bench.broadcast_arena(arena, src=0, chunk_bytes=1 << 20)
     ok = bool(torch.equal(arena, (torch.arange(n, dtype=torch.int64) % 251).to(torch.uint8)))
+    # the LIBRARY's schedule (sdxl_bcast_plan: scatter + all-gather + tail) on a real weight-arena byte image: the flat fp32
+    # parameters of the tiny UNet in sdxl_unet_param_spec order (what rank 0 holds; 48 odd bytes appended -> a ragged tail)
+    import numpy as np
+    import __graft_entry__ as ge
+    from oracle import config as OC
+    pkg = ge.load_package()
+    W = OC.synth_weights(OC.unet_param_specs(OC.tiny_config()), 5)
+    image = np.concatenate([W[p.name].reshape(-1) for p in OC.unet_param_specs(OC.tiny_config())]).view(np.uint8)
+    image = torch.from_numpy(np.concatenate([image, np.arange(48, dtype=np.uint8)]))
+    arena2 = image.clone() if rank == 0 else torch.full_like(image, 0xAB)
+    bench.scatter_allgather_arena(arena2, pkg.bcast_plan, src=0)
+    ok = ok and bool(torch.equal(arena2, image))
+    plan = pkg.bcast_plan(image.numel(), world, rank)
+    ok = ok and plan[1] % 256 == 0 and plan[0] == rank * plan[1] and plan[2] == world * plan[1] and plan[2] + plan[3] == image.numel()
     bench.barrier()
     t = bench.max_over_ranks(1.0 + rank, torch.device("cpu"))
     total = bench.sum_over_ranks(3.0, torch.device("cpu"))

@@ -319,3 +319,18 @@ def test_empty_replica_receives_weight_arena(pkg, ctx, dtype):
     ref = src.sample_latent(_pkg_cond(pkg, c, res), 7.5, 4, noise.cuda()).cpu()
     out = dst.sample_latent(_pkg_cond(pkg, c, res), 7.5, 4, noise.cuda()).cpu()
     assert torch.equal(out, ref)
+
+
+def test_library_comm_single_rank(pkg, ctx):
+    # the library's own RCCL communicator (csrc/comm.cpp, bound with dlopen): a world of one rank must initialise next to
+    # torch's RCCL in the same process, and the weight broadcasts degenerate to no-ops that leave the arena untouched.
+    # (N > 1 needs N GPUs: the schedule itself is executed over gloo in tests/test_cpu_distributed.py.)
+    ocfg = OC.tiny_config()
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), 1, seed=0)
+    before = u.weight_arena_tensor().clone()
+    comm = pkg.Comm(0, 0, 1, pkg.Comm.unique_id())
+    comm.bcast_unet(u)
+    buf = torch.arange(1000, dtype=torch.float32, device="cuda")
+    comm.bcast_buffer(buf)
+    assert torch.equal(u.weight_arena_tensor(), before) and torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float32))
+    assert pkg.bcast_plan(10_000_000, 8, 3) == (3 * 1249792, 1249792, 8 * 1249792, 10_000_000 - 8 * 1249792)
