@@ -36,7 +36,7 @@ typedef struct sdxl_clip sdxl_clip;
 enum { SDXL_OK = 0, SDXL_ERR_INVALID = 1, SDXL_ERR_RUNTIME = 2 };
 /* precision of a model instance */
 enum {
-  SDXL_DTYPE_F32 = 0,       /* strict-parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)      */
+  SDXL_DTYPE_F32 = 0,       /* strict-parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)      */
   SDXL_DTYPE_F16 = 1,       /* fp16 storage + fp16 MFMA operands, fp32 accumulation/statistics/softmax           */
   SDXL_DTYPE_F16_F32RES = 2 /* fp16 MFMA operands, fp32 residual stream                                         */
 };
@@ -84,7 +84,8 @@ typedef struct {
 } sdxl_conditioning;
 
 /* parameter kinds reported by sdxl_*_param_spec */
-enum { SDXL_PARAM_LINEAR_W = 0, SDXL_PARAM_CONV_W = 1, SDXL_PARAM_BIAS = 2, SDXL_PARAM_GAMMA = 3, SDXL_PARAM_BETA = 4 };
+enum { SDXL_PARAM_LINEAR_W = 0, SDXL_PARAM_CONV_W = 1, SDXL_PARAM_BIAS = 2, SDXL_PARAM_GAMMA = 3, SDXL_PARAM_BETA = 4,
+       SDXL_PARAM_EPS = 5 /* [1]: the norm's eps, read per module by the reference (groupnorm/load.rs:19, layernorm/load.rs:17) */ };
 
 const char* sdxl_last_error(void);
 /* library / build identification (target arch string, e.g. "gfx950") */
@@ -110,6 +111,10 @@ int sdxl_vae_param_spec(const sdxl_vae_config* cfg, int encoder, int index, cons
 
 /* ---- UNet: replaces DiffuserConfig::init + load_record (stablediffusion/mod.rs:281-305, bin/sample/main.rs:35-43) */
 int sdxl_unet_create(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const float* weights_flat, sdxl_unet** out);
+/* the same from a flat IEEE-f16 buffer (host or device), same order and layouts: burn's HalfPrecisionSettings records hold
+ * the weights as f16 (src/bin/sample/main.rs:37, src/bin/convert/main.rs:65-70), so a Rust host hands them over without the
+ * 2x fp32 expansion (5.1 GB instead of 10.3 GB for the base UNet).  Likewise sdxl_{diffuser,vae,clip}_create_f16. */
+int sdxl_unet_create_f16(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const uint16_t* weights_flat_f16, sdxl_unet** out);
 /* seeded synthetic weights generated on the device (no checkpoint needed); bit-identical to oracle/config.py */
 int sdxl_unet_create_synthetic(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, uint64_t seed, sdxl_unet** out);
 void sdxl_unet_destroy(sdxl_unet* u);
@@ -133,6 +138,8 @@ int sdxl_attn_decoder_mask(sdxl_ctx* ctx, void* stream, int seq_length, float* o
 /* ---- Diffuser (src/model/stablediffusion/mod.rs:308-542); alphas_cumprod = alpha_cumulative_products param (:311) */
 int sdxl_diffuser_create(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const float* weights_flat,
                          const float* alphas_cumprod_host, int n_train_steps, sdxl_diffuser** out);
+int sdxl_diffuser_create_f16(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const uint16_t* weights_flat_f16,
+                             const float* alphas_cumprod_host, int n_train_steps, sdxl_diffuser** out);
 int sdxl_diffuser_create_synthetic(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, uint64_t seed,
                                    const float* alphas_cumprod_host, int n_train_steps, sdxl_diffuser** out);
 void sdxl_diffuser_destroy(sdxl_diffuser* d);
@@ -163,6 +170,8 @@ int sdxl_diffuser_set_trace(sdxl_diffuser* d, float* trace_dev, int capacity_ste
 /* ---- LatentDecoder / Autoencoder (stablediffusion/mod.rs:193-267, autoencoder/mod.rs:46-70) */
 int sdxl_vae_create(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, const float* decoder_weights_flat,
                     const float* encoder_weights_flat, sdxl_vae** out);   /* either side may be NULL */
+int sdxl_vae_create_f16(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, const uint16_t* decoder_weights_flat_f16,
+                        const uint16_t* encoder_weights_flat_f16, sdxl_vae** out);
 int sdxl_vae_create_synthetic(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, uint64_t seed, int with_encoder,
                               sdxl_vae** out);
 void sdxl_vae_destroy(sdxl_vae* v);
@@ -186,6 +195,7 @@ int sdxl_clip_param_spec(const sdxl_clip_config* cfg, int index, const char** na
                          float* synth_scale, float* synth_mean);
 /* CLIPConfig::init + load (clip/mod.rs:30-59) */
 int sdxl_clip_create(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, const float* weights_flat, sdxl_clip** out);
+int sdxl_clip_create_f16(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, const uint16_t* weights_flat_f16, sdxl_clip** out);
 int sdxl_clip_create_synthetic(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, uint64_t seed, sdxl_clip** out);
 void sdxl_clip_destroy(sdxl_clip* c);
 /* CLIP::forward_hidden (clip/mod.rs:94-112): tokens int32 [n,seq] (device) -> hidden [n,seq,n_state] after the first

@@ -1,0 +1,634 @@
+//! Rust shim: the public model API of Gadersd/stable-diffusion-xl-burn on top of `libsdxl_mi355.so`.
+//!
+//! The reference's types keep their names and signatures (file:line = the reference repository):
+//!
+//! | here                                         | replaces                                             |
+//! |----------------------------------------------|------------------------------------------------------|
+//! | `Conditioning<B>`                            | `src/model/stablediffusion/mod.rs:544-555`           |
+//! | `Diffuser::<B>::sample_latent`               | `:317-332`                                           |
+//! | `Diffuser::<B>::sample_latent_with_inpainting` | `:334-353`                                         |
+//! | `Diffuser::<B>::refine_latent`               | `:355-376`                                           |
+//! | `LatentDecoder::<B>::{latent_to_image, image_to_latent, encode_image, decode_latent}` | `:200-266`  |
+//! | `Embedder::<B>::text_to_conditioning`        | `:661-696`                                           |
+//! | `UNet::<B>::forward`                         | `src/model/unet/mod.rs:450-456`                      |
+//! | `trait Backend { qkv_attention, attn_decoder_mask }` + `Mi355Attention` | `src/backend.rs:3-24`     |
+//!
+//! The reference draws its noise from an unseeded generator inside `sample_latent` (`gen_noise`, `:378-388`); the engine
+//! takes noise as an argument so results are reproducible.  The reference-shaped methods therefore draw
+//! `Tensor::random(Normal(0,1))` exactly where the reference does and forward to `*_with_noise` companions, which are the
+//! ones parity tests use.
+//!
+//! Tensors cross the boundary as fp32 device buffers in the reference's own layouts.  `bridge` is the generic path for ANY
+//! burn backend (host hop, like the reference's own `DefaultBackendConverter`, `src/backend_converter.rs:25-39`); the
+//! `tch-bridge` feature passes `data_ptr()` of burn-tch tensors that already live in HIP memory.
+//!
+//! Status: written against `include/sdxl_mi355.h`; NOT compiled in the build container (no cargo/rustc there).
+#![allow(non_camel_case_types, non_upper_case_globals, non_snake_case, dead_code)]
+
+pub mod ffi {
+    include!(concat!(env!("OUT_DIR"), "/bindings.rs"));
+}
+
+use burn::tensor::{backend::Backend as BurnBackend, Bool, Data, Distribution, ElementConversion, Int, Shape, Tensor};
+use std::ffi::CStr;
+use std::os::raw::{c_int, c_void};
+use std::ptr;
+
+// ------------------------------------------------------------------------------------------------ errors
+/// model code in the reference asserts / unwraps (`unet/mod.rs:73-76`, `:967-972`, `groupnorm/mod.rs:19-24`): a non-zero
+/// status from the engine becomes a panic carrying the engine's message, loaders get a `Result`
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(ffi::sdxl_last_error()).to_string_lossy().into_owned() }
+}
+fn check(rc: c_int) {
+    if rc != 0 {
+        panic!("sdxl_mi355: {}", last_error());
+    }
+}
+fn try_check(rc: c_int) -> Result<(), Box<dyn std::error::Error>> {
+    if rc != 0 {
+        Err(last_error().into())
+    } else {
+        Ok(())
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ HIP runtime (bridge)
+extern "C" {
+    fn hipMalloc(ptr: *mut *mut c_void, bytes: usize) -> c_int;
+    fn hipFree(ptr: *mut c_void) -> c_int;
+    fn hipMemcpy(dst: *mut c_void, src: *const c_void, bytes: usize, kind: c_int) -> c_int;
+}
+const HIP_MEMCPY_HOST_TO_DEVICE: c_int = 1;
+const HIP_MEMCPY_DEVICE_TO_HOST: c_int = 2;
+
+/// an owned fp32 (or raw byte) device buffer
+pub struct DeviceBuf {
+    ptr: *mut c_void,
+    bytes: usize,
+}
+impl DeviceBuf {
+    pub fn new(bytes: usize) -> Self {
+        let mut p = ptr::null_mut();
+        assert_eq!(unsafe { hipMalloc(&mut p, bytes.max(16)) }, 0, "hipMalloc({bytes}) failed");
+        DeviceBuf { ptr: p, bytes }
+    }
+    pub fn from_f32(v: &[f32]) -> Self {
+        let b = Self::new(v.len() * 4);
+        assert_eq!(unsafe { hipMemcpy(b.ptr, v.as_ptr() as *const c_void, v.len() * 4, HIP_MEMCPY_HOST_TO_DEVICE) }, 0);
+        b
+    }
+    pub fn from_u8(v: &[u8]) -> Self {
+        let b = Self::new(v.len());
+        assert_eq!(unsafe { hipMemcpy(b.ptr, v.as_ptr() as *const c_void, v.len(), HIP_MEMCPY_HOST_TO_DEVICE) }, 0);
+        b
+    }
+    pub fn to_f32(&self) -> Vec<f32> {
+        let mut v = vec![0f32; self.bytes / 4];
+        assert_eq!(unsafe { hipMemcpy(v.as_mut_ptr() as *mut c_void, self.ptr, self.bytes, HIP_MEMCPY_DEVICE_TO_HOST) }, 0);
+        v
+    }
+    pub fn to_u8(&self) -> Vec<u8> {
+        let mut v = vec![0u8; self.bytes];
+        assert_eq!(unsafe { hipMemcpy(v.as_mut_ptr() as *mut c_void, self.ptr, self.bytes, HIP_MEMCPY_DEVICE_TO_HOST) }, 0);
+        v
+    }
+    pub fn f32_ptr(&self) -> *const f32 {
+        self.ptr as *const f32
+    }
+    pub fn f32_mut(&self) -> *mut f32 {
+        self.ptr as *mut f32
+    }
+}
+impl Drop for DeviceBuf {
+    fn drop(&mut self) {
+        unsafe { hipFree(self.ptr) };
+    }
+}
+
+/// burn tensor <-> fp32 device buffer, for any backend (host hop; see the module docs for the zero-copy feature)
+pub mod bridge {
+    use super::*;
+    pub fn upload<B: BurnBackend, const D: usize>(t: Tensor<B, D>) -> DeviceBuf {
+        let data: Data<f32, D> = t.into_data().convert();
+        DeviceBuf::from_f32(&data.value)
+    }
+    pub fn upload_int<B: BurnBackend, const D: usize>(t: Tensor<B, D, Int>) -> (DeviceBuf, Vec<i32>) {
+        let v: Vec<i32> = t.into_data().value.iter().map(|x| x.elem::<i32>()).collect();
+        let b = DeviceBuf::new(v.len() * 4);
+        assert_eq!(unsafe { hipMemcpy(b.ptr, v.as_ptr() as *const c_void, v.len() * 4, HIP_MEMCPY_HOST_TO_DEVICE) }, 0);
+        (b, v)
+    }
+    pub fn download<B: BurnBackend, const D: usize>(b: &DeviceBuf, shape: [usize; D], device: &B::Device) -> Tensor<B, D> {
+        Tensor::from_data(Data::new(b.to_f32(), Shape::new(shape)).convert(), device)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ context / precision
+#[derive(Clone, Copy, Debug, PartialEq)]
+pub enum Precision {
+    /// strict parity with the fp32 CPU reference (exact-fp32 MFMA)
+    F32 = ffi::SDXL_DTYPE_F32 as isize,
+    /// fp16 storage and MFMA operands, fp32 accumulation (what `LibTorch<f16>` is in `src/bin/sample/main.rs:122`)
+    F16 = ffi::SDXL_DTYPE_F16 as isize,
+    F16F32Res = ffi::SDXL_DTYPE_F16_F32RES as isize,
+}
+
+/// one per GPU (the reference hard-codes `LibTorchDevice::Cuda(0)`, `src/bin/sample/main.rs:131`)
+pub struct Mi355Context {
+    raw: *mut ffi::sdxl_ctx,
+}
+impl Mi355Context {
+    pub fn new(device_id: i32) -> Result<Self, Box<dyn std::error::Error>> {
+        let mut raw = ptr::null_mut();
+        try_check(unsafe { ffi::sdxl_ctx_create(device_id, &mut raw) })?;
+        Ok(Mi355Context { raw })
+    }
+    pub fn synchronize(&self) {
+        check(unsafe { ffi::sdxl_ctx_synchronize(self.raw) });
+    }
+}
+impl Drop for Mi355Context {
+    fn drop(&mut self) {
+        unsafe { ffi::sdxl_ctx_destroy(self.raw) };
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Conditioning
+/// `Conditioning<B>` of the reference, field for field (`stablediffusion/mod.rs:544-555`)
+#[derive(Clone, Debug)]
+pub struct Conditioning<B: BurnBackend> {
+    pub unconditional_context_full: Tensor<B, 2>,
+    pub unconditional_context_open_clip: Tensor<B, 2>,
+    pub context_full: Tensor<B, 3>,
+    pub context_open_clip: Tensor<B, 3>,
+    pub unconditional_channel_context: Tensor<B, 1>,
+    pub unconditional_channel_context_refiner: Tensor<B, 1>,
+    pub channel_context: Tensor<B, 2>,
+    pub channel_context_refiner: Tensor<B, 2>,
+    pub resolution: [usize; 2], // (height, width)
+}
+
+/// the eight tensors on the device + the C view of them; the buffers live as long as this value
+struct DeviceConditioning {
+    _bufs: Vec<DeviceBuf>,
+    c: ffi::sdxl_conditioning,
+}
+fn to_c_conditioning<B: BurnBackend>(c: &Conditioning<B>) -> DeviceConditioning {
+    let [n, n_ctx, _] = c.context_full.dims();
+    let bufs = vec![
+        bridge::upload(c.unconditional_context_full.clone()),
+        bridge::upload(c.unconditional_context_open_clip.clone()),
+        bridge::upload(c.context_full.clone()),
+        bridge::upload(c.context_open_clip.clone()),
+        bridge::upload(c.unconditional_channel_context.clone()),
+        bridge::upload(c.unconditional_channel_context_refiner.clone()),
+        bridge::upload(c.channel_context.clone()),
+        bridge::upload(c.channel_context_refiner.clone()),
+    ];
+    let raw = ffi::sdxl_conditioning {
+        unconditional_context_full: bufs[0].f32_ptr(),
+        unconditional_context_open_clip: bufs[1].f32_ptr(),
+        context_full: bufs[2].f32_ptr(),
+        context_open_clip: bufs[3].f32_ptr(),
+        unconditional_channel_context: bufs[4].f32_ptr(),
+        unconditional_channel_context_refiner: bufs[5].f32_ptr(),
+        channel_context: bufs[6].f32_ptr(),
+        channel_context_refiner: bufs[7].f32_ptr(),
+        n: n as i32,
+        n_ctx: n_ctx as i32,
+        height: c.resolution[0] as i32,
+        width: c.resolution[1] as i32,
+    };
+    DeviceConditioning { _bufs: bufs, c: raw }
+}
+
+// ------------------------------------------------------------------------------------------------ configs
+/// `DiffuserConfig` (`stablediffusion/mod.rs:269-278`), same fields
+#[derive(Clone, Debug)]
+pub struct DiffuserConfig {
+    pub adm_in_channels: usize,
+    pub model_channels: usize,
+    pub channel_mults: Vec<usize>,
+    pub num_head_channels: usize,
+    pub transformer_depths: Vec<usize>,
+    pub context_dim: usize,
+    pub is_refiner: bool,
+}
+impl DiffuserConfig {
+    pub fn sdxl_base() -> Self {
+        DiffuserConfig { adm_in_channels: 2816, model_channels: 320, channel_mults: vec![1, 2, 4], num_head_channels: 64,
+                         transformer_depths: vec![0, 2, 10], context_dim: 2048, is_refiner: false }
+    }
+    pub fn sdxl_refiner() -> Self {
+        DiffuserConfig { adm_in_channels: 2560, model_channels: 384, channel_mults: vec![1, 2, 4, 4], num_head_channels: 64,
+                         transformer_depths: vec![0, 4, 4, 4], context_dim: 1280, is_refiner: true }
+    }
+    fn to_c(&self) -> ffi::sdxl_unet_config {
+        assert!(self.channel_mults.len() == self.transformer_depths.len() && self.channel_mults.len() <= 8);
+        let mut c: ffi::sdxl_unet_config = unsafe { std::mem::zeroed() };
+        c.adm_in_channels = self.adm_in_channels as i32;
+        c.in_channels = 4;
+        c.out_channels = 4;
+        c.model_channels = self.model_channels as i32;
+        c.n_levels = self.channel_mults.len() as i32;
+        for (i, (&m, &d)) in self.channel_mults.iter().zip(&self.transformer_depths).enumerate() {
+            c.channel_mults[i] = m as i32;
+            c.transformer_depths[i] = d as i32;
+        }
+        c.n_head_channels = self.num_head_channels as i32;
+        c.context_dim = self.context_dim as i32;
+        c.is_refiner = self.is_refiner as i32;
+        c
+    }
+    /// replaces `DiffuserConfig::init` + `load_record` (`stablediffusion/mod.rs:281-305`, `bin/sample/main.rs:35-43`):
+    /// `weights_flat` = the tensors of `sdxl_unet_param_spec` order back to back, fp32 (see `param_names`)
+    pub fn init_with_weights<B: BurnBackend>(&self, ctx: &Mi355Context, precision: Precision, weights_flat: &[f32],
+                                             alphas_cumprod: &[f32]) -> Result<Diffuser<B>, Box<dyn std::error::Error>> {
+        let cfg = self.to_c();
+        let need = param_numel(&cfg);
+        if weights_flat.len() != need {
+            return Err(format!("expected {need} weight values, got {}", weights_flat.len()).into());
+        }
+        let mut raw = ptr::null_mut();
+        try_check(unsafe {
+            ffi::sdxl_diffuser_create(ctx.raw, &cfg, precision as c_int, weights_flat.as_ptr(), alphas_cumprod.as_ptr(),
+                                      alphas_cumprod.len() as c_int, &mut raw)
+        })?;
+        Ok(Diffuser { raw, n_steps: alphas_cumprod.len(), is_refiner: self.is_refiner, _b: std::marker::PhantomData })
+    }
+    /// seeded synthetic weights generated on the device (no checkpoint): what the parity tests and `bench.py` run
+    pub fn init_synthetic<B: BurnBackend>(&self, ctx: &Mi355Context, precision: Precision, seed: u64, alphas_cumprod: &[f32]) -> Diffuser<B> {
+        let cfg = self.to_c();
+        let mut raw = ptr::null_mut();
+        check(unsafe {
+            ffi::sdxl_diffuser_create_synthetic(ctx.raw, &cfg, precision as c_int, seed, alphas_cumprod.as_ptr(),
+                                                alphas_cumprod.len() as c_int, &mut raw)
+        });
+        Diffuser { raw, n_steps: alphas_cumprod.len(), is_refiner: self.is_refiner, _b: std::marker::PhantomData }
+    }
+}
+fn param_numel(cfg: &ffi::sdxl_unet_config) -> usize {
+    let n = unsafe { ffi::sdxl_unet_param_count(cfg) };
+    assert!(n > 0, "sdxl_mi355: {}", last_error());
+    let mut total = 0usize;
+    for i in 0..n {
+        let (mut name, mut ndim, mut shape, mut kind, mut sc, mut mean) = (ptr::null(), 0, [0i64; 4], 0, 0f32, 0f32);
+        check(unsafe { ffi::sdxl_unet_param_spec(cfg, i, &mut name, &mut ndim, shape.as_mut_ptr(), &mut kind, &mut sc, &mut mean) });
+        total += shape[..ndim as usize].iter().product::<i64>() as usize;
+    }
+    total
+}
+/// the reference's struct-field paths of every parameter, in hand-over order (`unet/load.rs:286-401`)
+pub fn param_names(cfg: &DiffuserConfig) -> Vec<(String, Vec<usize>)> {
+    let c = cfg.to_c();
+    let n = unsafe { ffi::sdxl_unet_param_count(&c) };
+    (0..n)
+        .map(|i| {
+            let (mut name, mut ndim, mut shape, mut kind, mut sc, mut mean) = (ptr::null(), 0, [0i64; 4], 0, 0f32, 0f32);
+            check(unsafe { ffi::sdxl_unet_param_spec(&c, i, &mut name, &mut ndim, shape.as_mut_ptr(), &mut kind, &mut sc, &mut mean) });
+            (unsafe { CStr::from_ptr(name) }.to_string_lossy().into_owned(), shape[..ndim as usize].iter().map(|&d| d as usize).collect())
+        })
+        .collect()
+}
+
+// ------------------------------------------------------------------------------------------------ Diffuser
+/// `Diffuser<B>` (`stablediffusion/mod.rs:308-542`): the DDIM loop, CFG pair and UNet run on the MI355X
+pub struct Diffuser<B: BurnBackend> {
+    raw: *mut ffi::sdxl_diffuser,
+    n_steps: usize,
+    is_refiner: bool,
+    _b: std::marker::PhantomData<B>,
+}
+impl<B: BurnBackend> Drop for Diffuser<B> {
+    fn drop(&mut self) {
+        unsafe { ffi::sdxl_diffuser_destroy(self.raw) };
+    }
+}
+impl<B: BurnBackend> Diffuser<B> {
+    /// reference signature (`:317-322`); noise = `gen_noise` (`:378-388`)
+    pub fn sample_latent(&self, conditioning: Conditioning<B>, unconditional_guidance_scale: f64, n_steps: usize) -> Tensor<B, 4> {
+        let noise = Self::gen_noise(&conditioning);
+        self.sample_latent_with_noise(conditioning, unconditional_guidance_scale, n_steps, noise)
+    }
+    pub fn sample_latent_with_noise(&self, conditioning: Conditioning<B>, unconditional_guidance_scale: f64, n_steps: usize,
+                                    noise0: Tensor<B, 4>) -> Tensor<B, 4> {
+        let device = conditioning.context_full.device();
+        let dims = noise0.dims();
+        let dc = to_c_conditioning(&conditioning);
+        let noise = bridge::upload(noise0);
+        let out = DeviceBuf::new(dims.iter().product::<usize>() * 4);
+        check(unsafe {
+            ffi::sdxl_sample_latent(self.raw, ptr::null_mut(), &dc.c, unconditional_guidance_scale, n_steps as c_int, noise.f32_ptr(), out.f32_mut())
+        });
+        bridge::download(&out, dims, &device)
+    }
+    /// reference signature (`:334-341`): mask true = keep the generated latent (`mask_where`, `:465`); the per-step re-noise
+    /// of the reference (`:463`) is drawn here, one `gen_noise` per iteration
+    pub fn sample_latent_with_inpainting(&self, conditioning: Conditioning<B>, unconditional_guidance_scale: f64, n_steps: usize,
+                                         reference: Tensor<B, 4>, mask: Tensor<B, 4, Bool>) -> Tensor<B, 4> {
+        let iters = unsafe { ffi::sdxl_step_count(n_steps as c_int, 0, self.n_steps as c_int) } as usize;
+        let noise0 = Self::gen_noise(&conditioning);
+        let step_noise: Vec<Tensor<B, 4>> = (0..iters).map(|_| Self::gen_noise(&conditioning)).collect();
+        self.sample_latent_with_inpainting_and_noise(conditioning, unconditional_guidance_scale, n_steps, reference, mask, noise0, step_noise)
+    }
+    #[allow(clippy::too_many_arguments)]
+    pub fn sample_latent_with_inpainting_and_noise(&self, conditioning: Conditioning<B>, unconditional_guidance_scale: f64, n_steps: usize,
+                                                   reference: Tensor<B, 4>, mask: Tensor<B, 4, Bool>, noise0: Tensor<B, 4>,
+                                                   step_noise: Vec<Tensor<B, 4>>) -> Tensor<B, 4> {
+        let device = conditioning.context_full.device();
+        let dims = noise0.dims();
+        let dc = to_c_conditioning(&conditioning);
+        let mask_u8: Vec<u8> = mask.into_data().value.iter().map(|&m| m as u8).collect();
+        let (d_ref, d_mask, d_noise) = (bridge::upload(reference), DeviceBuf::from_u8(&mask_u8), bridge::upload(noise0));
+        let d_steps = bridge::upload(Tensor::cat(step_noise.into_iter().map(|t| t.unsqueeze::<5>()).collect(), 0));
+        let out = DeviceBuf::new(dims.iter().product::<usize>() * 4);
+        check(unsafe {
+            ffi::sdxl_sample_latent_with_inpainting(self.raw, ptr::null_mut(), &dc.c, unconditional_guidance_scale, n_steps as c_int,
+                                                    d_ref.f32_ptr(), d_mask.ptr as *const u8, d_noise.f32_ptr(), d_steps.f32_ptr(), out.f32_mut())
+        });
+        bridge::download(&out, dims, &device)
+    }
+    /// reference signature (`:355-362`)
+    pub fn refine_latent(&self, latent: Tensor<B, 4>, conditioning: Conditioning<B>, unconditional_guidance_scale: f64, step_start: usize,
+                         n_steps: usize) -> Tensor<B, 4> {
+        let noise = Self::gen_noise(&conditioning);
+        self.refine_latent_with_noise(latent, conditioning, unconditional_guidance_scale, step_start, n_steps, noise)
+    }
+    pub fn refine_latent_with_noise(&self, latent: Tensor<B, 4>, conditioning: Conditioning<B>, unconditional_guidance_scale: f64,
+                                    step_start: usize, n_steps: usize, noise: Tensor<B, 4>) -> Tensor<B, 4> {
+        let device = conditioning.context_full.device();
+        let dims = latent.dims();
+        let dc = to_c_conditioning(&conditioning);
+        let (d_lat, d_noise) = (bridge::upload(latent), bridge::upload(noise));
+        let out = DeviceBuf::new(dims.iter().product::<usize>() * 4);
+        check(unsafe {
+            ffi::sdxl_refine_latent(self.raw, ptr::null_mut(), d_lat.f32_ptr(), &dc.c, unconditional_guidance_scale, step_start as c_int,
+                                    n_steps as c_int, d_noise.f32_ptr(), out.f32_mut())
+        });
+        bridge::download(&out, dims, &device)
+    }
+    /// `gen_noise` (`:378-388`)
+    fn gen_noise(conditioning: &Conditioning<B>) -> Tensor<B, 4> {
+        let device = conditioning.context_full.device();
+        let [n_batches, _, _] = conditioning.context_full.dims();
+        let [height, width] = conditioning.resolution;
+        Tensor::random([n_batches, 4, height / 8, width / 8], Distribution::Normal(0.0, 1.0), &device)
+    }
+    /// `Diffuser.diffusion` (`:312`): the UNet alone, reference signature of `UNet::forward` (`unet/mod.rs:450-456`)
+    pub fn unet_forward(&self, x: Tensor<B, 4>, timesteps: Tensor<B, 1, Int>, context: Tensor<B, 3>, label: Tensor<B, 2>) -> Tensor<B, 4> {
+        let device = x.device();
+        let [b, c_in, h, w] = x.dims();
+        let [_, n_ctx, _] = context.dims();
+        let (d_x, (d_t, _), d_c, d_y) = (bridge::upload(x), bridge::upload_int(timesteps), bridge::upload(context), bridge::upload(label));
+        let out = DeviceBuf::new(b * c_in * h * w * 4);
+        let unet = unsafe { ffi::sdxl_diffuser_unet(self.raw) };
+        check(unsafe {
+            ffi::sdxl_unet_forward(unet, ptr::null_mut(), d_x.f32_ptr(), d_t.ptr as *const i32, d_c.f32_ptr(), d_y.f32_ptr(), b as c_int,
+                                   h as c_int, w as c_int, n_ctx as c_int, out.f32_mut())
+        });
+        bridge::download(&out, [b, c_in, h, w], &device)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LatentDecoder
+/// `RawImages` (`stablediffusion/mod.rs:170-174`)
+pub struct RawImages {
+    pub buffer: Vec<Vec<u8>>,
+    pub width: usize,
+    pub height: usize,
+}
+/// `LatentDecoder<B>` (`:193-267`) over the engine's VAE; the reference runs it in f32 (`bin/sample/main.rs:121,271-278`)
+pub struct LatentDecoder<B: BurnBackend> {
+    raw: *mut ffi::sdxl_vae,
+    _b: std::marker::PhantomData<B>,
+}
+impl<B: BurnBackend> Drop for LatentDecoder<B> {
+    fn drop(&mut self) {
+        unsafe { ffi::sdxl_vae_destroy(self.raw) };
+    }
+}
+impl<B: BurnBackend> LatentDecoder<B> {
+    pub fn synthetic(ctx: &Mi355Context, precision: Precision, seed: u64, with_encoder: bool) -> Self {
+        let mut cfg: ffi::sdxl_vae_config = unsafe { std::mem::zeroed() };
+        unsafe { ffi::sdxl_vae_config_default(&mut cfg) };
+        let mut raw = ptr::null_mut();
+        check(unsafe { ffi::sdxl_vae_create_synthetic(ctx.raw, &cfg, precision as c_int, seed, with_encoder as c_int, &mut raw) });
+        LatentDecoder { raw, _b: std::marker::PhantomData }
+    }
+    pub fn with_weights(ctx: &Mi355Context, precision: Precision, decoder_flat: Option<&[f32]>, encoder_flat: Option<&[f32]>)
+                        -> Result<Self, Box<dyn std::error::Error>> {
+        let mut cfg: ffi::sdxl_vae_config = unsafe { std::mem::zeroed() };
+        unsafe { ffi::sdxl_vae_config_default(&mut cfg) };
+        let mut raw = ptr::null_mut();
+        try_check(unsafe {
+            ffi::sdxl_vae_create(ctx.raw, &cfg, precision as c_int, decoder_flat.map_or(ptr::null(), |w| w.as_ptr()),
+                                 encoder_flat.map_or(ptr::null(), |w| w.as_ptr()), &mut raw)
+        })?;
+        Ok(LatentDecoder { raw, _b: std::marker::PhantomData })
+    }
+    /// `:200-237`: the `(x+1)/2*255`, NHWC reorder, clamp and truncating u8 cast run on the device
+    pub fn latent_to_image(&self, latent: Tensor<B, 4>) -> RawImages {
+        let [n, _, lh, lw] = latent.dims();
+        let (height, width) = (lh * 8, lw * 8);
+        let d_lat = bridge::upload(latent);
+        let out = DeviceBuf::new(n * height * width * 3);
+        check(unsafe { ffi::sdxl_latent_to_image(self.raw, ptr::null_mut(), d_lat.f32_ptr(), n as c_int, lh as c_int, lw as c_int, out.ptr as *mut u8) });
+        let flat = out.to_u8();
+        let per = height * width * 3;
+        RawImages { buffer: (0..n).map(|b| flat[b * per..(b + 1) * per].to_vec()).collect(), width, height }
+    }
+    /// `:239-255`
+    pub fn image_to_latent(&self, images: &RawImages, device: &B::Device) -> Tensor<B, 4> {
+        let n = images.buffer.len();
+        let flat: Vec<u8> = images.buffer.iter().flatten().copied().collect();
+        let d_img = DeviceBuf::from_u8(&flat);
+        let dims = [n, 4, images.height / 8, images.width / 8];
+        let out = DeviceBuf::new(dims.iter().product::<usize>() * 4);
+        check(unsafe {
+            ffi::sdxl_image_to_latent(self.raw, ptr::null_mut(), d_img.ptr as *const u8, n as c_int, images.height as c_int,
+                                      images.width as c_int, out.f32_mut())
+        });
+        bridge::download(&out, dims, device)
+    }
+    /// `:257-261`
+    pub fn encode_image(&self, x: Tensor<B, 4>) -> Tensor<B, 4> {
+        let device = x.device();
+        let [n, _, h, w] = x.dims();
+        let d_x = bridge::upload(x);
+        let dims = [n, 4, h / 8, w / 8];
+        let out = DeviceBuf::new(dims.iter().product::<usize>() * 4);
+        check(unsafe { ffi::sdxl_vae_encode_image(self.raw, ptr::null_mut(), d_x.f32_ptr(), n as c_int, h as c_int, w as c_int, out.f32_mut()) });
+        bridge::download(&out, dims, &device)
+    }
+    /// `:263-266`
+    pub fn decode_latent(&self, x: Tensor<B, 4>) -> Tensor<B, 4> {
+        let device = x.device();
+        let [n, _, h, w] = x.dims();
+        let d_x = bridge::upload(x);
+        let dims = [n, 3, 8 * h, 8 * w];
+        let out = DeviceBuf::new(dims.iter().product::<usize>() * 4);
+        check(unsafe { ffi::sdxl_vae_decode_latent(self.raw, ptr::null_mut(), d_x.f32_ptr(), n as c_int, h as c_int, w as c_int, out.f32_mut()) });
+        bridge::download(&out, dims, &device)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Embedder
+/// the reference's tokenizer trait (`src/token/mod.rs:4-11`): the host keeps its own BPE implementations
+pub trait Tokenizer {
+    fn encode(&self, text: &str, add_sot: bool, add_eot: bool) -> Vec<u32>;
+    fn padding_token(&self) -> u32;
+}
+/// `Embedder<B>` (`stablediffusion/mod.rs:652-757`): both CLIP text towers run on the device, tokenisation stays host code
+pub struct Embedder<B: BurnBackend, T1: Tokenizer, T2: Tokenizer> {
+    ctx: *mut ffi::sdxl_ctx,
+    clip: *mut ffi::sdxl_clip,
+    open_clip: *mut ffi::sdxl_clip,
+    clip_tokenizer: T1,
+    open_clip_tokenizer: T2,
+    _b: std::marker::PhantomData<B>,
+}
+impl<B: BurnBackend, T1: Tokenizer, T2: Tokenizer> Drop for Embedder<B, T1, T2> {
+    fn drop(&mut self) {
+        unsafe {
+            ffi::sdxl_clip_destroy(self.clip);
+            ffi::sdxl_clip_destroy(self.open_clip);
+        }
+    }
+}
+impl<B: BurnBackend, T1: Tokenizer, T2: Tokenizer> Embedder<B, T1, T2> {
+    pub fn synthetic(ctx: &Mi355Context, precision: Precision, seed: u64, clip_tokenizer: T1, open_clip_tokenizer: T2) -> Self {
+        let (mut c1, mut c2): (ffi::sdxl_clip_config, ffi::sdxl_clip_config) = unsafe { (std::mem::zeroed(), std::mem::zeroed()) };
+        unsafe {
+            ffi::sdxl_clip_config_clip_l(&mut c1);
+            ffi::sdxl_clip_config_open_clip_bigg(&mut c2);
+        }
+        let (mut clip, mut open_clip) = (ptr::null_mut(), ptr::null_mut());
+        check(unsafe { ffi::sdxl_clip_create_synthetic(ctx.raw, &c1, precision as c_int, seed, &mut clip) });
+        check(unsafe { ffi::sdxl_clip_create_synthetic(ctx.raw, &c2, precision as c_int, seed + 1, &mut open_clip) });
+        Embedder { ctx: ctx.raw, clip, open_clip, clip_tokenizer, open_clip_tokenizer, _b: std::marker::PhantomData }
+    }
+    fn tokens(tok: &dyn Tokenizer, text: &str, n_ctx: usize) -> Vec<i32> {
+        // tokenize_text (`:785-801`): sot + text + eot, padded to the context length
+        let mut ids: Vec<i32> = tok.encode(text, true, true).into_iter().map(|t| t as i32).collect();
+        ids.truncate(n_ctx);
+        ids.resize(n_ctx, tok.padding_token() as i32);
+        ids
+    }
+    /// one prompt through one tower: (penultimate hidden state [77, n_state], pooled projection [embed_dim] when asked for)
+    fn run_tower(&self, tower: *mut ffi::sdxl_clip, ids: &[i32], n_state: usize, embed_dim: usize, hidden_idx: i32, pooled: bool) -> (Vec<f32>, Vec<f32>) {
+        let d_ids = DeviceBuf::new(ids.len() * 4);
+        assert_eq!(unsafe { hipMemcpy(d_ids.ptr, ids.as_ptr() as *const c_void, ids.len() * 4, HIP_MEMCPY_HOST_TO_DEVICE) }, 0);
+        let hidden = DeviceBuf::new(ids.len() * n_state * 4);
+        let pool = DeviceBuf::new(embed_dim * 4);
+        if pooled {
+            check(unsafe {
+                ffi::sdxl_clip_forward_hidden_pooled(tower, ptr::null_mut(), d_ids.ptr as *const i32, 1, ids.len() as c_int, hidden_idx,
+                                                     hidden.f32_mut(), pool.f32_mut())
+            });
+        } else {
+            check(unsafe { ffi::sdxl_clip_forward_hidden(tower, ptr::null_mut(), d_ids.ptr as *const i32, 1, ids.len() as c_int, hidden_idx, hidden.f32_mut()) });
+        }
+        (hidden.to_f32(), pool.to_f32())
+    }
+    /// reference signature (`:661-667`)
+    pub fn text_to_conditioning(&self, text: &str, size: Tensor<B, 2, Int>, crop: Tensor<B, 2, Int>, ar: Tensor<B, 1, Int>) -> Conditioning<B> {
+        let device = size.device();
+        let ar_v: Vec<i64> = ar.clone().into_data().value.iter().map(|x| x.elem::<i64>()).collect();
+        let resolution = [ar_v[0] as usize, ar_v[1] as usize];
+        const N_CTX: usize = 77;
+        // CLIP-L: hidden state after 11 of 12 blocks; OpenCLIP bigG: after 31 of 32 + pooled text embedding (`:676-688`)
+        let embed = |text: &str| {
+            let (h1, _) = self.run_tower(self.clip, &Self::tokens(&self.clip_tokenizer, text, N_CTX), 768, 768, 11, false);
+            let (h2, pooled) = self.run_tower(self.open_clip, &Self::tokens(&self.open_clip_tokenizer, text, N_CTX), 1280, 1280, 31, true);
+            let mut full = Vec::with_capacity(N_CTX * 2048);
+            for t in 0..N_CTX {
+                full.extend_from_slice(&h1[t * 768..(t + 1) * 768]);
+                full.extend_from_slice(&h2[t * 1280..(t + 1) * 1280]);
+            }
+            (full, h2, pooled)
+        };
+        let (full, open, pooled) = embed(text);
+        let (ufull, uopen, upooled) = embed("");
+        // conditioning_embedding (`unet/mod.rs:41-57`): pooled | sinusoid(size, crop, ar); the refiner variant swaps ar for
+        // the aesthetic score 6 (`stablediffusion/mod.rs:709,740`)
+        let ints = |t: Tensor<B, 2, Int>| -> Vec<i32> { t.into_data().value.iter().map(|x| x.elem::<i32>()).collect() };
+        let (size_v, crop_v) = (ints(size), ints(crop));
+        let cond_emb = |pooled: &[f32], vals: &[i32]| -> Vec<f32> {
+            let (d_p, d_v) = (DeviceBuf::from_f32(pooled), DeviceBuf::new(vals.len() * 4));
+            assert_eq!(unsafe { hipMemcpy(d_v.ptr, vals.as_ptr() as *const c_void, vals.len() * 4, HIP_MEMCPY_HOST_TO_DEVICE) }, 0);
+            let out = DeviceBuf::new((pooled.len() + vals.len() * 256) * 4);
+            check(unsafe {
+                ffi::sdxl_conditioning_embedding(self.ctx, ptr::null_mut(), d_p.f32_ptr(), 1, pooled.len() as c_int, d_v.ptr as *const i32,
+                                                 vals.len() as c_int, 256, out.f32_mut())
+            });
+            out.to_f32()
+        };
+        let base_vals: Vec<i32> = [&size_v[..2], &crop_v[..2], &[ar_v[0] as i32, ar_v[1] as i32][..]].concat();
+        let refiner_vals: Vec<i32> = [&size_v[..2], &crop_v[..2], &[6][..]].concat();
+        let t2 = |v: Vec<f32>, c: usize| Tensor::<B, 2>::from_data(Data::new(v, Shape::new([N_CTX, c])).convert(), &device);
+        let t1 = |v: Vec<f32>| { let n = v.len(); Tensor::<B, 1>::from_data(Data::new(v, Shape::new([n])).convert(), &device) };
+        Conditioning {
+            unconditional_context_full: t2(ufull, 2048),
+            unconditional_context_open_clip: t2(uopen, 1280),
+            context_full: t2(full, 2048).unsqueeze(),
+            context_open_clip: t2(open, 1280).unsqueeze(),
+            unconditional_channel_context: t1(cond_emb(&upooled, &base_vals)),
+            unconditional_channel_context_refiner: t1(cond_emb(&upooled, &refiner_vals)),
+            channel_context: t1(cond_emb(&pooled, &base_vals)).unsqueeze(),
+            channel_context_refiner: t1(cond_emb(&pooled, &refiner_vals)).unsqueeze(),
+            resolution,
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ operator plug-in
+/// the reference's own operator plug-in point (`src/backend.rs:3-24`).  Same trait, same default bodies; a backend opts into
+/// the MI355X kernels by overriding the two methods with the functions below, exactly as the reference overrides them for
+/// `LibTorch<E>` (`src/backend.rs:31-80`).
+pub trait Backend: BurnBackend {
+    fn qkv_attention(q: Self::FloatTensorPrimitive<3>, k: Self::FloatTensorPrimitive<3>, v: Self::FloatTensorPrimitive<3>,
+                     mask: Option<Self::FloatTensorPrimitive<2>>, n_head: usize) -> Self::FloatTensorPrimitive<3> {
+        mi355_qkv_attention::<Self>(Tensor::from_primitive(q), Tensor::from_primitive(k), Tensor::from_primitive(v),
+                                    mask.map(Tensor::from_primitive), n_head)
+            .into_primitive()
+    }
+    fn attn_decoder_mask(seq_length: usize, device: &Self::Device) -> Self::FloatTensorPrimitive<2> {
+        mi355_attn_decoder_mask::<Self>(seq_length, device).into_primitive()
+    }
+}
+thread_local! {
+    /// the context the operator plug-in launches on (the trait's functions are static: no `self` to carry it)
+    static OP_CTX: std::cell::RefCell<Option<Mi355Context>> = const { std::cell::RefCell::new(None) };
+}
+fn with_op_ctx<R>(f: impl FnOnce(*mut ffi::sdxl_ctx) -> R) -> R {
+    OP_CTX.with(|c| {
+        let mut c = c.borrow_mut();
+        if c.is_none() {
+            *c = Some(Mi355Context::new(0).expect("sdxl_mi355: no MI355X visible (the engine has no CPU path)"));
+        }
+        f(c.as_ref().unwrap().raw)
+    })
+}
+/// `qkv_attention` (`src/backend.rs:88-128`): q [B,Nq,C], k/v [B,Nk,C], additive mask [Nq,Nk] -> [B,Nq,C]
+pub fn mi355_qkv_attention<B: BurnBackend>(q: Tensor<B, 3>, k: Tensor<B, 3>, v: Tensor<B, 3>, mask: Option<Tensor<B, 2>>, n_head: usize) -> Tensor<B, 3> {
+    let device = q.device();
+    let [b, nq, c] = q.dims();
+    let [_, nk, _] = k.dims();
+    let (d_q, d_k, d_v) = (bridge::upload(q), bridge::upload(k), bridge::upload(v));
+    let d_m = mask.map(|m| bridge::upload(m.slice([0..nq, 0..nk])));
+    let out = DeviceBuf::new(b * nq * c * 4);
+    with_op_ctx(|ctx| {
+        check(unsafe {
+            ffi::sdxl_qkv_attention(ctx, ptr::null_mut(), d_q.f32_ptr(), d_k.f32_ptr(), d_v.f32_ptr(), d_m.as_ref().map_or(ptr::null(), |m| m.f32_ptr()),
+                                    b as c_int, nq as c_int, nk as c_int, c as c_int, n_head as c_int, ffi::SDXL_DTYPE_F32 as c_int, out.f32_mut())
+        })
+    });
+    bridge::download(&out, [b, nq, c], &device)
+}
+/// `attn_decoder_mask` (`src/backend.rs:130-136`)
+pub fn mi355_attn_decoder_mask<B: BurnBackend>(seq_length: usize, device: &B::Device) -> Tensor<B, 2> {
+    let out = DeviceBuf::new(seq_length * seq_length * 4);
+    with_op_ctx(|ctx| check(unsafe { ffi::sdxl_attn_decoder_mask(ctx, ptr::null_mut(), seq_length as c_int, out.f32_mut()) }));
+    bridge::download(&out, [seq_length, seq_length], device)
+}

@@ -76,6 +76,7 @@ ABI_SYMBOLS = [
     "sdxl_clip_config_clip_l", "sdxl_clip_config_open_clip_bigg", "sdxl_clip_param_count", "sdxl_clip_param_spec",
     "sdxl_clip_create", "sdxl_clip_create_synthetic", "sdxl_clip_destroy", "sdxl_clip_forward_hidden",
     "sdxl_clip_forward_hidden_pooled", "sdxl_conditioning_embedding", "sdxl_clip_weight_arena",
+    "sdxl_unet_create_f16", "sdxl_diffuser_create_f16", "sdxl_vae_create_f16", "sdxl_clip_create_f16",
     "sdxl_comm_unique_id", "sdxl_comm_create", "sdxl_comm_destroy", "sdxl_bcast_buffer", "sdxl_unet_bcast_weights",
     "sdxl_vae_bcast_weights", "sdxl_clip_bcast_weights", "sdxl_bcast_plan",
 ]
@@ -317,6 +318,9 @@ class UNet:
         c = cfg.to_c()
         if weights is None:
             _check(lib().sdxl_unet_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), ctypes.byref(self.h)))
+        elif np.asarray(weights).dtype == np.float16:     # flat f16 (burn HalfPrecisionSettings records): no fp32 expansion
+            w = np.ascontiguousarray(weights)
+            _check(lib().sdxl_unet_create_f16(ctx.h, ctypes.byref(c), dtype, w.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self.h)))
         else:
             w = np.ascontiguousarray(weights, dtype=np.float32)
             _check(lib().sdxl_unet_create(ctx.h, ctypes.byref(c), dtype, w.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self.h)))
@@ -398,6 +402,9 @@ class CLIP:
         c = cfg.to_c()
         if weights is None:
             _check(lib().sdxl_clip_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), ctypes.byref(self.h)))
+        elif np.asarray(weights).dtype == np.float16:
+            w = np.ascontiguousarray(weights)
+            _check(lib().sdxl_clip_create_f16(ctx.h, ctypes.byref(c), dtype, w.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self.h)))
         else:
             w = np.ascontiguousarray(weights, dtype=np.float32)
             _check(lib().sdxl_clip_create(ctx.h, ctypes.byref(c), dtype, w.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self.h)))
@@ -561,6 +568,10 @@ class Diffuser:
         elif weights is None:
             _check(lib().sdxl_diffuser_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), ap,
                                                        self.n_train, ctypes.byref(self.h)))
+        elif np.asarray(weights).dtype == np.float16:
+            w = np.ascontiguousarray(weights)
+            _check(lib().sdxl_diffuser_create_f16(ctx.h, ctypes.byref(c), dtype, w.ctypes.data_as(ctypes.c_void_p), ap,
+                                                 self.n_train, ctypes.byref(self.h)))
         else:
             w = np.ascontiguousarray(weights, dtype=np.float32)
             _check(lib().sdxl_diffuser_create(ctx.h, ctypes.byref(c), dtype, w.ctypes.data_as(ctypes.c_void_p), ap,
@@ -655,6 +666,12 @@ class LatentDecoder:
         elif decoder_weights is None and encoder_weights is None:
             _check(lib().sdxl_vae_create_synthetic(ctx.h, ctypes.byref(c), dtype, ctypes.c_uint64(seed), int(with_encoder),
                                                   ctypes.byref(self.h)))
+        elif any(w is not None and np.asarray(w).dtype == np.float16 for w in (decoder_weights, encoder_weights)):
+            d = None if decoder_weights is None else np.ascontiguousarray(decoder_weights, dtype=np.float16)
+            e = None if encoder_weights is None else np.ascontiguousarray(encoder_weights, dtype=np.float16)
+            _check(lib().sdxl_vae_create_f16(ctx.h, ctypes.byref(c), dtype,
+                                            None if d is None else d.ctypes.data_as(ctypes.c_void_p),
+                                            None if e is None else e.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self.h)))
         else:
             d = None if decoder_weights is None else np.ascontiguousarray(decoder_weights, dtype=np.float32)
             e = None if encoder_weights is None else np.ascontiguousarray(encoder_weights, dtype=np.float32)

@@ -334,6 +334,15 @@ int sdxl_unet_create(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, cons
   return unet_create_impl(ctx, cfg, dtype, src, out);
   API_END
 }
+int sdxl_unet_create_f16(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const uint16_t* weights_flat_f16, sdxl_unet** out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && weights_flat_f16 != nullptr, "null argument");
+  use(ctx);
+  const std::vector<ParamSpec> specs = unet_param_specs(to_cfg(cfg));
+  FlatSourceF16 src(weights_flat_f16, specs);
+  return unet_create_impl(ctx, cfg, dtype, src, out);
+  API_END
+}
 int sdxl_unet_create_synthetic(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, uint64_t seed, sdxl_unet** out) {
   API_BEGIN
   SyntheticSource src(seed);
@@ -477,6 +486,15 @@ int sdxl_clip_create(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, cons
   return clip_create_impl(ctx, cfg, dtype, src, out);
   API_END
 }
+int sdxl_clip_create_f16(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, const uint16_t* weights_flat_f16, sdxl_clip** out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && weights_flat_f16 != nullptr, "null argument");
+  use(ctx);
+  const std::vector<ParamSpec> specs = clip_param_specs(to_ccfg(cfg));
+  FlatSourceF16 src(weights_flat_f16, specs);
+  return clip_create_impl(ctx, cfg, dtype, src, out);
+  API_END
+}
 int sdxl_clip_create_synthetic(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, uint64_t seed, sdxl_clip** out) {
   API_BEGIN
   SyntheticSource src(seed);
@@ -537,6 +555,16 @@ int sdxl_diffuser_create(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, 
   SDXL_REQUIRE(weights_flat != nullptr, "null weights");
   const std::vector<ParamSpec> specs = unet_param_specs(to_cfg(cfg));
   FlatSource src(weights_flat, specs);
+  return diffuser_create_impl(ctx, cfg, dtype, src, alphas, n_train, out);
+  API_END
+}
+int sdxl_diffuser_create_f16(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const uint16_t* weights_flat_f16,
+                             const float* alphas, int n_train, sdxl_diffuser** out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && weights_flat_f16 != nullptr, "null argument");
+  use(ctx);
+  const std::vector<ParamSpec> specs = unet_param_specs(to_cfg(cfg));
+  FlatSourceF16 src(weights_flat_f16, specs);
   return diffuser_create_impl(ctx, cfg, dtype, src, alphas, n_train, out);
   API_END
 }
@@ -645,6 +673,22 @@ int sdxl_diffuser_step_times(sdxl_diffuser* d, float* out_ms, int capacity) {
 }
 
 // ---------------------------------------------------------------------------------------------- VAE
+int sdxl_vae_create_f16(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, const uint16_t* dec_w, const uint16_t* enc_w, sdxl_vae** out) {
+  API_BEGIN
+  SDXL_REQUIRE(ctx && out && (dec_w || enc_w), "bad argument");
+  use(ctx);
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  const VaeCfg vc = to_vcfg(cfg);
+  const std::vector<ParamSpec> ds = vae_decoder_param_specs(vc), es = vae_encoder_param_specs(vc);
+  std::unique_ptr<FlatSourceF16> d, e;
+  if (dec_w) d.reset(new FlatSourceF16(dec_w, ds));
+  if (enc_w) e.reset(new FlatSourceF16(enc_w, es));
+  sdxl_vae* h = new sdxl_vae();
+  h->ctx = ctx;
+  try { h->v = new Vae(vc, cdt, d.get(), e.get(), ctx->stream); } catch (...) { delete h; throw; }
+  *out = h;
+  API_END
+}
 int sdxl_vae_create(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, const float* dec_w, const float* enc_w, sdxl_vae** out) {
   API_BEGIN
   SDXL_REQUIRE(ctx && out && (dec_w || enc_w), "bad argument");

@@ -100,6 +100,15 @@ struct FlatSource : WeightSource {   // flat fp32 buffer (host or device) in spe
   void fetch(const ParamSpec& s, size_t index, float* dst_dev, hipStream_t st) override;
 };
 
+struct FlatSourceF16 : WeightSource {   // flat IEEE-f16 buffer (host or device) in spec order -- how burn's HalfPrecisionSettings
+  // records store the weights (src/bin/sample/main.rs:37, src/bin/convert/main.rs:65-70): half the host memory of the fp32 path
+  const uint16_t* base; std::vector<size_t> offsets;
+  void* stage = nullptr; size_t stage_numel = 0;
+  FlatSourceF16(const uint16_t* b, const std::vector<ParamSpec>& specs);
+  ~FlatSourceF16() override;
+  void fetch(const ParamSpec& s, size_t index, float* dst_dev, hipStream_t st) override;
+};
+
 struct Lin {        // packed dense weight: [Npad][Kpad] compute dtype + fp32 bias [Npad]
   const void* w = nullptr; const float* b = nullptr;
   int N = 0, K = 0, Kpad = 0, Npad = 0, ksize = 1, cin = 0;

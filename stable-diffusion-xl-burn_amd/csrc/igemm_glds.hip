@@ -1119,7 +1119,6 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   }
 }
 
-#ifdef SDXL_MEASURE   // experiments that lost their A/B: built only by `build.py --measure`
 // ---------------------------------------------------------------------------------------------------------
 // Wide-tile variant for the GEGLU projections: block tile 256 x 320, k-tile 32.
 //
@@ -1198,7 +1197,10 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
     }
   };
 
-  f32x16 acc[TM][TN];
+  // the two 32-row halves of the wave tile live in SEPARATE accumulator arrays: the epilogue runs once per half, and handing
+  // it `&acc[i]` of one [2][5] array made hipcc address the accumulators through scratch (the round-1 build of this kernel
+  // lost 35 us in its epilogue to exactly that)
+  f32x16 acc0[1][TN], acc1[1][TN];
   const int nk = p.Kpad / KT;
   const int fr = lane & 31, fh = lane >> 5;
   unsigned basea, baseb;
@@ -1218,7 +1220,8 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
     __builtin_amdgcn_s_setprio(1);
     static_for<TM * TN>([&](auto X) {
       constexpr int x = decltype(X)::value, i = x / TN, j = x % TN;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[j], fA[i], acc[i][j], 0, 0, 0);
+      if constexpr (i == 0) acc0[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[j], fA[0], acc0[0][j], 0, 0, 0);
+      else acc1[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[j], fA[1], acc1[0][j], 0, 0, 0);
       if constexpr ((x & 1) == 0 && x / 2 < PER) {
         __builtin_amdgcn_sched_barrier(0);
         if (dma) issue(buf, std::integral_constant<int, x / 2>{});
@@ -1241,11 +1244,9 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   __builtin_amdgcn_sched_barrier(0);
   // (zeroed only now: keeping 160 accumulator registers live across the statistics loads of ln_prologue spills)
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc0[0][j][r] = 0.f; acc1[0][j][r] = 0.f; }
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned so = cur * STAGE;
@@ -1269,15 +1270,18 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   if (p.act == 1) {
     // two passes of 32 rows: a full 64 x 80 fp32 staging region per wave would not fit next to seven others
     char* region = smem + wave * (32 * (WN / 2) * 4);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const float la1[1] = {lnA[i]}, lc1[1] = {lnC[i]};
-      igemm_epilogue_staged_impl<1, TN, true>(p, *reinterpret_cast<const f32x16(*)[1][TN]>(&acc[i]), m0 + wm * WM + i * 32,
-                                              n0 + wn * WN, lane, region, false, la1, lc1, zeros);
+    {
+      const float la1[1] = {lnA[0]}, lc1[1] = {lnC[0]};
+      igemm_epilogue_staged_impl<1, TN, true>(p, acc0, m0 + wm * WM, n0 + wn * WN, lane, region, false, la1, lc1, zeros);
+    }
+    {
+      const float la1[1] = {lnA[1]}, lc1[1] = {lnC[1]};
+      igemm_epilogue_staged_impl<1, TN, true>(p, acc1, m0 + wm * WM + 32, n0 + wn * WN, lane, region, false, la1, lc1, zeros);
     }
   }   // (the launcher only admits GEGLU projections)
 }
 
+#ifdef SDXL_MEASURE   // experiment that lost its A/B: built only by `build.py --measure`
 // ---------------------------------------------------------------------------------------------------------
 // Warp-specialised variant: 8 compute waves + NL loader waves per workgroup.
 //
@@ -1532,6 +1536,8 @@ static void launch_ws(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_ws_kernel<BM, BN, NS, NL>), dim3(tilesM * tilesN), dim3(512 + 64 * NL), lds, s, p, g_zero_pages[dev]);
 }
 
+#endif  // SDXL_MEASURE
+
 static void launch_wide(const IgemmParams& p, hipStream_t s) {
   constexpr int NS = 4;
   const int tilesM = (p.M + 255) / 256, tilesN = (p.N + 319) / 320;
@@ -1542,7 +1548,6 @@ static void launch_wide(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_wide_kernel<NS>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_pages[dev]);
 }
 
-#endif  // SDXL_MEASURE
 
 // variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
 // 6 = 64x128 ring 2; 7 = 128x128 ring 4; 8 = 64x128 ring 3.  Returns false when the shape needs the generic kernel.
@@ -1555,7 +1560,9 @@ int igemm_splitk_slices(const IgemmParams& p) {
   if (!p.splitk_ws || !p.splitk_cnt) return 1;
   if (p.act != 0 || p.n_split < p.N || p.ln_stat) return 1;
   const int nk = p.Kpad / 64;
-  if (p.rpb <= 0 || p.rpb > 1024 || p.N > 1280 || nk < 36) return 1;
+  // measured (profiles/r02_splitk_sweep.txt): pays from K ~ 11520 (the 32^2 convs: +4 % at K = 11520, +22 % at K = 23040); at
+  // K = 5120 (FF-out) the serial combine costs more than the 24 % fewer bytes moved buy (57 vs 44 us), so the bar is 160 k-tiles
+  if (p.rpb <= 0 || p.rpb > 1024 || p.N > 1280 || nk < 160) return 1;
   return 3;
 }
 size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max) {
@@ -1584,28 +1591,30 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     return true;
   }
   if (variant == 0) {
-    // measured on MI355X (tools/igemm_sweep.py, profiles/r01_igemm_sweep.txt).  The global->LDS path sustains ~22 B/clk/CU,
-    // so the MFMA rate of a tile is ~ BM*BN/(BM+BN) flop per DMA byte: 256x128 (8 waves, pipelined) beats 128x128 wherever
-    // its grid still fills the chip; grids of <= 256 tiles run as ONE round, where the 8-wave 128x128 pipeline (one
-    // workgroup per CU, counted waits) beats two co-resident 4-wave blocks; ragged multi-round grids keep the 4-wave kernels
-    // (2..3 co-resident blocks per CU smooth the tail).
-    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-    const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-    if (t128 <= 256) variant = 36;
-    else if (t256 <= 256 || eff256 >= 0.8) variant = 35;
-    else variant = t128 >= 400 ? 4 : 6;
-    if (p.act == 1 && p.N % 160 == 0 && variant != 35) {
-      // single-prompt (M = 1024) GEGLU: 256x160 gives exactly one round of 256 tiles where 128x128 needs 2.5
-      const long t160 = (long)((p.M + 255) / 256) * (p.N / 160);
-      if (t160 <= 256 && t160 * 160 * 2 >= t128 * 128) variant = 38;
-    }
-    if (p.act == 1 && p.N % 160 == 0 && variant == 35) {
-      // GEGLU projections: the 256x160 tile (8x1 waves) when it saves whole rounds of 256 CUs (N = 10240 at M = 2048: 512
-      // tiles = 2 rounds instead of 640 = 2.5 -> 3); it pays ~10 % more LDS reads per MFMA, so it must win >= 15 % of area
-      const long t160 = (long)((p.M + 255) / 256) * (p.N / 160);
-      const double cost128 = (double)((t256 + 255) / 256) * 128.0, cost160 = (double)((t160 + 255) / 256) * 160.0 * 1.12;
-      if (cost160 < cost128) variant = 38;
+    // Tile choice by a two-term cost model fitted to the sweeps (profiles/r01_igemm_sweep.txt, r02_tile_sweep_256x160_256x320.txt).
+    // These GEMMs run against the chip's aggregate global->LDS rate (~9-10 TB/s whatever the tile), so a workgroup's k-loop
+    // time goes with the bytes it stages per k-tile, (BM + BN) x 128, and the grid costs whole ROUNDS of 256 CUs -- a last
+    // round that is only partly filled still costs >= 2/3 of a full one (fewer busy CUs stream faster, not proportionally):
+    //     cost = rounds_eff * (BM + BN) * k_tiles * w  +  ceil(rounds) * FIXED        FIXED ~ 8 us of launch/prologue/epilogue
+    // w = 1.2 for the 8x1-wave 256x160 tile (6 fragment reads per 5 MFMAs).  What the model buys: N = 320 / 1280 convs at
+    // 128^2 / 64^2 get 256x160 tiles = exactly one round (conv128 320: 95 -> 69 us, conv64 1280up: 353 -> 235 us) and the
+    // GEGLU projections the one-round 256x320 tile (lin64 geglu 88 -> 77 us, lin32 geglu 67 -> 63 us).
+    const int nk = p.Kpad / 64;
+    struct Cand { int v, bm, bn; double w; bool ok; };
+    const bool lin = p.ksize == 1 && p.stride == 1 && p.up == 0;
+    const Cand cands[4] = {
+        {35, 256, 128, 1.0, true},
+        {36, 128, 128, 1.0, true},
+        {38, 256, 160, 1.2, p.N % 160 == 0 && !p.stat_out},
+        {26, 256, 320, 1.05, p.act == 1 && lin && p.N % 320 == 0}};
+    double best = 1e300;
+    for (const Cand& c : cands) {
+      if (!c.ok) continue;
+      const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+      const long full = tiles / 256, rem = tiles % 256;
+      const double frac = rem ? (rem / 256.0 > 2.0 / 3.0 ? rem / 256.0 : 2.0 / 3.0) : 0.0;
+      const double cost = ((double)full + frac) * (c.bm + c.bn) * nk * c.w + (double)(full + (rem ? 1 : 0)) * 3000.0;
+      if (cost < best) { best = cost; variant = c.v; }
     }
   }
 #ifdef SDXL_MEASURE
@@ -1624,6 +1633,9 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 38:                                                                // 256x160 GEGLU tile (8x1 waves)
       if (p.N % 160 != 0) return false;
       launch_pipe<256, 160, 3, false, 0, 8, 8, true>(psk, s); break;
+    case 26:                                                                // 256x320, k-tile 32: linear GEGLU projections only
+      if (p.act != 1 || p.ksize != 1 || p.stride != 1 || p.up != 0 || p.N % 320 != 0 || p.Kpad % 32 != 0) return false;
+      launch_wide(psk, s); break;
 #ifdef SDXL_MEASURE
     // ---- A/B partners and experiments (build.py --measure): rolled loops, other rings, loader waves, measurement modes
     case 1: launch_glds<128, 128, 3>(psk, s); break;
@@ -1644,9 +1656,6 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 16: launch_pipe<128, 128, 4, true, 1>(psk, s); break;
     case 17: launch_pipe<256, 128, 3, true, 2>(psk, s); break;    // measurement only: no k advance (WRONG results)
     case 18: launch_pipe<256, 128, 3, true, 3>(psk, s); break;    // measurement only: no DMA in the loop (WRONG results)
-    case 26:                                                    // 256x320, k-tile 32: linear GEGLU projections only
-      if (p.act != 1 || p.ksize != 1 || p.stride != 1 || p.up != 0 || p.N % 320 != 0 || p.Kpad % 32 != 0) return false;
-      launch_wide(psk, s); break;
     case 24: launch_pipe<256, 128, 3, true, 4>(psk, s); break;    // lookahead-2 fragment prefetch
     case 27: launch_pipe<256, 128, 3, true, 5>(psk, s); break;    // measurement only: DMA-only / contiguous-source modes
     case 28: launch_pipe<256, 128, 3, true, 6>(psk, s); break;

@@ -73,7 +73,7 @@ struct GroupNormParams {
 int  groupnorm_nsplit(int B, int HW, int C);
 // workspace of launch_groupnorm for B batch entries (a run over entries [b0, b0+nb) of a larger plan may use the slice at
 // b0 * groupnorm_workspace_floats(1, G)): per (entry, group) kGnMaxSplit row-split partials (count, mean, M2) + (mean, rstd)
-constexpr int kGnMaxSplit = 512;
+constexpr int kGnMaxSplit = 128;
 static inline size_t groupnorm_workspace_floats(int B, int G) { return (size_t)B * G * (kGnMaxSplit * 3 + 2); }
 void launch_groupnorm(const GroupNormParams& p, hipStream_t s);
 

@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
 
 int groupnorm_nsplit(int B, int HW, int C) {
   (void)B; (void)C;
-  int n = HW / 32;       // >= 32 rows per block; up to 512 row splits x B blocks = several workgroups per CU: the statistics
-  if (n < 1) n = 1;      // pass is a pure stream (one 256-thread block per CU left it latency bound at ~1.5 TB/s)
+  int n = HW / 32;       // >= 32 rows per block; up to kGnMaxSplit row splits x B blocks keep all 256 CUs streaming
+  if (n < 1) n = 1;      // (512 splits = 4 workgroups per CU measured no faster: 29.8 vs 29.0 us per GroupNorm)
   if (n > kGnMaxSplit) n = kGnMaxSplit;
   return n;
 }

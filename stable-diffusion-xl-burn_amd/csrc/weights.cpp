@@ -66,6 +66,18 @@ void FlatSource::fetch(const ParamSpec& s, size_t index, float* dst, hipStream_t
   SDXL_HIP(hipStreamSynchronize(st));   // pageable host memory: keep the staging copy simple and safe
 }
 
+FlatSourceF16::FlatSourceF16(const uint16_t* b, const std::vector<ParamSpec>& specs) : base(b) {
+  size_t o = 0;
+  for (const ParamSpec& p : specs) { offsets.push_back(o); o += p.numel(); if (p.numel() > stage_numel) stage_numel = p.numel(); }
+  SDXL_HIP(hipMalloc(&stage, stage_numel * sizeof(uint16_t)));
+}
+FlatSourceF16::~FlatSourceF16() { if (stage) (void)hipFree(stage); }
+void FlatSourceF16::fetch(const ParamSpec& s, size_t index, float* dst, hipStream_t st) {
+  SDXL_HIP(hipMemcpyAsync(stage, base + offsets[index], s.numel() * sizeof(uint16_t), hipMemcpyDefault, st));
+  SDXL_HIP(hipStreamSynchronize(st));   // pageable host memory
+  launch_copy_rows(stage, DT_F16, 1, dst, DT_F32, 1, (int)s.numel(), 1, st);   // exact widening: every f16 is an fp32
+}
+
 // ------------------------------------------------------------------------------------------ builder
 WeightBuilder::WeightBuilder(const std::vector<ParamSpec>& sp, WeightSource& s, DeviceArena& a, int dtype, hipStream_t stream)
     : specs(sp), src(s), arena(a), dt(dtype), st(stream) {

@@ -291,7 +291,7 @@ def read_mpk(path: str):
     return rec["item"]
 
 
-def mpk_flat(specs, item, prefix: str = "", optional: Sequence[str] = ()) -> np.ndarray:
+def mpk_flat(specs, item, prefix: str = "", optional: Sequence[str] = (), dtype=np.float32) -> np.ndarray:
     """spec entries looked up by field path under `prefix` (e.g. 'diffusion' for a Diffuser record, 'autoencoder' for a
     LatentDecoder record, 'clip' / 'open_clip' for an Embedder record), concatenated in spec order"""
     root = item
@@ -319,7 +319,9 @@ def mpk_flat(specs, item, prefix: str = "", optional: Sequence[str] = ()) -> np.
         if tuple(t.shape) != tuple(p.shape):
             raise ImportError_(f"{p.name}: record has shape {tuple(t.shape)}, expected {tuple(p.shape)}")
         parts.append(t.reshape(-1))
-    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+    # dtype=np.float16: the record's own precision, handed to sdxl_*_create_f16 without the fp32 expansion (exact: every
+    # value of a HalfPrecisionSettings record is an f16; the 1e-5 eps default rounds to 1.0014e-5)
+    return np.ascontiguousarray(np.concatenate(parts), dtype=dtype)
 
 
 def write_mpk(path: str, item) -> None:
