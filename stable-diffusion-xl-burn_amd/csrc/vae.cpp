@@ -1,7 +1,8 @@
 // SDXL KL-VAE decoder / encoder on MI355X (reference autoencoder/mod.rs; LatentDecoder stablediffusion/mod.rs:193-267).
 // Same NHWC implicit-GEMM / GroupNorm kernels as the UNet; nearest-2x upsample (:313-318) is fused into the conv gather,
 // the asymmetric-pad stride-2 PaddedConv2d (:326-407) is a plain stride-2 gather with zero fill on the bottom/right
-// edge, and the single-head d=512 mid-block attention (:550-586) runs as QK^T GEMM -> row softmax -> PV GEMM.
+// edge, and the single-head d=512 mid-block attention (:550-586) runs as QK^T GEMM -> row softmax -> PV GEMM over passes of
+// 2048 queries (scores bounded, never materialised for the whole image).
 #include "engine.h"
 
 #include <cmath>
@@ -113,8 +114,11 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
     void* kbuf = ex.act->alloc((size_t)B * rows_k * C * dt_size(ex.cdt));
     void* vt = ex.act->alloc((size_t)B * rows_v * kpad * dt_size(ex.cdt));
     Act o = ex.alloc(M, C, ex.cdt);
-    float* S = (float*)ex.act->alloc((size_t)HW * HW * sizeof(float));
-    void* P = ex.act->alloc((size_t)HW * kpad * dt_size(ex.cdt));
+    // scores are never materialised for the whole image: queries go through in passes of QT rows, so S / P stay bounded
+    // (QT x HW: 134 MB + 67..134 MB at a 128x128 latent instead of 1.07 GB + 0.5..1 GB, and linear in HW beyond it)
+    const int QT = HW < 2048 ? HW : 2048;
+    float* S = (float*)ex.act->alloc((size_t)QT * HW * sizeof(float));
+    void* P = ex.act->alloc((size_t)QT * kpad * dt_size(ex.cdt));
     if (!ex.dry) {
       launch_fill_zero(kbuf, (size_t)B * rows_k * C * dt_size(ex.cdt), ex.s);
       launch_fill_zero(vt, (size_t)B * rows_v * kpad * dt_size(ex.cdt), ex.s);
@@ -130,10 +134,14 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
     const float scale = (float)(1.0 / std::sqrt((double)C));   // (d^-0.25)^2, backend.rs:98
     for (int b = 0; b < B; ++b) {
       Lin lk; lk.w = (char*)kbuf + (size_t)b * rows_k * C * dt_size(ex.cdt); lk.N = HW; lk.K = C; lk.Kpad = C; lk.Npad = rows_k; lk.cin = C;
-      run_linear(ex, lk, Act((char*)q.p + (size_t)b * HW * C * dt_size(ex.cdt), C, ex.cdt), HW, Act(S, HW, DT_F32));
-      if (!ex.dry) launch_softmax_rows(S, HW, P, ex.cdt, kpad, HW, HW, kpad, scale, nullptr, 0, 0, ex.s);
       Lin lv; lv.w = (char*)vt + (size_t)b * rows_v * kpad * dt_size(ex.cdt); lv.N = C; lv.K = HW; lv.Kpad = kpad; lv.Npad = rows_v; lv.cin = HW;
-      run_linear(ex, lv, Act(P, kpad, ex.cdt), HW, Act((char*)o.p + (size_t)b * HW * C * dt_size(ex.cdt), C, ex.cdt));
+      for (int q0 = 0; q0 < HW; q0 += QT) {
+        const int nq = HW - q0 < QT ? HW - q0 : QT;
+        const size_t row0 = ((size_t)b * HW + q0) * C * dt_size(ex.cdt);
+        run_linear(ex, lk, Act((char*)q.p + row0, C, ex.cdt), nq, Act(S, HW, DT_F32));
+        if (!ex.dry) launch_softmax_rows(S, HW, P, ex.cdt, kpad, nq, HW, kpad, scale, nullptr, 0, 0, ex.s);
+        run_linear(ex, lv, Act(P, kpad, ex.cdt), nq, Act((char*)o.p + row0, C, ex.cdt));
+      }
     }
     Epi ep; ep.R = y;
     run_conv(ex, w.proj, o, C, g1, y, ep);
