@@ -1005,6 +1005,163 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v3_kernel(const AttnParams p,
 
 #endif  // SDXL_MEASURE
 
+// ---------------------------------------------------------------------------------------------------------
+// Flash attention for ONE wide head: head dim 512 (the VAE mid block, ConvSelfAttentionBlock::forward, reference
+// autoencoder/mod.rs:550-586 -> Backend::qkv_attention backend.rs:88-128 with n_head = 1; N = 16 384 at a 128x128 latent).
+// Scores are never materialised: the reference's default path would hold N^2 = 268 M of them per image.
+//
+//   * 64 queries per workgroup, 4 waves x 16 queries; a wave keeps its queries' whole Q^T in registers as the B operand of
+//     S^T = K Q^T (v_mfma_f32_16x16x32_f16: 16 d-steps, 64 VGPRs) and its whole O^T = V^T P^T as 32 accumulator tiles
+//     (128 VGPRs) -- "split-d" only in the sense that every d-tile is its own accumulator; no cross-wave reduction exists.
+//   * 32-key tiles: K tile [32][512] (32 KiB) and V^T tile [512][32] (32 KiB) by global_load_lds into a 2-stage ring
+//     (128 KiB), counted vmcnt, two raw barriers per tile.  LDS images are lane-linear, so the bank swizzles sit on the
+//     SOURCE address: K chunk ^= row & 15 (the 16-lane service groups of ds_read_b128 then hit 16 distinct 16-byte slots),
+//     V^T chunk ^= (row >> 2) & 3 (ds_read_b64 over 16 rows of 64 bytes).
+//   * the S^T accumulator layout (lane = query, 4 consecutive keys of each 16-key sub-tile) IS the B-operand layout of the
+//     PV product once the key order inside a 32-key step is permuted (keys {4g..4g+3, 16+4g..16+4g+3} per lane group g); the
+//     V^T fragment is read with the same permutation (two 8-byte reads), so P never leaves the registers.
+//   * fp32 online softmax in the exp2 domain (Q pre-scaled by d^-1/2 log2 e); O / l rescale only when some query's running
+//     max moved (wave vote).
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_hd_kernel(const AttnParams p, const void* zeros) {
+  static_assert(D == 512, "one K row = one 1-KiB DMA instruction");
+  constexpr int KV = 32, NDS = D / 32, NDT = D / 16;
+  constexpr int KTILE = KV * D * 2, VTILE = D * KV * 2, STAGE = KTILE + VTILE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fq = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const half_t* Qg = reinterpret_cast<const half_t*>(p.Q) + (size_t)b * p.Nq * p.ldq + hd * D;
+  const half_t* Kg = reinterpret_cast<const half_t*>(p.K) + (size_t)b * p.Nk * p.ldk + hd * D;
+  const half_t* Vg = reinterpret_cast<const half_t*>(p.Vt) + ((size_t)b * p.H + hd) * D * p.vt_ld;
+  const int ntiles = (p.Nk + KV - 1) / KV;
+
+  // ---- DMA: per tile and wave 8 K rows (one instruction each) + 8 V^T pieces of 16 rows x 64 bytes
+  auto stage = [&](int t, int buf) {
+    char* ks = smem + buf * STAGE;
+    char* vs = ks + KTILE;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = j * 4 + wave;                       // key row of the tile
+      const int key = t * KV + row;
+      const half_t* src = key < p.Nk ? Kg + (size_t)key * p.ldk + (((lane & 48) | ((lane ^ row) & 15)) << 3)
+                                     : reinterpret_cast<const half_t*>(zeros) + ((lane & 15) << 3);
+      __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)(ks + row * (D * 2)), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = (j * 4 + wave) * 16 + (lane >> 2);    // d row of the tile; V^T rows are zero beyond Nk (vt_ld padding)
+      const int c = (lane & 3) ^ ((r >> 2) & 3);
+      const half_t* src = Vg + (size_t)r * p.vt_ld + t * KV + c * 8;
+      __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)(vs + (j * 4 + wave) * 1024), 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+
+  // ---- Q^T fragments (B operand): lane (query fq, k-chunk g) holds Q[q][32 s + 8 g .. +8], pre-scaled
+  const float qs = p.scale * 1.44269504088896340736f;
+  half8 qf[NDS];
+  {
+    const int q = q0 + fq;
+    const half_t* qp = Qg + (size_t)(q < p.Nq ? q : 0) * p.ldq + g * 8;
+#pragma unroll
+    for (int s = 0; s < NDS; ++s) {
+      half8 v = *reinterpret_cast<const half8*>(qp + s * 32);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * qs);
+      qf[s] = v;
+    }
+  }
+  f32x4 o[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -1e30f, l = 0.f;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) { stage(t + 1, buf ^ 1); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // every wave's pieces of tile t have landed
+    asm volatile("" ::: "memory");
+    const char* ks = smem + buf * STAGE;
+    const char* vs = ks + KTILE;
+    // S^T sub-tiles: keys 16 u + fq x the wave's 16 queries
+    f32x4 st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const char* kr = ks + (u * 16 + fq) * (D * 2);
+#pragma unroll
+      for (int s = 0; s < NDS; ++s) {
+        const int c = s * 4 + g;
+        const half8 kf = *reinterpret_cast<const half8*>(kr + (((c & 48) | ((c ^ fq) & 15)) << 4));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], acc, 0, 0, 0);
+      }
+      st[u] = acc;
+    }
+    // lane holds S^T[key = 16 u + 4 g + r][query fq]
+    float mx = -1e30f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * KV + u * 16 + g * 4 + r;
+        if (key >= p.Nk) st[u][r] = -1e30f;
+        mx = fmaxf(mx, st[u][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    m = mnew;
+    half8 pf;
+    float rs = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(st[u][r] - mnew);
+        rs += e;
+        pf[u * 4 + r] = (half_t)e;
+      }
+    l = l * alpha + rs;                                   // per-lane partial row sum (reduced over g at the end)
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < NDT; ++i) o[i] *= alpha;
+    }
+    // O^T tiles: d rows 16 i + fq, keys in the permuted order {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3}
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) {
+      const int r = i * 16 + fq;
+      const int sw = (r >> 2) & 3;
+      const char* vr = vs + r * 64;
+      const int b0 = g * 8, b1 = 32 + g * 8;
+      const i32x2 lo = *reinterpret_cast<const i32x2*>(vr + ((((b0 >> 4) ^ sw) << 4) | (b0 & 15)));
+      const i32x2 hi = *reinterpret_cast<const i32x2*>(vr + ((((b1 >> 4) ^ sw) << 4) | (b1 & 15)));
+      const i32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+      o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, vv), pf, o[i], 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // stage `buf` is free for tile t + 2
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+  const int q = q0 + fq;
+  if (q < p.Nq) {
+    half_t* og = reinterpret_cast<half_t*>(p.O) + ((size_t)b * p.Nq + q) * p.ldo + hd * D + g * 4;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) {   // lane holds O^T[d = 16 i + 4 g + r][query fq]
+      half4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = (half_t)(o[i][r] * inv);
+      *reinterpret_cast<half4*>(og + i * 16) = h;
+    }
+  }
+}
+
 // per-DEVICE zero page (key-tail / padded rows of the DMA-staged kernels) and dynamic-LDS attribute flags
 constexpr int kMaxDev = 64;
 static const void* g_attn_zeros[kMaxDev] = {};
@@ -1082,6 +1239,26 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
     }
     hipLaunchKernelGGL(attn_d64_kernel<float>, grid, dim3(256), lds, s, p);
   }
+}
+
+// one wide head (d = 512, f16, no mask): see attn_hd_kernel.  Returns false when the shape / alignment needs the unfused path.
+bool launch_attention_hd512(const AttnParams& p, hipStream_t s) {
+  const int dev = attn_device();
+  const void* zero = g_attn_zeros[dev];
+  if (!zero || p.dt != DT_F16 || p.mask) return false;
+  const bool aligned = ((p.ldq | p.ldk | p.vt_ld | p.ldo) & 7) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
+                         reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) == 0;
+  if (!aligned || p.vt_ld < ((p.Nk + 31) / 32) * 32) return false;      // V^T rows must exist (zero) up to the last 32-key tile
+  constexpr int LDS = 2 * (32 * 512 * 2 + 512 * 32 * 2);
+  static bool set[kMaxDev] = {};
+  if (!set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_hd_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      throw std::runtime_error("attention: hipFuncSetAttribute failed");
+    set[dev] = true;
+  }
+  hipLaunchKernelGGL(attn_hd_kernel<512>, dim3((p.Nq + 63) / 64, p.B * p.H), dim3(256), LDS, s, p, zero);
+  return true;
 }
 
 }  // namespace sdxl

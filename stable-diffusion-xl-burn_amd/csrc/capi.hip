@@ -393,7 +393,7 @@ int sdxl_qkv_attention(sdxl_ctx* ctx, void* stream, const float* q, const float*
   const int d = n_state / n_head;
   const size_t es = dt_size(cdt);
   Tmp tmp;
-  if (d == 64) {
+  if (d == 64 || (d == 512 && cdt == DT_F16 && !mask)) {
     const int npad = (int)round_up(Nk, 64);
     void* qd = tmp.get((size_t)B * Nq * n_state * es);
     void* kd = tmp.get((size_t)B * Nk * n_state * es);
@@ -409,8 +409,9 @@ int sdxl_qkv_attention(sdxl_ctx* ctx, void* stream, const float* q, const float*
     }
     AttnParams p{};
     p.Q = qd; p.ldq = n_state; p.K = kd; p.ldk = n_state; p.Vt = vt; p.vt_ld = npad; p.O = od; p.ldo = n_state;
-    p.dt = cdt; p.B = B; p.H = n_head; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = mask; p.ldmask = Nk;
-    launch_attention_d64(p, s);
+    p.dt = cdt; p.B = B; p.H = n_head; p.Nq = Nq; p.Nk = Nk; p.scale = (float)(1.0 / std::sqrt((double)d)); p.mask = mask; p.ldmask = Nk;
+    if (d == 64) launch_attention_d64(p, s);
+    else SDXL_REQUIRE(launch_attention_hd512(p, s), "wide-head attention kernel refused an aligned f16 shape");
     launch_copy_rows(od, cdt, n_state, out, DT_F32, n_state, B * Nq, n_state, s);
   } else {
     // generic head dim: QK^T GEMM -> row softmax -> PV GEMM per (batch, head)

@@ -100,6 +100,10 @@ struct AttnParams {
   const float* mask; int ldmask;   // optional additive [Nq][Nk] fp32 (0 / -inf), null in UNet/VAE
 };
 void launch_attention_d64(const AttnParams& p, hipStream_t s);
+// the same contraction for ONE wide head of 512 channels (VAE mid block): flash kernel, scores never materialised; Q/K/O rows
+// hold the heads at columns h*512, Vt is [B][H*512][vt_ld] with zero columns up to a multiple of 32 keys.  f16, no mask;
+// returns false when the shape / alignment needs the unfused path.  p.scale = d^-1/2.
+bool launch_attention_hd512(const AttnParams& p, hipStream_t s);
 void attention_init();                 // zero page for the DMA-staged f16 kernel (once per process)
 void attention_set_variant(int v);     // -1: generic kernel only, 0: auto, 1: DMA-staged 16x16x32 kernel, 2: 32x32x16 deferred-max kernel, 6: key-split kernel
 

@@ -1,8 +1,8 @@
 // SDXL KL-VAE decoder / encoder on MI355X (reference autoencoder/mod.rs; LatentDecoder stablediffusion/mod.rs:193-267).
 // Same NHWC implicit-GEMM / GroupNorm kernels as the UNet; nearest-2x upsample (:313-318) is fused into the conv gather,
 // the asymmetric-pad stride-2 PaddedConv2d (:326-407) is a plain stride-2 gather with zero fill on the bottom/right
-// edge, and the single-head d=512 mid-block attention (:550-586) runs as QK^T GEMM -> row softmax -> PV GEMM over passes of
-// 2048 queries (scores bounded, never materialised for the whole image).
+// edge, and the single-head d=512 mid-block attention (:550-586) runs in the f16 mode as ONE flash kernel (attn_hd_kernel: scores
+// never materialised) and in the strict-fp32 mode as QK^T GEMM -> row softmax -> PV GEMM over passes of 2048 queries (bounded).
 #include "engine.h"
 
 #include <cmath>
@@ -110,6 +110,32 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
     SDXL_REQUIRE(C % kt == 0, "VAE attention channel count must be a multiple of the k-tile");
     Act hn = ex.alloc(M, C, ex.cdt);
     run_groupnorm(ex, w.an, y, B, HW, hn, false, cfg_.n_group);
+    const float scale = (float)(1.0 / std::sqrt((double)C));   // (d^-0.25)^2, backend.rs:98
+    if (ex.cdt == DT_F16 && C == 512) {
+      // one head of 512 channels: the flash kernel (attn_hd_kernel) -- scores never materialised.  q | k from the 1x1 convs as
+      // plain [M][C] rows, V^T straight out of the v conv's transposed epilogue (zero padded to whole key tiles)
+      Act q = ex.alloc(M, C, ex.cdt), kk = ex.alloc(M, C, ex.cdt), o = ex.alloc(M, C, ex.cdt);
+      void* vt = ex.act->alloc((size_t)B * C * kpad * dt_size(ex.cdt));
+      if (!ex.dry && kpad != HW) launch_fill_zero(vt, (size_t)B * C * kpad * dt_size(ex.cdt), ex.s);
+      run_conv(ex, w.q, hn, C, g1, q);
+      run_conv(ex, w.k, hn, C, g1, kk);
+      Epi ev; ev.n_split = 0; ev.Ct = vt; ev.ct_rows = C; ev.ct_ld = kpad; ev.rpb = HW;
+      run_conv(ex, w.v, hn, C, g1, Act(nullptr, C, ex.cdt), ev);
+      if (!ex.dry) {
+        AttnParams p{};
+        p.Q = q.p; p.ldq = C; p.K = kk.p; p.ldk = C; p.Vt = vt; p.vt_ld = kpad; p.O = o.p; p.ldo = C;
+        p.dt = ex.cdt; p.B = B; p.H = 1; p.Nq = HW; p.Nk = HW; p.scale = scale; p.mask = nullptr; p.ldmask = 0;
+        if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * (double)HW * HW * C, ex.s, HW, HW, B, 0);
+        SDXL_REQUIRE(launch_attention_hd512(p, ex.s), "VAE mid attention: flash kernel refused the shape");
+        SDXL_HIP(hipGetLastError());
+        if (ex.prof) ex.prof->end(ex.s);
+      }
+      Epi ep; ep.R = y;
+      run_conv(ex, w.proj, o, C, g1, y, ep);
+      res_block(ex, w.b2, y, B, H, W, x);
+      ex.act->reset(mk);
+      return;
+    }
     Act q = ex.alloc(M, C, ex.cdt);
     void* kbuf = ex.act->alloc((size_t)B * rows_k * C * dt_size(ex.cdt));
     void* vt = ex.act->alloc((size_t)B * rows_v * kpad * dt_size(ex.cdt));
@@ -131,7 +157,6 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
     }
     Epi ev; ev.n_split = 0; ev.Ct = vt; ev.ct_rows = rows_v; ev.ct_ld = kpad; ev.rpb = HW;
     run_conv(ex, w.v, hn, C, g1, Act(nullptr, C, ex.cdt), ev);
-    const float scale = (float)(1.0 / std::sqrt((double)C));   // (d^-0.25)^2, backend.rs:98
     for (int b = 0; b < B; ++b) {
       Lin lk; lk.w = (char*)kbuf + (size_t)b * rows_k * C * dt_size(ex.cdt); lk.N = HW; lk.K = C; lk.Kpad = C; lk.Npad = rows_k; lk.cin = C;
       Lin lv; lv.w = (char*)vt + (size_t)b * rows_v * kpad * dt_size(ex.cdt); lv.N = C; lv.K = HW; lv.Kpad = kpad; lv.Npad = rows_v; lv.cin = HW;

@@ -191,6 +191,30 @@ def test_qkv_attention_online_softmax_rescale(pkg, ctx, dtype, variant):
     assert rel_err(out, ref) < (1e-4 if dtype == 0 else 6e-3)
 
 
+@pytest.mark.parametrize("B,Nq,Nk,heads", [(1, 96, 96, 1), (2, 200, 77, 1), (1, 1024, 1024, 1), (2, 130, 333, 2), (1, 64, 1, 1),
+                                           (1, 4096, 4096, 1)])
+def test_qkv_attention_wide_head_flash(pkg, ctx, B, Nq, Nk, heads):
+    # head dim 512 (the VAE mid block's single head, autoencoder/mod.rs:550-586): the flash kernel attn_hd_kernel -- ragged
+    # query / key counts (tails of the 64-query blocks and 32-key tiles), several heads and batch entries
+    C = 512 * heads
+    q, k, v = seeded(B, Nq, C, seed=16), seeded(B, Nk, C, seed=17), seeded(B, Nk, C, seed=18)
+    ref = OM.qkv_attention(q, k, v, None, heads)
+    out = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, heads, 1)
+    assert rel_err(out, ref) < 6e-3
+
+
+def test_qkv_attention_wide_head_flash_rescale(pkg, ctx):
+    # the running max must move late in the key sequence: one key aligned with one query far beyond the rest (the O / l
+    # rescale branch is taken in a late tile for that query only), against a full fp32 reference
+    B, N, C = 1, 512, 512
+    q, k, v = seeded(B, N, C, seed=21) * 0.3, seeded(B, N, C, seed=22) * 0.3, seeded(B, N, C, seed=23)
+    k[0, 400] = q[0, 37] * 3.0
+    k[0, 17] = q[0, 300] * 2.0
+    ref = OM.qkv_attention(q, k, v, None, 1)
+    out = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, 1, 1)
+    assert rel_err(out, ref) < 6e-3
+
+
 @pytest.mark.parametrize("variant", [1, 2, 6])     # 6 = key-split kernel (64-query blocks, waves = query sub-tile x key half)
 @pytest.mark.parametrize("B,Nq,Nk,C,heads", [(2, 256, 256, 128, 2), (2, 300, 77, 640, 10), (1, 1024, 1024, 1280, 20),
                                              (1, 130, 200, 64, 1), (2, 64, 1, 64, 1), (2, 100, 128, 128, 2), (1, 33, 192, 64, 1)])
