@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 TFLOP_PER_UNET_FWD_1024 = 6.761      # SURVEY section 8(d), base UNet, latent 128x128, B=1
 TFLOP_VAE_DECODE_1024 = 10.470
 TFLOP_PER_UNET_FWD_512 = 1.589
+TFLOP_VAE_DECODE_512 = 2.515
 PEAK_F16_TFLOPS = 2500.0             # dense fp16 MFMA peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
@@ -243,7 +244,7 @@ def cpu_oracle_config1():
         ref = torch.from_numpy(np.load(gold)["latent"])
         dev = float((lat - ref).abs().max() / ref.abs().max())
     total = t2 - t0
-    tflop = 8 * TFLOP_PER_UNET_FWD_512 + TFLOP_VAE_DECODE_1024 / 4
+    tflop = 8 * TFLOP_PER_UNET_FWD_512 + TFLOP_VAE_DECODE_512
     return {"value": 1.0 / total, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": (f"the WHOLE config-1 job on the host: oracle sample_latent (8 UNet forwards at 512x512) {t1 - t0:.1f} s + "
                        f"latent_to_image {t2 - t1:.1f} s = {total:.1f} s on {threads} threads (host reports {os.cpu_count()} cpus, "
@@ -451,11 +452,14 @@ def main():
     decode_ms = e0.elapsed_time(e1) / 3
 
     sc = (res / 1024.0) ** 2
-    tflop_image = iters * 2 * TFLOP_PER_UNET_FWD_1024 * sc + TFLOP_VAE_DECODE_1024 * sc
+    # SURVEY section 8(d) gives exact counts at 1024^2 and 512^2 (attention is quadratic in the pixel count); other sizes scale by area
+    fwd_tf = {1024: TFLOP_PER_UNET_FWD_1024, 512: TFLOP_PER_UNET_FWD_512}.get(res, TFLOP_PER_UNET_FWD_1024 * sc)
+    dec_tf = {1024: TFLOP_VAE_DECODE_1024, 512: TFLOP_VAE_DECODE_512}.get(res, TFLOP_VAE_DECODE_1024 * sc)
+    tflop_image = iters * 2 * fwd_tf + dec_tf
     if args.config == 4:
         tflop_image += r_iters * TFLOP_REFINER_FWD_1024 * sc
     if args.config == 5:
-        tflop_image += TFLOP_VAE_DECODE_1024 * sc        # encoder ~ mirror of the decoder
+        tflop_image += dec_tf                            # encoder ~ mirror of the decoder
     value = n_images / elapsed
 
     # --- roofline of the dominant kernel, measured live with hipEvents on the timed configuration (B=2 CFG pair)

@@ -25,6 +25,11 @@ for p in $PARTS; do
         for f in $(find /tmp/pm$i -name '*counter_collection*'); do python tools/pmc_summarise.py $f > $OUT/pmc_step_$i.txt 2>&1; done
         tail -20 $OUT/pmc_step_$i.txt
       done;;
+    traffic) # HBM-side bytes of one UNet step (separate --pmc passes, kernel trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/tr_$c; (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/tr_$c -o t -- python $GRAFT_REPO_ROOT/tools/profile_step.py > $GRAFT_REPO_ROOT/$OUT/traffic_$c.log 2>&1)
+      done
+      python tools/pmc_traffic.py $OUT/pmc_traffic.json $(find /tmp/tr_FETCH_SIZE -name '*counter_collection*' | head -1) $(find /tmp/tr_WRITE_SIZE -name '*counter_collection*' | head -1) 3;;
     sweep) timeout 600 python tools/igemm_sweep.py ${SWEEP_VARIANTS:-0} > $OUT/igemm_sweep.txt 2>&1; tail -25 $OUT/igemm_sweep.txt;;
     custom) bash -c "${CUSTOM_CMD}" > $OUT/custom.log 2>&1; tail -40 $OUT/custom.log;;
   esac
