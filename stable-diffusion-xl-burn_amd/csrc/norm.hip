@@ -189,12 +189,42 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GroupNormParams 
 
 // apply: grid (row chunks, B).  thread -> (row lane, fixed vector column): the 8 channels' (mean, rstd*gamma, beta)
 // stay in registers while the thread walks its rows, so the inner loop is load / 8 FMA(+SiLU) / store.
-template <typename XT, typename YT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, const float* stat, int rows_per_block) {
+// FIN: the (mean, rstd) of this batch entry's groups are merged from the row-split partials in the block's own prologue
+// (256 / G threads per group: each Chan-merges its share of the nsplit partials, then a butterfly across the group's
+// threads) instead of a separate finalize launch -- one kernel boundary and a 4.7 us launch less per GroupNorm; every apply
+// block redoes the 12 KB merge, which the 256 CUs do in parallel.  Needs a power-of-two G <= 256; other group counts keep
+// the finalize kernel.
+template <typename XT, typename YT, bool FIN>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, const float* stat_in, int rows_per_block) {
   const int C = p.C, NV = C >> 3;
   const int VPR = NV < 256 ? NV : 256;
   const int RL = 256 / VPR;
   const int tid = threadIdx.x, b = blockIdx.y;
+  __shared__ float sstat[512];
+  if constexpr (FIN) {
+    const int tpg = 256 / p.G;                       // threads per group (power of two)
+    const int g = tid / tpg, sub = tid - g * tpg;
+    const float* part = p.partial + ((size_t)b * p.G + g) * p.nsplit * 3;
+    float na = 0.f, ma = 0.f, qa = 0.f;
+    for (int s = sub; s < p.nsplit; s += tpg) chan_merge(na, ma, qa, part[s * 3], part[s * 3 + 1], part[s * 3 + 2]);
+    for (int o = 1; o < tpg; o <<= 1) {              // symmetric merge: every thread of the group ends with the same triple
+      const float nb = __shfl_xor(na, o), mb = __shfl_xor(ma, o), qb = __shfl_xor(qa, o);
+      const float n = na + nb;
+      if (n > 0.f) {
+        const float d = mb - ma;
+        const float f = nb / n;
+        const float mnew = (sub & o) ? mb + (ma - mb) * (na / n) : ma + d * f;
+        qa = qa + qb + d * d * na * f;
+        ma = mnew;
+      }
+      na = n;
+    }
+    if (sub == 0) {
+      sstat[g * 2] = ma;
+      sstat[g * 2 + 1] = 1.0f / sqrtf(qa / na + (p.eps_ptr ? *p.eps_ptr : p.eps));
+    }
+    __syncthreads();
+  }
   const int rl = tid / VPR, vl = tid - rl * VPR;
   const int cpg = C / p.G;
   const int row0 = blockIdx.x * rows_per_block;
@@ -210,8 +240,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
     for (int j = 0; j < 8; ++j) {
       const int c = vc * 8 + j;
       const int g = c / cpg;
-      mean[j] = stat[((size_t)b * p.G + g) * 2];
-      scale[j] = stat[((size_t)b * p.G + g) * 2 + 1] * p.gamma[c];
+      const float* st = FIN ? sstat + g * 2 : stat_in + ((size_t)b * p.G + g) * 2;
+      mean[j] = st[0];
+      scale[j] = st[1] * p.gamma[c];
       beta[j] = p.beta[c];
     }
     int row = row0 + rl;
@@ -262,22 +293,25 @@ void launch_groupnorm(const GroupNormParams& pin, hipStream_t s) {
   dim3 g1(p.nsplit, p.B);
   if (p.x_dt == DT_F16) hipLaunchKernelGGL(gn_stats_kernel<half_t>, g1, dim3(256), lds_stats, s, p);
   else hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds_stats, s, p);
-  // (mean, rstd) per (batch, group) live right after the partials: workspace is [B][G][128][3] + [B][G][2] floats
+  // (mean, rstd) per (batch, group) live right after the partials: workspace is [B][G][kGnMaxSplit][3] + [B][G][2] floats
   float* stat = p.partial + (size_t)p.B * p.G * kGnMaxSplit * 3;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.G + 3) / 4), dim3(256), 0, s, p, stat);
+  const bool fin = p.G <= 256 && (p.G & (p.G - 1)) == 0 && 256 / p.G <= 64;   // merge in the apply prologue (see gn_apply_kernel)
+  if (!fin) hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.G + 3) / 4), dim3(256), 0, s, p, stat);
   // apply: aim for >= ~512 blocks, each row lane walking >= 4 rows
   int rows_per_block = (int)(((long)p.B * p.HW + 511) / 512);
   if (rows_per_block < 4 * RL) rows_per_block = 4 * RL;
   if (rows_per_block > p.HW) rows_per_block = p.HW;
   dim3 g2((p.HW + rows_per_block - 1) / rows_per_block, p.B);
-  if (p.x_dt == DT_F16 && p.y_dt == DT_F16)
-    hipLaunchKernelGGL((gn_apply_kernel<half_t, half_t>), g2, dim3(256), 0, s, p, stat, rows_per_block);
-  else if (p.x_dt == DT_F32 && p.y_dt == DT_F16)
-    hipLaunchKernelGGL((gn_apply_kernel<float, half_t>), g2, dim3(256), 0, s, p, stat, rows_per_block);
-  else if (p.x_dt == DT_F32 && p.y_dt == DT_F32)
-    hipLaunchKernelGGL((gn_apply_kernel<float, float>), g2, dim3(256), 0, s, p, stat, rows_per_block);
-  else
-    hipLaunchKernelGGL((gn_apply_kernel<half_t, float>), g2, dim3(256), 0, s, p, stat, rows_per_block);
+#define GN_APPLY(XT, YT)                                                                                              \
+  do {                                                                                                                \
+    if (fin) hipLaunchKernelGGL((gn_apply_kernel<XT, YT, true>), g2, dim3(256), 0, s, p, stat, rows_per_block);       \
+    else hipLaunchKernelGGL((gn_apply_kernel<XT, YT, false>), g2, dim3(256), 0, s, p, stat, rows_per_block);          \
+  } while (0)
+  if (p.x_dt == DT_F16 && p.y_dt == DT_F16) GN_APPLY(half_t, half_t);
+  else if (p.x_dt == DT_F32 && p.y_dt == DT_F16) GN_APPLY(float, half_t);
+  else if (p.x_dt == DT_F32 && p.y_dt == DT_F32) GN_APPLY(float, float);
+  else GN_APPLY(half_t, float);
+#undef GN_APPLY
 }
 
 // ---------------------------------------------------------------------------------------------------------

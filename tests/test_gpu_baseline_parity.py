@@ -70,8 +70,17 @@ def _write_report():
     yield
     try:
         os.makedirs(OUT_DIR, exist_ok=True)
-        with open(os.path.join(OUT_DIR, "r02_parity_baseline.json"), "w") as fh:
-            json.dump(REPORT, fh, indent=1)
+        path = os.path.join(OUT_DIR, "r02_parity_baseline.json")
+        merged = {}
+        if os.path.exists(path):          # a partial run (-k ...) updates its own entries only
+            try:
+                with open(path) as fh:
+                    merged = json.load(fh)
+            except ValueError:
+                merged = {}
+        merged.update(REPORT)
+        with open(path, "w") as fh:
+            json.dump(merged, fh, indent=1)
     except OSError:
         pass
 

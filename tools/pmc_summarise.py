@@ -37,11 +37,16 @@ def main():
         for c, d in agg.items():
             e = out.setdefault(c, {"dispatches": len(n[c])})
             e.update({k: v for k, v in d.items()})
+    # MFMA utilisation = matrix-pipe busy cycles / SIMD-cycles the kernels had the chip for.  rocprofv3 reports
+    # SQ_VALU_MFMA_BUSY_CYCLES summed over all 1024 SIMDs (32 cycles per v_mfma_f32_32x32x16_f16: busy / 32 x 32768 flop
+    # reproduces the algorithmic FLOPs of the profiled steps) and GRBM_GUI_ACTIVE summed over the 8 XCDs (its sum / 8 / kernel
+    # time is the shader clock), so:  util = MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 * 1024).  The two counters come from separate
+    # passes of the same command (pass a file of each).
     for c, e in out.items():
-        mf = e.get("SQ_VALU_MFMA_BUSY_CYCLES")
-        for den in ("SQ_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"):
-            if mf is not None and e.get(den):
-                e[f"mfma_busy_over_{den}"] = mf / e[den]
+        mf, ga = e.get("SQ_VALU_MFMA_BUSY_CYCLES"), e.get("GRBM_GUI_ACTIVE")
+        if mf is not None and ga:
+            e["mfma_util"] = mf / (ga / 8.0 * 1024.0)
+            e["mfma_flop_from_counter"] = mf / 32.0 * 32768.0
     print(json.dumps(out, indent=1))
 
 

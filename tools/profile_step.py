@@ -12,7 +12,7 @@ r = lambda *s: torch.randn(*s, device="cuda", generator=g)
 cond = pkg.Conditioning(context_full=r(1, 77, 2048), channel_context=r(1, 2816), unconditional_context_full=r(77, 2048),
                         unconditional_channel_context=r(2816), resolution=(1024, 1024))
 d.diffusion.set_graph(False)
-lat = d.sample_latent(cond, 7.5, 500, r(1, 4, 128, 128))     # 2 iterations (t = 999, 997): warm-up + plan
+lat = d.sample_latent(cond, 7.5, 2, r(1, 4, 128, 128))       # n_steps = 2 -> step 500 -> 2 iterations (t = 999, 499): warm-up + plan
 torch.cuda.synchronize()
 prof = d.diffusion.profile(2, 128, 128)
 print({k: (round(v[0], 3), v[1]) for k, v in prof.items()})
