@@ -719,7 +719,13 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
 // WGM = waves along M (4: 4x2 wave grid, 8: 8x1 -- the 256x160 GEGLU tile: N = 10240 / 5120 gives 512 / 1024 tiles = whole
 // rounds of 256 CUs where 256x128 leaves the last round 44 % empty).  BN need not be a multiple of 64: the weight tile's
 // BN/8 eight-row pieces are dealt round-robin, waves below REM carry one more piece and wait on their own count.
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t>
+// PF > 0 (linear layers): L2 PREFETCH PF k-tiles ahead of the DMA.  Measured (tools/l2_probe.hip, profiles/r02_l2_probe.txt): a CU
+// pulls L2-RESIDENT data at ~145 GB/s through this same LDS-DMA path, yet the k-loop only streams ~45 GB/s per CU -- every
+// workgroup of an XCD asks for a new operand line at about the same time, so nobody finds it in the L2: all of them wait out
+// the Infinity-Cache / HBM latency (~2 us under load) with only NS-1 tiles in flight.  So each wave touches, one k-tile-row
+// line per lane (a 4-byte LDS-DMA into a scratch slot: no register, no compiler-visible hazard), the lines the DMA will ask
+// for PF k-tiles later; by then they are L2 hits.
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t, int PF = 0>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
   typedef typename PipeElem<T>::frag frag_t;
   constexpr int CE = 16 / (int)sizeof(T);     // elements per 16-byte chunk: 8 (f16) or 4 (f32, strict mode)
@@ -776,6 +782,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     if constexpr (REM == 0) wait_vmcnt<PER * k>();
     else { if (lastb) wait_vmcnt<PER * k>(); else wait_vmcnt<(PER - 1) * k>(); }
   };
+  static_assert(PF == 0 || (REM == 0 && UNR && DMODE == 0 && NW * 64 >= BM + BN), "L2 prefetch: unrolled production kernels only");
 
   // ---- DMA geometry: piece j of this wave covers tile rows (j*8 + wave)*8 .. +7; lane -> (row, slot)
   const int lrow = lane >> 3, slot = lane & 7;
@@ -825,6 +832,17 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     }
   };
   retap();
+  // L2 prefetch: line L = wave * 64 + lane of the tile's BM activation rows then BN weight rows (one 128-byte line per k-tile)
+  const T* pfp = reinterpret_cast<const T*>(zeros);
+  int pfadv = 0;
+  if constexpr (PF > 0) {
+    const int L = wave * 64 + lane;
+    if (p.ksize == 1 && p.stride == 1 && p.up == 0) {
+      if (L < BM) { if (m0 + L < p.M) { pfp = Ag + (size_t)(m0 + L) * p.lda; pfadv = KT; } }
+      else if (L < BM + BN) { pfp = reinterpret_cast<const T*>(p.W) + (size_t)(n0 + L - BM) * p.Kpad; pfadv = KT; }
+    }
+    if (pfadv) pfp += (size_t)(kbeg + NS - 1 + PF) * KT;
+  }
   if constexpr (CONTIG) {
     const int nkc = p.Kpad / KT;
 #pragma unroll
@@ -950,7 +968,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     // beyond 64 KiB go through a second address set (+ 65536).
     static_assert(DMODE == 0, "unrolled ring: production schedule only");
     // wave tiles of up to 4 MFMA tiles per operand: two address sets (+0, +64 KiB); wider ones (256x160: 5): one set per slot
-    constexpr bool PERSLOT = TM > 4 || TN > 4;
+    constexpr bool PERSLOT = TM > 4 || TN > 4 || NS * STAGE > 131072;
     constexpr int NSET = PERSLOT ? NS : 2;
     unsigned fa[NSET][4], fb[NSET][4];
 #pragma unroll
@@ -984,9 +1002,24 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       ldf(SO{}, I3{}, I1{});
       wait_lgkmcnt<NF>();
       mma(I0{}, fl, I2{}, more);
+      if constexpr (PF > 0) {
+        if (more) {   // one more VM op per tile and wave: the line touches of tile kt + NS - 1 + PF (zero page beyond the end)
+          const T* q = kt + NS - 1 + PF < nk ? pfp : reinterpret_cast<const T*>(zeros);
+          __builtin_amdgcn_global_load_lds((gptr_t)q, (lptr_t)(smem + NS * STAGE + wave * 256), 4, 0, 0);
+          pfp += pfadv;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       if (more) tile_done();
       if (kt + 1 < nk) {
-        if (more) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
+        if constexpr (PF > 0) {
+          // in flight stay tiles kt+2 .. kt+NS-1: NS-2 tiles of PER pieces, each loop-issued one with its prefetch op
+          if (!more) wait_vmcnt<0>();
+          else if (NS == 3 || kt >= NS - 3) wait_vmcnt<(PER + 1) * (NS - 2)>();
+          else wait_vmcnt<PER * (NS - 2) + 1>();
+        } else {
+          if (more) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
+        }
         wait_lgkmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1511,18 +1544,18 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_pages[dev]);
 }
 
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t>
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t, int PF = 0>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
-  const size_t lds = (size_t)NS * (BM + BN) * 128;
+  const size_t lds = (size_t)NS * (BM + BN) * 128 + (PF > 0 ? NW * 256 : 0);   // + the scratch slots of the L2-prefetch touches
   static bool attr_set[kMaxDev] = {};
   const int dev = current_device();
-  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T>, lds, attr_set, dev);
+  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T, PF>, lds, attr_set, dev);
   const int sk = (BN == 128 && DMODE == 0 && p.splitk > 1) ? p.splitk : 1;
   if (sk > 1 && (size_t)tilesM * tilesN * sk * BM * BN * 4 > p.splitk_ws_bytes) throw std::runtime_error("igemm: split-K workspace too small");
   IgemmParams q = p;
   q.splitk = sk;
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T, PF>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
 }
 
 #ifdef SDXL_MEASURE
@@ -1616,6 +1649,7 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
       const double cost = ((double)full + frac) * (c.bm + c.bn) * nk * c.w + (double)(full + (rem ? 1 : 0)) * 3000.0;
       if (cost < best) { best = cost; variant = c.v; }
     }
+    if (variant == 36 && nk >= 40) variant = 44;   // long contractions: the 5-slot ring (4 tiles in flight) is 3-6 % faster (profiles/r02_ring5_ab.txt)
   }
 #ifdef SDXL_MEASURE
   if (was_auto && !g_igemm_unrolled) {   // A/B against the rolled loops (profiles/r01_igemm_unrolled_ab.txt)
@@ -1633,10 +1667,15 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 38:                                                                // 256x160 GEGLU tile (8x1 waves)
       if (p.N % 160 != 0) return false;
       launch_pipe<256, 160, 3, false, 0, 8, 8, true>(psk, s); break;
+    case 44: launch_pipe<128, 128, 5, false, 0, 4, 8, true>(psk, s); break;   // 5-slot ring = all 160 KiB of LDS: 4 tiles in flight
     case 26:                                                                // 256x320, k-tile 32: linear GEGLU projections only
       if (p.act != 1 || p.ksize != 1 || p.stride != 1 || p.up != 0 || p.N % 320 != 0 || p.Kpad % 32 != 0) return false;
       launch_wide(psk, s); break;
 #ifdef SDXL_MEASURE
+    case 40: launch_pipe<256, 128, 3, false, 0, 4, 8, true, half_t, 4>(psk, s); break;   // + L2 prefetch touches 4 / 8 k-tiles ahead:
+    case 41: launch_pipe<128, 128, 4, false, 0, 4, 8, true, half_t, 4>(psk, s); break;   //   measured SLOWER (profiles/r02_l2_prefetch_ab.txt)
+    case 42: launch_pipe<128, 128, 4, false, 0, 4, 8, true, half_t, 8>(psk, s); break;
+    case 43: launch_pipe<256, 128, 3, false, 0, 4, 8, true, half_t, 8>(psk, s); break;
     // ---- A/B partners and experiments (build.py --measure): rolled loops, other rings, loader waves, measurement modes
     case 1: launch_glds<128, 128, 3>(psk, s); break;
     case 2: launch_glds<128, 64, 4>(psk, s); break;

@@ -25,7 +25,8 @@ for name, B, H, W, Cin, Cout, k, g, cnt in S:
     row = f"{name}  {fl/1e9:7.1f}  "
     for v in variants:
         pkg.debug_set("igemm_variant", v)
-        ms = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, k, bool(g), 10)
+        # COLD=1: rotate through > 256 MB of weight copies so every launch streams its weights from HBM, as inside a UNet step
+        ms = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, k, int(g) | (8 if os.environ.get("COLD") == "1" else 0), 10)
         tot[v] += ms * cnt
         row += f" {ms:7.3f} {fl/ms/1e9:6.0f}  "
     print(row, flush=True)
