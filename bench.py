@@ -312,8 +312,6 @@ def main():
     ap.add_argument("--pipeline-decode", action="store_true",
                     help="decode image i on a second HIP stream under the sampling of image i+1 (measured +0.3 %% only: both legs "
                          "are chip-filling MFMA work; off by default)")
-    ap.add_argument("--warm-weights", type=int, default=0, metavar="LOOKAHEAD",
-                    help="weight warmer: touch the weights of the GEMM LOOKAHEAD launches ahead on a side stream (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--split-cfg", action="store_true",
@@ -372,8 +370,6 @@ def main():
         diffuser.diffusion.set_graph(False)
     if args.split_cfg:
         diffuser.diffusion.set_split_cfg(True)
-    if args.warm_weights > 0:
-        diffuser.diffusion.set_weight_warmer(True, args.warm_weights)
     diffuser.enable_step_timing(True)
 
     lat = res // 8
@@ -518,7 +514,7 @@ def main():
                        "precision": args.dtype, "vae_dtype": args.vae_dtype,
                        "weights": "synthetic seeded (random-init SDXL-base architecture)",
                        "parallelism": f"replica x{world}, 1 prompt per GPU, weights broadcast once over RCCL",
-                       "hipgraph": not args.no_graph, "split_cfg": bool(args.split_cfg), "weight_warmer_lookahead": args.warm_weights,
+                       "hipgraph": not args.no_graph, "split_cfg": bool(args.split_cfg),
                        "pipelined_decode": bool(pipelined)},
             "images_per_sec_per_gpu": round(value / world, 4),
             "unet_step_ms_p50": None if p50 is None else round(p50, 3),

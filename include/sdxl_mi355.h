@@ -127,10 +127,6 @@ int sdxl_unet_set_graph(sdxl_unet* u, int enabled);   /* hipGraph replay of the 
  * runs as two concurrent batch-1 chains on two streams inside the captured graph, the second released after
  * `release_offset` GEMM launches of the first.  Bit-identical results; measured -2.6 % step time. */
 int sdxl_unet_set_split_cfg(sdxl_unet* u, int enabled, int release_offset);
-/* per-handle option (default off): a side stream inside the captured graph touches the weights of the GEMM `lookahead`
- * launches ahead so they sit in the 256 MB Infinity Cache when that GEMM starts (a step streams 5.1 GB of weights: every GEMM
- * otherwise finds its own cold in HBM).  Results are unaffected. */
-int sdxl_unet_set_weight_warmer(sdxl_unet* u, int enabled, int lookahead);
 
 /* ---- Backend::qkv_attention (src/backend.rs:4-19; generic body :88-128, LibTorch override :32-79)
  * q [B,Nq,n_head*d], k,v [B,Nk,n_head*d], mask additive [Nq,Nk] or NULL, out [B,Nq,n_head*d]; fp32 device tensors */

@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "sdxl_last_error", "sdxl_build_info", "sdxl_ctx_create", "sdxl_ctx_destroy", "sdxl_ctx_synchronize",
     "sdxl_unet_config_base", "sdxl_unet_config_refiner", "sdxl_vae_config_default",
     "sdxl_unet_param_count", "sdxl_unet_param_spec", "sdxl_vae_param_count", "sdxl_vae_param_spec",
-    "sdxl_unet_create", "sdxl_unet_create_synthetic", "sdxl_unet_destroy", "sdxl_unet_forward", "sdxl_unet_set_graph", "sdxl_unet_set_split_cfg", "sdxl_unet_set_weight_warmer",
+    "sdxl_unet_create", "sdxl_unet_create_synthetic", "sdxl_unet_destroy", "sdxl_unet_forward", "sdxl_unet_set_graph", "sdxl_unet_set_split_cfg",
     "sdxl_qkv_attention", "sdxl_attn_decoder_mask",
     "sdxl_diffuser_create", "sdxl_diffuser_create_synthetic", "sdxl_diffuser_destroy", "sdxl_diffuser_unet",
     "sdxl_sample_latent", "sdxl_sample_latent_with_inpainting", "sdxl_refine_latent", "sdxl_step_count",
@@ -341,10 +341,6 @@ class UNet:
     def set_split_cfg(self, enabled: bool, release_offset: int = 0):
         """per-handle: run the CFG pair (batch-2 forward) as two concurrent batch-1 chains; bit-identical results"""
         _check(lib().sdxl_unet_set_split_cfg(self.h, int(enabled), int(release_offset)))
-
-    def set_weight_warmer(self, enabled: bool, lookahead: int = 2):
-        """per-handle: side-stream touches of the weights `lookahead` GEMM launches ahead (Infinity-Cache warm-up)"""
-        _check(lib().sdxl_unet_set_weight_warmer(self.h, int(enabled), int(lookahead)))
 
     def set_graph(self, enabled: bool):
         _check(lib().sdxl_unet_set_graph(self.h, int(enabled)))

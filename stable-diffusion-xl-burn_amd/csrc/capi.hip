@@ -368,12 +368,6 @@ int sdxl_unet_set_graph(sdxl_unet* u, int enabled) {
   u->u->set_use_graph(enabled != 0);
   API_END
 }
-int sdxl_unet_set_weight_warmer(sdxl_unet* u, int enabled, int lookahead) {
-  API_BEGIN
-  SDXL_REQUIRE(u != nullptr, "null argument");
-  u->u->set_weight_warmer(enabled != 0, lookahead);
-  API_END
-}
 int sdxl_unet_set_split_cfg(sdxl_unet* u, int enabled, int release_offset) {
   API_BEGIN
   SDXL_REQUIRE(u != nullptr && release_offset >= 0, "bad argument");

@@ -8,7 +8,6 @@ namespace sdxl {
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float ld_f(const void* p, size_t i, int dt) {
   return dt == DT_F16 ? (float)reinterpret_cast<const half_t*>(p)[i] : reinterpret_cast<const float*>(p)[i];
@@ -199,32 +198,6 @@ void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s) {
   hipLaunchKernelGGL(i32_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
 }
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s) { (void)hipMemsetAsync(p, 0, bytes, s); }
-
-// Weight warmer: streams `bytes` of a weight matrix through a few workgroups so that the lines sit in the 256 MB Infinity
-// Cache when the GEMM that owns them starts.  A UNet step touches 5.1 GB of weights, so every GEMM finds its weights cold in
-// HBM; measured cold vs resident: +12 us per FF-out, +3 us per N = K = 1280 projection (profiles/r02_weights_cold_vs_warm.txt).
-// No LDS, 20 VGPRs: the workgroups co-reside with the running GEMM's.  The loaded values are only xor-ed into a never-taken store.
-__global__ __launch_bounds__(256) void warm_lines_kernel(const i32x4* src, size_t n16, int* sink) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  i32x4 acc = {0, 0, 0, 0};
-  for (; i + 7 * stride < n16; i += 8 * stride) {
-    i32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc ^= v[u];
-  }
-  for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(src + i);
-  if (acc[0] == 0x7f31aa55 && acc[1] == 0x13572468 && acc[2] == 0x2468aceb) sink[0] = acc[3];
-}
-void launch_warm_lines(const void* p, size_t bytes, int* sink, hipStream_t s) {
-  const size_t n16 = bytes / 16;
-  if (!n16) return;
-  int blocks = (int)((n16 + 256 * 8 - 1) / (256 * 8));
-  if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(warm_lines_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const i32x4*>(p), n16, sink);
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // CLIP text-encoder glue (clip/mod.rs:99-105 embedding sum, :139-147 eot pooling, backend.rs attn_decoder_mask)

@@ -173,13 +173,6 @@ struct Exec {
   DeviceArena* act = nullptr;
   float* gn_partial = nullptr;
   float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0; unsigned* splitk_cnt = nullptr;   // igemm split-K workspace (optional)
-  // weight warmer (optional): the dry run records every GEMM's (weights, bytes) in launch order; the real run, before GEMM i,
-  // forks a touch of GEMM (i + lookahead)'s weights onto the side stream
-  struct WarmItem { const void* w; size_t bytes; };
-  std::vector<WarmItem>* warm_rec = nullptr;           // dry run: record
-  const std::vector<WarmItem>* warm_list = nullptr;    // real run: play
-  int warm_idx = 0, warm_ahead = 2;
-  hipStream_t warm_stream = nullptr; std::vector<hipEvent_t>* warm_events = nullptr; int* warm_sink = nullptr; bool warm_used = false;
   const float* ebias = nullptr;   // [nb][emb_total] per-ResBlock time-embedding biases of this run's batch entries
   int b0 = 0;                      // first batch entry of this run (split-CFG chains address the K/V caches with it)
   hipEvent_t fork_ev = nullptr;    // split-CFG: recorded on s after the fork_after-th GEMM launch of chain 0 -- the second
@@ -234,9 +227,6 @@ class UNet {
   // per-handle option: run the two entries of a batch-2 forward (the CFG pair) as two concurrent batch-1 chains on two
   // streams, the second released after `release_offset` GEMM launches of the first; bit-identical results
   void set_split_cfg(bool on, int release_offset) { split_cfg_ = on; split_offset_ = release_offset; }
-  // per-handle option: warm the Infinity Cache with the weights of the GEMM `lookahead` launches ahead (side stream inside the
-  // captured graph); results are unaffected
-  void set_weight_warmer(bool on, int lookahead);
   // one eager forward of the current plan/context with hipEvents around every launch, summed per kernel class
   void profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[Profiler::NCLS], double flops[Profiler::NCLS],
                hipStream_t s);
@@ -277,9 +267,6 @@ class UNet {
   // split-CFG mode: the two entries of a batch-2 forward run as two independent batch-1 chains on two streams (fork / join
   // by events, captured into the same graph); the second chain has its own scratch arena
   bool split_cfg_ = false; int split_offset_ = 0;
-  bool warm_on_ = false; int warm_ahead_ = 2;
-  std::vector<Exec::WarmItem> warm_list_; std::vector<hipEvent_t> warm_events_; hipStream_t warm_stream_ = nullptr;
-  hipEvent_t warm_join_ = nullptr; int* warm_sink_ = nullptr;
   bool plan_split_ = false; int graph_off_ = 0;
   hipStream_t s2_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena act2_;

@@ -137,8 +137,6 @@ void launch_nhwc_to_nchw(const void* src, int dt, int lds, float* dst, int B, in
 // generic cast copy rows: dst[r][c] = src[r][c]
 void launch_copy_rows(const void* src, int sdt, int lds, void* dst, int ddt, int ldd, int rows, int C, hipStream_t s);
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
-// streams a (16-byte aligned) buffer through <= 64 small workgroups: warms the Infinity Cache for the GEMM that will read it
-void launch_warm_lines(const void* p, size_t bytes, int* sink, hipStream_t s);
 void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s);
 // CLIP text encoder (clip/mod.rs:99-105,139-147): x[b][t][:] = tok[ids[b][t]][:] + pos[t][:] (tables in dtype w_dt);
 // eot[b] = first index of max(ids[b][:]); sel[b][:] = x[b][eot[b]][:] as fp32; additive causal mask [n][n] (0 / -inf)

@@ -103,22 +103,7 @@ UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src,
   fuse_ln_ = compute_dt == DT_F16 && stream_dt == DT_F16;
   build_weights(src, st);
 }
-void UNet::set_weight_warmer(bool on, int lookahead) {
-  SDXL_REQUIRE(lookahead >= 1 && lookahead <= 16, "weight warmer lookahead out of range");
-  if (on == warm_on_ && lookahead == warm_ahead_) return;
-  warm_on_ = on; warm_ahead_ = lookahead;
-  if (graph_) { (void)hipGraphExecDestroy(graph_); graph_ = nullptr; plan_runs_ = 0; }   // the captured graph holds the fork
-  if (on && !warm_stream_) {
-    SDXL_HIP(hipStreamCreateWithFlags(&warm_stream_, hipStreamNonBlocking));
-    SDXL_HIP(hipEventCreateWithFlags(&warm_join_, hipEventDisableTiming));
-    SDXL_HIP(hipMalloc((void**)&warm_sink_, 64));
-  }
-}
 UNet::~UNet() {
-  for (hipEvent_t e : warm_events_) (void)hipEventDestroy(e);
-  if (warm_join_) (void)hipEventDestroy(warm_join_);
-  if (warm_stream_) (void)hipStreamDestroy(warm_stream_);
-  if (warm_sink_) (void)hipFree(warm_sink_);
   if (graph_) (void)hipGraphExecDestroy(graph_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
@@ -439,8 +424,6 @@ void UNet::ensure_plan(int B, int H, int W) {
   act_.dry = true; act_.off = 0; act_.peak = 0;
   persist();
   Exec ex; ex.dry = true; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_;
-  warm_list_.clear();
-  ex.warm_rec = &warm_list_;
   const size_t m = act_.mark();
   const bool had_kv = !kv_.empty();
   if (!had_kv) {   // plan built before set_context: fake cache entries for the dry run
@@ -483,21 +466,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
   const size_t m = act_.mark();
   // one batched chain, or (split-CFG) entry 0 on s and entry 1 on the side stream between a fork and a join event
   auto go = [&]() {
-    if (!plan_split_) {
-      if (warm_on_ && cdt_ == DT_F16) {
-        while (warm_events_.size() < warm_list_.size()) {
-          hipEvent_t e; SDXL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); warm_events_.push_back(e);
-        }
-        ex.warm_list = &warm_list_; ex.warm_events = &warm_events_; ex.warm_stream = warm_stream_; ex.warm_sink = warm_sink_;
-        ex.warm_ahead = warm_ahead_; ex.warm_idx = 0; ex.warm_used = false;
-      }
-      run(ex, t_dev, t_stride, 0, B);
-      if (ex.warm_used) {   // join the side stream (stream capture requires it; eager runs keep the streams ordered)
-        SDXL_HIP(hipEventRecord(warm_join_, warm_stream_));
-        SDXL_HIP(hipStreamWaitEvent(s, warm_join_, 0));
-      }
-      return;
-    }
+    if (!plan_split_) { run(ex, t_dev, t_stride, 0, B); return; }
     Exec e2; e2.s = s2_; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_;
     e2.splitk_ws = skws_[1]; e2.splitk_ws_bytes = skws_bytes_; e2.splitk_cnt = skcnt_[1];
     act2_.off = 0;

@@ -246,20 +246,7 @@ NormW WeightBuilder::norm(const std::string& name) {
 
 // ------------------------------------------------------------------------------------------ launch helpers
 void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e) {
-  if (ex.dry) {
-    if (ex.warm_rec) ex.warm_rec->push_back(Exec::WarmItem{w.w, (size_t)w.Npad * w.Kpad * dt_size(ex.cdt)});
-    return;
-  }
-  if (ex.warm_list && ex.warm_stream) {
-    const int i = ex.warm_idx++, j = i + ex.warm_ahead;
-    if (j < (int)ex.warm_list->size() && i < (int)ex.warm_events->size() && (*ex.warm_list)[j].bytes >= (1u << 20)) {
-      hipEvent_t ev = (*ex.warm_events)[i];
-      SDXL_HIP(hipEventRecord(ev, ex.s));
-      SDXL_HIP(hipStreamWaitEvent(ex.warm_stream, ev, 0));
-      launch_warm_lines((*ex.warm_list)[j].w, (*ex.warm_list)[j].bytes, ex.warm_sink, ex.warm_stream);
-      ex.warm_used = true;
-    }
-  }
+  if (ex.dry) return;
   SDXL_REQUIRE(cin == w.cin, "run_conv: channel mismatch");
   IgemmParams p{};
   p.A = a.p; p.W = w.w; p.a_dt = a.dt;

@@ -35,11 +35,6 @@ def test_fullsize_unet_properties(pkg, ctx, base_inputs):
         one = u.forward(x[i:i + 1].cuda(), t[i:i + 1].cuda(), ctxt[i:i + 1].cuda(), y[i:i + 1].cuda()).cpu()
         assert torch.equal(one[0], outs[0][i]), f"batch entry {i} depends on its batch neighbour"
     # (accuracy at this size is held against the ORACLE in test_gpu_baseline_parity.py::test_unet_forward_1024_matches_oracle)
-    # weight warmer (side-stream touches of the weights two GEMMs ahead, forked inside the captured graph): same bits
-    u.set_weight_warmer(True, 2)
-    warm = [u.forward(x.cuda(), t.cuda(), ctxt.cuda(), y.cuda()).cpu() for _ in range(3)]      # eager, capture, replay
-    u.set_weight_warmer(False)
-    assert all(torch.equal(w, outs[0]) for w in warm), "the weight warmer changed the result"
 
 
 def _prompt_ids(seed, n_tok, pad):
