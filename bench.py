@@ -314,6 +314,8 @@ def main():
                          "are chip-filling MFMA work; off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--unfused-xattn", action="store_true",
+                    help="A/B: run the cross-attention as projection + attention kernel instead of inside the projection's epilogue")
     ap.add_argument("--split-cfg", action="store_true",
                     help="run the CFG pair as two concurrent batch-1 chains (measured -2.6 %% step time; off by default so "
                          "the timed launches are the ones the roofline object and the rocprofv3 summary describe)")
@@ -370,6 +372,8 @@ def main():
         diffuser.diffusion.set_graph(False)
     if args.split_cfg:
         diffuser.diffusion.set_split_cfg(True)
+    if args.unfused_xattn:
+        diffuser.diffusion.set_fused_cross_attention(False)
     diffuser.enable_step_timing(True)
 
     lat = res // 8
@@ -514,7 +518,7 @@ def main():
                        "precision": args.dtype, "vae_dtype": args.vae_dtype,
                        "weights": "synthetic seeded (random-init SDXL-base architecture)",
                        "parallelism": f"replica x{world}, 1 prompt per GPU, weights broadcast once over RCCL",
-                       "hipgraph": not args.no_graph, "split_cfg": bool(args.split_cfg),
+                       "hipgraph": not args.no_graph, "split_cfg": bool(args.split_cfg), "fused_xattn": not args.unfused_xattn,
                        "pipelined_decode": bool(pipelined)},
             "images_per_sec_per_gpu": round(value / world, 4),
             "unet_step_ms_p50": None if p50 is None else round(p50, 3),

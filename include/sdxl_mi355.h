@@ -127,6 +127,9 @@ int sdxl_unet_set_graph(sdxl_unet* u, int enabled);   /* hipGraph replay of the 
  * runs as two concurrent batch-1 chains on two streams inside the captured graph, the second released after
  * `release_offset` GEMM launches of the first.  Bit-identical results; measured -2.6 % step time. */
 int sdxl_unet_set_split_cfg(sdxl_unet* u, int enabled, int release_offset);
+/* per-handle option (default on, f16 engines): the transformer blocks' cross-attention (77 context keys; unet/mod.rs:731-795)
+ * runs inside the epilogue of the query projection instead of as its own kernel.  Off = projection + attention kernel. */
+int sdxl_unet_set_fused_cross_attention(sdxl_unet* u, int enabled);
 
 /* ---- Backend::qkv_attention (src/backend.rs:4-19; generic body :88-128, LibTorch override :32-79)
  * q [B,Nq,n_head*d], k,v [B,Nk,n_head*d], mask additive [Nq,Nk] or NULL, out [B,Nq,n_head*d]; fp32 device tensors */
@@ -272,6 +275,15 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
  * epilogue), otherwise the stand-alone LayerNorm kernel.  K % 64 == 0. */
 int sdxl_layer_norm_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, float eps,
                            const float* weight, const float* bias, int M, int K, int N, int geglu, int dtype, float* out);
+
+/* LayerNorm -> attn2 query projection (no bias) -> qkv_attention over the already projected context, 64 channels per head:
+ * SpatialTransformer block attn2 up to its output projection (src/model/unet/mod.rs:731-795, attention via backend.rs:88-128).
+ * x [B,Nq,C], wq [C,C] (in,out), k,v [B,Nk,C], out [B,Nq,C]; fp32 device tensors, f16 engine arithmetic.
+ * fused != 0: ONE launch, the attention runs in the projection's epilogue (needs Nq % 64 == 0, Nk <= 96);
+ * fused == 0: projection + attention kernel. */
+int sdxl_ln_query_cross_attention(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, float eps,
+                                  const float* wq, const float* k, const float* v, int B, int Nq, int Nk, int C, int fused,
+                                  float* out);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "sdxl_last_error", "sdxl_build_info", "sdxl_ctx_create", "sdxl_ctx_destroy", "sdxl_ctx_synchronize",
     "sdxl_unet_config_base", "sdxl_unet_config_refiner", "sdxl_vae_config_default",
     "sdxl_unet_param_count", "sdxl_unet_param_spec", "sdxl_vae_param_count", "sdxl_vae_param_spec",
-    "sdxl_unet_create", "sdxl_unet_create_synthetic", "sdxl_unet_destroy", "sdxl_unet_forward", "sdxl_unet_set_graph", "sdxl_unet_set_split_cfg",
+    "sdxl_unet_create", "sdxl_unet_create_synthetic", "sdxl_unet_destroy", "sdxl_unet_forward", "sdxl_unet_set_graph", "sdxl_unet_set_split_cfg", "sdxl_unet_set_fused_cross_attention",
     "sdxl_qkv_attention", "sdxl_attn_decoder_mask",
     "sdxl_diffuser_create", "sdxl_diffuser_create_synthetic", "sdxl_diffuser_destroy", "sdxl_diffuser_unet",
     "sdxl_sample_latent", "sdxl_sample_latent_with_inpainting", "sdxl_refine_latent", "sdxl_step_count",
@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "sdxl_latent_to_image", "sdxl_vae_encode_image", "sdxl_image_to_latent",
     "sdxl_unet_weight_arena", "sdxl_vae_weight_arena", "sdxl_diffuser_create_empty", "sdxl_vae_create_empty",
     "sdxl_unet_profile", "sdxl_bench_igemm", "sdxl_bench_attention", "sdxl_debug_set",
-    "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear", "sdxl_layer_norm_linear",
+    "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear", "sdxl_layer_norm_linear", "sdxl_ln_query_cross_attention",
     "sdxl_clip_config_clip_l", "sdxl_clip_config_open_clip_bigg", "sdxl_clip_param_count", "sdxl_clip_param_spec",
     "sdxl_clip_create", "sdxl_clip_create_synthetic", "sdxl_clip_destroy", "sdxl_clip_forward_hidden",
     "sdxl_clip_forward_hidden_pooled", "sdxl_conditioning_embedding", "sdxl_clip_weight_arena",
@@ -341,6 +341,10 @@ class UNet:
     def set_split_cfg(self, enabled: bool, release_offset: int = 0):
         """per-handle: run the CFG pair (batch-2 forward) as two concurrent batch-1 chains; bit-identical results"""
         _check(lib().sdxl_unet_set_split_cfg(self.h, int(enabled), int(release_offset)))
+
+    def set_fused_cross_attention(self, enabled: bool):
+        """per-handle (default on): cross-attention inside the query projection's epilogue"""
+        _check(lib().sdxl_unet_set_fused_cross_attention(self.h, int(enabled)))
 
     def set_graph(self, enabled: bool):
         _check(lib().sdxl_unet_set_graph(self.h, int(enabled)))
@@ -836,6 +840,25 @@ def layer_norm_linear(ctx: Context, x, gamma, beta, weight, bias, eps: float = 1
     out = torch.empty(tuple(x.shape[:-1]) + ((N // 2) if geglu else N,), device=x.device, dtype=torch.float32)
     _check(lib().sdxl_layer_norm_linear(ctx.h, _stream(), px, pg, pbeta, ctypes.c_float(eps), pw, pb, M, K, N, int(geglu),
                                        dtype, ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
+def ln_query_cross_attention(ctx: Context, x, gamma, beta, wq, k, v, eps: float = 1e-5, fused: bool = True):
+    """attn2 of a transformer block up to its output projection (unet/mod.rs:731-795): LayerNorm -> query projection (no
+    bias) -> qkv_attention over the projected context k, v [B,Nk,C] with 64 channels per head.  f16 engine arithmetic.
+    fused=True runs the attention inside the projection's epilogue (one launch), False as projection + attention kernel."""
+    torch = _torch()
+    x, px = _dev(x)
+    gamma, pg = _dev(gamma)
+    beta, pbeta = _dev(beta)
+    wq, pw = _dev(wq)
+    k, pk = _dev(k)
+    v, pv = _dev(v)
+    B, Nq, C = x.shape
+    Nk = int(k.shape[1])
+    out = torch.empty((B, Nq, C), device=x.device, dtype=torch.float32)
+    _check(lib().sdxl_ln_query_cross_attention(ctx.h, _stream(), px, pg, pbeta, ctypes.c_float(eps), pw, pk, pv, int(B), int(Nq),
+                                              Nk, int(C), int(fused), ctypes.c_void_p(out.data_ptr())))
     return out
 
 

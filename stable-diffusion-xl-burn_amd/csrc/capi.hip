@@ -374,6 +374,12 @@ int sdxl_unet_set_split_cfg(sdxl_unet* u, int enabled, int release_offset) {
   u->u->set_split_cfg(enabled != 0, release_offset);
   API_END
 }
+int sdxl_unet_set_fused_cross_attention(sdxl_unet* u, int enabled) {
+  API_BEGIN
+  SDXL_REQUIRE(u != nullptr, "bad argument");
+  u->u->set_fused_cross_attention(enabled != 0);
+  API_END
+}
 int sdxl_unet_weight_arena(sdxl_unet* u, void** base, size_t* bytes) {
   API_BEGIN
   SDXL_REQUIRE(u && base && bytes, "null argument");
@@ -934,6 +940,87 @@ int sdxl_layer_norm_linear(sdxl_ctx* ctx, void* stream, const float* x, const fl
     Epi e; e.act = geglu ? 1 : 0;
     run_linear(ex, l, Act(ln, K, cdt), M, o, e);
   }
+  SDXL_HIP(hipStreamSynchronize(s));
+  API_END
+}
+
+int sdxl_ln_query_cross_attention(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, float eps,
+                                  const float* wq, const float* k, const float* v, int B, int Nq, int Nk, int C, int fused,
+                                  float* out) {
+  // attn2 of a transformer block up to (not including) the output projection: LayerNorm -> query projection (no bias) ->
+  // qkv_attention over the projected context, 64 channels per head.  f16 engine only (the UNet's production mode); fused != 0
+  // runs the attention inside the projection's epilogue, fused == 0 as projection + attention kernel.
+  API_BEGIN
+  SDXL_REQUIRE(ctx && x && gamma && beta && wq && k && v && out, "null argument");
+  SDXL_REQUIRE(C % 64 == 0 && B >= 1 && Nq >= 1 && Nk >= 1, "State size must be a multiple of head size");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  const int M = B * Nq, vt_ld = (int)round_up(Nk, 64);
+  SDXL_REQUIRE(!fused || igemm_xattn_ok(DT_F16, DT_F16, M, C, C, Nq, Nk), "fused cross-attention: unsupported shape");
+  std::vector<ParamSpec> specs(5);
+  specs[0].name = "lin.weight"; specs[0].shape = {C, C}; specs[0].kind = PK_LINEAR_W;
+  specs[1].name = "lin.bias"; specs[1].shape = {C}; specs[1].kind = PK_BIAS;
+  specs[2].name = "norm.gamma"; specs[2].shape = {C}; specs[2].kind = PK_GAMMA;
+  specs[3].name = "norm.beta"; specs[3].shape = {C}; specs[3].kind = PK_BETA;
+  specs[4].name = "norm.eps"; specs[4].shape = {1}; specs[4].kind = PK_EPS;
+  Tmp tmp;
+  const size_t cc = (size_t)C * C;
+  float* flat = (float*)tmp.get((cc + 3 * (size_t)C + 1) * sizeof(float));
+  SDXL_HIP(hipMemcpyAsync(flat, wq, cc * sizeof(float), hipMemcpyDefault, s));
+  SDXL_HIP(hipMemsetAsync(flat + cc, 0, (size_t)C * sizeof(float), s));
+  SDXL_HIP(hipMemcpyAsync(flat + cc + C, gamma, (size_t)C * sizeof(float), hipMemcpyDefault, s));
+  SDXL_HIP(hipMemcpyAsync(flat + cc + 2 * (size_t)C, beta, (size_t)C * sizeof(float), hipMemcpyDefault, s));
+  SDXL_HIP(hipMemcpyAsync(flat + cc + 3 * (size_t)C, &eps, sizeof(float), hipMemcpyHostToDevice, s));
+  SDXL_HIP(hipStreamSynchronize(s));
+  FlatSource src(flat, specs);
+  DeviceArena arena;
+  arena.reserve(WeightBuilder::arena_bound(specs, DT_F16) + ((size_t)round_up(C, 128) * C * 2 + (1 << 16)));
+  WeightBuilder wb(specs, src, arena, DT_F16, s);
+  Exec ex; ex.s = s; ex.cdt = DT_F16; ex.sdt = DT_F16;
+  // beta W is folded into the packed bias; attn2.query has none of its own, so fold with beta as given (zero beta -> no bias)
+  Lin l = wb.linear_ln("lin", false, "norm");
+  Lin id; id.N = C; id.K = C; id.cin = C; id.ksize = 1; id.Kpad = C; id.Npad = (int)round_up(C, 128);
+  void* ip = arena.alloc((size_t)id.Npad * id.Kpad * 2);
+  float* eye = (float*)tmp.get(cc * sizeof(float));
+  {
+    std::vector<float> h(cc, 0.f);
+    for (int i = 0; i < C; ++i) h[(size_t)i * C + i] = 1.0f;
+    SDXL_HIP(hipMemcpyAsync(eye, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    SDXL_HIP(hipStreamSynchronize(s));
+  }
+  launch_pack_linear(eye, ip, DT_F16, C, C, id.Kpad, id.Npad, 0, 0, s);
+  id.w = ip; id.b = nullptr;
+  void* x16 = tmp.get((size_t)M * C * 2);
+  void* xi = tmp.get((size_t)M * C * 2);
+  launch_copy_rows(x, DT_F32, C, x16, DT_F16, C, M, C, s);
+  float* stat = (float*)tmp.get((size_t)M * (C / 64) * 2 * sizeof(float));
+  { Epi ep; ep.stat_out = stat; run_linear(ex, id, Act(x16, C, DT_F16), M, Act(xi, C, DT_F16), ep); }
+  // context keys [B][Nk][C] and V^T [B][C][vt_ld] (zero key padding), f16
+  void* kd = tmp.get((size_t)B * Nk * C * 2);
+  void* vt = tmp.get((size_t)B * C * vt_ld * 2);
+  launch_copy_rows(k, DT_F32, C, kd, DT_F16, C, B * Nk, C, s);
+  launch_fill_zero(vt, (size_t)B * C * vt_ld * 2, s);
+  for (int b = 0; b < B; ++b) {
+    const size_t tot = (size_t)Nk * C;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, v + (size_t)b * Nk * C, C, Nk, C,
+                       (char*)vt + (size_t)b * C * vt_ld * 2, DT_F16, vt_ld);
+  }
+  void* od = tmp.get((size_t)M * C * 2);
+  Epi e; e.ln_stat = stat; e.rpb = Nq;
+  if (fused) {
+    void* xa = tmp.get(xattn_pack_bytes(B, C));
+    launch_xattn_pack(kd, vt, xa, B, C, Nk, vt_ld, s);
+    e.xa_k = xa; e.xa_nctx = Nk; e.xa_scale = 0.125f;
+    run_linear(ex, l, Act(xi, C, DT_F16), M, Act(od, C, DT_F16), e);
+  } else {
+    void* qd = tmp.get((size_t)M * C * 2);
+    run_linear(ex, l, Act(xi, C, DT_F16), M, Act(qd, C, DT_F16), e);
+    AttnParams p{};
+    p.Q = qd; p.ldq = C; p.K = kd; p.ldk = C; p.Vt = vt; p.vt_ld = vt_ld; p.O = od; p.ldo = C;
+    p.dt = DT_F16; p.B = B; p.H = C / 64; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+    launch_attention_d64(p, s);
+  }
+  launch_copy_rows(od, DT_F16, C, out, DT_F32, C, M, C, s);
   SDXL_HIP(hipStreamSynchronize(s));
   API_END
 }

@@ -193,6 +193,8 @@ struct Epi {
   int n_split = -1;  // >=0: columns >= n_split go transposed into Ct
   void* Ct = nullptr; int ct_rows = 0, ct_ld = 0;
   int rpb = 0;       // rows per batch for ebias / transposed store (0 -> Hout*Wout)
+  // cross-attention fused into the projection's epilogue (IgemmParams::xa_*): packed context of this run's batch entries
+  const void* xa_k = nullptr; int xa_nctx = 0; float xa_scale = 0.f;   // xa_k: operand-order image (launch_xattn_pack)
 };
 void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());
 void run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());
@@ -227,6 +229,7 @@ class UNet {
   // per-handle option: run the two entries of a batch-2 forward (the CFG pair) as two concurrent batch-1 chains on two
   // streams, the second released after `release_offset` GEMM launches of the first; bit-identical results
   void set_split_cfg(bool on, int release_offset) { split_cfg_ = on; split_offset_ = release_offset; }
+  void set_fused_cross_attention(bool on) { fuse_xattn_ = on; }
   // one eager forward of the current plan/context with hipEvents around every launch, summed per kernel class
   void profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[Profiler::NCLS], double flops[Profiler::NCLS],
                hipStream_t s);
@@ -249,7 +252,7 @@ class UNet {
   NormW norm_out_; Lin conv_out_;
   int emb_total_ = 0;
   // cross-attention K / V^T caches (one per transformer block, in execution order)
-  struct KV { void* k = nullptr; void* vt = nullptr; };
+  struct KV { void* k = nullptr; void* vt = nullptr; void* xa = nullptr; };   // xa: operand-order image for the fused epilogue (f16)
   std::vector<std::vector<KV>> kv_;     // [spatial transformer][block]
   std::vector<const STW*> st_list_;
   DeviceArena ctx_arena_;
@@ -268,6 +271,7 @@ class UNet {
   // by events, captured into the same graph); the second chain has its own scratch arena
   bool split_cfg_ = false; int split_offset_ = 0;
   bool plan_split_ = false; int graph_off_ = 0;
+  bool fuse_xattn_ = true, plan_xattn_ = true;   // cross-attention inside the query projection's epilogue (f16 engines)
   hipStream_t s2_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena act2_;
   hipGraphExec_t graph_ = nullptr;

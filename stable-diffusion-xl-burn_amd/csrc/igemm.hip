@@ -352,6 +352,7 @@ void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s) {
   if (compute_dt == DT_F16 && g_igemm_variant >= 0 && launch_igemm_glds(p, g_igemm_variant, s)) return;
   if (compute_dt == DT_F16 && g_igemm_variant > 0 && launch_igemm_glds(p, 0, s)) return;   // forced tile refused the shape
   if (compute_dt == DT_F32 && g_igemm_variant >= 0 && launch_igemm_f32_pipe(p, s)) return;
+  if (p.xa_k) throw std::runtime_error("fused cross-attention needs the f16 direct-to-LDS kernels");
   if (p.ln_stat || p.stat_out)
     throw std::runtime_error("LayerNorm-folded GEMM (ln_stat / stat_out) needs the f16 direct-to-LDS kernels");
   if (compute_dt == DT_F16) {

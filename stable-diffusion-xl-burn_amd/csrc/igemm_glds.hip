@@ -725,7 +725,111 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
 // the Infinity-Cache / HBM latency (~2 us under load) with only NS-1 tiles in flight.  So each wave touches, one k-tile-row
 // line per lane (a 4-byte LDS-DMA into a scratch slot: no register, no compiler-visible hazard), the lines the DMA will ask
 // for PF k-tiles later; by then they are L2 hits.
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t, int PF = 0>
+
+// ---- cross-attention fused into the query projection (transformer attn2: unet/mod.rs:731-763 + attention at 765-795) ----
+// The context K / V^T of a trajectory are constant (projected once per prompt, UNet::set_context) and short (77 keys), and a
+// wave tile of the 128- / 256-row kernels is 32 (64) queries x 64 columns = exactly ONE head.  So the wave that holds the
+// finished q tile in its accumulators runs the whole attention on it, in registers, before the store:
+//   S^T[key][query] = K_h q^T      A = K fragments read straight from global (12 KiB per head, pre-packed in operand order), B = q (f16)
+//   P = softmax over the 77 keys   a lane owns ONE query (column lane&31) and 16 keys of each 32-key tile: max / sum are
+//                                  in-lane plus one xor-32 exchange
+//   O^T[d][query] = V_h^T P^T      A = V^T fragments from global, B = P (f16) -- the S accumulators re-used as operands
+// The contraction index of an MFMA is free to permute as long as A and B agree, so the accumulator registers 8qq..8qq+7 of
+// column tile j ARE the B fragment of "k-step (j, qq)": element e <-> d = 32j + 16qq + 8(e>>2) + 4(lane>>5) + (e&3); the K
+// fragments are packed with the same map (xattn_pack_kernel, once per prompt), and likewise keys for P / V^T.  O^T comes out in the layout
+// the q tile came in, so the normal staged store follows unchanged.  No LDS, no cross-wave traffic, one launch less per block.
+template <int TM>
+__device__ __forceinline__ void xattn_inplace(const IgemmParams& p, f32x16 (&acc)[TM][2], int mw, int nw, int lane,
+                                              float (&lnA)[TM], float (&lnC)[TM], const void* zeros) {
+  if (nw >= p.N) return;                                              // zero-padded weight columns: nothing is stored
+  const int fr = lane & 31, fh = lane >> 5;
+  const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
+  const int nctx = p.xa_nctx;
+  const int mclamp = mw < p.M ? mw : p.M - 1;
+  const int b = __builtin_amdgcn_readfirstlane(mclamp / p.rpb);       // rpb % WM == 0: one batch entry per wave tile
+  // K / V^T fragments in MFMA operand order (launch_xattn_pack): one coalesced 1-KiB load per fragment, shared through L1/L2 by
+  // the waves of the same head.  Gathering them from the row-major caches cost 48 eight-byte loads with 32 different rows per
+  // instruction -- 11 us per projection, as much as the attention kernel this fusion removes.
+  const half8* fx = reinterpret_cast<const half8*>(p.xa_k) + ((size_t)b * (p.N >> 6) + (nw >> 6)) * (24 * 64) + lane;
+  half8 kf[3][4], vf[2][6];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) kf[t][s4] = fx[(t * 4 + s4) * 64];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) vf[dt][s6] = fx[(12 + dt * 6 + s6) * 64];
+  f32x4 cz[2][4], bz[2][4];                                          // folded-LayerNorm column sums, bias (beta W of the folded norm)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nb = nw + j * 32 + 8 * q + 4 * fh;
+      cz[j][q] = *(p.ln_stat ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
+      bz[j][q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
+    }
+  const float sc = p.xa_scale * 1.44269504088896340736f;             // p = exp2(s - m)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const float lna = lnA[i], lnc = lnC[i];
+    half8 qf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int j = s4 >> 1, qq = s4 & 1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int q = 2 * qq + (e >> 2), r = e & 3;
+        qf[s4][e] = (half_t)((lna * acc[i][j][8 * qq + e] + lnc * cz[j][q][r] + bz[j][q][r]) * sc);
+      }
+    }
+    f32x16 sv[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[t][r] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) sv[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t][s4], qf[s4], sv[t], 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (32 * t + 8 * (r >> 2) + 4 * fh + (r & 3) >= nctx) sv[t][r] = -INFINITY;
+        mx = fmaxf(mx, sv[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float l = 0.f;
+    half8 pf[6];
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) {
+      float ls = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(sv[s6 >> 1][8 * (s6 & 1) + e] - mx);
+        ls += pe;
+        pf[s6][e] = (half_t)pe;
+      }
+      l += ls;
+    }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][s6], pf[s6], o, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][dt][r] = o[r] * inv;
+    }
+    lnA[i] = 1.f; lnC[i] = 0.f;                                       // the staged store adds nothing more
+  }
+}
+
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t, int PF = 0, bool XA = false>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
   typedef typename PipeElem<T>::frag frag_t;
   constexpr int CE = 16 / (int)sizeof(T);     // elements per 16-byte chunk: 8 (f16) or 4 (f32, strict mode)
@@ -1143,6 +1247,15 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       __syncthreads();          // every wave has read the flag before the staging regions are written
     }
   }
+  if constexpr (XA) {
+    static_assert(TN == 2 && sizeof(T) == 2, "fused cross-attention: wave tile = one 64-wide head, f16");
+    static_assert(NW * WM * WN * 4 <= NS * STAGE, "staging regions must fit the dead ring");
+    xattn_inplace<TM>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros);
+    IgemmParams pe = p;                       // bias and the LayerNorm affine went into q: the store adds nothing
+    pe.bias = nullptr; pe.ln_stat = nullptr;
+    igemm_epilogue_staged<TM, TN>(pe, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC, zeros);
+    return;
+  }
   constexpr bool FITS = NW * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
   if (FITS || p.act == 1) {
     const int region = p.act == 1 ? WM * (WN / 2) * 4 : WM * WN * 4;   // GEGLU halves the staged width
@@ -1544,18 +1657,18 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_pages[dev]);
 }
 
-template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t, int PF = 0>
+template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t, int PF = 0, bool XA = false>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)NS * (BM + BN) * 128 + (PF > 0 ? NW * 256 : 0);   // + the scratch slots of the L2-prefetch touches
   static bool attr_set[kMaxDev] = {};
   const int dev = current_device();
-  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T, PF>, lds, attr_set, dev);
+  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T, PF, XA>, lds, attr_set, dev);
   const int sk = (BN == 128 && DMODE == 0 && p.splitk > 1) ? p.splitk : 1;
   if (sk > 1 && (size_t)tilesM * tilesN * sk * BM * BN * 4 > p.splitk_ws_bytes) throw std::runtime_error("igemm: split-K workspace too small");
   IgemmParams q = p;
   q.splitk = sk;
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T, PF>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T, PF, XA>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
 }
 
 #ifdef SDXL_MEASURE
@@ -1604,6 +1717,44 @@ size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max) {
   return (size_t)((rows + 255) / 256) * (size_t)((n_max + 127) / 128) * 3 * 256 * 128 * 4;
 }
 
+bool igemm_xattn_ok(int a_dt, int c_dt, int M, int N, int K, int rpb, int n_ctx) {
+  return a_dt == DT_F16 && c_dt == DT_F16 && M > 0 && N % 64 == 0 && K % 64 == 0 && rpb > 0 && rpb % 64 == 0 && M % rpb == 0 &&
+         n_ctx >= 1 && n_ctx <= 96;
+}
+
+// Context K [B][n_ctx][C] / V^T [B][C][vt_ld] (f16) -> the operand-order image xattn_inplace reads: per (batch entry, head) 24
+// fragments of 64 lanes x 8 halfs -- 12 of K (key tile t, k-step s4: key = 32t + lane&31, d = 16 s4 + 8(e>>2) + 4(lane>>5) + (e&3))
+// then 12 of V^T (d tile dt, k-step s6: d = 32dt + lane&31, key = 16 s6 + 8(e>>2) + 4(lane>>5) + (e&3)); keys >= n_ctx are zero.
+__global__ void xattn_pack_kernel(const half_t* K, const half_t* Vt, half8* out, int B, int C, int nctx, int vt_ld) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = C >> 6;
+  if (i >= (size_t)B * H * 24 * 64) return;
+  const int lane = (int)(i & 63), f = (int)((i >> 6) % 24);
+  const int bh = (int)(i / (24 * 64)), b = bh / H, h = bh - b * H;
+  const int fr = lane & 31, fh = lane >> 5;
+  half8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int sub = 8 * (e >> 2) + 4 * fh + (e & 3);
+    half_t x = (half_t)0.f;
+    if (f < 12) {
+      const int key = 32 * (f >> 2) + fr, d = 16 * (f & 3) + sub;
+      if (key < nctx) x = K[((size_t)b * nctx + key) * C + h * 64 + d];
+    } else {
+      const int g = f - 12, d = 32 * (g / 6) + fr, key = 16 * (g % 6) + sub;
+      if (key < nctx) x = Vt[((size_t)b * C + h * 64 + d) * vt_ld + key];
+    }
+    v[e] = x;
+  }
+  out[i] = v;
+}
+size_t xattn_pack_bytes(int B, int C) { return (size_t)B * (C / 64) * 24 * 64 * 16; }
+void launch_xattn_pack(const void* K, const void* Vt, void* out, int B, int C, int nctx, int vt_ld, hipStream_t s) {
+  const size_t n = (size_t)B * (C / 64) * 24 * 64;
+  hipLaunchKernelGGL(xattn_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const half_t*>(K),
+                     reinterpret_cast<const half_t*>(Vt), reinterpret_cast<half8*>(out), B, C, nctx, vt_ld);
+}
+
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if (!g_zero_pages[current_device()]) return false;
   if (p.act > 1) return false;   // GELU / QuickGELU epilogues (CLIP MLP, once per prompt) live in the generic kernel
@@ -1616,6 +1767,24 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   const bool was_auto = variant == 0;
   IgemmParams psk = p;
   psk.splitk = 1;
+  if (p.xa_k) {
+    // fused cross-attention: wave tiles of 64 columns only (256x128 / 128x128), chosen by the same cost model
+    if (p.act != 0 || p.n_split < p.N || p.stat_out || p.R || p.ebias ||
+        !igemm_xattn_ok(p.a_dt, p.c_dt, p.M, p.N, p.K, p.rpb, p.xa_nctx))
+      throw std::runtime_error("igemm: fused cross-attention needs a plain f16 projection (no residual / split outputs)");
+    const int nk = p.Kpad / 64;
+    auto cost = [&](int bm) {
+      const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + 127) / 128);
+      const long full = tiles / 256, rem = tiles % 256;
+      const double frac = rem ? (rem / 256.0 > 2.0 / 3.0 ? rem / 256.0 : 2.0 / 3.0) : 0.0;
+      return ((double)full + frac) * (bm + 128) * nk + (double)(full + (rem ? 1 : 0)) * 3000.0;
+    };
+    int v = variant == 35 || variant == 36 || variant == 44 ? variant : (cost(256) <= cost(128) ? 35 : (nk >= 40 ? 44 : 36));
+    if (v == 35) launch_pipe<256, 128, 3, false, 0, 4, 8, true, half_t, 0, true>(psk, s);
+    else if (v == 36) launch_pipe<128, 128, 4, false, 0, 4, 8, true, half_t, 0, true>(psk, s);
+    else launch_pipe<128, 128, 5, false, 0, 4, 8, true, half_t, 0, true>(psk, s);
+    return true;
+  }
   if (variant == 0 && igemm_splitk_slices(p) > 1) {
     // long contractions over a small output (FF-out and the 32^2 convs of the CFG pair: M = 2048, N = 1280 is 80 tiles of
     // 256x128 on 256 CUs): three k-slices per tile fill the chip with the tile shape that moves the fewest bytes per flop

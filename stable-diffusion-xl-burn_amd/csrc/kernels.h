@@ -48,7 +48,17 @@ struct IgemmParams {
   // split-K workspace (optional): fp32 partial slabs [tile][slice][256 x 128] + one arrival counter per tile (zero between
   // launches: the last-arriving slice re-arms it).  splitk is filled by the launcher (igemm_splitk_slices); 0 / 1 = off.
   float* splitk_ws; size_t splitk_ws_bytes; unsigned* splitk_cnt; int splitk;
+  // cross-attention fused into this (query) projection: when xa_k is set the epilogue replaces the q tile by
+  // softmax(q K_h^T * xa_scale) V_h per 64-column head before the store (igemm_glds.hip xattn_inplace).  xa_k = the context
+  // keys / values of the batch entries in MFMA operand order (launch_xattn_pack); batch entry of a row = m / rpb.
+  const void* xa_k; int xa_nctx; float xa_scale;
 };
+// shapes the fused cross-attention epilogue takes (f16 operands, head dim 64, <= 96 context tokens); otherwise run the
+// projection and the attention kernel separately
+bool igemm_xattn_ok(int a_dt, int c_dt, int M, int N, int K, int rpb, int n_ctx);
+// K [B][n_ctx][C], V^T [B][C][vt_ld] (f16) -> operand-order image of xattn_pack_bytes(B, C) bytes (once per prompt)
+size_t xattn_pack_bytes(int B, int C);
+void launch_xattn_pack(const void* K, const void* Vt, void* out, int B, int C, int n_ctx, int vt_ld, hipStream_t s);
 int igemm_splitk_slices(const IgemmParams& p);                       // 1 or 3: depends on one batch entry's shape only
 size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max);   // slab bytes a plan must provide
 constexpr int kSplitkCounters = 4096;                                // arrival counters a plan must provide (zeroed once)

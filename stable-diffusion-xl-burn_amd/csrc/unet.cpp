@@ -156,6 +156,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
 void UNet::set_context(const float* context, int n_ctx, const float* label, int B, hipStream_t s) {
   SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
   const int vt_ld = (int)round_up(n_ctx, 64);
+  const bool pack_xa = cdt_ == DT_F16 && n_ctx <= 96;   // operand-order copies for the fused cross-attention epilogue
   const int emb = 4 * cfg_.model_channels;
   if (B != ctx_B_ || n_ctx != n_ctx_) {
     // (re)allocate the caches; captured graphs hold these addresses
@@ -163,7 +164,8 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
     size_t bytes = 1 << 16;
     for (const STW* st : st_list_)
       bytes += st->blocks.size() * (round_up((size_t)B * n_ctx * st->C * dt_size(cdt_), 256) +
-                                    round_up((size_t)B * st->C * vt_ld * dt_size(cdt_), 256) + 512);
+                                    round_up((size_t)B * st->C * vt_ld * dt_size(cdt_), 256) +
+                                    (pack_xa ? round_up(xattn_pack_bytes(B, st->C), 256) : 0) + 768);
     bytes += 3 * round_up((size_t)B * emb * sizeof(float), 256);
     ctx_arena_.reserve(bytes);
     ctx_arena_.off = 0;
@@ -175,6 +177,7 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
         KV kv;
         kv.k = ctx_arena_.alloc((size_t)B * n_ctx * st->C * dt_size(cdt_));
         kv.vt = ctx_arena_.alloc((size_t)B * st->C * vt_ld * dt_size(cdt_));
+        if (pack_xa) kv.xa = ctx_arena_.alloc(xattn_pack_bytes(B, st->C));
         v.push_back(kv);
       }
       kv_.push_back(v);
@@ -189,6 +192,7 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
     for (size_t j = 0; j < st->blocks.size(); ++j) {
       Epi e; e.n_split = st->C; e.Ct = kv_[si][j].vt; e.ct_rows = st->C; e.ct_ld = vt_ld; e.rpb = n_ctx;
       run_linear(ex, st->blocks[j].kv2, ctx, B * n_ctx, Act(kv_[si][j].k, st->C, cdt_), e);
+      if (kv_[si][j].xa) launch_xattn_pack(kv_[si][j].k, kv_[si][j].vt, kv_[si][j].xa, B, st->C, n_ctx, vt_ld, s);
     }
   }
   // label embedding MLP (unet/mod.rs:464-466); scratch after the caches
@@ -228,10 +232,13 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   const int npad = (int)round_up(HW, 64);
   // cross-attention caches of this run's batch entries (dry runs carry null caches)
   auto kv_k = [&](int s_, size_t j) { char* k = (char*)kv_[s_][j].k; return (void*)(k ? k + (size_t)ex.b0 * n_ctx_ * C * dt_size(ex.cdt) : k); };
+  auto kv_xa = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].xa; return (const void*)(v ? v + xattn_pack_bytes(ex.b0, C) : v); };
   auto kv_vt = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].vt; return (const void*)(v ? v + (size_t)ex.b0 * C * vt_ld_ctx_ * dt_size(ex.cdt) : v); };
   Act gn = ex.alloc(M, C, ex.cdt);
   run_groupnorm(ex, w.norm, x, B, HW, gn, false);
   Act t = ex.alloc(M, C, ex.sdt);
+  // cross-attention fused into the query projection (f16 operands, <= 96 context tokens; igemm_xattn_ok)
+  const bool xattn = plan_xattn_ && igemm_xattn_ok(fuse_ln_ ? ex.sdt : ex.cdt, ex.cdt, (int)M, C, C, HW, n_ctx_);
   // folded LayerNorms: two ping-pong [M][C/64][2] partial-sum buffers -- each is written by one GEMM and read by the next
   float* stbuf[2] = {nullptr, nullptr};
   if (fuse_ln_) for (int i = 0; i < 2; ++i) stbuf[i] = (float*)ex.act->alloc(M * (size_t)(C / 64) * 2 * sizeof(float));
@@ -257,8 +264,13 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       Epi e1; e1.R = t; e1.stat_out = stbuf[stp]; e1.rpb = HW;
       run_linear(ex, b.out1, ao, (int)M, t, e1);
       Epi e2q; e2q.ln_stat = stbuf[stp]; e2q.rpb = HW;
-      run_linear(ex, b.q2, t, (int)M, q, e2q);
-      attention(ex, q, Act(kv_k(si, j), C, ex.cdt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
+      if (xattn) {   // the projection's waves run the 77-key attention on their own q tiles: no q round trip, no launch
+        e2q.xa_k = kv_xa(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
+        run_linear(ex, b.q2, t, (int)M, ao, e2q);
+      } else {
+        run_linear(ex, b.q2, t, (int)M, q, e2q);
+        attention(ex, q, Act(kv_k(si, j), C, ex.cdt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
+      }
       stp ^= 1;
       Epi e2; e2.R = t; e2.stat_out = stbuf[stp]; e2.rpb = HW;
       run_linear(ex, b.out2, ao, (int)M, t, e2);
@@ -278,8 +290,14 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     Epi er; er.R = t; er.rpb = HW;
     run_linear(ex, b.out1, ao, (int)M, t, er);
     run_layernorm(ex, b.n2, t, (int)M, ln);
-    run_linear(ex, b.q2, ln, (int)M, q);
-    attention(ex, q, Act(kv_k(si, j), C, ex.cdt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
+    if (xattn) {
+      Epi e2q; e2q.rpb = HW;
+      e2q.xa_k = kv_xa(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
+      run_linear(ex, b.q2, ln, (int)M, ao, e2q);
+    } else {
+      run_linear(ex, b.q2, ln, (int)M, q);
+      attention(ex, q, Act(kv_k(si, j), C, ex.cdt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
+    }
     run_linear(ex, b.out2, ao, (int)M, t, er);
     run_layernorm(ex, b.n3, t, (int)M, ln);
     Epi eg; eg.act = 1;
@@ -394,7 +412,7 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
 
 void UNet::ensure_plan(int B, int H, int W) {
   const bool split = split_cfg_ && B == 2;
-  if (B == pB_ && H == pH_ && W == pW_ && split == plan_split_) return;
+  if (B == pB_ && H == pH_ && W == pW_ && split == plan_split_ && fuse_xattn_ == plan_xattn_) return;
   SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
   const int div = 1 << (cfg_.channel_mults.size() - 1);
   SDXL_REQUIRE(H >= div && W >= div && H % div == 0 && W % div == 0,
@@ -446,6 +464,7 @@ void UNet::ensure_plan(int B, int H, int W) {
     }
   }
   plan_split_ = split;
+  plan_xattn_ = fuse_xattn_;
   if (!had_kv) kv_.clear();
   act_.reset(m);
   const size_t peak = act_.peak;

@@ -264,6 +264,8 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.ln_stat = e.ln_stat; p.ln_slots = w.K / 64; p.ln_cs = w.cs; p.ln_invc = 1.0f / (float)w.K; p.ln_eps = 1e-5f; p.ln_eps_ptr = w.ln_eps;
   p.stat_out = e.stat_out; p.stat_slots = w.N / 64;
   p.splitk_ws = ex.splitk_ws; p.splitk_ws_bytes = ex.splitk_ws_bytes; p.splitk_cnt = ex.splitk_cnt; p.splitk = 0;
+  p.xa_k = e.xa_k; p.xa_nctx = e.xa_nctx; p.xa_scale = e.xa_scale;
+  SDXL_REQUIRE(!e.xa_k || igemm_xattn_ok(a.dt, out.dt, p.M, p.N, p.K, p.rpb, e.xa_nctx), "fused cross-attention: unsupported shape");
   SDXL_REQUIRE(!e.ln_stat || w.K % 64 == 0, "LayerNorm-folded GEMM needs K % 64 == 0");
   SDXL_REQUIRE(!e.stat_out || (w.N % 64 == 0 && (e.n_split < 0 || e.n_split >= w.N) && e.act == 0), "row statistics need a plain N % 64 == 0 output");
   SDXL_REQUIRE(!e.ln_stat || w.cs, "ln_stat given but the weight is not LayerNorm-folded");

@@ -122,6 +122,30 @@ def test_split_cfg_chains_equal_batched_pair(pkg, ctx, dtype):
     assert torch.equal(u.forward(x, t, context, y), ref)
 
 
+def test_fused_cross_attention_matches_two_kernel_path(pkg, ctx):
+    # sdxl_unet_set_fused_cross_attention (per handle, default on): attn2 inside the query projection's epilogue against the
+    # projection + attention-kernel path of the same engine, and both against the oracle (unet/mod.rs:731-795)
+    ocfg = OC.tiny_config()
+    W = unet_weights(ocfg)
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), 1, seed=0)
+    x = torch.from_numpy(OC.arb_tensor(2, 4, 32, 32))
+    context = torch.from_numpy(OC.arb_tensor(2, 7, ocfg.context_dim))
+    y = torch.from_numpy(OC.arb_tensor(2, ocfg.adm_in_channels))
+    t = torch.tensor([999, 1], dtype=torch.int32)
+    ref = OM.unet_forward(ocfg, W, x, t.long(), context, y)
+    fused = [u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu() for _ in range(3)]   # eager, capture, replay
+    assert all(torch.equal(o, fused[0]) for o in fused)
+    try:
+        u.set_fused_cross_attention(False)
+        plain = u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu()
+    finally:
+        u.set_fused_cross_attention(True)
+    assert torch.equal(u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu(), fused[0])
+    e_f, e_p, e_fp = rel_err(fused[0], ref), rel_err(plain, ref), rel_err(fused[0], plain)
+    print(f"fused cross-attention: vs oracle {e_f:.3e}, two-kernel vs oracle {e_p:.3e}, fused vs two-kernel {e_fp:.3e}")
+    assert e_f < FWD_TOL[1] and e_p < FWD_TOL[1] and e_fp < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [0, 1, 2])
 def test_unet_forward_batch_independence(pkg, ctx, dtype):
     # the engine batches the CFG pair; per-sample results must not depend on what else is in the batch

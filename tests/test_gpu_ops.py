@@ -77,6 +77,39 @@ def test_layer_norm_linear(pkg, ctx, dtype, M, K, N, geglu):
     assert e < TOL[dtype]
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("B,Nq,Nk,C", [(2, 1024, 77, 1280), (1, 4096, 77, 640), (2, 64, 77, 128), (1, 128, 96, 64),
+                                        (3, 192, 5, 192), (2, 256, 33, 1280)])
+def test_ln_query_cross_attention(pkg, ctx, fused, B, Nq, Nk, C):
+    # attn2 up to its output projection (unet/mod.rs:731-795): LayerNorm -> query projection -> attention over the projected
+    # context, 64 channels per head.  fused=True is the production path of the f16 UNet: the projection's waves run the
+    # attention on their own accumulator tiles (128x128 tiles at 32^2, 256x128 at 64^2); fused=False = projection + kernel.
+    x = (seeded(B, Nq, C, seed=21) * 1.5 + 0.2).half().float()
+    gamma, beta = 1 + 0.1 * seeded(C, seed=5), 0.1 * seeded(C, seed=6)
+    wq = seeded(C, C, seed=22) / math.sqrt(C)
+    k, v = seeded(B, Nk, C, seed=23), seeded(B, Nk, C, seed=24)
+    k[0, 0] *= 3.0                                   # one dominant key: the softmax is not near-uniform
+    eps = 1e-5
+    q = OM.layer_norm(x, gamma, beta, eps) @ wq
+    ref = OM.qkv_attention(q, k, v, None, C // 64)
+    out = pkg.ln_query_cross_attention(ctx, x.cuda(), gamma.cuda(), beta.cuda(), wq.cuda(), k.cuda(), v.cuda(), eps, fused)
+    e = rel_err(out, ref)
+    print(f"ln_query_cross_attention fused={fused} B={B} Nq={Nq} Nk={Nk} C={C}: rel err {e:.3e}")
+    assert e < TOL[1]
+
+
+def test_ln_query_cross_attention_refuses_long_context(pkg, ctx):
+    # more than 96 keys do not fit the in-register softmax: the fused entry refuses, the two-kernel path takes it
+    B, Nq, Nk, C = 1, 64, 100, 64
+    x, k, v = seeded(B, Nq, C, seed=1), seeded(B, Nk, C, seed=2), seeded(B, Nk, C, seed=3)
+    g, b_, wq = torch.ones(C), torch.zeros(C), seeded(C, C, seed=4) / 8
+    with pytest.raises(RuntimeError):
+        pkg.ln_query_cross_attention(ctx, x.cuda(), g.cuda(), b_.cuda(), wq.cuda(), k.cuda(), v.cuda(), 1e-5, True)
+    out = pkg.ln_query_cross_attention(ctx, x.cuda(), g.cuda(), b_.cuda(), wq.cuda(), k.cuda(), v.cuda(), 1e-5, False)
+    ref = OM.qkv_attention(OM.layer_norm(x.half().float(), g, b_, 1e-5) @ wq, k, v, None, 1)
+    assert rel_err(out, ref) < TOL[1]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layer_norm_linear_large_mean(pkg, ctx, dtype):
     # rows with |mean| >> sigma (outlier channels of a real residual stream): a (sum, sum^2) variance loses every digit here
