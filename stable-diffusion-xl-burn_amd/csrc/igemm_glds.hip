@@ -1717,6 +1717,19 @@ size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max) {
   return (size_t)((rows + 255) / 256) * (size_t)((n_max + 127) / 128) * 3 * 256 * 128 * 4;
 }
 
+// Cost of a grid of bm x bn tiles over an M x N output with nk k-tiles (arbitrary units, ~ns).  A workgroup's k-loop time goes
+// with the bytes it stages per k-tile, (bm + bn) x 128 -- operand staging, not MFMA issue, bounds these kernels --
+// and that holds per CU: a single round costs a full tile time however few CUs it fills (128x128 over 2048 x 1280 = 160
+// workgroups takes as long per k-tile as 256 would).  Rounds after the first overlap with their predecessors' tails: a partly
+// filled last round costs its fill fraction, but never less than 2/3.  FIXED ~ 8 us of launch / prologue / epilogue per round.
+// w = 1.2 for the 8x1-wave 256x160 tile (6 fragment reads per 5 MFMAs), 1.05 for 256x320.
+static double tile_cost(int M, int N, int nk, int bm, int bn, double w) {
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  const long full = tiles / 256, rem = tiles % 256;
+  const double frac = rem == 0 ? 0.0 : (full == 0 ? 1.0 : (rem / 256.0 > 2.0 / 3.0 ? rem / 256.0 : 2.0 / 3.0));
+  return ((double)full + frac) * (bm + bn) * nk * w + (double)(full + (rem ? 1 : 0)) * 3000.0;
+}
+
 bool igemm_xattn_ok(int a_dt, int c_dt, int M, int N, int K, int rpb, int n_ctx) {
   return a_dt == DT_F16 && c_dt == DT_F16 && M > 0 && N % 64 == 0 && K % 64 == 0 && rpb > 0 && rpb % 64 == 0 && M % rpb == 0 &&
          n_ctx >= 1 && n_ctx <= 96;
@@ -1773,16 +1786,15 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
         !igemm_xattn_ok(p.a_dt, p.c_dt, p.M, p.N, p.K, p.rpb, p.xa_nctx))
       throw std::runtime_error("igemm: fused cross-attention needs a plain f16 projection (no residual / split outputs)");
     const int nk = p.Kpad / 64;
-    auto cost = [&](int bm) {
-      const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + 127) / 128);
-      const long full = tiles / 256, rem = tiles % 256;
-      const double frac = rem ? (rem / 256.0 > 2.0 / 3.0 ? rem / 256.0 : 2.0 / 3.0) : 0.0;
-      return ((double)full + frac) * (bm + 128) * nk + (double)(full + (rem ? 1 : 0)) * 3000.0;
-    };
-    int v = variant == 35 || variant == 36 || variant == 44 ? variant : (cost(256) <= cost(128) ? 35 : (nk >= 40 ? 44 : 36));
+    int v = variant;
+    if (v != 35 && v != 36 && v != 44 && v != 45) {
+      const double c256 = tile_cost(p.M, p.N, nk, 256, 128, 1.0), c128 = tile_cost(p.M, p.N, nk, 128, 128, 1.0), c96 = tile_cost(p.M, p.N, nk, 96, 128, 1.0);
+      v = c256 <= c128 && c256 <= c96 ? 35 : (c96 < c128 ? 45 : (nk >= 40 ? 44 : 36));
+    }
     if (v == 35) launch_pipe<256, 128, 3, false, 0, 4, 8, true, half_t, 0, true>(psk, s);
     else if (v == 36) launch_pipe<128, 128, 4, false, 0, 4, 8, true, half_t, 0, true>(psk, s);
-    else launch_pipe<128, 128, 5, false, 0, 4, 8, true, half_t, 0, true>(psk, s);
+    else if (v == 44) launch_pipe<128, 128, 5, false, 0, 4, 8, true, half_t, 0, true>(psk, s);
+    else launch_pipe<96, 128, 5, false, 0, 3, 6, true, half_t, 0, true>(psk, s);
     return true;
   }
   if (variant == 0 && igemm_splitk_slices(p) > 1) {
@@ -1793,29 +1805,25 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     return true;
   }
   if (variant == 0) {
-    // Tile choice by a two-term cost model fitted to the sweeps (profiles/r01_igemm_sweep.txt, r02_tile_sweep_256x160_256x320.txt).
-    // These GEMMs run against the chip's aggregate global->LDS rate (~9-10 TB/s whatever the tile), so a workgroup's k-loop
-    // time goes with the bytes it stages per k-tile, (BM + BN) x 128, and the grid costs whole ROUNDS of 256 CUs -- a last
-    // round that is only partly filled still costs >= 2/3 of a full one (fewer busy CUs stream faster, not proportionally):
-    //     cost = rounds_eff * (BM + BN) * k_tiles * w  +  ceil(rounds) * FIXED        FIXED ~ 8 us of launch/prologue/epilogue
-    // w = 1.2 for the 8x1-wave 256x160 tile (6 fragment reads per 5 MFMAs).  What the model buys: N = 320 / 1280 convs at
-    // 128^2 / 64^2 get 256x160 tiles = exactly one round (conv128 320: 95 -> 69 us, conv64 1280up: 353 -> 235 us) and the
-    // GEGLU projections the one-round 256x320 tile (lin64 geglu 88 -> 77 us, lin32 geglu 67 -> 63 us).
+    // Tile choice by a two-term cost model fitted to the sweeps (profiles/r01_igemm_sweep.txt, r02_tile_sweep_256x160_256x320.txt,
+    // r02_tile_96x128.txt) -- tile_cost() above.  What the model buys: N = 320 / 1280 convs at 128^2 / 64^2 get 256x160 tiles =
+    // exactly one round (conv128 320: 95 -> 69 us, conv64 1280up: 353 -> 235 us), the GEGLU projections the one-round 256x320 tile
+    // (lin64 geglu 88 -> 77 us, lin32 geglu 67 -> 63 us), and the M = 2048 x N = 1280 linears (attention out / query projections,
+    // FF-out: 240 launches per step) 96x128 tiles -- 220 workgroups that each stage 12.5 % fewer bytes than the 160 of 128x128
+    // (19 -> 17 us, 54 -> 47 us).
     const int nk = p.Kpad / 64;
     struct Cand { int v, bm, bn; double w; bool ok; };
     const bool lin = p.ksize == 1 && p.stride == 1 && p.up == 0;
-    const Cand cands[4] = {
+    const Cand cands[5] = {
         {35, 256, 128, 1.0, true},
         {36, 128, 128, 1.0, true},
+        {45, 96, 128, 1.0, true},
         {38, 256, 160, 1.2, p.N % 160 == 0 && !p.stat_out},
         {26, 256, 320, 1.05, p.act == 1 && lin && p.N % 320 == 0}};
     double best = 1e300;
     for (const Cand& c : cands) {
       if (!c.ok) continue;
-      const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
-      const long full = tiles / 256, rem = tiles % 256;
-      const double frac = rem ? (rem / 256.0 > 2.0 / 3.0 ? rem / 256.0 : 2.0 / 3.0) : 0.0;
-      const double cost = ((double)full + frac) * (c.bm + c.bn) * nk * c.w + (double)(full + (rem ? 1 : 0)) * 3000.0;
+      const double cost = tile_cost(p.M, p.N, nk, c.bm, c.bn, c.w);
       if (cost < best) { best = cost; variant = c.v; }
     }
     if (variant == 36 && nk >= 40) variant = 44;   // long contractions: the 5-slot ring (4 tiles in flight) is 3-6 % faster (profiles/r02_ring5_ab.txt)
@@ -1837,6 +1845,8 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
       if (p.N % 160 != 0) return false;
       launch_pipe<256, 160, 3, false, 0, 8, 8, true>(psk, s); break;
     case 44: launch_pipe<128, 128, 5, false, 0, 4, 8, true>(psk, s); break;   // 5-slot ring = all 160 KiB of LDS: 4 tiles in flight
+    case 45: launch_pipe<96, 128, 5, false, 0, 3, 6, true>(psk, s); break;    // 6 waves (3 x 2), 96-row tile: M = 2048 x N = 1280 -> 220 workgroups
+    case 46: launch_pipe<96, 128, 4, false, 0, 3, 6, true>(psk, s); break;
     case 26:                                                                // 256x320, k-tile 32: linear GEGLU projections only
       if (p.act != 1 || p.ksize != 1 || p.stride != 1 || p.up != 0 || p.N % 320 != 0 || p.Kpad % 32 != 0) return false;
       launch_wide(psk, s); break;
