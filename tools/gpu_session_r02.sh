@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 GPU-box session.  usage: tools/gpu_session_r02.sh <tag> [parts...]
-# parts: tests ptests bench bench16 cfg1 cfg4 cfg5 rocprof pmc sweep
+# parts: tests ptests optests bench bench16 cfg1 cfg4 cfg5 rocprof pmc traffic trace sweep custom
 set -u
 TAG=${1:-s}; shift || true
 PARTS=${*:-tests bench}
@@ -29,6 +29,10 @@ for p in $PARTS; do
         rm -rf /tmp/tr_$c; (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/tr_$c -o t -- python $GRAFT_REPO_ROOT/tools/profile_step.py > $GRAFT_REPO_ROOT/$OUT/traffic_$c.log 2>&1)
       done
       python tools/pmc_traffic.py $OUT/pmc_traffic.json $(find /tmp/tr_FETCH_SIZE -name '*counter_collection*' | head -1) $(find /tmp/tr_WRITE_SIZE -name '*counter_collection*' | head -1) 3;;   # 2 trajectory iterations + 1 profiled step
+    trace) # per-kernel durations of ONE replayed UNet step + kernel-to-kernel gaps (kernel trace only)
+      rm -rf /tmp/kt; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
+      f=$(find /tmp/kt -name '*kernel_trace*' | head -1)
+      python tools/trace_step_summary.py $f > $OUT/step_kernels.txt 2>&1; python tools/trace_gaps.py $f $OUT/trace_gaps.json > /dev/null 2>&1; head -20 $OUT/step_kernels.txt;;
     sweep) timeout 600 python tools/igemm_sweep.py ${SWEEP_VARIANTS:-0} > $OUT/igemm_sweep.txt 2>&1; tail -25 $OUT/igemm_sweep.txt;;
     custom) bash -c "${CUSTOM_CMD}" > $OUT/custom.log 2>&1; tail -40 $OUT/custom.log;;
   esac
