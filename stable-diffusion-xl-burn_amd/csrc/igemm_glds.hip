@@ -738,20 +738,14 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
 // column tile j ARE the B fragment of "k-step (j, qq)": element e <-> d = 32j + 16qq + 8(e>>2) + 4(lane>>5) + (e&3); the K
 // fragments are packed with the same map (xattn_pack_kernel, once per prompt), and likewise keys for P / V^T.  O^T comes out in the layout
 // the q tile came in, so the normal staged store follows unchanged.  No LDS, no cross-wave traffic, one launch less per block.
-template <int TM>
-__device__ __forceinline__ void xattn_inplace(const IgemmParams& p, f32x16 (&acc)[TM][2], int mw, int nw, int lane,
-                                              float (&lnA)[TM], float (&lnC)[TM], const void* zeros) {
-  if (nw >= p.N) return;                                              // zero-padded weight columns: nothing is stored
-  const int fr = lane & 31, fh = lane >> 5;
-  const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
-  const int nctx = p.xa_nctx;
+// K / V^T fragments in MFMA operand order (launch_xattn_pack): one coalesced 1-KiB load per fragment, shared through L1/L2 by
+// the waves of the same head.  Gathering them from the row-major caches cost 48 eight-byte loads with 32 different rows per
+// instruction -- 11 us per projection, as much as the attention kernel this fusion removes.
+__device__ __forceinline__ void xattn_load_frags(const IgemmParams& p, int mw, int nw, int lane, half8 (&kf)[3][4], half8 (&vf)[2][6]) {
   const int mclamp = mw < p.M ? mw : p.M - 1;
   const int b = __builtin_amdgcn_readfirstlane(mclamp / p.rpb);       // rpb % WM == 0: one batch entry per wave tile
-  // K / V^T fragments in MFMA operand order (launch_xattn_pack): one coalesced 1-KiB load per fragment, shared through L1/L2 by
-  // the waves of the same head.  Gathering them from the row-major caches cost 48 eight-byte loads with 32 different rows per
-  // instruction -- 11 us per projection, as much as the attention kernel this fusion removes.
-  const half8* fx = reinterpret_cast<const half8*>(p.xa_k) + ((size_t)b * (p.N >> 6) + (nw >> 6)) * (24 * 64) + lane;
-  half8 kf[3][4], vf[2][6];
+  const int head = (nw < p.N ? nw : 0) >> 6;                          // zero-padded weight columns: any valid head (never used)
+  const half8* fx = reinterpret_cast<const half8*>(p.xa_k) + ((size_t)b * (p.N >> 6) + head) * (24 * 64) + lane;
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -760,6 +754,15 @@ __device__ __forceinline__ void xattn_inplace(const IgemmParams& p, f32x16 (&acc
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int s6 = 0; s6 < 6; ++s6) vf[dt][s6] = fx[(12 + dt * 6 + s6) * 64];
+}
+template <int TM>
+__device__ __forceinline__ void xattn_inplace(const IgemmParams& p, f32x16 (&acc)[TM][2], int mw, int nw, int lane,
+                                              float (&lnA)[TM], float (&lnC)[TM], const void* zeros,
+                                              const half8 (&kf)[3][4], const half8 (&vf)[2][6]) {
+  if (nw >= p.N) return;                                              // zero-padded weight columns: nothing is stored
+  const int fr = lane & 31, fh = lane >> 5;
+  const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
+  const int nctx = p.xa_nctx;
   f32x4 cz[2][4], bz[2][4];                                          // folded-LayerNorm column sums, bias (beta W of the folded norm)
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -845,6 +848,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   static_assert(BM % (8 * NW) == 0 && WM % 32 == 0 && WN % 32 == 0 && BN % 8 == 0, "bad tile");
   constexpr int KT = 8 * CE;                  // elements per k-tile = one 128-byte row (64 f16 / 32 f32)
   constexpr int STAGE = (BM + BN) * 128;
+  constexpr bool LIN = XA;                    // linear-only instantiation: scalar-base DMA addressing, no tap walk
   // measurement-only modes (results wrong by construction): 5 = schedule of mode 0 WITHOUT ds_reads / MFMAs (DMA-only
   // ceiling), 6 = 5 with every DMA piece reading 1 KiB CONTIGUOUS (operands as if pre-tiled [rows/8][K/64][8][64]),
   // 7 = mode 0 (full compute) with the contiguous sources of 6
@@ -936,6 +940,30 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     }
   };
   retap();
+  // Linear layers (LIN; today = the fused cross-attention projections): scalar-base DMA addressing.  A row of the tile is a
+  // contiguous K-run, so piece q reads {wave-uniform 64-bit base in SGPRs} + {loop-invariant 32-bit lane offset}: the k-loop
+  // advances TWO scalar bases per k-tile (s_add_u32 / s_addc_u32) instead of PER 64-bit VGPR pointers (2 VALU each) and drops
+  // the tap walk.  Rows past M read row M - 1 (never stored).
+  unsigned long long abase = 0, wbase = 0;
+  unsigned aoff[AJ], woff[BJ];
+  if constexpr (LIN) {
+    abase = (unsigned long long)(uintptr_t)(Ag + (size_t)m0 * p.lda + (size_t)kbeg * KT);
+    wbase = (unsigned long long)(uintptr_t)(reinterpret_cast<const T*>(p.W) + (size_t)n0 * p.Kpad + (size_t)kbeg * KT);
+    abase = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(abase >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)abase);
+    wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(wbase >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)wbase);
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      int row = (j * NW + wave) * 8 + lrow;
+      const int sw = (slot ^ ((row >> 1) & 7)) * 16;
+      if (m0 + row >= p.M) row = p.M - 1 - m0;
+      aoff[j] = (unsigned)row * (unsigned)(p.lda * (int)sizeof(T)) + sw;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int row = (j * NW + wave) * 8 + lrow;
+      woff[j] = (unsigned)row * (unsigned)(p.Kpad * (int)sizeof(T)) + (slot ^ ((row >> 1) & 7)) * 16;
+    }
+  }
   // L2 prefetch: line L = wave * 64 + lane of the tile's BM activation rows then BN weight rows (one 128-byte line per k-tile)
   const T* pfp = reinterpret_cast<const T*>(zeros);
   int pfadv = 0;
@@ -967,7 +995,18 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       constexpr int HALF = (PER + 1) / 2;
       if constexpr (ph < 0 || (ph < 3 && q % 3 == ph) || (ph >= 10 && q / PPG == ph - 10) || (ph == 5 && q < HALF) ||
                     (ph == 6 && q >= HALF)) {
-        if constexpr (q < AJ) {
+        if constexpr (LIN) {
+          // saddr form: global_load_lds_dwordx4 voffset, sbase -- M0 = LDS byte address of this wave's 1-KiB piece
+          if constexpr (q < AJ) {
+            const unsigned m = lds0 + buf * STAGE + wave * 1024 + q * (NW * 1024), vo = aoff[q];
+            const unsigned long long sb = abase;      // (asm operands do not capture into the generic lambda by themselves)
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(vo), "s"(sb) : "memory");
+          } else if (q - AJ < BJ - 1 || lastb) {
+            const unsigned m = lds0 + buf * STAGE + BM * 128 + wave * 1024 + (q - AJ) * (NW * 1024), vo = woff[q - AJ];
+            const unsigned long long sb = wbase;
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(vo), "s"(sb) : "memory");
+          }
+        } else if constexpr (q < AJ) {
           __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(la + q * (NW * 1024)), 16, 0, 0);
           if constexpr (DMODE != 2) aptr[q] += aadv[q];
         } else if (q - AJ < BJ - 1 || lastb) {     // ragged weight tile: wave-uniform predicate on the last piece
@@ -979,6 +1018,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   };
   auto tile_done = [&]() {
     if constexpr (DMODE == 2 || CONTIG) return;
+    if constexpr (LIN) { abase += KT * sizeof(T); wbase += KT * sizeof(T); return; }
     s_c0 += KT;
     if (s_c0 == p.Cin) {
       s_c0 = 0;
@@ -1051,6 +1091,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   using I5 = std::integral_constant<int, 5>; using I6 = std::integral_constant<int, 6>;
   constexpr int NPRO = SCHED0 ? NS - 1 : NS;   // tiles staged by the prologue
 
+  // fused cross-attention, one-MFMA-row wave tiles: the 24 context fragments (96 VGPRs -- these kernels have the room) are
+  // requested BEFORE the first DMA piece, so they are the oldest entries of the in-order vmcnt queue and ride under the
+  // prologue's wait for tile 0 instead of adding a memory round trip to the epilogue
+  constexpr bool XA_EARLY = XA && TM == 1;
+  half8 xkf[XA ? 3 : 1][4], xvf[XA ? 2 : 1][6];
+  if constexpr (XA_EARLY) xattn_load_frags(p, m0 + wm * WM, n0 + wn * WN, lane, xkf, xvf);
   // ---- prologue: tiles 0 .. NPRO-1 in flight, wait for tile 0 only
 #pragma unroll
   for (int s = 0; s < NPRO; ++s)
@@ -1250,7 +1296,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   if constexpr (XA) {
     static_assert(TN == 2 && sizeof(T) == 2, "fused cross-attention: wave tile = one 64-wide head, f16");
     static_assert(NW * WM * WN * 4 <= NS * STAGE, "staging regions must fit the dead ring");
-    xattn_inplace<TM>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros);
+    if constexpr (!XA_EARLY) xattn_load_frags(p, m0 + wm * WM, n0 + wn * WN, lane, xkf, xvf);
+    xattn_inplace<TM>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros, xkf, xvf);
     IgemmParams pe = p;                       // bias and the LayerNorm affine went into q: the store adds nothing
     pe.bias = nullptr; pe.ln_stat = nullptr;
     igemm_epilogue_staged<TM, TN>(pe, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC, zeros);
