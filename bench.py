@@ -314,6 +314,9 @@ def main():
                          "are chip-filling MFMA work; off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--prompts-per-call", type=int, default=1, choices=[1, 2, 4],
+                    help="serving-shape extra (config 2 only): n independent prompts per sample_latent call = UNet batch 2n; "
+                         "the default 1 is BASELINE.json's batch-1 configuration")
     ap.add_argument("--unfused-xattn", action="store_true",
                     help="A/B: run the cross-attention as projection + attention kernel instead of inside the projection's epilogue")
     ap.add_argument("--split-cfg", action="store_true",
@@ -380,10 +383,14 @@ def main():
     iters = pkg.step_count(n_steps)
     r_iters = pkg.step_count(n_steps, 800) if args.config == 4 else 0
 
+    npc = args.prompts_per_call
+    if npc != 1 and args.config != 2:
+        raise SystemExit("--prompts-per-call > 1 is defined for --config 2 only")
+
     def make_prompt(seed):
         g = torch.Generator(device=dev).manual_seed(seed)
         r = lambda *s: torch.randn(*s, device=dev, generator=g)   # noqa: E731
-        kw = dict(context_full=r(1, 77, cfg.context_dim), channel_context=r(1, cfg.adm_in_channels),
+        kw = dict(context_full=r(npc, 77, cfg.context_dim), channel_context=r(npc, cfg.adm_in_channels),
                   unconditional_context_full=r(77, cfg.context_dim), unconditional_channel_context=r(cfg.adm_in_channels),
                   resolution=(res, res))
         if args.config == 4:
@@ -399,7 +406,7 @@ def main():
             m = torch.zeros(1, 4, lat, lat, dtype=torch.bool, device=dev)
             m[:, :, 0:200 // 8, :] = True          # README: crop rows 0..200 px -> latent rows 0..25 (sample/main.rs:164-169)
             extra["mask"] = m
-        return pkg.Conditioning(**kw), r(1, 4, lat, lat), extra
+        return pkg.Conditioning(**kw), r(npc, 4, lat, lat), extra
 
     # throughput pipelining (serving shape): latent_to_image of image i runs on a second HIP stream while the UNet steps of
     # image i+1 start on the sampling stream -- the f32 VAE is matrix-pipe bound, the batch-2 UNet step leaves CUs idle.
@@ -444,7 +451,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = max_over_ranks(time.perf_counter() - t0, dev)
     finite = bool(torch.isfinite(latent).all().item())
-    n_images = sum_over_ranks(float(args.steps), dev)
+    n_images = sum_over_ranks(float(args.steps * npc), dev)
 
     # decode leg on its own (outside the timed region): ms per latent_to_image at this resolution and VAE precision
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -454,7 +461,7 @@ def main():
         decoder.latent_to_image(latent)
     e1.record()
     torch.cuda.synchronize()
-    decode_ms = e0.elapsed_time(e1) / 3
+    decode_ms = e0.elapsed_time(e1) / 3 / npc      # per image
 
     sc = (res / 1024.0) ** 2
     # SURVEY section 8(d) gives exact counts at 1024^2 and 512^2 (attention is quadratic in the pixel count); other sizes scale by area
@@ -468,7 +475,7 @@ def main():
     value = n_images / elapsed
 
     # --- roofline of the dominant kernel, measured live with hipEvents on the timed configuration (B=2 CFG pair)
-    prof = diffuser.diffusion.profile(2, lat, lat)
+    prof = diffuser.diffusion.profile(2 * npc, lat, lat)
     ig_ms, ig_n, ig_fl = prof["igemm"]
     peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_F16_TFLOPS
     achieved = ig_fl / 1e12 / (ig_ms / 1e3) if ig_ms > 0 else 0.0
@@ -509,6 +516,8 @@ def main():
         p50 = statistics.median(step_ms) if step_ms else None
         wl = (f"SDXL-base {res}x{res}, n_steps={n_steps} ({iters} CFG UNet step pairs), CFG {cfg_scale}, batch 1 prompt/GPU + VAE decode "
               f"to u8 ({C['label']})")
+        if npc > 1:
+            wl = wl.replace("batch 1 prompt/GPU", f"{npc} independent prompts per call (UNet batch {2 * npc}) -- NOT BASELINE.json's batch-1 configuration")
         out = {
             "metric": "images/sec SDXL-base 1024x1024 30-step CFG7.5 (whole job); UNet step ms p50",
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -519,7 +528,7 @@ def main():
                        "weights": "synthetic seeded (random-init SDXL-base architecture)",
                        "parallelism": f"replica x{world}, 1 prompt per GPU, weights broadcast once over RCCL",
                        "hipgraph": not args.no_graph, "split_cfg": bool(args.split_cfg), "fused_xattn": not args.unfused_xattn,
-                       "pipelined_decode": bool(pipelined)},
+                       "pipelined_decode": bool(pipelined), "prompts_per_call": npc},
             "images_per_sec_per_gpu": round(value / world, 4),
             "unet_step_ms_p50": None if p50 is None else round(p50, 3),
             "vae_dtype": args.vae_dtype, "decode_ms": round(decode_ms, 2),
