@@ -389,6 +389,17 @@ impl<B: BurnBackend> Diffuser<B> {
         });
         bridge::download(&out, [b, c_in, h, w], &device)
     }
+    /// Engine options of this handle's UNet (no reference counterpart; results stay within the same tolerance class):
+    /// split-CFG = the CFG pair of `forward_diffuser` (`:523-537`) as two concurrent batch-1 chains; fused cross-attention
+    /// (default on) = `attn2` (`unet/mod.rs:731-795`) inside the query projection's epilogue.
+    pub fn set_split_cfg(&self, enabled: bool, release_offset: usize) {
+        let unet = unsafe { ffi::sdxl_diffuser_unet(self.raw) };
+        check(unsafe { ffi::sdxl_unet_set_split_cfg(unet, enabled as c_int, release_offset as c_int) });
+    }
+    pub fn set_fused_cross_attention(&self, enabled: bool) {
+        let unet = unsafe { ffi::sdxl_diffuser_unet(self.raw) };
+        check(unsafe { ffi::sdxl_unet_set_fused_cross_attention(unet, enabled as c_int) });
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ LatentDecoder
