@@ -130,6 +130,9 @@ int sdxl_unet_set_split_cfg(sdxl_unet* u, int enabled, int release_offset);
 /* per-handle option (default on, f16 engines): the transformer blocks' cross-attention (77 context keys; unet/mod.rs:731-795)
  * runs inside the epilogue of the query projection instead of as its own kernel.  Off = projection + attention kernel. */
 int sdxl_unet_set_fused_cross_attention(sdxl_unet* u, int enabled);
+/* per-handle option (default on, f16 engines): GroupNorm statistics come out of the producing convolution's epilogue where
+ * its kernel can leave them (256-row tiles: the 64^2 / 32^2 levels at 1024^2) -- groupnorm/mod.rs:52-82 without the statistics pass */
+int sdxl_unet_set_gn_from_producer(sdxl_unet* u, int enabled);
 
 /* ---- Backend::qkv_attention (src/backend.rs:4-19; generic body :88-128, LibTorch override :32-79)
  * q [B,Nq,n_head*d], k,v [B,Nk,n_head*d], mask additive [Nq,Nk] or NULL, out [B,Nq,n_head*d]; fp32 device tensors */
@@ -284,6 +287,14 @@ int sdxl_layer_norm_linear(sdxl_ctx* ctx, void* stream, const float* x, const fl
 int sdxl_ln_query_cross_attention(sdxl_ctx* ctx, void* stream, const float* x, const float* gamma, const float* beta, float eps,
                                   const float* wq, const float* k, const float* v, int B, int Nq, int Nk, int C, int fused,
                                   float* out);
+
+/* conv3x3 (pad 1, optional residual) -> GroupNorm (+SiLU): the conv -> norm pairs of ResBlock::forward (src/model/unet/mod.rs:
+ * 1082-1106) and of the SpatialTransformer entry (:820-845), f16 engine arithmetic.  x [B,Cin,H,W], weight [Cout,Cin,3,3],
+ * residual / out [B,Cout,H,W]; fp32 device tensors.  fused != 0: the convolution's epilogue leaves the GroupNorm statistics
+ * (no statistics pass); *fused_taken (may be NULL) reports whether the selected kernel could (256-row tiles, 64-column waves). */
+int sdxl_conv2d_group_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* weight, const float* bias, const float* residual,
+                           const float* gamma, const float* beta, float eps, int B, int Cin, int H, int W, int Cout, int n_group,
+                           int silu, int fused, int* fused_taken, float* out);
 
 #ifdef __cplusplus
 }

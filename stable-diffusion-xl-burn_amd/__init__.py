@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "sdxl_last_error", "sdxl_build_info", "sdxl_ctx_create", "sdxl_ctx_destroy", "sdxl_ctx_synchronize",
     "sdxl_unet_config_base", "sdxl_unet_config_refiner", "sdxl_vae_config_default",
     "sdxl_unet_param_count", "sdxl_unet_param_spec", "sdxl_vae_param_count", "sdxl_vae_param_spec",
-    "sdxl_unet_create", "sdxl_unet_create_synthetic", "sdxl_unet_destroy", "sdxl_unet_forward", "sdxl_unet_set_graph", "sdxl_unet_set_split_cfg", "sdxl_unet_set_fused_cross_attention",
+    "sdxl_unet_create", "sdxl_unet_create_synthetic", "sdxl_unet_destroy", "sdxl_unet_forward", "sdxl_unet_set_graph", "sdxl_unet_set_split_cfg", "sdxl_unet_set_fused_cross_attention", "sdxl_unet_set_gn_from_producer",
     "sdxl_qkv_attention", "sdxl_attn_decoder_mask",
     "sdxl_diffuser_create", "sdxl_diffuser_create_synthetic", "sdxl_diffuser_destroy", "sdxl_diffuser_unet",
     "sdxl_sample_latent", "sdxl_sample_latent_with_inpainting", "sdxl_refine_latent", "sdxl_step_count",
@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "sdxl_latent_to_image", "sdxl_vae_encode_image", "sdxl_image_to_latent",
     "sdxl_unet_weight_arena", "sdxl_vae_weight_arena", "sdxl_diffuser_create_empty", "sdxl_vae_create_empty",
     "sdxl_unet_profile", "sdxl_bench_igemm", "sdxl_bench_attention", "sdxl_debug_set",
-    "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear", "sdxl_layer_norm_linear", "sdxl_ln_query_cross_attention",
+    "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear", "sdxl_layer_norm_linear", "sdxl_ln_query_cross_attention", "sdxl_conv2d_group_norm",
     "sdxl_clip_config_clip_l", "sdxl_clip_config_open_clip_bigg", "sdxl_clip_param_count", "sdxl_clip_param_spec",
     "sdxl_clip_create", "sdxl_clip_create_synthetic", "sdxl_clip_destroy", "sdxl_clip_forward_hidden",
     "sdxl_clip_forward_hidden_pooled", "sdxl_conditioning_embedding", "sdxl_clip_weight_arena",
@@ -345,6 +345,10 @@ class UNet:
     def set_fused_cross_attention(self, enabled: bool):
         """per-handle (default on): cross-attention inside the query projection's epilogue"""
         _check(lib().sdxl_unet_set_fused_cross_attention(self.h, int(enabled)))
+
+    def set_gn_from_producer(self, enabled: bool):
+        """per-handle (default on): GroupNorm statistics from the producing convolution's epilogue where its kernel can"""
+        _check(lib().sdxl_unet_set_gn_from_producer(self.h, int(enabled)))
 
     def set_graph(self, enabled: bool):
         _check(lib().sdxl_unet_set_graph(self.h, int(enabled)))
@@ -860,6 +864,30 @@ def ln_query_cross_attention(ctx: Context, x, gamma, beta, wq, k, v, eps: float 
     _check(lib().sdxl_ln_query_cross_attention(ctx.h, _stream(), px, pg, pbeta, ctypes.c_float(eps), pw, pk, pv, int(B), int(Nq),
                                               Nk, int(C), int(fused), ctypes.c_void_p(out.data_ptr())))
     return out
+
+
+def conv2d_group_norm(ctx: Context, x, weight, bias, gamma, beta, eps: float = 1e-5, n_group: int = 32, silu: bool = True,
+                      residual=None, fused: bool = True):
+    """conv3x3 (pad 1, + residual) -> GroupNorm (+SiLU) as ResBlock::forward pairs them (unet/mod.rs:1082-1106), f16 engine.
+    fused=True asks the convolution's epilogue for the GroupNorm statistics.  Returns (out, fused_taken)."""
+    torch = _torch()
+    x, px = _dev(x)
+    weight, pw = _dev(weight)
+    gamma, pg = _dev(gamma)
+    beta, pbeta = _dev(beta)
+    pb = pr = None
+    if bias is not None:
+        bias, pb = _dev(bias)
+    if residual is not None:
+        residual, pr = _dev(residual)
+    B, Cin, H, W = x.shape
+    Cout = int(weight.shape[0])
+    out = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
+    took = ctypes.c_int(0)
+    _check(lib().sdxl_conv2d_group_norm(ctx.h, _stream(), px, pw, pb, pr, pg, pbeta, ctypes.c_float(eps), int(B), int(Cin), int(H),
+                                       int(W), Cout, int(n_group), int(silu), int(fused), ctypes.byref(took),
+                                       ctypes.c_void_p(out.data_ptr())))
+    return out, bool(took.value)
 
 
 # ---------------------------------------------------------------------------------------------------------------- multi-GPU

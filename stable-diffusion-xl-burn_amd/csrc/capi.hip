@@ -380,6 +380,12 @@ int sdxl_unet_set_fused_cross_attention(sdxl_unet* u, int enabled) {
   u->u->set_fused_cross_attention(enabled != 0);
   API_END
 }
+int sdxl_unet_set_gn_from_producer(sdxl_unet* u, int enabled) {
+  API_BEGIN
+  SDXL_REQUIRE(u != nullptr, "bad argument");
+  u->u->set_gn_from_producer(enabled != 0);
+  API_END
+}
 int sdxl_unet_weight_arena(sdxl_unet* u, void** base, size_t* bytes) {
   API_BEGIN
   SDXL_REQUIRE(u && base && bytes, "null argument");
@@ -1021,6 +1027,52 @@ int sdxl_ln_query_cross_attention(sdxl_ctx* ctx, void* stream, const float* x, c
     launch_attention_d64(p, s);
   }
   launch_copy_rows(od, DT_F16, C, out, DT_F32, C, M, C, s);
+  SDXL_HIP(hipStreamSynchronize(s));
+  API_END
+}
+
+int sdxl_conv2d_group_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* weight, const float* bias, const float* residual,
+                           const float* gamma, const float* beta, float eps, int B, int Cin, int H, int W, int Cout, int n_group,
+                           int silu, int fused, int* fused_taken, float* out) {
+  // conv3x3 (pad 1, + optional residual) followed by GroupNorm(+SiLU) -- the conv -> norm pairs of ResBlock::forward
+  // (unet/mod.rs:1082-1106) and of the SpatialTransformer entry (:820-845) on the f16 engine.  fused != 0 asks the convolution's
+  // epilogue for the GroupNorm statistics (no statistics pass); *fused_taken reports whether the selected kernel provided them.
+  API_BEGIN
+  SDXL_REQUIRE(ctx && x && weight && gamma && beta && out, "null argument");
+  SDXL_REQUIRE(n_group > 0 && Cout % n_group == 0, "The number of channels must be divisible by the number of groups");
+  SDXL_REQUIRE(Cout % 8 == 0 && n_group <= 256, "unsupported GroupNorm shape");
+  use(ctx);
+  hipStream_t s = pick(ctx, stream);
+  const int cdt = DT_F16, HW = H * W;
+  Lin l; l.N = Cout; l.cin = Cin; l.ksize = 3; l.K = Cin * 9;
+  l.Kpad = (int)round_up(l.K, 64); l.Npad = (int)round_up(Cout, 128);
+  Tmp tmp;
+  void* wp = tmp.get((size_t)l.Npad * l.Kpad * 2);
+  float* bp = (float*)tmp.get((size_t)l.Npad * sizeof(float));
+  void* xi = tmp.get((size_t)B * HW * Cin * 2);
+  void* hh = tmp.get((size_t)B * HW * Cout * 2);
+  void* yo = tmp.get((size_t)B * HW * Cout * 2);
+  void* ri = residual ? tmp.get((size_t)B * HW * Cout * 2) : nullptr;
+  float* part = (float*)tmp.get(groupnorm_workspace_floats(B, n_group) * sizeof(float));
+  float* eps_d = (float*)tmp.get(sizeof(float));
+  launch_pack_conv(weight, wp, cdt, Cout, Cin, 3, l.Kpad, l.Npad, s);
+  launch_pack_bias(bias, bp, Cout, l.Npad, 0, 0, s);
+  l.w = wp; l.b = bp;
+  launch_nchw_to_nhwc(x, Cin * HW, xi, cdt, B, Cin, HW, Cin, 1.0f, s);
+  if (residual) launch_nchw_to_nhwc(residual, Cout * HW, ri, cdt, B, Cout, HW, Cout, 1.0f, s);
+  SDXL_HIP(hipMemcpyAsync(eps_d, &eps, sizeof(float), hipMemcpyHostToDevice, s));
+  Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = cdt; ex.gn_partial = part;
+  give_splitk_ws(ex, tmp, B, HW, Cout, s);
+  Act h(hh, Cout, cdt);
+  Epi e;
+  if (residual) e.R = Act(ri, Cout, cdt);
+  if (fused && HW % 256 == 0) e.gn_part = (float*)tmp.get((size_t)B * HW / 256 * Cout * 2 * sizeof(float));
+  const bool took = run_conv(ex, l, Act(xi, Cin, cdt), Cin, ConvGeom{B, H, W, H, W, 3, 1, 1, 0}, h, e);
+  if (took) { h.gn_part = e.gn_part; h.gn_rt = HW / 256; }
+  if (fused_taken) *fused_taken = took ? 1 : 0;
+  NormW n; n.gamma = gamma; n.beta = beta; n.eps = eps_d; n.C = Cout;
+  run_groupnorm(ex, n, h, B, HW, Act(yo, Cout, cdt), silu != 0, n_group);
+  launch_nhwc_to_nchw(yo, cdt, Cout, out, B, Cout, HW, 1.0f, s);
   SDXL_HIP(hipStreamSynchronize(s));
   API_END
 }

@@ -149,9 +149,12 @@ struct WeightBuilder {
 // activation view: rows of `ld` elements
 struct Act {
   void* p = nullptr; int ld = 0; int dt = DT_F16;
+  // GroupNorm statistics of this tensor left behind by the GEMM that produced it (Epi::gn_part -> IgemmParams::gn_part):
+  // [B][gn_rt][C] (mean, M2) per 256-row tile and channel.  A GroupNorm over exactly this tensor skips its statistics pass.
+  const float* gn_part = nullptr; int gn_rt = 0;
   Act() {}
   Act(void* p_, int ld_, int dt_) : p(p_), ld(ld_), dt(dt_) {}
-  Act cols(int c0) const { return Act((char*)p + (size_t)c0 * dt_size(dt), ld, dt); }
+  Act cols(int c0) const { return Act((char*)p + (size_t)c0 * dt_size(dt), ld, dt); }   // (a column slice drops the statistics)
 };
 
 // per-kernel-class hipEvent profiler (eager runs only): live measurement of the dominant kernel for bench.py's roofline
@@ -195,9 +198,12 @@ struct Epi {
   int rpb = 0;       // rows per batch for ebias / transposed store (0 -> Hout*Wout)
   // cross-attention fused into the projection's epilogue (IgemmParams::xa_*): packed context of this run's batch entries
   const void* xa_k = nullptr; int xa_nctx = 0; float xa_scale = 0.f;   // xa_k: operand-order image (launch_xattn_pack)
+  // room for the GroupNorm statistics of the output ([M/256][N] float pairs); run_conv reports whether the kernel it picked
+  // filled it (igemm_gn_part_ok), the caller then tags the output Act
+  float* gn_part = nullptr;
 };
-void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());
-void run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());
+bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());   // true: e.gn_part was filled
+bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());
 void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups = 32);
 void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y);
 
@@ -230,6 +236,7 @@ class UNet {
   // streams, the second released after `release_offset` GEMM launches of the first; bit-identical results
   void set_split_cfg(bool on, int release_offset) { split_cfg_ = on; split_offset_ = release_offset; }
   void set_fused_cross_attention(bool on) { fuse_xattn_ = on; }
+  void set_gn_from_producer(bool on) { gn_from_producer_ = on; }   // call before the first forward / after set_use_graph(false)
   // one eager forward of the current plan/context with hipEvents around every launch, summed per kernel class
   void profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[Profiler::NCLS], double flops[Profiler::NCLS],
                hipStream_t s);
@@ -240,7 +247,7 @@ class UNet {
   void build_weights(WeightSource& src, hipStream_t st);
   void ensure_plan(int B, int H, int W);
   void run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb);
-  void res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, int H, int W, const Act& out);
+  const float* res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, int H, int W, const Act& out, float* out_gn_part = nullptr);
   void spatial_transformer(Exec& ex, const STW& w, int st_index, const Act& x, int B, int H, int W);
 
   UNetCfg cfg_;
@@ -272,6 +279,7 @@ class UNet {
   bool split_cfg_ = false; int split_offset_ = 0;
   bool plan_split_ = false; int graph_off_ = 0;
   bool fuse_xattn_ = true, plan_xattn_ = true;   // cross-attention inside the query projection's epilogue (f16 engines)
+  bool gn_from_producer_ = true;         // GroupNorm statistics from the producing convolution's epilogue where its kernel can (f16)
   hipStream_t s2_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena act2_;
   hipGraphExec_t graph_ = nullptr;

@@ -243,10 +243,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
 // chunks XOR-swizzled by row&7, transposed for the V^T part -- then re-reads it row-contiguously: 8 (or 4) lanes cover
 // one output row segment, add the residual with 16-byte loads and store whole 128-byte (64-byte) line segments.
 // `lds` = this wave's private region of WM*WN*4 bytes (the k-loop ring, dead by now; callers barrier first).
+// block context of the GroupNorm-statistics epilogue (IgemmParams::gn_part): 4 KiB of LDS scratch past the staging regions,
+// the wave's place in the 4 x 2 wave grid and the tile origin
+struct GnCtx { char* scratch; int wave, wm, wn, m0, n0; };
 template <int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw,
                                                            int lane, char* lds, bool transposed, const float (&lnA)[TM],
-                                                           const float (&lnC)[TM], const void* zeros) {
+                                                           const float (&lnC)[TM], const void* zeros, const GnCtx* gc = nullptr) {
   constexpr int WM = TM * 32, WN = TN * 32;
   constexpr int ROWS = WM;                         // staged rows: m (normal) -- for the transposed part rows = n, cols = m
   constexpr int COLS = GEGLU ? WN / 2 : WN;
@@ -349,6 +352,13 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
     constexpr int NIT = (ITEMS + 63) / 64;
     half8 rpre[NIT];
     bool rfast[NIT];
+    // GroupNorm statistics of the stored tile (gn_part): a lane keeps the same 8 columns over the NIT row groups, so the column
+    // sums over the wave's 64 rows are 8 per-lane accumulators + one 3-step xor reduction; shifted by the tile's first row
+    constexpr bool GNP = TM == 2 && TN == 2 && !GEGLU;
+    const bool gnp = GNP && gc != nullptr && p.gn_part != nullptr;
+    float gpiv[8], gs1[8], gs2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gpiv[e] = 0.f; gs1[e] = 0.f; gs2[e] = 0.f; }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = it * 64 + lane;
@@ -399,7 +409,7 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
           }
         }
       }
-      if (p.stat_out) {
+      if (p.stat_out || gnp) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) rr[e] = p.c_dt == DT_F16 ? (float)(half_t)v[e] : v[e];
       }
@@ -425,6 +435,16 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
         }
       }
       }   // valid
+      if constexpr (GNP) {
+        if (gnp) {   // whole tiles only (M % 256 == 0, N % 64 == 0): every item is valid
+          if (it == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gpiv[e] = __shfl(rr[e], lane & 7);     // row 0 of the wave tile, this lane's columns
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = rr[e] - gpiv[e]; gs1[e] += d; gs2[e] = fmaf(d, d, gs2[e]); }
+        }
+      }
       if constexpr (COLS % 64 == 0) {
         if (p.stat_out) {
           // 8 consecutive lanes hold one 64-column slot of a row.  Shifted sums around a pivot inside the data (the slot's
@@ -440,6 +460,42 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
             float* dst = p.stat_out + ((size_t)(n0 >> 6) * p.M + m) * 2;
             dst[0] = piv + s1 * (1.0f / 64.0f);
             dst[1] = fmaxf(s2 - s1 * s1 * (1.0f / 64.0f), 0.f);
+          }
+        }
+      }
+    }
+    if constexpr (GNP) {
+      if (gnp) {
+        // lanes with the same piece (lane & 7) hold the same 8 columns: sum over the 8 row sub-lanes -> 64-row column sums
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) { gs1[e] += __shfl_xor(gs1[e], o); gs2[e] += __shfl_xor(gs2[e], o); }
+        }
+        float* sc = reinterpret_cast<float*>(gc->scratch);
+        if (lane < 8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dm = gs1[e] * (1.0f / 64.0f);
+            sc[(gc->wave * 64 + lane * 8 + e) * 2] = gpiv[e] + dm;                      // mean of the wave's 64 rows
+            sc[(gc->wave * 64 + lane * 8 + e) * 2 + 1] = fmaxf(gs2[e] - gs1[e] * dm, 0.f);   // M2
+          }
+        }
+        __syncthreads();
+        // the 4 row-waves of a column half merge (equal counts, Chan): wave (wm = 0, wn) writes the tile's 256-row statistics
+        if (gc->wm == 0) {
+          const int col = gc->n0 + gc->wn * 64 + lane;
+          float mk[4], qk[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { mk[k] = sc[((k * 2 + gc->wn) * 64 + lane) * 2]; qk[k] = sc[((k * 2 + gc->wn) * 64 + lane) * 2 + 1]; }
+          const float mu = ((mk[0] + mk[1]) + (mk[2] + mk[3])) * 0.25f;
+          float m2 = (qk[0] + qk[1]) + (qk[2] + qk[3]), sd = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const float d = mk[k] - mu; sd = fmaf(d, d, sd); }
+          m2 += 64.0f * sd;
+          if (col < p.N) {
+            float* dst = p.gn_part + ((size_t)(gc->m0 >> 8) * p.N + col) * 2;
+            dst[0] = mu; dst[1] = m2;
           }
         }
       }
@@ -499,12 +555,12 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
 template <int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw,
                                                       int lane, char* lds, const float (&lnA)[TM], const float (&lnC)[TM],
-                                                      const void* zeros) {
+                                                      const void* zeros, const GnCtx* gc = nullptr) {
   constexpr int WN = TN * 32;
   if (p.act == 1) { igemm_epilogue_staged_impl<TM, TN, true>(p, acc, mw, nw, lane, lds, false, lnA, lnC, zeros); return; }
   const bool all_normal = nw + WN <= p.n_split || p.n_split >= p.N;
   const bool all_transposed = nw >= p.n_split;
-  if (all_normal) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, false, lnA, lnC, zeros);
+  if (all_normal) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, false, lnA, lnC, zeros, gc);
   else if (all_transposed) igemm_epilogue_staged_impl<TM, TN, false>(p, acc, mw, nw, lane, lds, true, lnA, lnC, zeros);
   else igemm_epilogue<TM, TN>(p, acc, mw, nw, lane & 31, lane >> 5, lnA, lnC);
 }
@@ -1306,6 +1362,11 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   constexpr bool FITS = NW * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
   if (FITS || p.act == 1) {
     const int region = p.act == 1 ? WM * (WN / 2) * 4 : WM * WN * 4;   // GEGLU halves the staged width
+    if constexpr (BM == 256 && BN == 128 && NW == 8 && WGM == 4 && sizeof(T) == 2) {
+      static_assert(NW * WM * WN * 4 + 4096 <= NS * STAGE, "GroupNorm-statistics scratch must fit behind the staging regions");
+      const GnCtx gc{smem + NW * WM * WN * 4, wave, wm, wn, m0, n0};
+      igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * region, lnA, lnC, zeros, &gc);
+    } else
     igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * region, lnA, lnC, zeros);
   } else {
     igemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, fr, fh, lnA, lnC);
@@ -1777,6 +1838,43 @@ static double tile_cost(int M, int N, int nk, int bm, int bn, double w) {
   return ((double)full + frac) * (bm + bn) * nk * w + (double)(full + (rem ? 1 : 0)) * 3000.0;
 }
 
+// Tile choice by a two-term cost model fitted to the sweeps (profiles/r01_igemm_sweep.txt, r02_tile_sweep_256x160_256x320.txt,
+// r02_tile_96x128.txt) -- tile_cost() above.  What the model buys: N = 320 / 1280 convs at 128^2 / 64^2 get 256x160 tiles =
+// exactly one round (conv128 320: 95 -> 69 us, conv64 1280up: 353 -> 235 us), the GEGLU projections the one-round 256x320 tile
+// (lin64 geglu 88 -> 77 us, lin32 geglu 67 -> 63 us), and the M = 2048 x N = 1280 linears (attention out / query projections,
+// FF-out: 240 launches per step) 96x128 tiles -- 220 workgroups that each stage 12.5 % fewer bytes than the 160 of 128x128
+// (19 -> 17 us, 54 -> 47 us).  Returns the production variant id (35, 36 / 44, 45, 38, 26).
+static int pick_tile(const IgemmParams& p) {
+  const int nk = p.Kpad / 64;
+  struct Cand { int v, bm, bn; double w; bool ok; };
+  const bool lin = p.ksize == 1 && p.stride == 1 && p.up == 0;
+  const Cand cands[5] = {
+      {35, 256, 128, 1.0, true},
+      {36, 128, 128, 1.0, true},
+      {45, 96, 128, 1.0, true},
+      {38, 256, 160, 1.2, p.N % 160 == 0 && !p.stat_out},
+      {26, 256, 320, 1.05, p.act == 1 && lin && p.N % 320 == 0}};
+  double best = 1e300;
+  int variant = 35;
+  for (const Cand& c : cands) {
+    if (!c.ok) continue;
+    const double cost = tile_cost(p.M, p.N, nk, c.bm, c.bn, c.w);
+    if (cost < best) { best = cost; variant = c.v; }
+  }
+  if (variant == 36 && nk >= 40) variant = 44;   // long contractions: the 5-slot ring (4 tiles in flight) is 3-6 % faster (profiles/r02_ring5_ab.txt)
+  return variant;
+}
+
+// GroupNorm statistics from the producing GEMM's epilogue (IgemmParams::gn_part): taken by the 256x128 kernel (plain or split-K)
+// when that is the tile the selection picks anyway, whole 256-row tiles inside one batch entry, f16 operands, plain epilogue.
+bool igemm_gn_part_ok(const IgemmParams& p) {
+  if (p.a_dt != DT_F16 || p.c_dt != DT_F16 || (p.Cin % 64) != 0 || (p.lda % 8) != 0 || (p.Kpad % 64) != 0) return false;
+  if (p.act != 0 || p.n_split < p.N || p.stat_out || p.ln_stat || p.xa_k) return false;
+  if (p.M % 256 != 0 || p.rpb <= 0 || p.rpb % 256 != 0 || p.N % 64 != 0) return false;
+  if (p.ebias && (p.ebias_ld & 3) != 0) return false;
+  return igemm_splitk_slices(p) > 1 || pick_tile(p) == 35;
+}
+
 bool igemm_xattn_ok(int a_dt, int c_dt, int M, int N, int K, int rpb, int n_ctx) {
   return a_dt == DT_F16 && c_dt == DT_F16 && M > 0 && N % 64 == 0 && K % 64 == 0 && rpb > 0 && rpb % 64 == 0 && M % rpb == 0 &&
          n_ctx >= 1 && n_ctx <= 96;
@@ -1844,6 +1942,10 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     else launch_pipe<96, 128, 5, false, 0, 3, 6, true, half_t, 0, true>(psk, s);
     return true;
   }
+  if (p.gn_part) {
+    if (!igemm_gn_part_ok(p)) throw std::runtime_error("igemm: GroupNorm statistics requested from a shape the 256x128 epilogue does not take");
+    variant = 0;            // (a forced test variant must not drop the statistics)
+  }
   if (variant == 0 && igemm_splitk_slices(p) > 1) {
     // long contractions over a small output (FF-out and the 32^2 convs of the CFG pair: M = 2048, N = 1280 is 80 tiles of
     // 256x128 on 256 CUs): three k-slices per tile fill the chip with the tile shape that moves the fewest bytes per flop
@@ -1851,30 +1953,7 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     launch_pipe<256, 128, 3, false, 0, 4, 8, true>(psk, s);
     return true;
   }
-  if (variant == 0) {
-    // Tile choice by a two-term cost model fitted to the sweeps (profiles/r01_igemm_sweep.txt, r02_tile_sweep_256x160_256x320.txt,
-    // r02_tile_96x128.txt) -- tile_cost() above.  What the model buys: N = 320 / 1280 convs at 128^2 / 64^2 get 256x160 tiles =
-    // exactly one round (conv128 320: 95 -> 69 us, conv64 1280up: 353 -> 235 us), the GEGLU projections the one-round 256x320 tile
-    // (lin64 geglu 88 -> 77 us, lin32 geglu 67 -> 63 us), and the M = 2048 x N = 1280 linears (attention out / query projections,
-    // FF-out: 240 launches per step) 96x128 tiles -- 220 workgroups that each stage 12.5 % fewer bytes than the 160 of 128x128
-    // (19 -> 17 us, 54 -> 47 us).
-    const int nk = p.Kpad / 64;
-    struct Cand { int v, bm, bn; double w; bool ok; };
-    const bool lin = p.ksize == 1 && p.stride == 1 && p.up == 0;
-    const Cand cands[5] = {
-        {35, 256, 128, 1.0, true},
-        {36, 128, 128, 1.0, true},
-        {45, 96, 128, 1.0, true},
-        {38, 256, 160, 1.2, p.N % 160 == 0 && !p.stat_out},
-        {26, 256, 320, 1.05, p.act == 1 && lin && p.N % 320 == 0}};
-    double best = 1e300;
-    for (const Cand& c : cands) {
-      if (!c.ok) continue;
-      const double cost = tile_cost(p.M, p.N, nk, c.bm, c.bn, c.w);
-      if (cost < best) { best = cost; variant = c.v; }
-    }
-    if (variant == 36 && nk >= 40) variant = 44;   // long contractions: the 5-slot ring (4 tiles in flight) is 3-6 % faster (profiles/r02_ring5_ab.txt)
-  }
+  if (variant == 0) variant = p.gn_part ? 35 : pick_tile(p);
 #ifdef SDXL_MEASURE
   if (was_auto && !g_igemm_unrolled) {   // A/B against the rolled loops (profiles/r01_igemm_unrolled_ab.txt)
     if (variant == 35) variant = 11; else if (variant == 36) variant = 13; else if (variant == 38) variant = 19;

@@ -52,7 +52,11 @@ struct IgemmParams {
   // softmax(q K_h^T * xa_scale) V_h per 64-column head before the store (igemm_glds.hip xattn_inplace).  xa_k = the context
   // keys / values of the batch entries in MFMA operand order (launch_xattn_pack); batch entry of a row = m / rpb.
   const void* xa_k; int xa_nctx; float xa_scale;
+  // GroupNorm statistics of the stored output, from the epilogue (256x128 kernel; igemm_gn_part_ok): gn_part[M/256][N] (mean, M2)
+  // of every column over the 256 rows of a tile -- the consumer's GroupNorm merges row tiles and channels (norm.hip, chan_part)
+  float* gn_part;
 };
+bool igemm_gn_part_ok(const IgemmParams& p);
 // shapes the fused cross-attention epilogue takes (f16 operands, head dim 64, <= 96 context tokens); otherwise run the
 // projection and the attention kernel separately
 bool igemm_xattn_ok(int a_dt, int c_dt, int M, int N, int K, int rpb, int n_ctx);
@@ -79,6 +83,9 @@ struct GroupNormParams {
   const float* eps_ptr; // optional device scalar overriding eps (per-norm eps stored with the weights)
   int silu;            // fuse x*sigmoid(x) after the affine
   int nsplit;          // filled by the launcher helper
+  // statistics left by the PRODUCER of X (IgemmParams::gn_part): chan_part[B][chan_rt][C] (mean, M2) over chan_rows rows each;
+  // when set, no statistics kernel runs -- the apply kernel merges row tiles and channels in its prologue
+  const float* chan_part; int chan_rt; int chan_rows;
 };
 int  groupnorm_nsplit(int B, int HW, int C);
 // workspace of launch_groupnorm for B batch entries (a run over entries [b0, b0+nb) of a larger plan may use the slice at

@@ -7,6 +7,7 @@
 // statistics kernel runs per-channel Welford updates and merges partial (count, mean, M2) triples with Chan's
 // formula (row lanes -> channels -> groups -> row splits), never E[x^2]-E[x]^2.
 #include "kernels.h"
+#include <stdexcept>
 
 namespace sdxl {
 
@@ -194,19 +195,39 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GroupNormParams 
 // threads) instead of a separate finalize launch -- one kernel boundary and a 4.7 us launch less per GroupNorm; every apply
 // block redoes the 12 KB merge, which the 256 CUs do in parallel.  Needs a power-of-two G <= 256; other group counts keep
 // the finalize kernel.
-template <typename XT, typename YT, bool FIN>
+template <typename XT, typename YT, int FIN>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, const float* stat_in, int rows_per_block) {
   const int C = p.C, NV = C >> 3;
   const int VPR = NV < 256 ? NV : 256;
   const int RL = 256 / VPR;
   const int tid = threadIdx.x, b = blockIdx.y;
   __shared__ float sstat[512];
-  if constexpr (FIN) {
+  if constexpr (FIN != 0) {
     const int tpg = 256 / p.G;                       // threads per group (power of two)
     const int g = tid / tpg, sub = tid - g * tpg;
-    const float* part = p.partial + ((size_t)b * p.G + g) * p.nsplit * 3;
     float na = 0.f, ma = 0.f, qa = 0.f;
-    for (int s = sub; s < p.nsplit; s += tpg) chan_merge(na, ma, qa, part[s * 3], part[s * 3 + 1], part[s * 3 + 2]);
+    if constexpr (FIN == 1) {
+      const float* part = p.partial + ((size_t)b * p.G + g) * p.nsplit * 3;
+      for (int s = sub; s < p.nsplit; s += tpg) chan_merge(na, ma, qa, part[s * 3], part[s * 3 + 1], part[s * 3 + 2]);
+    } else {
+      // FIN == 2: the statistics were left by the PRODUCER of x (implicit-GEMM epilogue, IgemmParams::gn_part): per 256-row tile
+      // and channel a (mean, M2) pair.  A group's entries are chan_rt row tiles x C/G channels; four loads in flight per thread.
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const int cpg_ = C / p.G, total = p.chan_rt * cpg_;
+      const f32x2* cp = reinterpret_cast<const f32x2*>(p.chan_part) + (size_t)b * p.chan_rt * C + g * cpg_;
+      const float cnt = (float)p.chan_rows;
+      for (int e0 = sub; e0 < total; e0 += 4 * tpg) {
+        f32x2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * tpg;
+          const int rt = e / cpg_, cc = e - rt * cpg_;
+          v[u] = e < total ? cp[(size_t)rt * C + cc] : f32x2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) chan_merge(na, ma, qa, e0 + u * tpg < total ? cnt : 0.f, v[u][0], v[u][1]);
+      }
+    }
     for (int o = 1; o < tpg; o <<= 1) {              // symmetric merge: every thread of the group ends with the same triple
       const float nb = __shfl_xor(na, o), mb = __shfl_xor(ma, o), qb = __shfl_xor(qa, o);
       const float n = na + nb;
@@ -240,7 +261,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
     for (int j = 0; j < 8; ++j) {
       const int c = vc * 8 + j;
       const int g = c / cpg;
-      const float* st = FIN ? sstat + g * 2 : stat_in + ((size_t)b * p.G + g) * 2;
+      const float* st = FIN != 0 ? sstat + g * 2 : stat_in + ((size_t)b * p.G + g) * 2;
       mean[j] = st[0];
       scale[j] = st[1] * p.gamma[c];
       beta[j] = p.beta[c];
@@ -290,12 +311,17 @@ void launch_groupnorm(const GroupNormParams& pin, hipStream_t s) {
   const int VPR = NV < 256 ? NV : 256;
   const int RL = 256 / VPR;
   const size_t lds_stats = (size_t)(2 * p.C + 2 * RL * VPR * 8 + RL) * sizeof(float);
+  const bool fin = p.G <= 256 && (p.G & (p.G - 1)) == 0 && 256 / p.G <= 64;   // merge in the apply prologue (see gn_apply_kernel)
+  const bool from_producer = p.chan_part != nullptr;     // statistics left by the producing GEMM: no statistics pass at all
+  if (from_producer && !(fin && p.C % p.G == 0 && p.chan_rt >= 1 && p.chan_rows >= 1))
+    throw std::runtime_error("groupnorm: producer statistics need a power-of-two group count");
   dim3 g1(p.nsplit, p.B);
-  if (p.x_dt == DT_F16) hipLaunchKernelGGL(gn_stats_kernel<half_t>, g1, dim3(256), lds_stats, s, p);
-  else hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds_stats, s, p);
+  if (!from_producer) {
+    if (p.x_dt == DT_F16) hipLaunchKernelGGL(gn_stats_kernel<half_t>, g1, dim3(256), lds_stats, s, p);
+    else hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds_stats, s, p);
+  }
   // (mean, rstd) per (batch, group) live right after the partials: workspace is [B][G][kGnMaxSplit][3] + [B][G][2] floats
   float* stat = p.partial + (size_t)p.B * p.G * kGnMaxSplit * 3;
-  const bool fin = p.G <= 256 && (p.G & (p.G - 1)) == 0 && 256 / p.G <= 64;   // merge in the apply prologue (see gn_apply_kernel)
   if (!fin) hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.G + 3) / 4), dim3(256), 0, s, p, stat);
   // apply: aim for >= ~512 blocks, each row lane walking >= 4 rows
   int rows_per_block = (int)(((long)p.B * p.HW + 511) / 512);
@@ -304,8 +330,9 @@ void launch_groupnorm(const GroupNormParams& pin, hipStream_t s) {
   dim3 g2((p.HW + rows_per_block - 1) / rows_per_block, p.B);
 #define GN_APPLY(XT, YT)                                                                                              \
   do {                                                                                                                \
-    if (fin) hipLaunchKernelGGL((gn_apply_kernel<XT, YT, true>), g2, dim3(256), 0, s, p, stat, rows_per_block);       \
-    else hipLaunchKernelGGL((gn_apply_kernel<XT, YT, false>), g2, dim3(256), 0, s, p, stat, rows_per_block);          \
+    if (from_producer) hipLaunchKernelGGL((gn_apply_kernel<XT, YT, 2>), g2, dim3(256), 0, s, p, stat, rows_per_block); \
+    else if (fin) hipLaunchKernelGGL((gn_apply_kernel<XT, YT, 1>), g2, dim3(256), 0, s, p, stat, rows_per_block);     \
+    else hipLaunchKernelGGL((gn_apply_kernel<XT, YT, 0>), g2, dim3(256), 0, s, p, stat, rows_per_block);              \
   } while (0)
   if (p.x_dt == DT_F16 && p.y_dt == DT_F16) GN_APPLY(half_t, half_t);
   else if (p.x_dt == DT_F32 && p.y_dt == DT_F16) GN_APPLY(float, half_t);

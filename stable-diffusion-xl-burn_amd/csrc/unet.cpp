@@ -204,23 +204,30 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
 }
 
 // ------------------------------------------------------------------------------------------ blocks
-void UNet::res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, int H, int W, const Act& out) {
-  // ResBlock::forward unet/mod.rs:1082-1106
+const float* UNet::res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, int H, int W, const Act& out, float* out_gn_part) {
+  // ResBlock::forward unet/mod.rs:1082-1106.  GroupNorm statistics ride on the producing convolutions where their kernel can
+  // leave them (256-row tiles: the 64^2 and 32^2 levels): the second norm never runs a statistics pass there, and the caller
+  // gets the statistics of `out` (returned pointer, null if not produced) for the SpatialTransformer norm that follows.
   const size_t mk = ex.act->mark();
   const size_t M = (size_t)B * H * W;
+  const int HW = H * W;
   const ConvGeom g3{B, H, W, H, W, 3, 1, 1, 0}, g1{B, H, W, H, W, 1, 1, 0, 0};
+  const bool tiles256 = gn_from_producer_ && HW % 256 == 0;
   Act gn1 = ex.alloc(M, w.cin, ex.cdt);
-  run_groupnorm(ex, w.norm_in, x, B, H * W, gn1, true);
+  run_groupnorm(ex, w.norm_in, x, B, HW, gn1, true);
   Act h = ex.alloc(M, w.cout, ex.cdt);
   Epi e1; e1.ebias = ex.ebias + w.emb_off; e1.ebias_ld = emb_total_;
-  run_conv(ex, w.conv_in, gn1, w.cin, g3, h, e1);
+  if (tiles256) e1.gn_part = (float*)ex.act->alloc(M / 256 * (size_t)w.cout * 2 * sizeof(float));
+  if (run_conv(ex, w.conv_in, gn1, w.cin, g3, h, e1)) { h.gn_part = e1.gn_part; h.gn_rt = HW / 256; }
   Act gn2 = ex.alloc(M, w.cout, ex.cdt);
-  run_groupnorm(ex, w.norm_out, h, B, H * W, gn2, true);
+  run_groupnorm(ex, w.norm_out, h, B, HW, gn2, true);
   Epi e2;
   if (w.has_skip) { run_conv(ex, w.skip, x, w.cin, g1, out); e2.R = out; }
   else e2.R = x;
-  run_conv(ex, w.conv_out, gn2, w.cout, g3, out, e2);
+  if (tiles256) e2.gn_part = out_gn_part;
+  const bool produced = run_conv(ex, w.conv_out, gn2, w.cout, g3, out, e2);
   ex.act->reset(mk);
+  return produced ? out_gn_part : nullptr;
 }
 
 void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int B, int H, int W) {
@@ -366,10 +373,15 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
         break;
       }
       case BK_RES: res_block(ex, b.res, cur, B, h, w, dest); break;
-      case BK_REST:
-        res_block(ex, b.res, cur, B, h, w, dest);
-        spatial_transformer(ex, b.st, si++, dest, B, h, w);
+      case BK_REST: {
+        Act d = dest;      // statistics of the ResBlock output for the transformer's GroupNorm (scratch outlives both calls)
+        const size_t mkp = ex.act->mark();
+        float* part = (float*)ex.act->alloc((size_t)B * h * w / 256 * b.d.c_out * 2 * sizeof(float) + 256);
+        d.gn_part = res_block(ex, b.res, cur, B, h, w, dest, part); d.gn_rt = h * w / 256;
+        spatial_transformer(ex, b.st, si++, d, B, h, w);
+        ex.act->reset(mkp);
         break;
+      }
       default: throw Error("unexpected input block kind");
     }
     cur = dest; cur_c = b.d.c_out;
@@ -378,8 +390,10 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
   {
     const size_t mk = ex.act->mark();
     Act m1 = ex.alloc((size_t)B * h * w, mid_res1_.d.c_out, ex.sdt);
-    res_block(ex, mid_res1_.res, cur, B, h, w, m1);
+    float* part = (float*)ex.act->alloc((size_t)B * h * w / 256 * mid_res1_.d.c_out * 2 * sizeof(float) + 256);
+    m1.gn_part = res_block(ex, mid_res1_.res, cur, B, h, w, m1, part); m1.gn_rt = h * w / 256;
     spatial_transformer(ex, mid_res1_.st, si++, m1, B, h, w);
+    m1.gn_part = nullptr;                 // the transformer rewrote m1 in place
     res_block(ex, mid_res2_.res, m1, B, h, w, cat[0].cols(0));
     ex.act->reset(mk);
   }
@@ -391,8 +405,14 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
     const Act next = j + 1 < n_out ? cat[j + 1].cols(0) : last;
     const size_t mk = ex.act->mark();
     Act dest = up ? ex.alloc((size_t)B * h * w, b.d.c_out, ex.sdt) : next;
-    res_block(ex, b.res, cat[j], B, h, w, dest);
-    if (b.d.kind == BK_REST || b.d.kind == BK_RESTU) spatial_transformer(ex, b.st, si++, dest, B, h, w);
+    if (b.d.kind == BK_REST || b.d.kind == BK_RESTU) {
+      float* part = (float*)ex.act->alloc((size_t)B * h * w / 256 * b.d.c_out * 2 * sizeof(float) + 256);
+      Act d = dest;
+      d.gn_part = res_block(ex, b.res, cat[j], B, h, w, dest, part); d.gn_rt = h * w / 256;
+      spatial_transformer(ex, b.st, si++, d, B, h, w);
+    } else {
+      res_block(ex, b.res, cat[j], B, h, w, dest);
+    }
     if (up) {   // Upsample::forward :742-752 -- nearest 2x fused into the conv gather
       run_conv(ex, b.conv, dest, b.d.c_out, ConvGeom{B, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next);
       h *= 2; w *= 2;

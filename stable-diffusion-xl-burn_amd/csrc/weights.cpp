@@ -245,8 +245,8 @@ NormW WeightBuilder::norm(const std::string& name) {
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
-void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e) {
-  if (ex.dry) return;
+bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e) {
+  if (ex.dry) return false;
   SDXL_REQUIRE(cin == w.cin, "run_conv: channel mismatch");
   IgemmParams p{};
   p.A = a.p; p.W = w.w; p.a_dt = a.dt;
@@ -265,6 +265,9 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.stat_out = e.stat_out; p.stat_slots = w.N / 64;
   p.splitk_ws = ex.splitk_ws; p.splitk_ws_bytes = ex.splitk_ws_bytes; p.splitk_cnt = ex.splitk_cnt; p.splitk = 0;
   p.xa_k = e.xa_k; p.xa_nctx = e.xa_nctx; p.xa_scale = e.xa_scale;
+  // GroupNorm statistics of the output from this GEMM's epilogue -- only when the kernel the selection picks anyway can do it
+  p.gn_part = nullptr;
+  if (e.gn_part && ex.cdt == DT_F16) { p.gn_part = e.gn_part; if (!igemm_gn_part_ok(p)) p.gn_part = nullptr; }
   SDXL_REQUIRE(!e.xa_k || igemm_xattn_ok(a.dt, out.dt, p.M, p.N, p.K, p.rpb, e.xa_nctx), "fused cross-attention: unsupported shape");
   SDXL_REQUIRE(!e.ln_stat || w.K % 64 == 0, "LayerNorm-folded GEMM needs K % 64 == 0");
   SDXL_REQUIRE(!e.stat_out || (w.N % 64 == 0 && (e.n_split < 0 || e.n_split >= w.N) && e.act == 0), "row statistics need a plain N % 64 == 0 output");
@@ -276,12 +279,13 @@ void run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   SDXL_HIP(hipGetLastError());     // a refused launch (bad grid / LDS attribute) must not pass silently
   if (ex.prof) ex.prof->end(ex.s);
   if (ex.fork_ev && ++ex.launches == ex.fork_after) SDXL_HIP(hipEventRecord(ex.fork_ev, ex.s));
+  return p.gn_part != nullptr;
 }
-void run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e) {
+bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e) {
   ConvGeom g{1, M, 1, M, 1, 1, 1, 0, 0};
   Epi e2 = e;
   if (e2.rpb == 0) e2.rpb = M;
-  run_conv(ex, w, a, w.cin, g, out, e2);
+  return run_conv(ex, w, a, w.cin, g, out, e2);
 }
 void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups) {
   if (ex.dry) return;
@@ -291,6 +295,8 @@ void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const 
   p.Y = y.p; p.y_dt = y.dt; p.ldy = y.ld;
   p.gamma = n.gamma; p.beta = n.beta; p.partial = ex.gn_partial;
   p.B = B; p.HW = HW; p.C = n.C; p.G = groups; p.eps = 1e-5f; p.eps_ptr = n.eps; p.silu = silu ? 1 : 0;
+  p.chan_part = x.gn_part; p.chan_rt = x.gn_rt; p.chan_rows = 256;          // statistics left by x's producer (Act::gn_part)
+  SDXL_REQUIRE(!x.gn_part || x.gn_rt * 256 == HW, "producer GroupNorm statistics do not cover the tensor");
   if (ex.prof) ex.prof->begin(Profiler::GROUPNORM, 0.0, ex.s);
   launch_groupnorm(p, ex.s);
   SDXL_HIP(hipGetLastError());

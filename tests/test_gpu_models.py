@@ -122,6 +122,30 @@ def test_split_cfg_chains_equal_batched_pair(pkg, ctx, dtype):
     assert torch.equal(u.forward(x, t, context, y), ref)
 
 
+def test_gn_statistics_from_producer_matches_statistics_pass(pkg, ctx):
+    # sdxl_unet_set_gn_from_producer (per handle, default on): the option's plumbing (scratch allocation, Act tagging, graph
+    # capture) on the tiny net, both settings vs the oracle.  The tiny net's grids are single rounds, where the tile selection
+    # prefers 96x128 tiles, so most norms keep their statistics pass here; the fused kernel path itself is covered by
+    # test_conv2d_group_norm_statistics_from_producer and by the full-size oracle comparisons (test_gpu_baseline_parity.py).
+    ocfg = OC.tiny_config()
+    W = unet_weights(ocfg)
+    x = torch.from_numpy(OC.arb_tensor(2, 4, 32, 32))
+    context = torch.from_numpy(OC.arb_tensor(2, 7, ocfg.context_dim))
+    y = torch.from_numpy(OC.arb_tensor(2, ocfg.adm_in_channels))
+    t = torch.tensor([999, 1], dtype=torch.int32)
+    ref = OM.unet_forward(ocfg, W, x, t.long(), context, y)
+    outs = {}
+    for on in (True, False):
+        u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), 1, seed=0)
+        u.set_gn_from_producer(on)
+        o = [u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu() for _ in range(3)]   # eager, capture, replay
+        assert all(torch.equal(a, o[0]) for a in o)
+        outs[on] = o[0]
+    e_on, e_off, e_x = rel_err(outs[True], ref), rel_err(outs[False], ref), rel_err(outs[True], outs[False])
+    print(f"GN statistics from producer: vs oracle {e_on:.3e}, statistics pass vs oracle {e_off:.3e}, between them {e_x:.3e}")
+    assert e_on < FWD_TOL[1] and e_off < FWD_TOL[1] and e_x < 1e-2
+
+
 def test_fused_cross_attention_matches_two_kernel_path(pkg, ctx):
     # sdxl_unet_set_fused_cross_attention (per handle, default on): attn2 inside the query projection's epilogue against the
     # projection + attention-kernel path of the same engine, and both against the oracle (unet/mod.rs:731-795)

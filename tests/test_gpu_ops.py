@@ -77,6 +77,38 @@ def test_layer_norm_linear(pkg, ctx, dtype, M, K, N, geglu):
     assert e < TOL[dtype]
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,res,expect", [
+    (2, 640, 64, 64, 640, False, True),        # ResBlock conv1 -> norm2 at the 64^2 level: 256x128 tiles
+    (2, 1280, 32, 32, 1280, True, True),       # 32^2 level, K = 11520: the split-K form of the same kernel, + skip residual
+    (2, 320, 64, 64, 640, True, True),         # channel-doubling ResBlock of the 64^2 level (K = 2880)
+    (1, 64, 16, 16, 128, False, False),        # a grid of one round: the selection prefers 96x128 tiles -> statistics pass stays
+    (2, 320, 128, 128, 320, False, False),     # 128^2 level of the CFG pair: the selection prefers 256x160 tiles -> statistics pass stays
+    (2, 128, 24, 24, 128, True, False),        # 576 rows per entry: not whole 256-row tiles
+])
+def test_conv2d_group_norm_statistics_from_producer(pkg, ctx, B, Cin, H, W, Cout, res, expect):
+    # conv3x3 -> GroupNorm(32)+SiLU as ResBlock::forward pairs them (unet/mod.rs:1082-1106).  fused: the convolution's epilogue
+    # leaves per-tile, per-channel (mean, M2) and the norm runs no statistics pass; both paths against the fp32 oracle, and the
+    # shapes the 256x128 kernel does not take must fall back (fused_taken False) with identical results.
+    x = (seeded(B, Cin, H, W, seed=31) * 1.2 + 0.3).half().float()
+    w = seeded(Cout, Cin, 3, 3, seed=32) / math.sqrt(9 * Cin)
+    b = 0.5 * seeded(Cout, seed=33) + 2.0                      # channel means well away from zero: |mean| > sigma
+    r = seeded(B, Cout, H, W, seed=34).half().float() if res else None
+    gamma, beta = 1 + 0.1 * seeded(Cout, seed=35), 0.1 * seeded(Cout, seed=36)
+    h = F.conv2d(x, w, b, padding=1)
+    if res:
+        h = h + r
+    ref = F.silu(OM.group_norm(h, gamma, beta, 32, 1e-5))
+    args = (ctx, x.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), 1e-5, 32, True, None if r is None else r.cuda())
+    out_f, took = pkg.conv2d_group_norm(*args, fused=True)
+    out_p, took_p = pkg.conv2d_group_norm(*args, fused=False)
+    e_f, e_p = rel_err(out_f, ref), rel_err(out_p, ref)
+    print(f"conv->GN B={B} Cin={Cin} {H}x{W} Cout={Cout} res={res}: fused taken={took} rel err {e_f:.3e}, stats-pass path {e_p:.3e}")
+    assert took == expect and not took_p
+    assert e_f < TOL[1] and e_p < TOL[1]
+    if not took:
+        assert torch.equal(out_f, out_p)
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("B,Nq,Nk,C", [(2, 1024, 77, 1280), (1, 4096, 77, 640), (2, 64, 77, 128), (1, 128, 96, 64),
                                         (3, 192, 5, 192), (2, 256, 33, 1280)])
