@@ -396,6 +396,11 @@ impl<B: BurnBackend> Diffuser<B> {
         let unet = unsafe { ffi::sdxl_diffuser_unet(self.raw) };
         check(unsafe { ffi::sdxl_unet_set_split_cfg(unet, enabled as c_int, release_offset as c_int) });
     }
+    /// GroupNorm statistics from the producing convolution's epilogue (default on)
+    pub fn set_gn_from_producer(&self, enabled: bool) {
+        let unet = unsafe { ffi::sdxl_diffuser_unet(self.raw) };
+        check(unsafe { ffi::sdxl_unet_set_gn_from_producer(unet, enabled as c_int) });
+    }
     pub fn set_fused_cross_attention(&self, enabled: bool) {
         let unet = unsafe { ffi::sdxl_diffuser_unet(self.raw) };
         check(unsafe { ffi::sdxl_unet_set_fused_cross_attention(unet, enabled as c_int) });
