@@ -1872,7 +1872,12 @@ bool igemm_gn_part_ok(const IgemmParams& p) {
   if (p.act != 0 || p.n_split < p.N || p.stat_out || p.ln_stat || p.xa_k) return false;
   if (p.M % 256 != 0 || p.rpb <= 0 || p.rpb % 256 != 0 || p.N % 64 != 0) return false;
   if (p.ebias && (p.ebias_ld & 3) != 0) return false;
-  return igemm_splitk_slices(p) > 1 || pick_tile(p) == 35;
+  // Like the split-K rule this must depend on ONE batch entry's shape only -- the statistics path rounds differently from the
+  // statistics kernel, and an entry has to come out bit-identical alone, in the CFG pair or in a larger batch.  The tile
+  // preference is therefore evaluated for the CFG pair (2 entries), whatever the actual batch.
+  IgemmParams q = p;
+  q.M = 2 * p.rpb;
+  return igemm_splitk_slices(p) > 1 || pick_tile(q) == 35;
 }
 
 bool igemm_xattn_ok(int a_dt, int c_dt, int M, int N, int K, int rpb, int n_ctx) {
