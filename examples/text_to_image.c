@@ -7,6 +7,7 @@
  *       -Lstable-diffusion-xl-burn_amd/lib -lsdxl_mi355 -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$PWD/stable-diffusion-xl-burn_amd/lib \
  *       -o text_to_image && ./text_to_image out.ppm 1024 30
  */
+#define _POSIX_C_SOURCE 199309L   /* clock_gettime under -std=c11 */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
