@@ -1843,16 +1843,19 @@ static double tile_cost(int M, int N, int nk, int bm, int bn, double w) {
 // exactly one round (conv128 320: 95 -> 69 us, conv64 1280up: 353 -> 235 us), the GEGLU projections the one-round 256x320 tile
 // (lin64 geglu 88 -> 77 us, lin32 geglu 67 -> 63 us), and the M = 2048 x N = 1280 linears (attention out / query projections,
 // FF-out: 240 launches per step) 96x128 tiles -- 220 workgroups that each stage 12.5 % fewer bytes than the 160 of 128x128
-// (19 -> 17 us, 54 -> 47 us).  Returns the production variant id (35, 36 / 44, 45, 38, 26).
-static int pick_tile(const IgemmParams& p) {
+// (19 -> 17 us, 54 -> 47 us), and the M = 8192 x N = 640 shapes of the 64^2 level 128x160 tiles (4 waves, 32x160 wave tiles) = exactly
+// 256 workgroups where 256x128 made 160 (conv64 640 82 -> 70 us, 1920>640 243 -> 201, lin64 ff 44 -> 39; profiles/r02_tile_128x160.txt).
+// Returns the production variant id (35, 36 / 44, 45, 38, 49, 26).
+static int pick_tile(const IgemmParams& p, bool allow_128x160 = true) {
   const int nk = p.Kpad / 64;
   struct Cand { int v, bm, bn; double w; bool ok; };
   const bool lin = p.ksize == 1 && p.stride == 1 && p.up == 0;
-  const Cand cands[5] = {
+  const Cand cands[6] = {
       {35, 256, 128, 1.0, true},
       {36, 128, 128, 1.0, true},
       {45, 96, 128, 1.0, true},
       {38, 256, 160, 1.2, p.N % 160 == 0 && !p.stat_out},
+      {49, 128, 160, 1.15, allow_128x160 && p.N % 160 == 0 && !p.stat_out && p.act == 0},
       {26, 256, 320, 1.05, p.act == 1 && lin && p.N % 320 == 0}};
   double best = 1e300;
   int variant = 35;
@@ -1877,7 +1880,13 @@ bool igemm_gn_part_ok(const IgemmParams& p) {
   // preference is therefore evaluated for the CFG pair (2 entries), whatever the actual batch.
   IgemmParams q = p;
   q.M = 2 * p.rpb;
-  return igemm_splitk_slices(p) > 1 || pick_tile(q) == 35;
+  if (igemm_splitk_slices(p) > 1) return true;
+  if (pick_tile(q, false) != 35) return false;
+  // 128x160 tiles cannot leave the statistics (32x160 wave tiles): keep 256x128 + statistics unless the other tile saves more than
+  // the statistics launch it brings back (~13 us ~ 6000 cost units)
+  const int nk = p.Kpad / 64;
+  const bool t160 = p.N % 160 == 0;
+  return !t160 || tile_cost(q.M, q.N, nk, 256, 128, 1.0) - tile_cost(q.M, q.N, nk, 128, 160, 1.15) < 6000.0;
 }
 
 bool igemm_xattn_ok(int a_dt, int c_dt, int M, int N, int K, int rpb, int n_ctx) {
@@ -1978,6 +1987,9 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 44: launch_pipe<128, 128, 5, false, 0, 4, 8, true>(psk, s); break;   // 5-slot ring = all 160 KiB of LDS: 4 tiles in flight
     case 45: launch_pipe<96, 128, 5, false, 0, 3, 6, true>(psk, s); break;    // 6 waves (3 x 2), 96-row tile: M = 2048 x N = 1280 -> 220 workgroups
     case 46: launch_pipe<96, 128, 4, false, 0, 3, 6, true>(psk, s); break;
+    case 49:                                                                // 4 waves 4x1 (32x160 wave tiles): N = 640 at 64^2 -> exactly 256 tiles
+      if (p.N % 160 != 0 || p.stat_out) return false;
+      launch_pipe<128, 160, 3, false, 0, 4, 4, true>(psk, s); break;
     case 26:                                                                // 256x320, k-tile 32: linear GEGLU projections only
       if (p.act != 1 || p.ksize != 1 || p.stride != 1 || p.up != 0 || p.N % 320 != 0 || p.Kpad % 32 != 0) return false;
       launch_wide(psk, s); break;

@@ -81,6 +81,7 @@ def test_layer_norm_linear(pkg, ctx, dtype, M, K, N, geglu):
     (2, 640, 64, 64, 640, False, True),        # ResBlock conv1 -> norm2 at the 64^2 level: 256x128 tiles
     (2, 1280, 32, 32, 1280, True, True),       # 32^2 level, K = 11520: the split-K form of the same kernel, + skip residual
     (2, 320, 64, 64, 640, True, True),         # channel-doubling ResBlock of the 64^2 level (K = 2880)
+    (2, 1920, 64, 64, 640, False, False),      # K = 17280 at 64^2: 128x160 tiles save more than the statistics launch costs
     (1, 64, 16, 16, 128, False, False),        # a grid of one round: the selection prefers 96x128 tiles -> statistics pass stays
     (2, 320, 128, 128, 320, False, False),     # 128^2 level of the CFG pair: the selection prefers 256x160 tiles -> statistics pass stays
     (2, 128, 24, 24, 128, True, False),        # 576 rows per entry: not whole 256-row tiles
@@ -330,7 +331,7 @@ def test_conv_split_k_matches_batch_entries(pkg, ctx):
 # ring slots, ragged M / N tiles, GEGLU pairs, 3x3 taps with halo zero-fill, stride 2 and the fused nearest-2x gather
 # production kernels (what the auto selection launches) -- always built; the A/B partners and dead-end experiments exist only
 # in a measure build (`build.py --measure`) and are exercised when the loaded library is one
-IGEMM_VARIANTS = [4, 6, 26, 35, 36, 38, 44, 45, 46]
+IGEMM_VARIANTS = [4, 6, 26, 35, 36, 38, 44, 45, 46, 49]
 IGEMM_MEASURE_VARIANTS = [40, 41, 42, 43, 1, 8, 10, 11, 12, 13, 14, 15, 16, 19, 20, 21, 22, 23, 24, 25, 33, 34, 37]
 
 
