@@ -50,96 +50,96 @@ __device__ __forceinline__ float gelu_erf2(float x) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
-// LayerNorm-folded GEMM: per output row m the epilogue needs a = rstd and c = -rstd*mu from the producer's row sums
+// LayerNorm-folded GEMM: per output row m the epilogue needs a = rstd and c = -rstd*mu from the producer's row statistics
+// ln_stat[slot][m] = (mean, M2) of columns [64 slot, 64 slot + 64) of row m (equal counts).  CANONICAL summation order -- every
+// path below produces the same bits, whatever tile / thread mapping evaluates it (a batch entry must not depend on the tile the
+// batch size selects): four class sums over the slots k = j (mod 4), k ascending, combined as (P0 + P1) + (P2 + P3); first the
+// means -> mu, then M2 and (mean_k - mu)^2 the same way:  var = (sum M2 + 64 sum (mean_k - mu)^2) / K  (Chan merge, biased,
+// eps inside the sqrt: layernorm/mod.rs:42-49).
+typedef float ln_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void ln_row_coef(const IgemmParams& p, int m, float& a, float& c) {
   a = 1.f; c = 0.f;
   if (p.ln_stat && m < p.M) {
-    // ln_stat[slot][m] = (sum, sum^2) of columns [64 slot, 64 slot + 64) of row m: lanes hold consecutive rows, so every
-    // load is coalesced; fixed summation order (four slots per step, then the rest) -> bit-reproducible
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stat) + m;
+    const ln_f32x2* st = reinterpret_cast<const ln_f32x2*>(p.ln_stat) + m;
     const size_t M = (size_t)p.M;
-    // pass 1: mean of the slot means (equal counts); pass 2: Chan merge  M2 = sum M2_k + 64 sum (mean_k - mu)^2
-    float s1 = 0.f;
-    int k = 0;
-    for (; k + 4 <= p.ln_slots; k += 4) {
-      const f32x2 v0 = st[(size_t)k * M], v1 = st[(size_t)(k + 1) * M], v2 = st[(size_t)(k + 2) * M], v3 = st[(size_t)(k + 3) * M];
-      s1 += (v0[0] + v1[0]) + (v2[0] + v3[0]);
-    }
-    for (; k < p.ln_slots; ++k) s1 += st[(size_t)k * M][0];
-    const float mu = s1 / (float)p.ln_slots;
-    float s2 = 0.f, sd = 0.f;
-    for (k = 0; k + 4 <= p.ln_slots; k += 4) {
-      const f32x2 v0 = st[(size_t)k * M], v1 = st[(size_t)(k + 1) * M], v2 = st[(size_t)(k + 2) * M], v3 = st[(size_t)(k + 3) * M];
-      const float d0 = v0[0] - mu, d1 = v1[0] - mu, d2 = v2[0] - mu, d3 = v3[0] - mu;
-      s2 += (v0[1] + v1[1]) + (v2[1] + v3[1]);
-      sd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-    for (; k < p.ln_slots; ++k) { const f32x2 v = st[(size_t)k * M]; const float d = v[0] - mu; s2 += v[1]; sd += d * d; }
-    const float var = (s2 + 64.f * sd) * p.ln_invc;             // biased variance, eps inside the sqrt (layernorm/mod.rs:42-49)
+    float P[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.ln_slots; ++k) P[k & 3] += st[(size_t)k * M][0];
+    const float mu = ((P[0] + P[1]) + (P[2] + P[3])) / (float)p.ln_slots;
+    float Q[4] = {0.f, 0.f, 0.f, 0.f}, D[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.ln_slots; ++k) { const ln_f32x2 v = st[(size_t)k * M]; const float d = v[0] - mu; Q[k & 3] += v[1]; D[k & 3] = fmaf(d, d, D[k & 3]); }
+    const float s2 = (Q[0] + Q[1]) + (Q[2] + Q[3]), sd = (D[0] + D[1]) + (D[2] + D[3]);
+    const float var = (s2 + 64.f * sd) * p.ln_invc;
     a = 1.0f / sqrtf(var + (p.ln_eps_ptr ? *p.ln_eps_ptr : p.ln_eps));
     c = -a * mu;
   }
 }
-// row coefficients of the folded LayerNorm for this lane's TM output rows; called in the kernel prologue so the loads overlap
-// the first DMA tiles.  Every (row, slot) partial is requested before the first one is consumed: ONE memory round trip (a
-// slot-by-slot loop serialises ln_slots round trips -- measured +6 us on the 32 us QKV projection).
+// per-lane form (kernels without LDS room for the cooperative one, K > 1536): every lane evaluates its own TM rows
 template <int TM>
 __device__ __forceinline__ void ln_prologue(const IgemmParams& p, int mw, int fr, float (&lnA)[TM], float (&lnC)[TM]) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) { lnA[i] = 1.f; lnC[i] = 0.f; }
-  if (!p.ln_stat) return;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  constexpr int MAXS = 24;                      // K <= 1536 (SDXL refiner); larger K takes the generic loop
-  if (p.ln_slots > MAXS) {
+  for (int i = 0; i < TM; ++i) ln_row_coef(p, mw + i * 32 + fr, lnA[i], lnC[i]);
+}
+// Cooperative form: the workgroup's NT threads evaluate the BM rows of the tile ONCE (TPR = NT / BM = 2 or 4 adjacent lanes per
+// row, each taking 4 / TPR of the slot classes) and park (a, c) in LDS; the waves pick their rows up behind the prologue's
+// barrier.  The per-lane form has every wave of a row group AND both lane halves load the same 20 x 8 bytes per row: 164 KB of
+// L2 requests per workgroup for 41 KB of statistics -- +17 % on the path that bounds these GEMMs (QKV projection +4.9 us of 31;
+// tools/igemm_epilogue_cost.py).  load() goes BEFORE the first DMA piece (oldest entries of the vmcnt queue), finish() after the
+// pieces are issued.  Up to 24 slots (K <= 1536).
+template <int BM, int NT>
+struct LnCoop {
+  static constexpr int TPR = NT / BM;
+  static constexpr bool OK = NT % BM == 0 && (TPR == 2 || TPR == 4);
+  static constexpr int NC = OK ? 4 / TPR : 1, PERC = 6;
+  ln_f32x2 v[NC][PERC];
+  int row, sub;
+  bool live;
+  __device__ __forceinline__ void load(const IgemmParams& p, int m0, int tid) {
+    row = tid / TPR; sub = tid - row * TPR;
+    const int m = m0 + row;
+    live = p.ln_stat != nullptr && p.ln_slots <= 24;
+    const ln_f32x2* st = reinterpret_cast<const ln_f32x2*>(p.ln_stat) + (m < p.M ? m : 0);
+    const size_t M = (size_t)p.M;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) ln_row_coef(p, mw + i * 32 + fr, lnA[i], lnC[i]);
-    return;
-  }
-  const size_t M = (size_t)p.M;
-  f32x2 v[TM][MAXS];
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = mw + i * 32 + fr;
-    const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stat) + (m < p.M ? m : 0);
-#pragma unroll
-    for (int k = 0; k < MAXS; ++k) v[i][k] = k < p.ln_slots ? st[(size_t)k * M] : f32x2{0.f, 0.f};
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    float s1 = 0.f;
-#pragma unroll
-    for (int k = 0; k + 4 <= MAXS; k += 4) {    // same association as ln_row_coef
-      if (k + 4 <= p.ln_slots) {
-        s1 += (v[i][k][0] + v[i][k + 1][0]) + (v[i][k + 2][0] + v[i][k + 3][0]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + e < p.ln_slots) s1 += v[i][k + e][0];
+      for (int q = 0; q < PERC; ++q) {
+        const int k = sub + c * TPR + 4 * q;
+        v[c][q] = (live && k < p.ln_slots) ? st[(size_t)k * M] : ln_f32x2{0.f, 0.f};
       }
-    }
-    const float mu = s1 / (float)p.ln_slots;
-    float s2 = 0.f, sd = 0.f;
+  }
+  __device__ __forceinline__ static float combine(const float (&P)[NC]) {   // (P0 + P1) + (P2 + P3), the four classes spread over TPR lanes
+    if constexpr (TPR == 4) { const float t = P[0] + __shfl_xor(P[0], 1); return t + __shfl_xor(t, 2); }
+    else { const float u = P[0] + __shfl_xor(P[0], 1), w = P[1] + __shfl_xor(P[1], 1); return u + w; }
+  }
+  __device__ __forceinline__ void finish(const IgemmParams& p, int m0, float* coef) {
+    if (!live) return;
+    float P[NC];
 #pragma unroll
-    for (int k = 0; k + 4 <= MAXS; k += 4) {
-      if (k + 4 <= p.ln_slots) {
-        const float d0 = v[i][k][0] - mu, d1 = v[i][k + 1][0] - mu, d2 = v[i][k + 2][0] - mu, d3 = v[i][k + 3][0] - mu;
-        s2 += (v[i][k][1] + v[i][k + 1][1]) + (v[i][k + 2][1] + v[i][k + 3][1]);
-        sd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      } else {
+    for (int c = 0; c < NC; ++c) {
+      P[c] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + e < p.ln_slots) { const float d = v[i][k + e][0] - mu; s2 += v[i][k + e][1]; sd += d * d; }
-      }
+      for (int q = 0; q < PERC; ++q) if (sub + c * TPR + 4 * q < p.ln_slots) P[c] += v[c][q][0];
     }
+    const float mu = combine(P) / (float)p.ln_slots;
+    float Q[NC], D[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      Q[c] = 0.f; D[c] = 0.f;
+#pragma unroll
+      for (int q = 0; q < PERC; ++q)
+        if (sub + c * TPR + 4 * q < p.ln_slots) { const float d = v[c][q][0] - mu; Q[c] += v[c][q][1]; D[c] = fmaf(d, d, D[c]); }
+    }
+    const float s2 = combine(Q), sd = combine(D);
     const float var = (s2 + 64.f * sd) * p.ln_invc;
     const float a = 1.0f / sqrtf(var + (p.ln_eps_ptr ? *p.ln_eps_ptr : p.ln_eps));
-    if (mw + i * 32 + fr < p.M) { lnA[i] = a; lnC[i] = -a * mu; }
+    if (sub == 0) {
+      const bool ok = m0 + row < p.M;
+      coef[row * 2] = ok ? a : 1.f;
+      coef[row * 2 + 1] = ok ? -a * mu : 0.f;
+    }
   }
-}
+};
 
-// ---- shared epilogue.  acc[i][j][reg] of a wave whose tile starts at (mw, nw):  m = mw + i*32 + (lane&31);
-// n = nw + j*32 + 8*(reg>>2) + 4*(lane>>5) + (reg&3)   (weights were the MFMA A operand, activations the B operand)
 template <int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int fr, int fh,
                                                const float (&lnA)[TM], const float (&lnC)[TM]) {
@@ -243,6 +243,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
 // chunks XOR-swizzled by row&7, transposed for the V^T part -- then re-reads it row-contiguously: 8 (or 4) lanes cover
 // one output row segment, add the residual with 16-byte loads and store whole 128-byte (64-byte) line segments.
 // `lds` = this wave's private region of WM*WN*4 bytes (the k-loop ring, dead by now; callers barrier first).
+// dynamic LDS of a pipelined kernel: ring (+ prefetch scratch) + 2 KiB for the cooperative LayerNorm coefficients when the CU's
+// 160 KiB leave the room (the 5-slot 128x128 ring does not: it keeps the per-lane form)
+__host__ __device__ constexpr int pipe_lds_total(int ring, int extra) { return ring + extra + 2048 <= 163840 ? ring + extra + 2048 : ring + extra; }
+
 // block context of the GroupNorm-statistics epilogue (IgemmParams::gn_part): 4 KiB of LDS scratch past the staging regions,
 // the wave's place in the 4 x 2 wave grid and the tile origin
 struct GnCtx { char* scratch; int wave, wm, wn, m0, n0; };
@@ -1153,16 +1157,31 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   constexpr bool XA_EARLY = XA && TM == 1;
   half8 xkf[XA ? 3 : 1][4], xvf[XA ? 2 : 1][6];
   if constexpr (XA_EARLY) xattn_load_frags(p, m0 + wm * WM, n0 + wn * WN, lane, xkf, xvf);
+  // folded LayerNorm: the tile's row coefficients, evaluated once per workgroup (LnCoop) where 2 KiB of LDS are left behind the ring
+  typedef LnCoop<BM, 64 * NW> LnC;
+  constexpr bool LN_COOP = LnC::OK && pipe_lds_total(NS * STAGE, PF > 0 ? NW * 256 : 0) > NS * STAGE + (PF > 0 ? NW * 256 : 0);
+  float* ln_coef = reinterpret_cast<float*>(smem + NS * STAGE + (PF > 0 ? NW * 256 : 0));
+  LnC lnc;
+  if constexpr (LN_COOP) { lnc.load(p, m0, tid); __builtin_amdgcn_sched_barrier(0); }
   // ---- prologue: tiles 0 .. NPRO-1 in flight, wait for tile 0 only
 #pragma unroll
   for (int s = 0; s < NPRO; ++s)
     if (s < nk) { issue(s, IALL{}); tile_done(); }
   float lnA[TM], lnC[TM];
-  ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
+  const bool ln_coop = LN_COOP && p.ln_slots <= 24;
+  if constexpr (LN_COOP) lnc.finish(p, m0, ln_coef);
+  if (!ln_coop) ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
   if (NPRO <= nk) wait_tiles(std::integral_constant<int, NPRO - 1>{}); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  if (ln_coop) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      lnA[i] = p.ln_stat ? ln_coef[(wm * WM + i * 32 + fr) * 2] : 1.f;
+      lnC[i] = p.ln_stat ? ln_coef[(wm * WM + i * 32 + fr) * 2 + 1] : 0.f;
+    }
+  }
   ldfrag(0, 0, I0{});
   int cur = 0;                      // ring slot of tile kt
   int fill = NS - 1;                // ring slot tile kt+NS-1 goes to (the slot tile kt-1 occupied)
@@ -1486,16 +1505,31 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // folded LayerNorm: the tile's 256 row coefficients once per workgroup (LnCoop, 2 KiB of LDS behind the ring)
+  typedef LnCoop<BM, 512> LnC;
+  float* ln_coef = reinterpret_cast<float*>(smem + NS * STAGE);
+  LnC lnc;
+  lnc.load(p, m0, tid);
+  __builtin_amdgcn_sched_barrier(0);
   // ---- prologue: the whole ring in flight, wait for tile 0 only
 #pragma unroll
   for (int s = 0; s < NS; ++s)
     if (s < nk) static_for<PER>([&](auto Q) { issue(s, Q); });
   float lnA[TM], lnC[TM];
-  ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
+  const bool ln_coop = p.ln_slots <= 24;
+  lnc.finish(p, m0, ln_coef);
+  if (!ln_coop) ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
   if (NS <= nk) wait_tiles(std::integral_constant<int, NS - 1>{}); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  if (ln_coop) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      lnA[i] = p.ln_stat ? ln_coef[(wm * WM + i * 32 + fr) * 2] : 1.f;
+      lnC[i] = p.ln_stat ? ln_coef[(wm * WM + i * 32 + fr) * 2 + 1] : 0.f;
+    }
+  }
   // (zeroed only now: keeping 160 accumulator registers live across the statistics loads of ln_prologue spills)
 #pragma unroll
   for (int j = 0; j < TN; ++j)
@@ -1768,7 +1802,7 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
 template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t, int PF = 0, bool XA = false>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
-  const size_t lds = (size_t)NS * (BM + BN) * 128 + (PF > 0 ? NW * 256 : 0);   // + the scratch slots of the L2-prefetch touches
+  const size_t lds = (size_t)pipe_lds_total(NS * (BM + BN) * 128, PF > 0 ? NW * 256 : 0);   // ring + L2-prefetch scratch + LayerNorm coefficients
   static bool attr_set[kMaxDev] = {};
   const int dev = current_device();
   set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, PRIO, DMODE, WGM, NW, UNR, T, PF, XA>, lds, attr_set, dev);
@@ -1795,7 +1829,7 @@ static void launch_ws(const IgemmParams& p, hipStream_t s) {
 static void launch_wide(const IgemmParams& p, hipStream_t s) {
   constexpr int NS = 4;
   const int tilesM = (p.M + 255) / 256, tilesN = (p.N + 319) / 320;
-  const size_t lds = (size_t)NS * (256 + 320) * 64;
+  const size_t lds = (size_t)NS * (256 + 320) * 64 + 2048;   // ring + LayerNorm coefficients
   static bool attr_set[kMaxDev] = {};
   const int dev = current_device();
   set_lds_attr(&igemm_wide_kernel<NS>, lds, attr_set, dev);
