@@ -363,6 +363,11 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
     float gpiv[8], gs1[8], gs2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gpiv[e] = 0.f; gs1[e] = 0.f; gs2[e] = 0.f; }
+    float st_piv[NIT], st_s1[NIT], st_s2[NIT];    // row statistics (stat_out): per-lane partials of every row group
+    size_t st_off[NIT];
+    bool st_ok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { st_piv[it] = 0.f; st_s1[it] = 0.f; st_s2[it] = 0.f; st_off[it] = 0; st_ok[it] = false; }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = it * 64 + lane;
@@ -454,18 +459,32 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
           // 8 consecutive lanes hold one 64-column slot of a row.  Shifted sums around a pivot inside the data (the slot's
           // first value) -> (mean, M2) of the slot, never sum x^2 - (sum x)^2: rows with |mean| >> sigma (outlier channels of
           // the residual stream) keep their variance.  The consumer Chan-merges the K/64 slots (ln_prologue).
+          // (only the per-lane partial sums here; the 8-lane reductions of ALL row groups run together behind the loop --
+          // done per group they were NIT chains of three dependent cross-lane round trips, ~1.5 us per GEMM)
           const float piv = __shfl(rr[0], lane & ~7);
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { const float d = rr[e] - piv; s1 += d; s2 = fmaf(d, d, s2); }
-#pragma unroll
-          for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-          if ((piece & 7) == 0 && valid) {
-            float* dst = p.stat_out + ((size_t)(n0 >> 6) * p.M + m) * 2;
-            dst[0] = piv + s1 * (1.0f / 64.0f);
-            dst[1] = fmaxf(s2 - s1 * s1 * (1.0f / 64.0f), 0.f);
-          }
+          st_piv[it] = piv; st_s1[it] = s1; st_s2[it] = s2;
+          st_ok[it] = (piece & 7) == 0 && valid;
+          st_off[it] = ((size_t)(n0 >> 6) * p.M + m) * 2;
         }
+      }
+    }
+    if constexpr (COLS % 64 == 0) {
+      if (p.stat_out) {
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) { st_s1[it] += __shfl_xor(st_s1[it], o); st_s2[it] += __shfl_xor(st_s2[it], o); }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (st_ok[it]) {
+            float* dst = p.stat_out + st_off[it];
+            dst[0] = st_piv[it] + st_s1[it] * (1.0f / 64.0f);
+            dst[1] = fmaxf(st_s2[it] - st_s1[it] * st_s1[it] * (1.0f / 64.0f), 0.f);
+          }
       }
     }
     if constexpr (GNP) {
