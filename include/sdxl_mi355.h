@@ -115,7 +115,10 @@ int sdxl_unet_create(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, cons
  * the weights as f16 (src/bin/sample/main.rs:37, src/bin/convert/main.rs:65-70), so a Rust host hands them over without the
  * 2x fp32 expansion (5.1 GB instead of 10.3 GB for the base UNet).  Likewise sdxl_{diffuser,vae,clip}_create_f16. */
 int sdxl_unet_create_f16(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, const uint16_t* weights_flat_f16, sdxl_unet** out);
-/* seeded synthetic weights generated on the device (no checkpoint needed); bit-identical to oracle/config.py */
+/* seeded synthetic weights generated on the device (no checkpoint needed); bit-identical to oracle/config.py.
+ * seed | SDXL_SEED_F16_WEIGHTS: every parameter is rounded to IEEE f16 first (and widened again) -- what a burn
+ * HalfPrecisionSettings record holds (src/bin/sample/main.rs:37); the per-norm eps (a module constant) is not. */
+#define SDXL_SEED_F16_WEIGHTS (1ull << 63)
 int sdxl_unet_create_synthetic(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtype, uint64_t seed, sdxl_unet** out);
 void sdxl_unet_destroy(sdxl_unet* u);
 /* UNet::forward(x, timesteps, context, label) -> Tensor<B,4>   (src/model/unet/mod.rs:450-492)
@@ -131,7 +134,8 @@ int sdxl_unet_set_split_cfg(sdxl_unet* u, int enabled, int release_offset);
  * runs inside the epilogue of the query projection instead of as its own kernel.  Off = projection + attention kernel. */
 int sdxl_unet_set_fused_cross_attention(sdxl_unet* u, int enabled);
 /* per-handle option (default on, f16 engines): GroupNorm statistics come out of the producing convolution's epilogue where
- * its kernel can leave them (256-row tiles: the 64^2 / 32^2 levels at 1024^2) -- groupnorm/mod.rs:52-82 without the statistics pass */
+ * its kernel can leave them (256-row tiles: the 64^2 / 32^2 levels at 1024^2) -- groupnorm/mod.rs:52-82 without the statistics pass.
+ * Like the two options above it is part of the plan: changing it re-sizes the arena and rebuilds the captured graph on the next forward. */
 int sdxl_unet_set_gn_from_producer(sdxl_unet* u, int enabled);
 
 /* ---- Backend::qkv_attention (src/backend.rs:4-19; generic body :88-128, LibTorch override :32-79)

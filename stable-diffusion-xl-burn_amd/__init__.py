@@ -19,7 +19,8 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsdxl_mi355.so")
+# SDXL_MEASURE_LIB=1 (tools/ only): the measurement build (`build.py --measure`: A/B partners, measurement modes, timeline stamps)
+LIB_PATH = os.path.join(_HERE, "lib", "libsdxl_mi355_measure.so" if os.environ.get("SDXL_MEASURE_LIB") == "1" else "libsdxl_mi355.so")
 
 DTYPE_F32 = 0        # strict parity: fp32 storage + exact fp32 MFMA
 DTYPE_F16 = 1        # fp16 storage / MFMA operands, fp32 accumulate
@@ -27,6 +28,9 @@ DTYPE_F16_F32RES = 2  # fp16 MFMA operands, fp32 residual stream
 
 _c_p = ctypes.c_void_p
 _f_p = ctypes.c_void_p   # device pointers travel as integers
+
+
+SEED_F16_WEIGHTS = 1 << 63   # include/sdxl_mi355.h SDXL_SEED_F16_WEIGHTS: synthetic parameters rounded to f16 (what a real record holds)
 
 
 class EngineError(RuntimeError):

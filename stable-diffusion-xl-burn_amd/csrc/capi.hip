@@ -150,6 +150,16 @@ int sdxl_debug_set(const char* key, int value) {
   else throw Error(std::string("unknown debug key ") + key);
   API_END
 }
+#ifdef SDXL_MEASURE
+// measure builds only: device buffer [workgroups][waves][sdxl_debug_timeline_words()] unsigned that the s_memtime-stamped kernel
+// variants (igemm_measure.hip, variants 135 / 136 / 145) dump their per-wave phase stamps into; null switches it off
+int sdxl_debug_timeline(void* device_buf) {
+  API_BEGIN
+  igemm_set_timeline(device_buf);
+  API_END
+}
+int sdxl_debug_timeline_words(void) { return igemm_timeline_words(); }
+#endif
 int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, int Cout, int ksize, int geglu, int iters,
                      float* avg_ms) {
   // times the implicit-GEMM kernel alone on seeded random f16 data: conv ksize x ksize (pad ksize/2) or, with ksize = 1,

@@ -230,6 +230,13 @@ void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s) {
   hipLaunchKernelGGL(i32_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
 }
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s) { (void)hipMemsetAsync(p, 0, bytes, s); }
+__global__ void round_f16_kernel(float* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (float)(half_t)p[i];
+}
+void launch_round_f16(float* p, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(round_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // CLIP text-encoder glue (clip/mod.rs:99-105 embedding sum, :139-147 eot pooling, backend.rs attn_decoder_mask)

@@ -89,6 +89,7 @@ struct NullSource : WeightSource {   // replica ranks: same arena layout, conten
   void fetch(const ParamSpec&, size_t, float*, hipStream_t) override {}
   bool empty() const override { return true; }
 };
+constexpr uint64_t kSeedF16Weights = 1ull << 63;   // seed flag (C ABI: SDXL_SEED_F16_WEIGHTS): synthetic parameters rounded to f16
 struct SyntheticSource : WeightSource {
   uint64_t seed;
   explicit SyntheticSource(uint64_t s) : seed(s) {}
@@ -236,7 +237,7 @@ class UNet {
   // streams, the second released after `release_offset` GEMM launches of the first; bit-identical results
   void set_split_cfg(bool on, int release_offset) { split_cfg_ = on; split_offset_ = release_offset; }
   void set_fused_cross_attention(bool on) { fuse_xattn_ = on; }
-  void set_gn_from_producer(bool on) { gn_from_producer_ = on; }   // call before the first forward / after set_use_graph(false)
+  void set_gn_from_producer(bool on) { gn_from_producer_ = on; }   // re-plans (arena + graph) on the next forward, like the two options above
   // one eager forward of the current plan/context with hipEvents around every launch, summed per kernel class
   void profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[Profiler::NCLS], double flops[Profiler::NCLS],
                hipStream_t s);
@@ -279,7 +280,7 @@ class UNet {
   bool split_cfg_ = false; int split_offset_ = 0;
   bool plan_split_ = false; int graph_off_ = 0;
   bool fuse_xattn_ = true, plan_xattn_ = true;   // cross-attention inside the query projection's epilogue (f16 engines)
-  bool gn_from_producer_ = true;         // GroupNorm statistics from the producing convolution's epilogue where its kernel can (f16)
+  bool gn_from_producer_ = true, plan_gn_ = true;   // GroupNorm statistics from the producing convolution's epilogue where its kernel can (f16); part of the plan key
   hipStream_t s2_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena act2_;
   hipGraphExec_t graph_ = nullptr;

@@ -353,6 +353,9 @@ void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s) {
   if (compute_dt == DT_F16 && g_igemm_variant > 0 && launch_igemm_glds(p, 0, s)) return;   // forced tile refused the shape
   if (compute_dt == DT_F32 && g_igemm_variant >= 0 && launch_igemm_f32_pipe(p, s)) return;
   if (p.xa_k) throw std::runtime_error("fused cross-attention needs the f16 direct-to-LDS kernels");
+  // the generic kernels below never write the GroupNorm statistics: a caller that was promised them (run_conv tags the output
+  // Act and the consumer skips its statistics pass) must not get uninitialised memory -- forced variants, unaligned A, no zero page
+  if (p.gn_part) throw std::runtime_error("GroupNorm statistics from the epilogue (gn_part) need the f16 direct-to-LDS 256x128 kernel");
   if (p.ln_stat || p.stat_out)
     throw std::runtime_error("LayerNorm-folded GEMM (ln_stat / stat_out) needs the f16 direct-to-LDS kernels");
   if (compute_dt == DT_F16) {

@@ -69,6 +69,10 @@ constexpr int kSplitkCounters = 4096;                                // arrival 
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
 void igemm_set_unrolled(int v);   // auto selection: pipelined kernels with the k-loop unrolled by the ring depth (default on)
+#ifdef SDXL_MEASURE
+void igemm_set_timeline(void* device_buf);   // igemm_measure.hip: stamp buffer of the timeline kernel variants
+int igemm_timeline_words();
+#endif
 void igemm_glds_init();          // allocates the zero page the DMA fast path reads halo pixels from (call once per process)
 
 // ---------------------------------------------------------------------------------------------------------
@@ -154,6 +158,7 @@ void launch_nhwc_to_nchw(const void* src, int dt, int lds, float* dst, int B, in
 // generic cast copy rows: dst[r][c] = src[r][c]
 void launch_copy_rows(const void* src, int sdt, int lds, void* dst, int ddt, int ldd, int rows, int C, hipStream_t s);
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+void launch_round_f16(float* p, size_t n, hipStream_t s);   // p[i] = float(half(p[i])): parameters as a HalfPrecisionSettings record holds them
 void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s);
 // CLIP text encoder (clip/mod.rs:99-105,139-147): x[b][t][:] = tok[ids[b][t]][:] + pos[t][:] (tables in dtype w_dt);
 // eot[b] = first index of max(ids[b][:]); sel[b][:] = x[b][eot[b]][:] as fp32; additive causal mask [n][n] (0 / -inf)

@@ -432,7 +432,7 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
 
 void UNet::ensure_plan(int B, int H, int W) {
   const bool split = split_cfg_ && B == 2;
-  if (B == pB_ && H == pH_ && W == pW_ && split == plan_split_ && fuse_xattn_ == plan_xattn_) return;
+  if (B == pB_ && H == pH_ && W == pW_ && split == plan_split_ && fuse_xattn_ == plan_xattn_ && gn_from_producer_ == plan_gn_) return;
   SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
   const int div = 1 << (cfg_.channel_mults.size() - 1);
   SDXL_REQUIRE(H >= div && W >= div && H % div == 0 && W % div == 0,
@@ -452,7 +452,8 @@ void UNet::ensure_plan(int B, int H, int W) {
     tconv_ = (float*)act_.alloc(8 * sizeof(float));
     if (cdt_ == DT_F16) {   // split-K slabs + counters: chain 0 (and the second split-CFG chain)
       skws_bytes_ = igemm_splitk_ws_bytes(B, 1024, 1280);
-      for (int c = 0; c < 2; ++c) {
+      skws_[1] = nullptr; skcnt_[1] = nullptr;
+      for (int c = 0; c < (split ? 2 : 1); ++c) {   // the second set only exists for the second split-CFG chain
         skws_[c] = (float*)act_.alloc(skws_bytes_);
         skcnt_[c] = (unsigned*)act_.alloc(kSplitkCounters * sizeof(unsigned));
       }
@@ -485,6 +486,7 @@ void UNet::ensure_plan(int B, int H, int W) {
   }
   plan_split_ = split;
   plan_xattn_ = fuse_xattn_;
+  plan_gn_ = gn_from_producer_;
   if (!had_kv) kv_.clear();
   act_.reset(m);
   const size_t peak = act_.peak;
@@ -492,7 +494,7 @@ void UNet::ensure_plan(int B, int H, int W) {
   act_.reserve(peak + 4096);
   act_.off = 0; act_.peak = 0;
   persist();
-  if (skcnt_[0]) for (int c = 0; c < 2; ++c) SDXL_HIP(hipMemset(skcnt_[c], 0, kSplitkCounters * sizeof(unsigned)));   // armed once
+  for (int c = 0; c < 2; ++c) if (skcnt_[c]) SDXL_HIP(hipMemset(skcnt_[c], 0, kSplitkCounters * sizeof(unsigned)));   // armed once
 }
 
 void* UNet::unet_in(int B, int H, int W) { ensure_plan(B, H, W); return in_; }

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace sdxl {
 
@@ -54,8 +55,11 @@ void Profiler::collect(float ms[NCLS], int launches[NCLS], double flops[NCLS]) {
 
 // ------------------------------------------------------------------------------------------ sources
 void SyntheticSource::fetch(const ParamSpec& s, size_t, float* dst, hipStream_t st) {
-  const uint64_t key = fnv1a64(s.name) ^ (seed * 0x9E3779B97F4A7C15ull);
+  const uint64_t key = fnv1a64(s.name) ^ ((seed & ~kSeedF16Weights) * 0x9E3779B97F4A7C15ull);
   launch_synth_fill(dst, s.numel(), key, s.scale, s.mean, st);
+  // kSeedF16Weights: every parameter rounded to IEEE f16 and widened again -- what a burn HalfPrecisionSettings record holds
+  // (src/bin/sample/main.rs:37); the per-norm eps is a module constant, not a record entry
+  if ((seed & kSeedF16Weights) && s.kind != PK_EPS) launch_round_f16(dst, s.numel(), st);
 }
 FlatSource::FlatSource(const float* b, const std::vector<ParamSpec>& specs) : base(b) {
   size_t o = 0;
@@ -72,7 +76,30 @@ FlatSourceF16::FlatSourceF16(const uint16_t* b, const std::vector<ParamSpec>& sp
   SDXL_HIP(hipMalloc(&stage, stage_numel * sizeof(uint16_t)));
 }
 FlatSourceF16::~FlatSourceF16() { if (stage) (void)hipFree(stage); }
+static float f16_bits_to_float(uint16_t h) {   // exact widening on the host (subnormals included)
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+  uint32_t bits;
+  if (e == 0) {
+    if (m == 0) bits = sign;
+    else { int sh = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; ++sh; } bits = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 1023u) << 13); }
+  } else if (e == 31) bits = sign | 0x7F800000u | (m << 13);
+  else bits = sign | ((e + 112u) << 23) | (m << 13);
+  float f; std::memcpy(&f, &bits, 4);
+  return f;
+}
 void FlatSourceF16::fetch(const ParamSpec& s, size_t index, float* dst, hipStream_t st) {
+  if (s.kind == PK_EPS) {
+    // an f16 stream cannot carry the norm eps: 1e-5 is subnormal in f16 (-> 1.0014e-5) and anything below ~3e-8 becomes 0.  A
+    // burn record never holds it (module constant: the .mpk path gets the Config default 1e-5), so the f16 image of the default
+    // is taken for the default itself; any other value is widened exactly, on the host (no device denormal mode involved)
+    uint16_t h = 0;
+    SDXL_HIP(hipMemcpyAsync(&h, base + offsets[index], sizeof(h), hipMemcpyDefault, st));
+    SDXL_HIP(hipStreamSynchronize(st));
+    const float v = h == 0x00A8u ? 1e-5f : f16_bits_to_float(h);
+    SDXL_HIP(hipMemcpyAsync(dst, &v, sizeof(float), hipMemcpyHostToDevice, st));
+    SDXL_HIP(hipStreamSynchronize(st));
+    return;
+  }
   SDXL_HIP(hipMemcpyAsync(stage, base + offsets[index], s.numel() * sizeof(uint16_t), hipMemcpyDefault, st));
   SDXL_HIP(hipStreamSynchronize(st));   // pageable host memory
   launch_copy_rows(stage, DT_F16, 1, dst, DT_F32, 1, (int)s.numel(), 1, st);   // exact widening: every f16 is an fp32

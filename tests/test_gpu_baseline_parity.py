@@ -13,14 +13,18 @@ What is compared, and to which bar:
       - one latent_to_image at 1024x1024 (stablediffusion/mod.rs:200-237);
       - config 2, the configuration bench.py times: 1024x1024, n_steps=30 (31 iterations), CFG 7.5 -- the oracle's own
         31-step trajectory (9 stored steps + final latent).
+      - round 3: BASELINE configs[3] / configs[4] at full size -- one refiner UNet::forward, a 2-iteration refine_latent, one
+        1024x1024 image_to_latent (Encoder::forward with its PaddedConv2d downsamples) and a 4-step inpainting trajectory
+        (fixtures: oracle/make_golden_r3.py), plus one base forward with f16-representable weights (what a real record
+        holds) that isolates activation rounding from weight rounding.
     Bar: north_star's 1e-3 on latents at SDXL's latent scale.  The synthetic-weight UNet is not a denoiser: its
     trajectories grow well past real SDXL latents (|x| <~ 4), so the absolute bound is scaled with the trajectory:
     1e-3 * max(1, max|latent_ref| / 4); both the raw absolute and the relative error are recorded.
   * SDXL_DTYPE_F16 / SDXL_DTYPE_F16_F32RES (the speed modes) against the now oracle-anchored F32 engine on the SAME 31-step
-    1024x1024 CFG-7.5 trajectory: per-step max-abs / relative / rms error -> gpurun_out/r02_drift_*.json (committed under
+    1024x1024 CFG-7.5 trajectory: per-step max-abs / relative / rms error -> gpurun_out/r03_drift_*.json (committed under
     profiles/).  fp16 operands cannot meet 1e-3 absolute (one rounding is 4.9e-4 relative, CFG 7.5 multiplies the error of
     eps by up to 7.5 per step); the bound asserted here is the measured class with headroom, stated in DESIGN.md section 5.
-Everything goes through the C ABI (ctypes); measured numbers are written to gpurun_out/r02_parity_baseline.json.
+Everything goes through the C ABI (ctypes); measured numbers are written to gpurun_out/r03_parity_baseline.json.
 """
 import json
 import os
@@ -42,7 +46,11 @@ CROPS = ((0, 0), (0, 960), (480, 480), (960, 0))
 LAT_ABS = 1e-3               # north_star bar at SDXL's latent scale ...
 LAT_SCALE_REF = 4.0          # ... |latent| <~ 4; synthetic trajectories are larger, the bound scales with them
 F32_FWD_REL = 1e-4           # one UNet::forward, strict mode
-F16_FWD_REL = 3e-2           # one UNet::forward, fp16 operands (measured value is recorded)
+# fp16-operand bounds = <= 2x the values measured on MI355X (profiles/r02_parity_baseline.json): a 2x regression fails
+F16_FWD_REL = 2.7e-3         # one base UNet::forward, fp16 operands (measured 1.31e-3)
+F16RES_FWD_REL = 2.0e-3      # ... with the fp32 residual stream (measured 9.6e-4)
+F16_DECODE_REL = 2.5e-3      # latent_to_image, fp16 VAE (measured 1.1e-3)
+F16_TRAJ_REL = {"f16": 3.8e-3, "f16_f32res": 2.3e-3}   # config 2, final latent after 31 CFG-7.5 steps (measured 1.85e-3 / 1.11e-3)
 IMG_ABS_F32 = 2e-3           # decode_latent, strict mode: fp32 image in [-1, 1]-ish units
 
 
@@ -70,7 +78,7 @@ def _write_report():
     yield
     try:
         os.makedirs(OUT_DIR, exist_ok=True)
-        path = os.path.join(OUT_DIR, "r02_parity_baseline.json")
+        path = os.path.join(OUT_DIR, "r03_parity_baseline.json")
         merged = {}
         if os.path.exists(path):          # a partial run (-k ...) updates its own entries only
             try:
@@ -163,7 +171,7 @@ def test_unet_forward_1024_matches_oracle(pkg, ctx):
     ref = torch.from_numpy(g["out"])
     rep = {}
     outs = {}
-    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f16", pkg.DTYPE_F16, F16_FWD_REL), ("f16_f32res", pkg.DTYPE_F16_F32RES, F16_FWD_REL)):
+    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f16", pkg.DTYPE_F16, F16_FWD_REL), ("f16_f32res", pkg.DTYPE_F16_F32RES, F16RES_FWD_REL)):
         u = pkg.UNet(ctx, cfg, dt, seed=0)
         outs[name] = u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu()
         rep[name] = errs(outs[name], ref)
@@ -206,7 +214,7 @@ def test_decode_1024_matches_oracle(pkg, ctx):
     assert rep["f32"]["image_sub"]["max_abs"] <= IMG_ABS_F32 * max(1.0, rep["f32"]["image_sub"]["ref_max"])
     assert rep["f32"]["crops"]["max_abs"] <= IMG_ABS_F32 * max(1.0, rep["f32"]["crops"]["ref_max"])
     assert rep["f32"]["u8_max_diff"] <= 1
-    assert rep["f16"]["image_sub"]["rel"] < 3e-2
+    assert rep["f16"]["image_sub"]["rel"] < F16_DECODE_REL
 
 
 def test_config2_trajectory_parity_and_drift(pkg, ctx):
@@ -251,11 +259,147 @@ def test_config2_trajectory_parity_and_drift(pkg, ctx):
               f"(max-abs {per[-1]['max_abs']:.3e}, rms-rel {per[-1]['rms_rel']:.2e}); {secs[name]:.2f} s")
         try:
             os.makedirs(OUT_DIR, exist_ok=True)
-            with open(os.path.join(OUT_DIR, f"r02_drift_{name}.json"), "w") as fh:
+            with open(os.path.join(OUT_DIR, f"r03_drift_{name}.json"), "w") as fh:
                 json.dump(dict(config="SDXL-base 1024x1024, n_steps=30 (31 iterations), CFG 7.5, synthetic weights seed 0",
-                               reference="SDXL_DTYPE_F32 engine trajectory (oracle-anchored: f32_vs_oracle in r02_parity_baseline.json)",
+                               reference="SDXL_DTYPE_F32 engine trajectory (oracle-anchored: f32_vs_oracle in r03_parity_baseline.json)",
                                mode=name, per_step=per, ref_absmax=rep["ref_absmax"]), fh, indent=1)
         except OSError:
             pass
-        assert per[-1]["rel"] < 0.25, (name, per[-1])        # measured class recorded in DESIGN.md section 5; fp16 operands
+        assert per[-1]["rel"] < F16_TRAJ_REL[name], (name, per[-1])        # <= 2x the measured drift
     REPORT["config2_trajectory"] = rep
+
+
+# ------------------------------------------------------------------------------------------ round 3: configs[3] / configs[4]
+def _refiner_cond(pkg, i, res=(1024, 1024)):
+    return pkg.Conditioning(context_open_clip=i["ctx"].cuda(), channel_context_refiner=i["y"].cuda(),
+                            unconditional_context_open_clip=i["uctx"].cuda(), unconditional_channel_context_refiner=i["uy"].cuda(),
+                            resolution=res)
+
+
+def test_refiner_forward_1024_matches_oracle(pkg, ctx):
+    """BASELINE configs[3]: one forward of the 4-level refiner UNet (384/768/1536/1536 channels, depth 4, context 1280) at
+    1024x1024 -- shapes (N = 1536, K = 13824, 24 LayerNorm slots) no base-model test reaches"""
+    g = np.load(os.path.join(GOLD, "fullsize_refiner1024.npz"))
+    cfg = pkg.sdxl_refiner_config()
+    x, t = seeded(1, 4, 128, 128, seed=141), torch.tensor([150], dtype=torch.int32)
+    c, y = seeded(1, 77, cfg.context_dim, seed=142), seeded(1, cfg.adm_in_channels, seed=143)
+    assert np.allclose(checksum(x, c, y), g["in_checksum"], rtol=1e-9), "torch CPU generator changed: regenerate the fixtures"
+    ref = torch.from_numpy(g["out"])
+    rep = {}
+    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f16", pkg.DTYPE_F16, 2 * F16_FWD_REL), ("f16_f32res", pkg.DTYPE_F16_F32RES, 2 * F16RES_FWD_REL)):
+        u = pkg.UNet(ctx, cfg, dt, seed=0)
+        outs = [u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu() for _ in range(3)]     # eager, capture, replay
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "hipGraph replay differs from the eager run"
+        rep[name] = errs(outs[0], ref)
+        del u
+        print(f"refiner UNet::forward 1024^2 {name} vs oracle: rel {rep[name]['rel']:.3e} rms-rel {rep[name]['rms_rel']:.3e} max-abs {rep[name]['max_abs']:.3e}")
+        assert rep[name]["rel"] < tol, (name, rep[name])       # (f16: first measurement this round, bound = 2x the base model's)
+    REPORT["refiner_forward_1024_vs_oracle"] = rep
+
+
+def test_refine_latent_1024_matches_oracle(pkg, ctx):
+    """Diffuser::refine_latent at full size (stablediffusion/mod.rs:355-376): step_start 800, n_steps 10 -> t = 199, 99"""
+    g = np.load(os.path.join(GOLD, "fullsize_refine1024.npz"))
+    cfg = pkg.sdxl_refiner_config()
+    i = dict(latent=seeded(1, 4, 128, 128, seed=151), noise=seeded(1, 4, 128, 128, seed=152), ctx=seeded(1, 77, cfg.context_dim, seed=153),
+             uctx=seeded(77, cfg.context_dim, seed=154), y=seeded(1, cfg.adm_in_channels, seed=155), uy=seeded(cfg.adm_in_channels, seed=156))
+    assert np.allclose(checksum(*i.values()), g["in_checksum"], rtol=1e-9), "torch CPU generator changed: regenerate the fixtures"
+    assert pkg.step_count(10, 800) == 2
+    ref_traj, ref = torch.from_numpy(g["traj"]), torch.from_numpy(g["latent"])
+    rep = {}
+    for name, dt in (("f32", pkg.DTYPE_F32), ("f16", pkg.DTYPE_F16)):
+        d = pkg.Diffuser(ctx, cfg, dt, seed=0)
+        trace = torch.zeros(2, 1, 4, 128, 128, device="cuda")
+        d.set_trace(trace)
+        out = d.refine_latent(i["latent"].cuda(), _refiner_cond(pkg, i), 7.5, 800, 10, i["noise"].cuda())
+        torch.cuda.synchronize()
+        d.set_trace(None)
+        assert torch.equal(trace[-1], out)
+        rep[name] = dict(per_step=[errs(trace[k], ref_traj[k]) for k in range(2)], final=errs(out, ref))
+        del d
+        print(f"refine_latent 1024^2 {name} vs oracle: per step {['%.2e' % s['max_abs'] for s in rep[name]['per_step']]} "
+              f"(rel {rep[name]['final']['rel']:.2e}, |ref| {rep[name]['final']['ref_max']:.2f})")
+    REPORT["refine_latent_1024_vs_oracle"] = rep
+    for k in range(2):
+        assert rep["f32"]["per_step"][k]["max_abs"] <= lat_bound(ref_traj[k]), (k, rep["f32"]["per_step"][k])
+    assert rep["f16"]["final"]["rel"] < 2 * F16_FWD_REL, rep["f16"]["final"]
+
+
+def _encode_image():
+    g = torch.Generator().manual_seed(161)
+    yy, xx = torch.meshgrid(torch.arange(1024, dtype=torch.float32), torch.arange(1024, dtype=torch.float32), indexing="ij")
+    base = torch.stack([torch.sin(xx / 37.0) * torch.cos(yy / 53.0), torch.sin((xx + yy) / 91.0), torch.cos(xx / 17.0 - yy / 29.0)], -1)
+    img = (base * 0.35 + 0.5 + 0.08 * torch.randn(1024, 1024, 3, generator=g)).clamp(0, 1) * 255.0
+    return img.to(torch.uint8)[None]
+
+
+def test_encode_1024_matches_oracle(pkg, ctx):
+    """BASELINE configs[4], first leg: LatentDecoder::image_to_latent of a 1024x1024 u8 image (stablediffusion/mod.rs:239-261,
+    Encoder::forward autoencoder/mod.rs:131-144 with the PaddedConv2d downsamples :384-407)"""
+    g = np.load(os.path.join(GOLD, "fullsize_encode1024.npz"))
+    img = _encode_image()
+    chk = np.array([float(img.numpy().astype(np.float64).sum()), float((img.numpy().astype(np.float64) ** 2).sum())])
+    assert np.allclose(chk, g["in_checksum"], rtol=1e-12), "u8 test image differs from the fixture's: regenerate"
+    ref = torch.from_numpy(g["latent"])
+    rep = {}
+    for name, dt in (("f32", pkg.DTYPE_F32), ("f16", pkg.DTYPE_F16)):
+        ld = pkg.LatentDecoder(ctx, None, dt, seed=0, with_encoder=True)
+        out = ld.image_to_latent(pkg.RawImages(img.cuda(), 1024, 1024)).cpu()
+        rep[name] = errs(out, ref)
+        del ld
+        print(f"image_to_latent 1024^2 {name} vs oracle: max-abs {rep[name]['max_abs']:.3e} rel {rep[name]['rel']:.3e} (|ref| {rep[name]['ref_max']:.3f})")
+    REPORT["encode_1024_vs_oracle"] = rep
+    assert rep["f32"]["max_abs"] <= LAT_ABS and rep["f32"]["rel"] < 1e-4, rep["f32"]
+    assert rep["f16"]["rel"] < 2 * F16_DECODE_REL, rep["f16"]
+
+
+def test_inpainting_1024_matches_oracle(pkg, ctx):
+    """BASELINE configs[4]: Diffuser::sample_latent_with_inpainting at 1024x1024, 4 CFG-7.5 steps, mask = latent rows 0..24
+    generated (the 200 px crop), reference latent = the oracle's encode, explicit per-step re-noise (stablediffusion/mod.rs:434-483)"""
+    g = np.load(os.path.join(GOLD, "fullsize_inpaint1024.npz"))
+    cfg = pkg.sdxl_base_config()
+    i = dict(noise=seeded(1, 4, 128, 128, seed=171), ctx=seeded(1, 77, cfg.context_dim, seed=172), uctx=seeded(77, cfg.context_dim, seed=173),
+             y=seeded(1, cfg.adm_in_channels, seed=174), uy=seeded(cfg.adm_in_channels, seed=175), step_noise=seeded(4, 1, 4, 128, 128, seed=176))
+    assert np.allclose(checksum(*i.values()), g["in_checksum"], rtol=1e-9), "torch CPU generator changed: regenerate the fixtures"
+    reference = torch.from_numpy(g["reference"])
+    mask = torch.zeros(1, 4, 128, 128, dtype=torch.bool)
+    mask[:, :, 0:25, :] = True
+    ref_traj, ref = torch.from_numpy(g["traj"]), torch.from_numpy(g["latent"])
+    rep = {}
+    for name, dt in (("f32", pkg.DTYPE_F32), ("f16", pkg.DTYPE_F16)):
+        d = pkg.Diffuser(ctx, cfg, dt, seed=0)
+        trace = torch.zeros(4, 1, 4, 128, 128, device="cuda")
+        d.set_trace(trace)
+        out = d.sample_latent_with_inpainting(_cond(pkg, i, (1024, 1024)), 7.5, 4, reference.cuda(), mask.cuda(), i["noise"].cuda(),
+                                              i["step_noise"].cuda())
+        torch.cuda.synchronize()
+        d.set_trace(None)
+        assert torch.equal(trace[-1], out)
+        rep[name] = dict(per_step=[errs(trace[k], ref_traj[k]) for k in range(4)], final=errs(out, ref))
+        del d
+        print(f"inpainting 1024^2 {name} vs oracle: per step {['%.2e' % s['max_abs'] for s in rep[name]['per_step']]} "
+              f"(final rel {rep[name]['final']['rel']:.2e}, |ref| {rep[name]['final']['ref_max']:.1f})")
+    REPORT["inpainting_1024_vs_oracle"] = rep
+    for k in range(4):
+        assert rep["f32"]["per_step"][k]["max_abs"] <= lat_bound(ref_traj[k]), (k, rep["f32"]["per_step"][k])
+    assert rep["f16"]["final"]["rel"] < F16_TRAJ_REL["f16"], rep["f16"]["final"]
+
+
+def test_unet_forward_1024_f16_representable_weights(pkg, ctx):
+    """Real SDXL records hold f16 parameters (HalfPrecisionSettings, src/bin/sample/main.rs:37): with such weights the engine's
+    f16 weight rounding is exact.  Same forward as test_unet_forward_1024_matches_oracle with every parameter rounded to f16 on
+    both sides (oracle fixture / SDXL_SEED_F16_WEIGHTS): what is left in the f16 modes is ACTIVATION rounding alone."""
+    g = np.load(os.path.join(GOLD, "fullsize_unet1024_f16w.npz"))
+    cfg = pkg.sdxl_base_config()
+    x, t = seeded(1, 4, 128, 128, seed=111), torch.tensor([500], dtype=torch.int32)
+    c, y = seeded(1, 77, cfg.context_dim, seed=112), seeded(1, cfg.adm_in_channels, seed=113)
+    assert np.allclose(checksum(x, c, y), g["in_checksum"], rtol=1e-9)
+    ref = torch.from_numpy(g["out"])
+    rep = {}
+    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f16", pkg.DTYPE_F16, F16_FWD_REL), ("f16_f32res", pkg.DTYPE_F16_F32RES, F16RES_FWD_REL)):
+        u = pkg.UNet(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS | 0)
+        rep[name] = errs(u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu(), ref)
+        del u
+        print(f"UNet::forward 1024^2, f16-representable weights, {name} vs oracle: rel {rep[name]['rel']:.3e} rms-rel {rep[name]['rms_rel']:.3e}")
+        assert rep[name]["rel"] < tol, (name, rep[name])
+    REPORT["unet_forward_1024_f16_weights_vs_oracle"] = rep

@@ -2,7 +2,7 @@
 Embedder::text_to_conditioning after tokenisation, against oracle/clip.py on seeded synthetic weights.
 
 Tolerances follow test_gpu_models.py: DTYPE_F32 1e-4 relative on a forward; the fp16-operand modes are held to the same
-3e-2 / 2e-2 bounds as a UNet forward (fp16 rounding of weights, embeddings and activations through <= 12 pre-LN blocks).
+2.5e-3 / 1.3e-3 bounds (<= 2x the measured values) (fp16 rounding of weights, embeddings and activations through <= 12 pre-LN blocks).
 Token ids are passed in (the tokenizer asset files do not travel to the GPU box; the tokenizers are CPU-tested).
 """
 import numpy as np
@@ -14,7 +14,7 @@ from util import max_abs, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = {0: 1e-4, 1: 3e-2, 2: 2e-2}
+TOL = {0: 1e-4, 1: 2.5e-3, 2: 1.3e-3}   # f16 modes: <= 2x measured (1.25e-3 / 6.4e-4, profiles/r02_gpu_tests_final.log)
 
 
 def _pcfg(pkg, c):

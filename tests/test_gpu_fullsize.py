@@ -58,7 +58,7 @@ def test_fullsize_embedder(pkg, ctx):
     out = clip_l.forward_hidden(ids, lcfg.n_layer - 1)
     e = rel_err(out, OCL.forward_hidden(lcfg, W, ids, lcfg.n_layer - 1))
     print(f"CLIP-L f16 vs fp32 oracle rel err {e:.3e}")
-    assert e < 3e-2
+    assert e < 3.6e-3                                   # measured 1.8e-3
     del W
 
     ids_o = _prompt_ids(1, 12, 0)
@@ -74,7 +74,7 @@ def test_fullsize_embedder(pkg, ctx):
     h32, p32 = OCL.forward_hidden_pooled(ocfg, Wo, ids_o, 31)
     eh, ep = rel_err(h16, h32), rel_err(p16, p32)
     print(f"OpenCLIP bigG f16 vs fp32 oracle: hidden {eh:.3e} pooled {ep:.3e}")
-    assert eh < 3e-2 and ep < 3e-2
+    assert eh < 5.7e-3 and ep < 3.3e-3                   # measured 2.8e-3 / 1.6e-3
     del Wo
 
     emb = pkg.Embedder(ctx, clip_l, bigg)

@@ -19,9 +19,13 @@ from util import max_abs, rel_err, seeded, to_pkg_cfg, to_pkg_vcfg, unet_weights
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL = {0: 1e-4, 1: 3e-2, 2: 2e-2}
+# f16-operand bounds: <= 2x the largest value measured for the class (profiles/r02_gpu_tests_final.log: forward 1.4e-3 on 16^2 /
+# 2.3e-3 on 32^2 inputs; F16_F32RES 1.2e-3), so a 2x regression fails
+FWD_TOL = {0: 1e-4, 1: 4.5e-3, 2: 2.5e-3}
+EPS_TOL = {0: 1e-4, 1: 6e-3, 2: 6e-3}    # the low-variance per-norm-eps probe (measured 1.2e-5 / 2.9e-3 / 2.7e-3)
 LAT_ABS_F32 = 1e-3           # north_star: latents within 1e-3 of the fp32 CPU reference (strict-parity mode)
-LAT_REL_F16 = 3e-2           # fp16-operand modes: max-abs error relative to max|latent| (CFG 7.5 amplifies eps error 7.5x)
+LAT_REL_F16 = 7.5e-3         # fp16-operand modes: max-abs error relative to max|latent|; measured 3.0e-3 (4 CFG-7.5 steps) and 3.8e-3
+                             # (5-step inpainting) on the tiny net -> <= 2x measured
 
 
 def lat_tol(dtype, ref):
@@ -96,7 +100,7 @@ def test_unet_forward_per_norm_eps(pkg, ctx, dtype):
     u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, weights=pkg.flatten_weights(specs, {k: v.numpy() for k, v in W.items()}))
     e = rel_err(u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu(), ref)
     print(f"unet_forward per-norm eps dtype={dtype}: rel err {e:.3e}")
-    assert e < FWD_TOL[dtype]
+    assert e < EPS_TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
@@ -143,7 +147,7 @@ def test_gn_statistics_from_producer_matches_statistics_pass(pkg, ctx):
         outs[on] = o[0]
     e_on, e_off, e_x = rel_err(outs[True], ref), rel_err(outs[False], ref), rel_err(outs[True], outs[False])
     print(f"GN statistics from producer: vs oracle {e_on:.3e}, statistics pass vs oracle {e_off:.3e}, between them {e_x:.3e}")
-    assert e_on < FWD_TOL[1] and e_off < FWD_TOL[1] and e_x < 1e-2
+    assert e_on < FWD_TOL[1] and e_off < FWD_TOL[1] and e_x < 4e-3
 
 
 def test_fused_cross_attention_matches_two_kernel_path(pkg, ctx):
@@ -167,7 +171,7 @@ def test_fused_cross_attention_matches_two_kernel_path(pkg, ctx):
     assert torch.equal(u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu(), fused[0])
     e_f, e_p, e_fp = rel_err(fused[0], ref), rel_err(plain, ref), rel_err(fused[0], plain)
     print(f"fused cross-attention: vs oracle {e_f:.3e}, two-kernel vs oracle {e_p:.3e}, fused vs two-kernel {e_fp:.3e}")
-    assert e_f < FWD_TOL[1] and e_p < FWD_TOL[1] and e_fp < 1e-2
+    assert e_f < FWD_TOL[1] and e_p < FWD_TOL[1] and e_fp < 4e-3
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
@@ -248,7 +252,7 @@ def test_vae_decode_and_image(pkg, ctx, dtype):
     out = ld.decode_latent(latent.cuda()).cpu()
     e = rel_err(out, ref)
     print(f"vae decode dtype={dtype}: rel err {e:.3e}")
-    assert e < (1e-4 if dtype == 0 else 3e-2)
+    assert e < (1e-4 if dtype == 0 else 3.2e-3)          # f16 measured 1.6e-3
     img = ld.latent_to_image(latent.cuda())
     assert (img.width, img.height) == (64, 64)
     ref8 = old.latent_to_image(latent)
@@ -269,10 +273,10 @@ def test_vae_encode(pkg, ctx, dtype):
     out = ld.image_to_latent(pkg.RawImages(img.cuda(), 48, 32)).cpu()
     e = rel_err(out, ref)
     print(f"vae encode dtype={dtype}: rel err {e:.3e}")
-    assert out.shape == ref.shape and e < (1e-4 if dtype == 0 else 3e-2)
+    assert out.shape == ref.shape and e < (1e-4 if dtype == 0 else 3.5e-3)   # f16 measured 1.7e-3
     x = torch.from_numpy(img.numpy().astype(np.float32) / 255.0).permute(0, 3, 1, 2) * 2 - 1
     out2 = ld.encode_image(x.cuda()).cpu()
-    assert rel_err(out2, ref) < (1e-4 if dtype == 0 else 3e-2)
+    assert rel_err(out2, ref) < (1e-4 if dtype == 0 else 3.5e-3)
 
 
 @pytest.mark.parametrize("dtype", [0, 1])

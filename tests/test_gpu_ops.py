@@ -158,7 +158,7 @@ def test_layer_norm_linear_large_mean(pkg, ctx, dtype):
     out = pkg.layer_norm_linear(ctx, x.cuda(), gamma.cuda(), beta.cuda(), w.cuda(), None, 1e-5, False, dtype)
     e = rel_err(out, ref)
     print(f"layer_norm_linear large-mean dtype={dtype}: rel err {e:.3e}")
-    assert e < (1e-3 if dtype == 0 else 1e-2)
+    assert e < (1e-3 if dtype == 0 else 1.1e-3)       # f16 stream: measured 5.2e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -400,4 +400,4 @@ def test_igemm_variants_unet(pkg, ctx, igemm_variant, variant):
     ref = OM.unet_forward(ocfg, W, x, t.long(), context, y)
     u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), 1, seed=0)
     out = u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu()
-    assert rel_err(out, ref) < 3e-2
+    assert rel_err(out, ref) < 4.5e-3          # <= 2x the measured class (test_gpu_models.FWD_TOL)
