@@ -174,7 +174,8 @@ int sdxl_diffuser_enable_step_timing(sdxl_diffuser* d, int enabled);
 int sdxl_diffuser_step_times(sdxl_diffuser* d, float* out_ms, int capacity);
 /* parity instrumentation: after DDIM iteration i (< capacity_steps) of every following trajectory the latent [n,4,h/8,w/8]
  * is copied to trace_dev + i * numel (device buffer owned by the caller); NULL / 0 switches it off.  These are the
- * per-step latents `diffuse_latent` rebinds at stablediffusion/mod.rs:424-428. */
+ * per-step latents `diffuse_latent` rebinds at stablediffusion/mod.rs:424-428.  With inpainting the copy is taken behind the fused
+ * DDIM kernel, i.e. it already carries the blend of the NEXT iteration outside the mask (:463-465); the last one carries none. */
 int sdxl_diffuser_set_trace(sdxl_diffuser* d, float* trace_dev, int capacity_steps);
 
 /* ---- LatentDecoder / Autoencoder (stablediffusion/mod.rs:193-267, autoencoder/mod.rs:46-70) */

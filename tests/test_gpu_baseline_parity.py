@@ -286,14 +286,14 @@ def test_refiner_forward_1024_matches_oracle(pkg, ctx):
     assert np.allclose(checksum(x, c, y), g["in_checksum"], rtol=1e-9), "torch CPU generator changed: regenerate the fixtures"
     ref = torch.from_numpy(g["out"])
     rep = {}
-    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f16", pkg.DTYPE_F16, 2 * F16_FWD_REL), ("f16_f32res", pkg.DTYPE_F16_F32RES, 2 * F16RES_FWD_REL)):
+    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f16", pkg.DTYPE_F16, F16_FWD_REL), ("f16_f32res", pkg.DTYPE_F16_F32RES, F16RES_FWD_REL)):
         u = pkg.UNet(ctx, cfg, dt, seed=0)
         outs = [u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu() for _ in range(3)]     # eager, capture, replay
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "hipGraph replay differs from the eager run"
         rep[name] = errs(outs[0], ref)
         del u
         print(f"refiner UNet::forward 1024^2 {name} vs oracle: rel {rep[name]['rel']:.3e} rms-rel {rep[name]['rms_rel']:.3e} max-abs {rep[name]['max_abs']:.3e}")
-        assert rep[name]["rel"] < tol, (name, rep[name])       # (f16: first measurement this round, bound = 2x the base model's)
+        assert rep[name]["rel"] < tol, (name, rep[name])       # measured 2.9e-6 / 1.33e-3 / 9.0e-4: the base model's bounds hold
     REPORT["refiner_forward_1024_vs_oracle"] = rep
 
 
@@ -322,7 +322,7 @@ def test_refine_latent_1024_matches_oracle(pkg, ctx):
     REPORT["refine_latent_1024_vs_oracle"] = rep
     for k in range(2):
         assert rep["f32"]["per_step"][k]["max_abs"] <= lat_bound(ref_traj[k]), (k, rep["f32"]["per_step"][k])
-    assert rep["f16"]["final"]["rel"] < 2 * F16_FWD_REL, rep["f16"]["final"]
+    assert rep["f16"]["final"]["rel"] < 5.5e-4, rep["f16"]["final"]          # measured 2.6e-4 (1.4e-3 abs on |latent| 5.3)
 
 
 def _encode_image():
@@ -350,7 +350,7 @@ def test_encode_1024_matches_oracle(pkg, ctx):
         print(f"image_to_latent 1024^2 {name} vs oracle: max-abs {rep[name]['max_abs']:.3e} rel {rep[name]['rel']:.3e} (|ref| {rep[name]['ref_max']:.3f})")
     REPORT["encode_1024_vs_oracle"] = rep
     assert rep["f32"]["max_abs"] <= LAT_ABS and rep["f32"]["rel"] < 1e-4, rep["f32"]
-    assert rep["f16"]["rel"] < 2 * F16_DECODE_REL, rep["f16"]
+    assert rep["f16"]["rel"] < 3.9e-3, rep["f16"]                            # measured 1.9e-3
 
 
 def test_inpainting_1024_matches_oracle(pkg, ctx):
@@ -364,7 +364,16 @@ def test_inpainting_1024_matches_oracle(pkg, ctx):
     reference = torch.from_numpy(g["reference"])
     mask = torch.zeros(1, 4, 128, 128, dtype=torch.bool)
     mask[:, :, 0:25, :] = True
-    ref_traj, ref = torch.from_numpy(g["traj"]), torch.from_numpy(g["latent"])
+    ref_traj, ref = torch.from_numpy(g["traj"]).clone(), torch.from_numpy(g["latent"])
+    # The engine's per-step trace is taken AFTER its fused DDIM kernel, which already holds the blend for the NEXT iteration
+    # (mask ? latent : reference * sqrt(a_next) + step_noise[next] * sqrt(1 - a_next), stablediffusion/mod.rs:463-465 at the top of
+    # the next loop pass); the oracle's trace is the latent at the bottom of the pass.  Apply the same blend to the oracle's
+    # per-step latents (host f64 scalars as the reference computes them) so whole tensors are compared; the last one has no next.
+    alphas = pkg.default_alphas_cumprod()
+    ts = [999, 749, 499, 249]
+    for k in range(3):
+        a_n = float(alphas[ts[k + 1]])
+        ref_traj[k] = torch.where(mask, ref_traj[k], reference * (a_n ** 0.5) + i["step_noise"][k + 1] * ((1.0 - a_n) ** 0.5))
     rep = {}
     for name, dt in (("f32", pkg.DTYPE_F32), ("f16", pkg.DTYPE_F16)):
         d = pkg.Diffuser(ctx, cfg, dt, seed=0)
@@ -396,7 +405,7 @@ def test_unet_forward_1024_f16_representable_weights(pkg, ctx):
     assert np.allclose(checksum(x, c, y), g["in_checksum"], rtol=1e-9)
     ref = torch.from_numpy(g["out"])
     rep = {}
-    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f16", pkg.DTYPE_F16, F16_FWD_REL), ("f16_f32res", pkg.DTYPE_F16_F32RES, F16RES_FWD_REL)):
+    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f16", pkg.DTYPE_F16, 2.4e-3), ("f16_f32res", pkg.DTYPE_F16_F32RES, 1.3e-3)):   # measured 3.1e-6 / 1.17e-3 / 6.4e-4
         u = pkg.UNet(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS | 0)
         rep[name] = errs(u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu(), ref)
         del u
