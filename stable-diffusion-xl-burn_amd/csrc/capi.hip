@@ -143,6 +143,7 @@ int sdxl_debug_set(const char* key, int value) {
   SDXL_REQUIRE(key != nullptr, "null key");
   if (std::strcmp(key, "igemm_variant") == 0) igemm_set_variant(value);
   else if (std::strcmp(key, "attn_variant") == 0) attention_set_variant(value);
+  else if (std::strcmp(key, "igemm_epilogue_staged") == 0) igemm_set_epilogue_staged(value);
 #ifdef SDXL_MEASURE
   else if (std::strcmp(key, "igemm_unrolled") == 0) igemm_set_unrolled(value);
   else if (std::strcmp(key, "no_cfg") == 0) g_debug_no_cfg = value != 0;

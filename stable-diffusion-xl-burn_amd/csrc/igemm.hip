@@ -345,9 +345,13 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s);   // i
 bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s);             // igemm_glds.hip (strict-fp32 mode)
 static std::atomic<int> g_igemm_variant_a{0};   // test hook (sdxl_debug_set "igemm_variant"): -1 generic kernel only, 0 auto, >0 forced tile
 void igemm_set_variant(int v) { g_igemm_variant_a = v; }
+static std::atomic<int> g_igemm_epi_staged{0};
+void igemm_set_epilogue_staged(int v) { g_igemm_epi_staged = v; }
 
-void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s) {
-  if (p.M <= 0 || p.N <= 0) return;
+void launch_igemm(const IgemmParams& pin, int compute_dt, hipStream_t s) {
+  if (pin.M <= 0 || pin.N <= 0) return;
+  IgemmParams p = pin;
+  p.epi_staged = g_igemm_epi_staged.load();
   const int g_igemm_variant = g_igemm_variant_a.load();
   if (compute_dt == DT_F16 && g_igemm_variant >= 0 && launch_igemm_glds(p, g_igemm_variant, s)) return;
   if (compute_dt == DT_F16 && g_igemm_variant > 0 && launch_igemm_glds(p, 0, s)) return;   // forced tile refused the shape

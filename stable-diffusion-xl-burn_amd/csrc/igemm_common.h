@@ -557,6 +557,171 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
   }
 }
 
+// ---- direct row-per-lane epilogue (whole wave tiles; the default).  Instruction-level timeline of the production kernels
+// (profiles/r03_timeline_*.txt, tools/timeline_probe.py): the LDS-staged epilogue above takes 6.4 k cycles per 32x64 wave tile and
+// 12.6 k per 64x64 -- 3.7 / 5.6 us of every launch, with the stores themselves draining in ~200 cycles: it is bound by its own
+// instruction stream (fp32 LDS round trip, per-item address / validity arithmetic), not by memory.  Here the accumulators never
+// leave the registers: in the operand-swapped 32x32 MFMA layout a lane holds, per 32-column tile, 4 groups of 4 consecutive
+// columns of ONE row (columns 8q + 4(lane>>5) + r), its partner lane^32 the other 4-column halves of the same row.  One
+// v_permlane32_swap per dword and group pair (q, q+1) leaves lanes 0..31 with columns 16t .. 16t+7 and lanes 32..63 with 16t+8 ..
+// 16t+15 of their row (cdna_hip_programming.md T21): 8 consecutive outputs = ONE 16-byte f16 store (two for fp32) and one 16-byte
+// residual load per piece.  Bias / folded-LayerNorm affine / time-embedding bias / GEGLU are applied before the swap in the
+// accumulator layout (same expressions as the staged path); the residual is added, the result rounded once, and the row
+// statistics of the stored values (stat_out) are taken behind it.
+// Row statistics: the 64 columns of a row slot sit in pieces 0,2,4,6 (lanes 0..31) and 1,3,5,7 (lanes 32..63); per-piece shifted
+// sums around the slot's first stored value, then the same pairwise tree as the staged path -- (p0+p1), (p2+p3), ... across the
+// lane halves first, then in-lane -- so both paths produce the same (mean, M2) bits for the same stored values.
+template <int TM, int TN, bool GEGLU>
+__device__ __forceinline__ bool igemm_rows_ok(const IgemmParams& p, int nw) {
+  constexpr int WN = TN * 32;
+  const int nlim = GEGLU ? (p.N >> 1) : (p.n_split < p.N ? p.n_split : p.N);
+  const int n_lo = GEGLU ? (nw >> 1) : nw, n_w = GEGLU ? WN / 2 : WN;
+  if (n_lo + n_w > nlim || p.gn_part) return false;
+  if ((p.ldc & 7) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0) return false;
+  if (p.R && ((p.ldr & 7) != 0 || (reinterpret_cast<uintptr_t>(p.R) & 15) != 0)) return false;
+  if (p.stat_out && (TN != 2 || GEGLU)) return false;
+  if (p.ebias && (p.ebias_ld & 3) != 0) return false;
+  return true;
+}
+template <int TM, int TN, bool GEGLU>
+__device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane,
+                                                    const float (&lnA)[TM], const float (&lnC)[TM], const void* zeros) {
+  const int fr = lane & 31, fh = lane >> 5;
+  const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
+  constexpr int NQ = GEGLU ? 2 : 4;            // value groups of 4 columns per 32-column MFMA tile and lane
+  constexpr int NP = NQ / 2;                   // 8-column pieces per tile and lane after the half swap
+  const int nwo = GEGLU ? (nw >> 1) : nw;
+  int m[TM], bidx[TM];
+  bool mok[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    m[i] = mw + i * 32 + fr;
+    mok[i] = m[i] < p.M;
+    bidx[i] = (p.ebias && mok[i]) ? m[i] / p.rpb : 0;
+  }
+  // residual pieces: requested first (oldest entries of the vmcnt queue), consumed last
+  const bool r16 = p.R && p.r_dt == DT_F16, r32 = p.R && p.r_dt == DT_F32;
+  half8 rh[TM][TN][NP];
+  f32x4 rf[TM][TN][NP][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        const int n0 = nwo + (GEGLU ? j * 16 : j * 32 + t * 16) + 8 * fh;
+        const size_t o = (size_t)(mok[i] ? m[i] : 0) * p.ldr + n0;
+        rh[i][j][t] = *((r16 && mok[i]) ? reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.R) + o) : reinterpret_cast<const half8*>(zeros));
+        if (r32) {   // (fp32 residual stream: wave-uniform branch, the f16 engines never take it)
+          rf[i][j][t][0] = *(mok[i] ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o) : zv);
+          rf[i][j][t][1] = *(mok[i] ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o + 4) : zv);
+        }
+      }
+  float st_s1[TM][4], st_s2[TM][4], st_piv[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    st_piv[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { st_s1[i][k] = 0.f; st_s2[i][k] = 0.f; }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nt = nw + j * 32;
+    // per-column vectors in the accumulator layout (pointer selects: one wait for the lot, see the staged path)
+    f32x4 bz[NQ], cz[NQ], gz[NQ], gc[NQ], ez[TM][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int nb = nt + 8 * q + 4 * fh;
+      bz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
+      cz[q] = *(p.ln_stat ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
+      if constexpr (GEGLU) {
+        gz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb + 16) : zv);
+        gc[q] = *(p.ln_stat ? reinterpret_cast<const f32x4*>(p.ln_cs + nb + 16) : zv);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        ez[i][q] = *(p.ebias ? reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx[i] * p.ebias_ld + nb) : zv);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float lna = lnA[i], lnc = lnC[i];
+      f32x4 v[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q][r] = acc[i][j][q * 4 + r];
+        v[q] = lna * v[q] + lnc * cz[q] + bz[q] + ez[i][q];
+        if constexpr (GEGLU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[q][r] *= gelu_erf2(lna * acc[i][j][(q + 2) * 4 + r] + lnc * gc[q][r] + gz[q][r]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        // half swap of the group pair (2t, 2t+1): lanes 0..31 keep group 2t and receive the partner's group 2t; lanes 32..63 receive
+        // the partner's group 2t+1 and keep their own -> w[0..7] = 8 consecutive columns from n0
+        float w[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * t][r]), __float_as_uint(v[2 * t + 1][r]), false, false);
+          w[r] = __uint_as_float(sw[0]);
+          w[4 + r] = __uint_as_float(sw[1]);
+        }
+        if (r16) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] += (float)rh[i][j][t][e];
+        } else if (r32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { w[e] += rf[i][j][t][0][e]; w[4 + e] += rf[i][j][t][1][e]; }
+        }
+        const int n0 = nwo + (GEGLU ? j * 16 : j * 32 + t * 16) + 8 * fh;
+        if (p.c_dt == DT_F16) {
+          half8 h;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] = (half_t)w[e];
+          if (mok[i]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.C) + (size_t)m[i] * p.ldc + n0) = h;
+          if constexpr (TN == 2 && !GEGLU) {
+            if (p.stat_out) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) w[e] = (float)h[e];      // the stored (rounded) values: what the consumer will read
+            }
+          }
+        } else if (mok[i]) {
+          float* cp = reinterpret_cast<float*>(p.C) + (size_t)m[i] * p.ldc + n0;
+          *reinterpret_cast<f32x4*>(cp) = f32x4{w[0], w[1], w[2], w[3]};
+          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{w[4], w[5], w[6], w[7]};
+        }
+        if constexpr (TN == 2 && !GEGLU) {
+          if (p.stat_out) {
+            if (j == 0 && t == 0) st_piv[i] = __shfl(w[0], fr);      // the slot's first stored value (lanes 0..31 hold it)
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = w[e] - st_piv[i]; s1 += d; s2 = fmaf(d, d, s2); }
+            st_s1[i][j * 2 + t] = s1; st_s2[i][j * 2 + t] = s2;
+          }
+        }
+      }
+    }
+  }
+  if constexpr (TN == 2 && !GEGLU) {
+    if (p.stat_out) {
+      // pieces 2k (lanes 0..31) and 2k+1 (lanes 32..63) pair up across the halves, then (p0+p1)+(p2+p3) and (p4+p5)+(p6+p7) in-lane
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { st_s1[i][k] += __shfl_xor(st_s1[i][k], 32); st_s2[i][k] += __shfl_xor(st_s2[i][k], 32); }
+        const float s1 = (st_s1[i][0] + st_s1[i][1]) + (st_s1[i][2] + st_s1[i][3]);
+        const float s2 = (st_s2[i][0] + st_s2[i][1]) + (st_s2[i][2] + st_s2[i][3]);
+        if (fh == 0 && mok[i]) {
+          float* dst = p.stat_out + ((size_t)(nw >> 6) * p.M + m[i]) * 2;
+          dst[0] = st_piv[i] + s1 * (1.0f / 64.0f);
+          dst[1] = fmaxf(s2 - s1 * s1 * (1.0f / 64.0f), 0.f);
+        }
+      }
+    }
+  }
+}
+
 // dispatch: the staged path needs the wave's column range on one side of n_split; anything else takes the direct epilogue
 template <int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw,

@@ -244,18 +244,27 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   const int lrow = lane >> 3, slot = lane & 7;
   const int HWo = p.Hout * p.Wout;
   const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+  // (prologue cost, tools/timeline_probe.py: the two integer divisions per tile row below took 1.5 - 2.7 k cycles of every launch.
+  // Linear layers / 1x1 convs -- output row m IS source row m -- skip the pixel decomposition altogether; power-of-two image
+  // sizes (every SDXL level) use shifts; anything else keeps the divisions.)
+  const bool lin_rows = p.ksize == 1 && p.stride == 1 && p.up == 0 && p.pad == 0;
+  const bool pow2 = (HWo & (HWo - 1)) == 0 && (p.Wout & (p.Wout - 1)) == 0;
+  const int sh_hw = __builtin_ctz((unsigned)HWo | 0x40000000u), sh_w = __builtin_ctz((unsigned)p.Wout | 0x40000000u);
   int rb[AJ], ry[AJ], rx[AJ], rsw[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int row = (j * NW + wave) * 8 + lrow;
     const int m = m0 + row;
     rsw[j] = (slot ^ ((row >> 1) & 7)) * CE;
-    if (m < p.M) {
-      const int b = m / HWo;
-      const int rem = m - b * HWo;
-      const int oy = rem / p.Wout;
-      rb[j] = b; ry[j] = oy * p.stride - p.pad; rx[j] = (rem - oy * p.Wout) * p.stride - p.pad;
-    } else { rb[j] = -1; ry[j] = -(1 << 28); rx[j] = 0; }
+    rb[j] = m < p.M ? m : -1; ry[j] = 0; rx[j] = 0;          // lin_rows: rb carries the row itself
+    if (!lin_rows) {
+      if (m < p.M) {
+        int b, rem, oy;
+        if (pow2) { b = m >> sh_hw; rem = m & (HWo - 1); oy = rem >> sh_w; }
+        else { b = m / HWo; rem = m - b * HWo; oy = rem / p.Wout; }
+        rb[j] = b; ry[j] = oy * p.stride - p.pad; rx[j] = (rem - oy * p.Wout) * p.stride - p.pad;
+      } else { rb[j] = -1; ry[j] = -(1 << 28); rx[j] = 0; }
+    }
   }
   const T* Ag = reinterpret_cast<const T*>(p.A);
   const T* wptr[BJ];
@@ -278,6 +287,15 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     for (int j = 0; j < BJ; ++j) wptr[j] += e0;
   }
   auto retap = [&]() {
+    if (lin_rows) {       // one tap, rows are contiguous K-runs: no bounds / pixel arithmetic
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const bool ok = rb[j] >= 0 && s_dy == 0;
+        aptr[j] = ok ? Ag + (size_t)rb[j] * p.lda + rsw[j] + s_c0 : reinterpret_cast<const T*>(zeros);
+        aadv[j] = ok ? KT : 0;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int iy = ry[j] + s_dy, ix = rx[j] + s_dx;
@@ -541,8 +559,22 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     xattn_inplace<TM>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros, xkf, xvf);
     IgemmParams pe = p;                       // bias and the LayerNorm affine went into q: the store adds nothing
     pe.bias = nullptr; pe.ln_stat = nullptr;
-    igemm_epilogue_staged<TM, TN>(pe, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC, zeros);
+    if (!p.epi_staged && igemm_rows_ok<TM, TN, false>(pe, n0 + wn * WN))
+      igemm_epilogue_rows<TM, TN, false>(pe, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros);
+    else
+      igemm_epilogue_staged<TM, TN>(pe, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC, zeros);
     return;
+  }
+  // whole wave tiles take the direct row-per-lane epilogue (registers -> permlane32 half swap -> 16-byte stores); tiles cut by N
+  // or n_split, the transposed V^T part, GroupNorm-statistics producers and unaligned outputs keep the LDS-staged one.  The
+  // choice depends on N / alignment only (never on the batch), and every wave makes it for itself (staging regions are private).
+  if (!p.epi_staged) {
+    if (p.act == 1) {
+      if (igemm_rows_ok<TM, TN, true>(p, n0 + wn * WN)) { igemm_epilogue_rows<TM, TN, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros); return; }
+    } else if (igemm_rows_ok<TM, TN, false>(p, n0 + wn * WN)) {
+      igemm_epilogue_rows<TM, TN, false>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros);
+      return;
+    }
   }
   constexpr bool FITS = NW * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
   if (FITS || p.act == 1) {
@@ -721,7 +753,11 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   }
   __builtin_amdgcn_s_barrier();                  // ring dead -> staging area
   asm volatile("" ::: "memory");
-  if (p.act == 1) {
+  if (p.act == 1 && !p.epi_staged && igemm_rows_ok<1, TN, true>(p, n0 + wn * WN)) {
+    const float la0[1] = {lnA[0]}, lc0[1] = {lnC[0]}, la1[1] = {lnA[1]}, lc1[1] = {lnC[1]};
+    igemm_epilogue_rows<1, TN, true>(p, acc0, m0 + wm * WM, n0 + wn * WN, lane, la0, lc0, zeros);
+    igemm_epilogue_rows<1, TN, true>(p, acc1, m0 + wm * WM + 32, n0 + wn * WN, lane, la1, lc1, zeros);
+  } else if (p.act == 1) {
     // two passes of 32 rows: a full 64 x 80 fp32 staging region per wave would not fit next to seven others
     char* region = smem + wave * (32 * (WN / 2) * 4);
     {

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_glds_m_kernel(const IgemmPara
 // done, T4 epilogue done.  Stamps are parked in LDS behind the ring (ds_write: no vmcnt traffic) and dumped at the end to
 // g_tl_buf[workgroup][wave][kTlWords] (igemm_set_timeline).  s_memtime returns through lgkmcnt, so the A stamp is taken behind a
 // lgkmcnt(0) that the schedule itself only issues a few instructions later: ~3 scalar round trips per k-tile of overhead.
-constexpr int kTlTiles = 120, kTlWords = 3 * kTlTiles + 8;
+constexpr int kTlTiles = 116, kTlWords = 3 * kTlTiles + 16;   // words 0..15: phase stamps + meta, then 3 per k-tile
 __device__ unsigned* g_tl_buf = nullptr;
 template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t, int PF = 0, bool XA = false, bool TL = false>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams p, const void* zeros) {
@@ -239,6 +239,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
   if ((size_t)p.N * p.K > (size_t)p.M * p.Cin) { tn = bid / tilesM; tm = bid - tn * tilesM; }
   else { tm = bid / tilesN; tn = bid - tm * tilesN; }
   const int m0 = tm * BM, n0 = tn * BN;
+  if constexpr (TL) { asm volatile("" :: "s"(m0), "s"(n0)); stamp(8); }   // kernel arguments have arrived
   // counted DMA wait: K tiles of this wave's pieces may stay in flight
   auto wait_tiles = [&](auto KK) {
     constexpr int k = decltype(KK)::value;
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
 #pragma unroll
     for (int j = 0; j < BJ; ++j) wptr[j] += e0;
   }
+  stamp(9);    // DMA geometry (row -> pixel divisions) done
   auto retap = [&]() {
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
     }
   };
   retap();
+  stamp(10);   // first tap's source pointers
   // Linear layers (LIN; today = the fused cross-attention projections): scalar-base DMA addressing.  A row of the tile is a
   // contiguous K-run, so piece q reads {wave-uniform 64-bit base in SGPRs} + {loop-invariant 32-bit lane offset}: the k-loop
   // advances TWO scalar bases per k-tile (s_add_u32 / s_addc_u32) instead of PER 64-bit VGPR pointers (2 VALU each) and drops
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
   float* ln_coef = reinterpret_cast<float*>(smem + NS * STAGE + (PF > 0 ? NW * 256 : 0));
   LnC lnc;
   if constexpr (LN_COOP) { lnc.load(p, m0, tid); __builtin_amdgcn_sched_barrier(0); }
+  stamp(11);   // accumulators zeroed, fragment addresses, LayerNorm statistics requested
   // ---- prologue: tiles 0 .. NPRO-1 in flight, wait for tile 0 only
 #pragma unroll
   for (int s = 0; s < NPRO; ++s)
@@ -540,15 +544,15 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
           else if (NS == 3 || kt >= NS - 3) wait_vmcnt<(PER + 1) * (NS - 2)>();
           else wait_vmcnt<PER * (NS - 2) + 1>();
         } else {
-          if constexpr (TL) { wait_lgkmcnt<0>(); stamp(8 + 3 * kt); }
+          if constexpr (TL) { wait_lgkmcnt<0>(); stamp(16 + 3 * kt); }
           if (more) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
-          stamp(9 + 3 * kt);
+          stamp(17 + 3 * kt);
         }
         wait_lgkmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        stamp(10 + 3 * kt);
+        stamp(18 + 3 * kt);
         ldf(SN{}, I0{}, I0{});
       } else {
         wait_lgkmcnt<0>();
@@ -692,6 +696,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
     igemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, fr, fh, lnA, lnC);
   }
   if constexpr (TL) {
+    stamp(12);                                           // epilogue instructions issued (stores in flight)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the epilogue's stores have left the wave
     stamp(4);
     if (lane == 0) { tl[5] = (unsigned)nk; tl[6] = (unsigned)tile_id; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); tl[7] = xcc; }

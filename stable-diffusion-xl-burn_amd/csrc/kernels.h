@@ -55,6 +55,7 @@ struct IgemmParams {
   // GroupNorm statistics of the stored output, from the epilogue (256x128 kernel; igemm_gn_part_ok): gn_part[M/256][N] (mean, M2)
   // of every column over the 256 rows of a tile -- the consumer's GroupNorm merges row tiles and channels (norm.hip, chan_part)
   float* gn_part;
+  int epi_staged;   // A/B knob (sdxl_debug_set "igemm_epilogue_staged"): 1 = LDS-staged epilogue everywhere, 0 = direct row-per-lane where it applies
 };
 bool igemm_gn_part_ok(const IgemmParams& p);
 // shapes the fused cross-attention epilogue takes (f16 operands, head dim 64, <= 96 context tokens); otherwise run the
@@ -68,6 +69,7 @@ size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max);   // sla
 constexpr int kSplitkCounters = 4096;                                // arrival counters a plan must provide (zeroed once)
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
+void igemm_set_epilogue_staged(int v);   // A/B: 1 forces the LDS-staged epilogue (default 0: direct row-per-lane epilogue on whole wave tiles)
 void igemm_set_unrolled(int v);   // auto selection: pipelined kernels with the k-loop unrolled by the ring depth (default on)
 #ifdef SDXL_MEASURE
 void igemm_set_timeline(void* device_buf);   // igemm_measure.hip: stamp buffer of the timeline kernel variants

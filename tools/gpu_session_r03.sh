@@ -34,7 +34,8 @@ for p in $PARTS; do
       f=$(find /tmp/kt -name '*kernel_trace*' | head -1)
       python tools/trace_step_summary.py $f > $OUT/step_kernels.txt 2>&1; python tools/trace_gaps.py $f $OUT/trace_gaps.json > /dev/null 2>&1; head -20 $OUT/step_kernels.txt;;
     sweep) timeout 600 python tools/igemm_sweep.py ${SWEEP_VARIANTS:-0} > $OUT/igemm_sweep.txt 2>&1; tail -25 $OUT/igemm_sweep.txt;;
-    timeline) SDXL_MEASURE_LIB=1 timeout 300 python tools/timeline_probe.py $OUT/timeline_probe.json > $OUT/timeline.txt 2>&1; cat $OUT/timeline.txt;;
+    timeline) SDXL_MEASURE_LIB=1 timeout 300 python tools/timeline_probe.py $OUT/timeline_probe.json > $OUT/timeline.txt 2>&1; cat $OUT/timeline.txt
+      for kv in 0 1; do echo "--- HIP_FORCE_DEV_KERNARG=$kv"; HIP_FORCE_DEV_KERNARG=$kv SDXL_MEASURE_LIB=1 timeout 300 python tools/timeline_probe.py $OUT/timeline_probe_kernarg$kv.json 2>&1 | tee $OUT/timeline_kernarg$kv.txt | grep -E "production|prologue:"; done;;
     vae) timeout 600 python tools/vae_bench.py > $OUT/vae_bench.txt 2>&1; tail -30 $OUT/vae_bench.txt;;
     custom) bash -c "${CUSTOM_CMD}" > $OUT/custom.log 2>&1; tail -40 $OUT/custom.log;;
   esac

@@ -59,17 +59,22 @@ def run(name, B, H, W, Cin, Cout, vprod, vtl, tile):
     # s_memtime is per-XCD: compare entry times only inside one XCD
     ramp = np.concatenate([d(T0[xcc == x], T0[xcc == x].min()).ravel() for x in np.unique(xcc)])
     kt = np.arange(nk - 1)
-    A, Bm, C = t[:, :, 8 + 3 * kt], t[:, :, 9 + 3 * kt], t[:, :, 10 + 3 * kt]
+    A, Bm, C = t[:, :, 16 + 3 * kt], t[:, :, 17 + 3 * kt], t[:, :, 18 + 3 * kt]
     dma_wait, bar_wait = d(Bm, A), d(C, Bm)
     compute = d(A[:, :, 1:], C[:, :, :-1])
     first_compute = d(A[:, :, 0], T2)
     tail = d(T3, C[:, :, -1])                       # last k-tile's compute (no barrier behind it)
     total = d(T4, T0)
     loop = d(T3, T2)
+    P1, P2, P3, P4, E1 = (t[:, :, i] for i in (8, 9, 10, 11, 12))
     st = lambda x: dict(mean=float(x.mean()), p50=float(np.median(x)), p90=float(np.percentile(x, 90)), max=float(x.max()))   # noqa: E731
     rep = dict(shape=name, M=M, N=Cout, K=Cin, tile=f"{bm}x{bn}", workgroups=nwg, waves=nw, k_tiles=nk,
                us_production=us_prod, us_with_stamps=us_tl,
                dispatch_ramp=st(ramp), prologue_issue=st(d(T1, T0)), first_tile_wait=st(d(T2, T1)),
+               prologue_parts=dict(kernel_args=st(d(P1, T0)), dma_geometry=st(d(P2, P1)), first_tap_pointers=st(d(P3, P2)),
+                                   acc_zero_frag_addr_ln_load=st(d(P4, P3)), dma_issue_ring_fill=st(d(T1, P4))),
+               epilogue_parts=dict(barrier_and_issue=st(d(E1, T3)), store_drain=st(d(T4, E1))),
+               kernarg_env=os.environ.get("HIP_FORCE_DEV_KERNARG"),
                first_compute=st(first_compute),
                per_ktile=dict(compute=st(compute), dma_wait=st(dma_wait), barrier_wait=st(bar_wait),
                               sum_mean=float(compute.mean() + dma_wait.mean() + bar_wait.mean())),
@@ -84,6 +89,8 @@ def run(name, B, H, W, Cin, Cout, vprod, vtl, tile):
     print(f"   ramp p50/max {rep['dispatch_ramp']['p50']:.0f}/{rep['dispatch_ramp']['max']:.0f}  prologue {rep['prologue_issue']['mean']:.0f}  "
           f"first-tile wait {rep['first_tile_wait']['mean']:.0f} (max {rep['first_tile_wait']['max']:.0f})  epilogue {rep['epilogue']['mean']:.0f} "
           f"(max {rep['epilogue']['max']:.0f})  lifetime {rep['kernel_wave_lifetime']['mean']:.0f} cycles")
+    pp, ep = rep["prologue_parts"], rep["epilogue_parts"]
+    print("   prologue: " + "  ".join(f"{k} {v['mean']:.0f}" for k, v in pp.items()) + " | epilogue: " + "  ".join(f"{k} {v['mean']:.0f}" for k, v in ep.items()))
     print(f"   per k-tile: compute {pk['compute']['mean']:.0f} (p90 {pk['compute']['p90']:.0f})  dma wait {pk['dma_wait']['mean']:.0f} (p90 {pk['dma_wait']['p90']:.0f})  "
           f"barrier wait {pk['barrier_wait']['mean']:.0f} (p90 {pk['barrier_wait']['p90']:.0f})  = {pk['sum_mean']:.0f} cycles")
     return rep
