@@ -415,6 +415,9 @@ def main():
         raise SystemExit(subprocess.call(cmd))
     import __graft_entry__ as ge
     pkg = ge.load_package()
+    for kv in filter(None, os.environ.get("SDXL_DEBUG_SET", "").split(",")):   # A/B knobs (sdxl_debug_set), e.g. igemm_epilogue_staged=1
+        k_, v_ = kv.split("=")
+        pkg.debug_set(k_, int(v_))
     rank, local_rank, world = init_dist("nccl")
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")

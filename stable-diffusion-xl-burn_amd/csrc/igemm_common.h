@@ -31,6 +31,26 @@ __device__ __forceinline__ float gelu_erf2(float x) {
   return 0.5f * x * (x >= 0.f ? 2.0f - e : e);
 }
 
+// Kernel-argument prefetch.  hipcc loads kernel arguments lazily (s_load right before the first use of each field), and a struct
+// as large as IgemmParams spans five 64-byte lines: the s_memtime timeline of the production kernels (tools/timeline_probe.py,
+// profiles/r03_timeline_*.txt) shows one ~1.5 k-cycle scalar-cache miss to memory at kernel entry, another in the DMA geometry,
+// and three to four more in the epilogue (bias / R / C / ln_* / stat_out live in different lines) -- ~3 us of a 17 us GEMM.
+// Touching every line at entry overlaps all of those misses into the one wait the kernel pays anyway; the later s_loads hit
+// the scalar cache.  (All loads and the wait sit in ONE asm statement: SMEM returns are asynchronous and the compiler does not
+// know these are loads.)
+template <int BYTES> __device__ __forceinline__ void kernarg_prefetch() {
+  const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+  static_assert(BYTES > 64 && BYTES <= 64 * 8, "kernarg_prefetch: 2..8 lines");
+  constexpr int L = (BYTES + 63) / 64;
+  unsigned d1, d2, d3, d4, d5, d6, d7;
+  if constexpr (L <= 2) asm volatile("s_load_dword %0, %1, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=s"(d1) : "s"(ka) : "memory");
+  else if constexpr (L == 3) asm volatile("s_load_dword %0, %2, 0x40\n\ts_load_dword %1, %2, 0x80\n\ts_waitcnt lgkmcnt(0)" : "=s"(d1), "=s"(d2) : "s"(ka) : "memory");
+  else if constexpr (L == 4) asm volatile("s_load_dword %0, %3, 0x40\n\ts_load_dword %1, %3, 0x80\n\ts_load_dword %2, %3, 0xc0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d1), "=s"(d2), "=s"(d3) : "s"(ka) : "memory");
+  else if constexpr (L == 5) asm volatile("s_load_dword %0, %4, 0x40\n\ts_load_dword %1, %4, 0x80\n\ts_load_dword %2, %4, 0xc0\n\ts_load_dword %3, %4, 0x100\n\ts_waitcnt lgkmcnt(0)" : "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4) : "s"(ka) : "memory");
+  else if constexpr (L == 6) asm volatile("s_load_dword %0, %5, 0x40\n\ts_load_dword %1, %5, 0x80\n\ts_load_dword %2, %5, 0xc0\n\ts_load_dword %3, %5, 0x100\n\ts_load_dword %4, %5, 0x140\n\ts_waitcnt lgkmcnt(0)" : "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5) : "s"(ka) : "memory");
+  else asm volatile("s_load_dword %0, %7, 0x40\n\ts_load_dword %1, %7, 0x80\n\ts_load_dword %2, %7, 0xc0\n\ts_load_dword %3, %7, 0x100\n\ts_load_dword %4, %7, 0x140\n\ts_load_dword %5, %7, 0x180\n\ts_load_dword %6, %7, 0x1c0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5), "=s"(d6), "=s"(d7) : "s"(ka) : "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 // LayerNorm-folded GEMM: per output row m the epilogue needs a = rstd and c = -rstd*mu from the producer's row statistics
@@ -583,9 +603,10 @@ __device__ __forceinline__ bool igemm_rows_ok(const IgemmParams& p, int nw) {
   if (p.ebias && (p.ebias_ld & 3) != 0) return false;
   return true;
 }
-template <int TM, int TN, bool GEGLU>
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };   // (timeline twins pass an s_memtime stamper)
+template <int TM, int TN, bool GEGLU, typename ST = NoStamp>
 __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane,
-                                                    const float (&lnA)[TM], const float (&lnC)[TM], const void* zeros) {
+                                                    const float (&lnA)[TM], const float (&lnC)[TM], const void* zeros, const ST& stamp = ST()) {
   const int fr = lane & 31, fh = lane >> 5;
   const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
   constexpr int NQ = GEGLU ? 2 : 4;            // value groups of 4 columns per 32-column MFMA tile and lane
@@ -617,6 +638,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, const 
           rf[i][j][t][1] = *(mok[i] ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o + 4) : zv);
         }
       }
+  stamp(0);      // residual requested
   float st_s1[TM][4], st_s2[TM][4], st_piv[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -642,6 +664,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, const 
       for (int i = 0; i < TM; ++i)
         ez[i][q] = *(p.ebias ? reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx[i] * p.ebias_ld + nb) : zv);
     }
+    stamp(1 + 2 * j);   // column vectors of tile j requested
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const float lna = lnA[i], lnc = lnC[i];
@@ -703,6 +726,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, const 
       }
     }
   }
+  stamp(7);      // all stores issued
   if constexpr (TN == 2 && !GEGLU) {
     if (p.stat_out) {
       // pieces 2k (lanes 0..31) and 2k+1 (lanes 32..63) pair up across the halves, then (p0+p1)+(p2+p3) and (p4+p5)+(p6+p7) in-lane

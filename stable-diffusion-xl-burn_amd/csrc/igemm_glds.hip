@@ -26,7 +26,8 @@
 namespace sdxl {
 
 template <int BM, int BN, int NS, int MINB = 2>
-__global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams p, const void* zeros) {   // >= MINB blocks per CU
+__global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams p, const void* zeros) {
+  kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();   // every argument line in flight at once (one wait instead of five)   // >= MINB blocks per CU
   constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
   constexpr int AJ = BM / 32, BJ = BN / 32;   // DMA instructions per wave per k-tile (8 rows each, 4 waves)
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams
 //     and wait on their own count.
 template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
+  kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();   // every argument line in flight at once (one wait instead of five)
   typedef typename PipeElem<T>::frag frag_t;
   constexpr int CE = 16 / (int)sizeof(T);     // elements per 16-byte chunk: 8 (f16) or 4 (f32, strict mode)
   constexpr int WGN = NW / WGM;               // NW waves per workgroup (8, or 4 with twice the wave tile)
@@ -370,13 +372,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     }
   };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc[TM][TN];   // (zeroed behind the prologue's DMA issue: the writes ride under the ring fill)
 
   const int fr = lane & 31, fh = lane >> 5;
   // per-lane fragment address inside a stage: A rows wm*WM + i*32 + fr (i -> +4096 B immediate), B rows likewise behind
@@ -432,6 +428,13 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
 #pragma unroll
   for (int s = 0; s < NPRO; ++s)
     if (s < nk) { issue(s, IALL{}); tile_done(); }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float lnA[TM], lnC[TM];
   const bool ln_coop = LN_COOP && p.ln_slots <= 24;
   if constexpr (LN_COOP) lnc.finish(p, m0, ln_coef);
@@ -568,13 +571,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   // whole wave tiles take the direct row-per-lane epilogue (registers -> permlane32 half swap -> 16-byte stores); tiles cut by N
   // or n_split, the transposed V^T part, GroupNorm-statistics producers and unaligned outputs keep the LDS-staged one.  The
   // choice depends on N / alignment only (never on the batch), and every wave makes it for itself (staging regions are private).
-  if (!p.epi_staged) {
-    if (p.act == 1) {
-      if (igemm_rows_ok<TM, TN, true>(p, n0 + wn * WN)) { igemm_epilogue_rows<TM, TN, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros); return; }
-    } else if (igemm_rows_ok<TM, TN, false>(p, n0 + wn * WN)) {
-      igemm_epilogue_rows<TM, TN, false>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros);
-      return;
-    }
+  // (GEGLU projections keep the staged epilogue: measured per shape in the step, tools/launch_ab.py, the direct form is 1 - 5 us
+  // faster on every plain shape and 23 - 50 us SLOWER on the 256x320 GEGLU kernel, whose 160 accumulator registers leave no
+  // room for the per-column vectors -- profiles/r03_epilogue_ab.txt)
+  if (!p.epi_staged && p.act != 1 && igemm_rows_ok<TM, TN, false>(p, n0 + wn * WN)) {
+    igemm_epilogue_rows<TM, TN, false>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros);
+    return;
   }
   constexpr bool FITS = NW * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
   if (FITS || p.act == 1) {
@@ -604,6 +606,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
 // tile kt+NS (slot just freed) issued between them}.  GEGLU epilogue only (staged through LDS in two 32-row passes).
 template <int NS>
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, const void* zeros) {
+  kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();   // every argument line in flight at once (one wait instead of five)
   constexpr int BM = 256, BN = 320, KT = 32;
   constexpr int WM = 64, WN = 160, TM = 2, TN = 5, NF = TM + TN;
   constexpr int ROWB = KT * 2;                 // 64 bytes per tile row
@@ -753,11 +756,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   }
   __builtin_amdgcn_s_barrier();                  // ring dead -> staging area
   asm volatile("" ::: "memory");
-  if (p.act == 1 && !p.epi_staged && igemm_rows_ok<1, TN, true>(p, n0 + wn * WN)) {
-    const float la0[1] = {lnA[0]}, lc0[1] = {lnC[0]}, la1[1] = {lnA[1]}, lc1[1] = {lnC[1]};
-    igemm_epilogue_rows<1, TN, true>(p, acc0, m0 + wm * WM, n0 + wn * WN, lane, la0, lc0, zeros);
-    igemm_epilogue_rows<1, TN, true>(p, acc1, m0 + wm * WM + 32, n0 + wn * WN, lane, la1, lc1, zeros);
-  } else if (p.act == 1) {
+  if (p.act == 1) {
     // two passes of 32 rows: a full 64 x 80 fp32 staging region per wave would not fit next to seven others
     char* region = smem + wave * (32 * (WN / 2) * 4);
     {

@@ -180,6 +180,7 @@ constexpr int kTlTiles = 116, kTlWords = 3 * kTlTiles + 16;   // words 0..15: ph
 __device__ unsigned* g_tl_buf = nullptr;
 template <int BM, int BN, int NS, bool PRIO, int DMODE = 0, int WGM = 4, int NW = 8, bool UNR = false, typename T = half_t, int PF = 0, bool XA = false, bool TL = false>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams p, const void* zeros) {
+  kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();   // every argument line in flight at once (one wait instead of five)
   typedef typename PipeElem<T>::frag frag_t;
   constexpr int CE = 16 / (int)sizeof(T);     // elements per 16-byte chunk: 8 (f16) or 4 (f32, strict mode)
   static_assert(sizeof(T) == 2 || DMODE == 0, "measurement modes exist for the f16 kernel only");
@@ -252,18 +253,24 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
   const int lrow = lane >> 3, slot = lane & 7;
   const int HWo = p.Hout * p.Wout;
   const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+  const bool lin_rows = p.ksize == 1 && p.stride == 1 && p.up == 0 && p.pad == 0 && !CONTIG;   // as the production kernel
+  const bool pow2 = (HWo & (HWo - 1)) == 0 && (p.Wout & (p.Wout - 1)) == 0;
+  const int sh_hw = __builtin_ctz((unsigned)HWo | 0x40000000u), sh_w = __builtin_ctz((unsigned)p.Wout | 0x40000000u);
   int rb[AJ], ry[AJ], rx[AJ], rsw[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int row = (j * NW + wave) * 8 + lrow;
     const int m = m0 + row;
     rsw[j] = (slot ^ ((row >> 1) & 7)) * CE;
-    if (m < p.M) {
-      const int b = m / HWo;
-      const int rem = m - b * HWo;
-      const int oy = rem / p.Wout;
-      rb[j] = b; ry[j] = oy * p.stride - p.pad; rx[j] = (rem - oy * p.Wout) * p.stride - p.pad;
-    } else { rb[j] = -1; ry[j] = -(1 << 28); rx[j] = 0; }
+    rb[j] = m < p.M ? m : -1; ry[j] = 0; rx[j] = 0;
+    if (!lin_rows) {
+      if (m < p.M) {
+        int b, rem, oy;
+        if (pow2) { b = m >> sh_hw; rem = m & (HWo - 1); oy = rem >> sh_w; }
+        else { b = m / HWo; rem = m - b * HWo; oy = rem / p.Wout; }
+        rb[j] = b; ry[j] = oy * p.stride - p.pad; rx[j] = (rem - oy * p.Wout) * p.stride - p.pad;
+      } else { rb[j] = -1; ry[j] = -(1 << 28); rx[j] = 0; }
+    }
   }
   const T* Ag = reinterpret_cast<const T*>(p.A);
   const T* wptr[BJ];
@@ -287,6 +294,15 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
   }
   stamp(9);    // DMA geometry (row -> pixel divisions) done
   auto retap = [&]() {
+    if (lin_rows) {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const bool ok = rb[j] >= 0 && s_dy == 0;
+        aptr[j] = ok ? Ag + (size_t)rb[j] * p.lda + rsw[j] + s_c0 : reinterpret_cast<const T*>(zeros);
+        aadv[j] = ok ? KT : 0;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int iy = ry[j] + s_dy, ix = rx[j] + s_dx;
@@ -385,13 +401,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
     }
   };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc[TM][TN];   // (zeroed behind the prologue's DMA issue: the writes ride under the ring fill)
 
   const int fr = lane & 31, fh = lane >> 5;
   // per-lane fragment address inside a stage: A rows wm*WM + i*32 + fr (i -> +4096 B immediate), B rows likewise behind
@@ -466,6 +476,13 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
 #pragma unroll
   for (int s = 0; s < NPRO; ++s)
     if (s < nk) { issue(s, IALL{}); tile_done(); }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   stamp(1);
   float lnA[TM], lnC[TM];
   const bool ln_coop = LN_COOP && p.ln_slots <= 24;
@@ -683,8 +700,18 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
     igemm_epilogue_staged<TM, TN>(pe, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (WM * WN * 4), lnA, lnC, zeros);
     return;
   }
+  bool rows_done = false;
+  if (!p.epi_staged) {       // the production kernel's direct row-per-lane epilogue
+    if (p.act != 1 && igemm_rows_ok<TM, TN, false>(p, n0 + wn * WN)) {
+      stamp(13);     // barrier passed, path chosen
+      auto est = [&](int i) { if (i == 0) stamp(14); else if (i == 1) stamp(15); else if (i == 7) stamp(7 - 1); };   // words 14, 15, 6 (tile_id moves out)
+      igemm_epilogue_rows<TM, TN, false>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros, est);
+      rows_done = true;
+    }
+  }
   constexpr bool FITS = NW * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
-  if (FITS || p.act == 1) {
+  if (rows_done) {
+  } else if (FITS || p.act == 1) {
     const int region = p.act == 1 ? WM * (WN / 2) * 4 : WM * WN * 4;   // GEGLU halves the staged width
     if constexpr (BM == 256 && BN == 128 && NW == 8 && WGM == 4 && sizeof(T) == 2) {
       static_assert(NW * WM * WN * 4 + 4096 <= NS * STAGE, "GroupNorm-statistics scratch must fit behind the staging regions");
@@ -699,7 +726,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_m_kernel(const IgemmParams
     stamp(12);                                           // epilogue instructions issued (stores in flight)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the epilogue's stores have left the wave
     stamp(4);
-    if (lane == 0) { tl[5] = (unsigned)nk; tl[6] = (unsigned)tile_id; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); tl[7] = xcc; }
+    if (lane == 0) { tl[5] = (unsigned)nk; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); tl[7] = xcc; }
     __builtin_amdgcn_s_waitcnt(0);
     if (g_tl_buf)
       for (int i = lane; i < kTlWords; i += 64) g_tl_buf[((size_t)blockIdx.x * NW + wave) * kTlWords + i] = tl[i];

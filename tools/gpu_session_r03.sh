@@ -35,8 +35,11 @@ for p in $PARTS; do
       python tools/trace_step_summary.py $f > $OUT/step_kernels.txt 2>&1; python tools/trace_gaps.py $f $OUT/trace_gaps.json > /dev/null 2>&1; head -20 $OUT/step_kernels.txt;;
     sweep) timeout 600 python tools/igemm_sweep.py ${SWEEP_VARIANTS:-0} > $OUT/igemm_sweep.txt 2>&1; tail -25 $OUT/igemm_sweep.txt;;
     timeline) SDXL_MEASURE_LIB=1 timeout 300 python tools/timeline_probe.py $OUT/timeline_probe.json > $OUT/timeline.txt 2>&1; cat $OUT/timeline.txt
-      for kv in 0 1; do echo "--- HIP_FORCE_DEV_KERNARG=$kv"; HIP_FORCE_DEV_KERNARG=$kv SDXL_MEASURE_LIB=1 timeout 300 python tools/timeline_probe.py $OUT/timeline_probe_kernarg$kv.json 2>&1 | tee $OUT/timeline_kernarg$kv.txt | grep -E "production|prologue:"; done;;
+      echo "--- LDS-staged epilogue"; EPI_STAGED=1 SDXL_MEASURE_LIB=1 timeout 300 python tools/timeline_probe.py $OUT/timeline_probe_staged.json 2>&1 | tee $OUT/timeline_staged.txt | grep -E "production|prologue:";;
+    timeline_kernarg) for kv in 0 1; do echo "--- HIP_FORCE_DEV_KERNARG=$kv"; HIP_FORCE_DEV_KERNARG=$kv SDXL_MEASURE_LIB=1 timeout 300 python tools/timeline_probe.py $OUT/timeline_probe_kernarg$kv.json 2>&1 | tee $OUT/timeline_kernarg$kv.txt | grep -E "production|prologue:"; done;;
     vae) timeout 600 python tools/vae_bench.py > $OUT/vae_bench.txt 2>&1; tail -30 $OUT/vae_bench.txt;;
+    benchab) # A/B of a debug knob on the bench line: AB_KNOB="igemm_epilogue_staged=1"
+      for kn in "" "${AB_KNOB:-}" "" "${AB_KNOB:-}"; do SDXL_DEBUG_SET="$kn" timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-parity 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('knob[%s]' % '$kn', d['value'], d['unet_step_ms_p50'], d['roofline']['class_ms_per_unet_step'], d['roofline']['frac'])"; done | tee $OUT/benchab.txt;;
     custom) bash -c "${CUSTOM_CMD}" > $OUT/custom.log 2>&1; tail -40 $OUT/custom.log;;
   esac
 done

@@ -74,6 +74,9 @@ def run(name, B, H, W, Cin, Cout, vprod, vtl, tile):
                prologue_parts=dict(kernel_args=st(d(P1, T0)), dma_geometry=st(d(P2, P1)), first_tap_pointers=st(d(P3, P2)),
                                    acc_zero_frag_addr_ln_load=st(d(P4, P3)), dma_issue_ring_fill=st(d(T1, P4))),
                epilogue_parts=dict(barrier_and_issue=st(d(E1, T3)), store_drain=st(d(T4, E1))),
+               epilogue_rows=dict(last_barrier=st(d(t[:, :, 13], T3)), residual_request=st(d(t[:, :, 14], t[:, :, 13])),
+                                  vectors_request=st(d(t[:, :, 15], t[:, :, 14])), math_swap_stores=st(d(t[:, :, 6], t[:, :, 15])),
+                                  tail=st(d(E1, t[:, :, 6]))) if int(t[0, 0, 13]) != 0 else None,
                kernarg_env=os.environ.get("HIP_FORCE_DEV_KERNARG"),
                first_compute=st(first_compute),
                per_ktile=dict(compute=st(compute), dma_wait=st(dma_wait), barrier_wait=st(bar_wait),
@@ -91,12 +94,16 @@ def run(name, B, H, W, Cin, Cout, vprod, vtl, tile):
           f"(max {rep['epilogue']['max']:.0f})  lifetime {rep['kernel_wave_lifetime']['mean']:.0f} cycles")
     pp, ep = rep["prologue_parts"], rep["epilogue_parts"]
     print("   prologue: " + "  ".join(f"{k} {v['mean']:.0f}" for k, v in pp.items()) + " | epilogue: " + "  ".join(f"{k} {v['mean']:.0f}" for k, v in ep.items()))
+    if rep["epilogue_rows"]:
+        print("   direct epilogue: " + "  ".join(f"{k} {v['mean']:.0f}" for k, v in rep["epilogue_rows"].items()))
     print(f"   per k-tile: compute {pk['compute']['mean']:.0f} (p90 {pk['compute']['p90']:.0f})  dma wait {pk['dma_wait']['mean']:.0f} (p90 {pk['dma_wait']['p90']:.0f})  "
           f"barrier wait {pk['barrier_wait']['mean']:.0f} (p90 {pk['barrier_wait']['p90']:.0f})  = {pk['sum_mean']:.0f} cycles")
     return rep
 
 
 def main():
+    if os.environ.get("EPI_STAGED"):
+        pkg.debug_set("igemm_epilogue_staged", int(os.environ["EPI_STAGED"]))
     out = [run(*s) for s in SHAPES]
     path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/timeline_probe.json"
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
