@@ -264,7 +264,7 @@ def load_parity():
                 out[f"config2_{k}_vs_f32_final_rel"] = t[k + "_vs_f32"][-1]["rel"]
                 out[f"config2_{k}_vs_f32_final_max_abs"] = t[k + "_vs_f32"][-1]["max_abs"]
         d = r.get("decode_1024_vs_oracle", {})
-        for k in ("f32", "f16"):
+        for k in ("f32", "f32_split", "f16"):
             if k in d:
                 out[f"decode_1024_{k}_vs_oracle_image_max_abs"] = d[k]["image_sub"]["max_abs"]
                 out[f"decode_1024_{k}_u8_max_diff"] = d[k]["u8_max_diff"]
@@ -372,8 +372,9 @@ def main():
     ap.add_argument("--n-steps", type=int, default=None, help="--n-diffusion-steps of the reference CLI (30 -> 31 iterations)")
     ap.add_argument("--cfg", type=float, default=None)
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res"])
-    ap.add_argument("--vae-dtype", default="f32", choices=["f16", "f32"],
-                    help="arithmetic of the VAE legs; the reference decodes in f32 (src/bin/sample/main.rs:121,271-278)")
+    ap.add_argument("--vae-dtype", default="f32", choices=["f16", "f32", "f32_split"],
+                    help="arithmetic of the VAE legs; the reference decodes in f32 (src/bin/sample/main.rs:121,271-278): f32 = exact-fp32 "
+                         "MFMA, f32_split = fp32-class results from three f16 MFMAs per product on (hi, lo) operand pairs")
     ap.add_argument("--pipeline-decode", action="store_true",
                     help="decode image i on a second HIP stream under the sampling of image i+1 (measured +0.3 %% only: both legs "
                          "are chip-filling MFMA work; off by default)")
@@ -423,7 +424,7 @@ def main():
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    dts = {"f16": pkg.DTYPE_F16, "f32": pkg.DTYPE_F32, "f16_f32res": pkg.DTYPE_F16_F32RES}
+    dts = {"f16": pkg.DTYPE_F16, "f32": pkg.DTYPE_F32, "f16_f32res": pkg.DTYPE_F16_F32RES, "f32_split": pkg.DTYPE_F32_SPLIT}
     dt, vdt = dts[args.dtype], dts[args.vae_dtype]
 
     ctx = pkg.Context(local_rank)

@@ -38,7 +38,11 @@ enum { SDXL_OK = 0, SDXL_ERR_INVALID = 1, SDXL_ERR_RUNTIME = 2 };
 enum {
   SDXL_DTYPE_F32 = 0,       /* strict-parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)      */
   SDXL_DTYPE_F16 = 1,       /* fp16 storage + fp16 MFMA operands, fp32 accumulation/statistics/softmax           */
-  SDXL_DTYPE_F16_F32RES = 2 /* fp16 MFMA operands, fp32 residual stream                                         */
+  SDXL_DTYPE_F16_F32RES = 2,/* fp16 MFMA operands, fp32 residual stream                                         */
+  SDXL_DTYPE_F32_SPLIT = 3  /* VAE only (sdxl_vae_create*): fp32 storage of the residual stream, GEMM operands as (hi, lo) f16 pairs and
+                             * three f16 MFMAs per product (a*w ~ ah*wh + al*wh + ah*wl, 22-bit significands, fp32 accumulation):
+                             * fp32-class results -- the reference decodes in f32, src/bin/sample/main.rs:121,271-278 -- at a third
+                             * of the f16 matrix rate instead of the 1/16 of the exact-fp32 MFMA                                   */
 };
 
 /* UNetConfig (src/model/unet/mod.rs:59-69) + DiffuserConfig.is_refiner (src/model/stablediffusion/mod.rs:269-278) */

@@ -25,6 +25,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsdxl_mi355_measure.so" if os.environ.g
 DTYPE_F32 = 0        # strict parity: fp32 storage + exact fp32 MFMA
 DTYPE_F16 = 1        # fp16 storage / MFMA operands, fp32 accumulate
 DTYPE_F16_F32RES = 2  # fp16 MFMA operands, fp32 residual stream
+DTYPE_F32_SPLIT = 3   # LatentDecoder only: fp32-class VAE on the f16 matrix pipe (operands as (hi, lo) f16 pairs, 3 MFMAs per product)
 
 _c_p = ctypes.c_void_p
 _f_p = ctypes.c_void_p   # device pointers travel as integers

@@ -63,8 +63,14 @@ void dtypes(int dtype, int& cdt, int& sdt) {
     case SDXL_DTYPE_F32: cdt = DT_F32; sdt = DT_F32; break;
     case SDXL_DTYPE_F16: cdt = DT_F16; sdt = DT_F16; break;
     case SDXL_DTYPE_F16_F32RES: cdt = DT_F16; sdt = DT_F32; break;
+    case SDXL_DTYPE_F32_SPLIT: throw Error("SDXL_DTYPE_F32_SPLIT is a VAE precision (sdxl_vae_create*)");
     default: throw Error("unknown dtype");
   }
+}
+void vae_dtype(int dtype, int& cdt) {     // the VAE additionally takes the split-operand fp32-class mode
+  int sdt;
+  if (dtype == SDXL_DTYPE_F32_SPLIT) { cdt = DT_HL; return; }
+  dtypes(dtype, cdt, sdt);
 }
 int spec_out(const std::vector<ParamSpec>& specs, int index, const char** name, int* ndim, int64_t shape[4], int* kind,
              float* sc, float* mean) {
@@ -701,7 +707,7 @@ int sdxl_vae_create_f16(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, co
   API_BEGIN
   SDXL_REQUIRE(ctx && out && (dec_w || enc_w), "bad argument");
   use(ctx);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt; vae_dtype(dtype, cdt);
   const VaeCfg vc = to_vcfg(cfg);
   const std::vector<ParamSpec> ds = vae_decoder_param_specs(vc), es = vae_encoder_param_specs(vc);
   std::unique_ptr<FlatSourceF16> d, e;
@@ -717,7 +723,7 @@ int sdxl_vae_create(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, const 
   API_BEGIN
   SDXL_REQUIRE(ctx && out && (dec_w || enc_w), "bad argument");
   use(ctx);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt; vae_dtype(dtype, cdt);
   const VaeCfg vc = to_vcfg(cfg);
   const std::vector<ParamSpec> ds = vae_decoder_param_specs(vc), es = vae_encoder_param_specs(vc);
   std::unique_ptr<FlatSource> d, e;
@@ -733,7 +739,7 @@ int sdxl_vae_create_synthetic(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dty
   API_BEGIN
   SDXL_REQUIRE(ctx && out, "bad argument");
   use(ctx);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt; vae_dtype(dtype, cdt);
   SyntheticSource src(seed);
   sdxl_vae* h = new sdxl_vae();
   h->ctx = ctx;
@@ -846,7 +852,10 @@ int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   SDXL_REQUIRE(ctx && x && weight && out, "null argument");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt, sdt;
+  if (dtype == SDXL_DTYPE_F32_SPLIT) { cdt = DT_HL; sdt = DT_HL; }   // split-operand GEMM as an operator (the VAE's precision): HL16 operands
+  else dtypes(dtype, cdt, sdt);
+  SDXL_REQUIRE(cdt != DT_HL || Cin % 32 == 0, "SDXL_DTYPE_F32_SPLIT convolutions need Cin % 32 == 0");
   const int Hs = upsample ? 2 * H : H, Ws = upsample ? 2 * W : W;
   const int Ho = (Hs + 2 * pad - ksize) / stride + 1, Wo = (Ws + 2 * pad - ksize) / stride + 1;
   const int kt = cdt == DT_F16 ? 64 : 32;
@@ -857,10 +866,26 @@ int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   float* bp = (float*)tmp.get((size_t)l.Npad * sizeof(float));
   void* xi = tmp.get((size_t)B * H * W * Cin * dt_size(sdt));
   float* yo = (float*)tmp.get((size_t)B * Ho * Wo * Cout * sizeof(float));
-  launch_pack_conv(weight, wp, cdt, Cout, Cin, ksize, l.Kpad, l.Npad, s);
+  float wscale = 1.f;
+  if (cdt == DT_HL) {     // power-of-two weight scale from max |w|, exactly as WeightBuilder::conv
+    float* sc = (float*)tmp.get(256);
+    launch_absmax(weight, (size_t)Cout * l.K, sc, s);
+    float h = 0.f;
+    SDXL_HIP(hipMemcpyAsync(&h, sc, sizeof(float), hipMemcpyDeviceToHost, s));
+    SDXL_HIP(hipStreamSynchronize(s));
+    int e = 0;
+    if (h > 0.f && std::isfinite(h)) { (void)std::frexp(h, &e); e = 14 - e; }
+    e = e > 24 ? 24 : (e < -24 ? -24 : e);
+    wscale = std::ldexp(1.0f, e);
+    const float inv = 1.0f / wscale;
+    SDXL_HIP(hipMemcpyAsync(sc, &inv, sizeof(float), hipMemcpyHostToDevice, s));
+    SDXL_HIP(hipStreamSynchronize(s));
+    l.acc_scale = sc;
+  }
+  launch_pack_conv(weight, wp, cdt, Cout, Cin, ksize, l.Kpad, l.Npad, s, wscale);
   launch_pack_bias(bias, bp, Cout, l.Npad, 0, 0, s);
   l.w = wp; l.b = bp;
-  launch_nchw_to_nhwc(x, Cin * H * W, xi, sdt, B, Cin, H * W, Cin, 1.0f, s);
+  launch_nchw_to_nhwc(x, Cin * H * W, xi, sdt, B, Cin, H * W, Cin, 1.0f, s);     // (st_f handles the HL16 layout: Cin % 16 == 0 rows)
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
   give_splitk_ws(ex, tmp, B, Ho * Wo, Cout, s);
   run_conv(ex, l, Act(xi, Cin, sdt), Cin, ConvGeom{B, H, W, Ho, Wo, ksize, stride, pad, upsample ? 1 : 0}, Act(yo, Cout, DT_F32));

@@ -11,11 +11,18 @@ typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// DT_HL (split-operand storage "HL16", kernels.h): logical element i of a tensor whose rows are multiples of 16 elements lives as
+// hi = f16(v) at half index (i/16)*32 + i%16 and lo = f16(v - hi) 16 halfs further
 __device__ __forceinline__ float ld_f(const void* p, size_t i, int dt) {
+  if (dt == DT_HL) { const half_t* b = reinterpret_cast<const half_t*>(p) + ((i >> 4) << 5) + (i & 15); return (float)b[0] + (float)b[16]; }
   return dt == DT_F16 ? (float)reinterpret_cast<const half_t*>(p)[i] : reinterpret_cast<const float*>(p)[i];
 }
 __device__ __forceinline__ void st_f(void* p, size_t i, int dt, float v) {
-  if (dt == DT_F16) reinterpret_cast<half_t*>(p)[i] = (half_t)v; else reinterpret_cast<float*>(p)[i] = v;
+  if (dt == DT_HL) {
+    half_t* b = reinterpret_cast<half_t*>(p) + ((i >> 4) << 5) + (i & 15);
+    const half_t hi = (half_t)v;
+    b[0] = hi; b[16] = (half_t)(v - (float)hi);
+  } else if (dt == DT_F16) reinterpret_cast<half_t*>(p)[i] = (half_t)v; else reinterpret_cast<float*>(p)[i] = v;
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
@@ -230,6 +237,30 @@ void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s) {
   hipLaunchKernelGGL(i32_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
 }
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s) { (void)hipMemsetAsync(p, 0, bytes, s); }
+// 8 channels per thread: two 16-byte loads -> hi / lo f16 octets, two 16-byte stores
+__global__ void f32_to_hl_kernel(const float* src, int lds_, half_t* dst, int ldd, size_t rows, int C8) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C8) return;
+  const size_t r = i / C8;
+  const int c = (int)(i - r * C8) * 8;
+  const float* sp = src + r * lds_ + c;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+  half8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (half_t)a[e]; lo[e] = (half_t)(a[e] - (float)hi[e]);
+    hi[4 + e] = (half_t)b[e]; lo[4 + e] = (half_t)(b[e] - (float)hi[4 + e]);
+  }
+  half_t* dp = dst + r * 2 * (size_t)ldd + ((c >> 4) << 5) + (c & 15);
+  *reinterpret_cast<half8*>(dp) = hi;
+  *reinterpret_cast<half8*>(dp + 16) = lo;
+}
+void launch_f32_to_hl(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, hipStream_t s) {
+  if ((C & 15) != 0 || (lds_ & 3) != 0 || (ldd & 15) != 0) throw std::runtime_error("f32_to_hl: C % 16 == 0 rows with aligned strides only");
+  const size_t total = rows * (size_t)(C / 8);
+  hipLaunchKernelGGL(f32_to_hl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
+                     reinterpret_cast<half_t*>(dst), ldd, rows, C / 8);
+}
 __global__ void round_f16_kernel(float* p, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = (float)(half_t)p[i];
@@ -403,6 +434,19 @@ __device__ __forceinline__ int geglu_unpermute(int pcol, int N) {
   const int g = pcol >> 5, w = pcol & 31, nh = N >> 1;
   return w < 16 ? g * 16 + w : nh + g * 16 + (w - 16);
 }
+// max |x| of a tensor (power-of-two weight scale of the split-operand packing): one atomicMax on the float bits per block
+__global__ void absmax_kernel(const float* src, size_t n, unsigned* out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s) {
+  (void)hipMemsetAsync(out_dev, 0, sizeof(float), s);
+  const unsigned blocks = (unsigned)std::min<size_t>(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, src, n, reinterpret_cast<unsigned*>(out_dev));
+}
 __global__ void pack_linear_kernel(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu,
                                    int n_offset, const float* kscale) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,7 +491,7 @@ __global__ void beta_dot_kernel(const float* w, const float* beta, const float* 
 void launch_beta_dot(const float* w, const float* beta, const float* bias, float* out, int K, int N, hipStream_t s) {
   hipLaunchKernelGGL(beta_dot_kernel, dim3((N + 255) / 256), dim3(256), 0, s, w, beta, bias, out, K, N);
 }
-__global__ void pack_conv_kernel(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad) {
+__global__ void pack_conv_kernel(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad, float wscale) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)Npad * Kpad) return;
   const int n = i / Kpad;
@@ -456,13 +500,13 @@ __global__ void pack_conv_kernel(const float* src, void* dst, int dt, int Cout, 
   if (n < Cout && k < ks * ks * Cin) {
     const int tap = k / Cin, c = k - tap * Cin;
     const int ky = tap / ks, kx = tap - ky * ks;
-    v = src[(((size_t)n * Cin + c) * ks + ky) * ks + kx];
+    v = src[(((size_t)n * Cin + c) * ks + ky) * ks + kx] * wscale;     // wscale: power of two (DT_HL packing), 1 otherwise
   }
   st_f(dst, i, dt, v);
 }
-void launch_pack_conv(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad, hipStream_t s) {
+void launch_pack_conv(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad, hipStream_t s, float wscale) {
   const size_t total = (size_t)Npad * Kpad;
-  hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, Cout, Cin, ks, Kpad, Npad);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, Cout, Cin, ks, Kpad, Npad, wscale);
 }
 __global__ void pack_bias_kernel(const float* src, float* dst, int N, int Npad, int geglu, int n_offset) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -117,6 +117,9 @@ struct Lin {        // packed dense weight: [Npad][Kpad] compute dtype + fp32 bi
   // packed rows; the GEMM then takes the RAW rows plus their per-64-column (mean, M2) statistics -- see IgemmParams::ln_stat
   const float* cs = nullptr;
   const float* ln_eps = nullptr;   // device scalar: eps of the folded LayerNorm
+  int dt = -1;                     // dtype the weight was packed in when it differs from the model's compute dtype (-1: the model's):
+                                   // a DT_HL model packs the layers its pipeline cannot take (Cin % 32 != 0) as fp32
+  const float* acc_scale = nullptr;   // DT_HL packing: device scalar (weight arena) 1 / (power-of-two factor the packed weights carry)
 };
 // eps lives in the weight arena (device scalar, read by the kernels): replicas that receive the arena by broadcast need no
 // host-side copy, and a checkpoint's per-norm eps (groupnorm/load.rs:19, layernorm/load.rs:17) travels with the weights
@@ -330,6 +333,9 @@ class Vae {
   DeviceArena act_;
   size_t act_peak_ = 0;
   float* gn_workspace(Exec& ex, int n);
+  // dtype of the residual stream and of the 3- / 4- / 8-channel ends: the compute dtype, except that the split-operand mode
+  // (DT_HL operands for the GEMMs) keeps them in plain fp32
+  int io_dt() const { return cdt_ == DT_HL ? DT_F32 : cdt_; }
 };
 
 // ------------------------------------------------------------------------------------------ CLIP text encoder (Embedder)

@@ -343,6 +343,7 @@ static void launch_tiles(const IgemmParams& p, hipStream_t s) {
 
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s);   // igemm_glds.hip
 bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s);             // igemm_glds.hip (strict-fp32 mode)
+bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s);              // igemm_glds.hip (split-operand fp32-class mode)
 static std::atomic<int> g_igemm_variant_a{0};   // test hook (sdxl_debug_set "igemm_variant"): -1 generic kernel only, 0 auto, >0 forced tile
 void igemm_set_variant(int v) { g_igemm_variant_a = v; }
 static std::atomic<int> g_igemm_epi_staged{0};
@@ -356,6 +357,10 @@ void launch_igemm(const IgemmParams& pin, int compute_dt, hipStream_t s) {
   if (compute_dt == DT_F16 && g_igemm_variant >= 0 && launch_igemm_glds(p, g_igemm_variant, s)) return;
   if (compute_dt == DT_F16 && g_igemm_variant > 0 && launch_igemm_glds(p, 0, s)) return;   // forced tile refused the shape
   if (compute_dt == DT_F32 && g_igemm_variant >= 0 && launch_igemm_f32_pipe(p, s)) return;
+  if (compute_dt == DT_HL) {     // no generic twin: layers the HL pipeline cannot take are packed (and launched) as fp32 by the host
+    if (launch_igemm_hl_pipe(p, s)) return;
+    throw std::runtime_error("split-operand (DT_HL) GEMM: shape / alignment outside the direct-to-LDS pipeline");
+  }
   if (p.xa_k) throw std::runtime_error("fused cross-attention needs the f16 direct-to-LDS kernels");
   // the generic kernels below never write the GroupNorm statistics: a caller that was promised them (run_conv tags the output
   // Act and the consumer skips its statistics pass) must not get uninitialised memory -- forced variants, unaligned A, no zero page

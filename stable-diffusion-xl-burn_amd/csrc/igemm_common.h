@@ -17,6 +17,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Split-operand element (DT_HL): a logical fp32 value x travels as TWO f16 numbers, hi = f16(x) and lo = f16(x - hi), i.e. 22
+// significand bits, and a product is three f16 MFMAs accumulated in fp32:  a * w ~ ah*wh + al*wh + ah*wl  (the dropped al*wl is
+// 2^-22 relative).  fp32-class accuracy at 1/3 of the f16 MFMA rate instead of 1/16 (v_mfma_f32_32x32x2_f32 runs at the fp32
+// VECTOR rate, 157 TFLOP/s) -- the VAE at the reference's precision (src/bin/sample/main.rs:121,271-278) without the fp32 pipe.
+// Memory format "HL16": 4 bytes per logical element like fp32; every group of 16 channels is 32 halfs [16 hi | 16 lo], so a
+// 128-byte tile row of the DMA ring holds 32 logical k: chunks {0,1} = hi of k 0..15, {2,3} = lo of k 0..15, {4,5} / {6,7} = the
+// same for k 16..31 -- the four kk-steps of the pipelined loop read hi0, lo0, hi1, lo1 with UNCHANGED fragment addressing.
+struct hl16_t { unsigned v; };
+template <typename T> struct is_hl { static constexpr bool value = false; };
+template <> struct is_hl<hl16_t> { static constexpr bool value = true; };
+// 8 consecutive logical columns n0 .. n0+7 (n0 % 8 == 0) of an HL16 row: hi halfs at (n0/16)*32 + n0%16, lo 16 halfs further
+__device__ __forceinline__ void store_hl8(void* row_base, int n0, const float (&w)[8]) {
+  half8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { hi[e] = (half_t)w[e]; lo[e] = (half_t)(w[e] - (float)hi[e]); }
+  half_t* b = reinterpret_cast<half_t*>(row_base) + ((n0 >> 4) << 5) + (n0 & 15);
+  *reinterpret_cast<half8*>(b) = hi;
+  *reinterpret_cast<half8*>(b + 16) = lo;
+}
+
 // exact-erf GELU (burn nn::Gelu, unet/mod.rs:954) for the f16 fast path: 1 + erf(x/sqrt2) through the complementary form
 // E = erfc(|z|) = poly(t) * exp(-z^2), t = 1/(1 + 0.3275911 |z|)  (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7, no
 // cancellation for negative x); ~12 VALU instead of ocml erff's branchy ~40.  The strict fp32 kernel keeps erff.
@@ -436,6 +456,8 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
 #pragma unroll
           for (int e = 0; e < 8; ++e) if (n0 + e < nlim) cp[e] = (half_t)v[e];
         }
+      } else if (p.c_dt == DT_HL) {       // (whole 8-column pieces only: the launcher admits N % 8 == 0, ldc % 16 == 0 outputs)
+        if (full) store_hl8(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc, n0, v);
       } else {
         float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0;
         if (full && (reinterpret_cast<uintptr_t>(cp) & 15) == 0) {
@@ -563,6 +585,8 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
             }
           }
         }
+      } else if (p.c_dt == DT_HL) {       // V^T rows in HL16 along the key axis (whole 8-key pieces inside one batch entry)
+        if (full) store_hl8(reinterpret_cast<float*>(p.Ct) + ((size_t)b0 * p.ct_rows + (n - p.n_split)) * p.ct_ld, key0, v);
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -709,6 +733,8 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, const 
               for (int e = 0; e < 8; ++e) w[e] = (float)h[e];      // the stored (rounded) values: what the consumer will read
             }
           }
+        } else if (p.c_dt == DT_HL) {
+          if (mok[i]) store_hl8(reinterpret_cast<float*>(p.C) + (size_t)m[i] * p.ldc, n0, w);
         } else if (mok[i]) {
           float* cp = reinterpret_cast<float*>(p.C) + (size_t)m[i] * p.ldc + n0;
           *reinterpret_cast<f32x4*>(cp) = f32x4{w[0], w[1], w[2], w[3]};
@@ -792,6 +818,7 @@ template <> struct PipeElem<float> {
     return c;
   }
 };
+template <> struct PipeElem<hl16_t> { typedef half8 frag; };
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);

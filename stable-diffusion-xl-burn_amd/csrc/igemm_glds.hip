@@ -384,7 +384,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     basea = lds0 + ra * 128 + ((fh ^ ((ra >> 1) & 7)) << 4);
     baseb = lds0 + BM * 128 + rbw * 128 + ((fh ^ ((rbw >> 1) & 7)) << 4);
   }
-  frag_t fA[2][TM], fB[2][TN];
+  constexpr bool HL = is_hl<T>::value;        // split-operand element: four fragment sets (hi0, lo0, hi1, lo1), three MFMAs per pair
+  frag_t fA[HL ? 4 : 2][TM], fB[HL ? 4 : 2][TN];
   auto ldfrag = [&](unsigned so, int kk, auto SET) {
     constexpr int set = decltype(SET)::value;
     const unsigned aa = (basea ^ (kk << 5)) + so, ab = (baseb ^ (kk << 5)) + so;
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   auto mma = [&](auto SET, int buf, auto PH, bool more) {
     constexpr int set = decltype(SET)::value;
     constexpr int ph = decltype(PH)::value;
+    if constexpr (!HL) {
     acc[0][0] = PipeElem<T>::mma(fB[set][0], fA[set][0], acc[0][0]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ph < 3) {
@@ -406,6 +408,31 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       acc[i][j] = PipeElem<T>::mma(fB[set][j], fA[set][i], acc[i][j]);
     });
     __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // split-operand MFMAs.  CROSS = false: hi x hi of fragment set SH (TM*TN MFMAs); CROSS = true: the two cross terms
+  // w_hi x a_lo and w_lo x a_hi of the pair (SH, SL) (2*TM*TN MFMAs).  DMA pieces PH go behind the first MFMA, as above.
+  auto mma_hl = [&](auto SHI, auto SLO, auto CROSS, int buf, auto PH, bool more) {
+    if constexpr (HL) {
+      constexpr int sh = decltype(SHI)::value, sl = decltype(SLO)::value, ph = decltype(PH)::value;
+      constexpr bool cross = decltype(CROSS)::value;
+      auto one = [&](auto X) {
+        constexpr int x = decltype(X)::value, i = x / TN, j = x % TN;
+        if constexpr (!cross) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[sh][j], fA[sh][i], acc[i][j], 0, 0, 0);
+        else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[sh][j], fA[sl][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[sl][j], fA[sh][i], acc[i][j], 0, 0, 0);
+        }
+      };
+      one(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ph < 3) {
+        if (more) issue(buf, PH);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      static_for<TM * TN - 1>([&](auto X) { one(std::integral_constant<int, decltype(X)::value + 1>{}); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -450,6 +477,11 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       lnC[i] = p.ln_stat ? ln_coef[(wm * WM + i * 32 + fr) * 2 + 1] : 0.f;
     }
   }
+  if constexpr (HL) {   // split-operand weights are packed times a power of two (exact): the row coefficient of the epilogue undoes it
+    const float sc = p.acc_scale ? *p.acc_scale : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { lnA[i] = sc; lnC[i] = 0.f; }
+  }
   ldfrag(0, 0, I0{});
   // The k-loop is unrolled by the ring depth: ring slots become compile-time constants, so every
   // fragment read is {one of 16 loop-invariant lane addresses} + immediate and the DMA destinations fold into M0
@@ -482,6 +514,32 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     using SO = std::integral_constant<unsigned, (unsigned)c * STAGE>;
     using SN = std::integral_constant<unsigned, (unsigned)nslot * STAGE>;
     const bool more = kt + NS - 1 < nk;
+    if constexpr (HL) {
+      // one 32-deep k-tile = the pairs (hi0, lo0) and (hi1, lo1) in sets 0..3; set 0 was requested behind the previous barrier
+      using F = std::false_type; using Tt = std::true_type;
+      ldf(SO{}, I1{}, I1{});
+      wait_lgkmcnt<NF>();
+      mma_hl(I0{}, I0{}, F{}, fl, I0{}, more);            // w_hi0 x a_hi0
+      ldf(SO{}, I2{}, I2{});
+      wait_lgkmcnt<NF>();
+      mma_hl(I0{}, I1{}, Tt{}, fl, I1{}, more);           // w_hi0 x a_lo0 + w_lo0 x a_hi0
+      ldf(SO{}, I3{}, I3{});
+      wait_lgkmcnt<NF>();
+      mma_hl(I2{}, I2{}, F{}, fl, I2{}, more);            // w_hi1 x a_hi1
+      if (more) tile_done();
+      if (kt + 1 < nk) {
+        if (more) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ldf(SN{}, I0{}, I0{});
+      } else {
+        wait_lgkmcnt<0>();
+      }
+      mma_hl(I2{}, I3{}, Tt{}, fl, I3{}, false);          // w_hi1 x a_lo1 + w_lo1 x a_hi1
+      return;
+    }
     ldf(SO{}, I1{}, I1{});
     wait_lgkmcnt<NF>();
     mma(I0{}, fl, I0{}, more);
@@ -1054,6 +1112,28 @@ bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s) {
   q.splitk = 1;
   if (eff256 >= eff128) launch_pipe<256, 128, 3, 4, 8, float>(q, s);
   else launch_pipe<128, 128, 4, 4, 8, float>(q, s);
+  return true;
+}
+
+// Split-operand mode (DT_HL; igemm_common.h): HL16 operands on the same direct-to-LDS pipeline, 3 f16 MFMAs per 16-deep product.
+// Returns false for shapes the generic kernel must take (none in the VAE: its Cin % 32 != 0 layers are packed fp32).
+bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
+  if (!g_zero_pages[current_device()]) return false;
+  if (p.act != 0 || p.ln_stat || p.stat_out || p.xa_k || p.gn_part) return false;
+  if (p.a_dt != DT_HL || (p.Cin % 32) != 0 || (p.lda % 4) != 0 || (p.Kpad % 32) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
+  if (p.n_split < p.N && p.n_split != 0) return false;                 // plain or fully transposed outputs only
+  if (p.c_dt == DT_HL && ((p.N & 7) != 0 || (p.n_split >= p.N && ((p.ldc & 15) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0)))) return false;
+  if (p.c_dt == DT_HL && p.n_split < p.N && ((p.ct_ld & 15) != 0 || (p.rpb & 7) != 0 || (p.M % 8) != 0)) return false;
+  if (p.ebias && (p.ebias_ld & 3) != 0) return false;
+  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+  const double eff128 = (double)t128 / (double)(((t128 + 255) / 256) * 256);
+  const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+  IgemmParams q = p;
+  q.splitk = 1;
+  if (eff256 >= eff128) launch_pipe<256, 128, 3, 4, 8, hl16_t>(q, s);
+  else launch_pipe<128, 128, 4, 4, 8, hl16_t>(q, s);
   return true;
 }
 

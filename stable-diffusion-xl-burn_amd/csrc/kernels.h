@@ -9,7 +9,9 @@
 namespace sdxl {
 
 // compute precision of a model instance
-enum DType : int { DT_F32 = 0, DT_F16 = 1 };
+// DT_HL: split-operand storage "HL16" (igemm_common.h): a logical fp32 value as two f16 numbers (hi, lo), 4 bytes per element,
+// every 16 channels = 32 halfs [16 hi | 16 lo] -- operands of the 3-MFMA fp32-class GEMM the VAE runs at the reference's precision
+enum DType : int { DT_F32 = 0, DT_F16 = 1, DT_HL = 2 };
 
 static inline size_t dt_size(int dt) { return dt == DT_F16 ? 2 : 4; }
 
@@ -55,6 +57,8 @@ struct IgemmParams {
   // GroupNorm statistics of the stored output, from the epilogue (256x128 kernel; igemm_gn_part_ok): gn_part[M/256][N] (mean, M2)
   // of every column over the 256 rows of a tile -- the consumer's GroupNorm merges row tiles and channels (norm.hip, chan_part)
   float* gn_part;
+  const float* acc_scale;  // DT_HL compute: the packed weights carry a power-of-two factor (exact); device scalar 1 / factor the epilogue multiplies the
+                           // accumulators by (lives in the weight arena, so replicas that receive the arena by broadcast need no host copy); null = 1
   int epi_staged;   // A/B knob (sdxl_debug_set "igemm_epilogue_staged"): 1 = LDS-staged epilogue everywhere, 0 = direct row-per-lane where it applies
 };
 bool igemm_gn_part_ok(const IgemmParams& p);
@@ -160,6 +164,8 @@ void launch_nhwc_to_nchw(const void* src, int dt, int lds, float* dst, int B, in
 // generic cast copy rows: dst[r][c] = src[r][c]
 void launch_copy_rows(const void* src, int sdt, int lds, void* dst, int ddt, int ldd, int rows, int C, hipStream_t s);
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+// fp32 rows -> split-operand HL16 rows (C % 16 == 0, row strides in logical elements, dst stride % 16 == 0)
+void launch_f32_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows, int C, hipStream_t s);
 void launch_round_f16(float* p, size_t n, hipStream_t s);   // p[i] = float(half(p[i])): parameters as a HalfPrecisionSettings record holds them
 void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s);
 // CLIP text encoder (clip/mod.rs:99-105,139-147): x[b][t][:] = tok[ids[b][t]][:] + pos[t][:] (tables in dtype w_dt);
@@ -208,7 +214,8 @@ void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs
 void launch_beta_dot(const float* w, const float* beta, const float* bias, float* out, int K, int N, hipStream_t s);
 // canonical conv [Cout][Cin][kh][kw] fp32 -> packed [Npad][Kpad], k = (kh*kw_idx)*Cin + c
 void launch_pack_conv(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad,
-                      hipStream_t s);
+                      hipStream_t s, float wscale = 1.0f);   // wscale: power-of-two factor of the DT_HL packing (undone by IgemmParams::acc_scale)
+void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s);   // *out_dev = max |src[i]|
 // bias vector permuted the same way as GEGLU-packed columns (fp32 -> fp32)
 void launch_pack_bias(const float* src, float* dst, int N, int Npad, int geglu, int n_offset, hipStream_t s);
 

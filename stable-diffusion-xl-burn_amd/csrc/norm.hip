@@ -40,6 +40,20 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
   *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
+// output in the split-operand format HL16 (kernels.h DT_HL): 4 bytes per logical element like fp32, every 16 channels stored as
+// 32 halfs [16 hi | 16 lo] with hi = f16(y), lo = f16(y - hi) -- what the 3-MFMA fp32-class GEMM stages (igemm_common.h)
+struct hlout_t { float logical; };
+// 8 channels starting at column `col` (multiple of 8) of the row at `row`
+template <typename YT> __device__ __forceinline__ void store8r(YT* row, int col, const float (&v)[8]) { store8<YT>(row + col, v); }
+template <> __device__ __forceinline__ void store8r<hlout_t>(hlout_t* row, int col, const float (&v)[8]) {
+  half8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { hi[j] = (half_t)v[j]; lo[j] = (half_t)(v[j] - (float)hi[j]); }
+  half_t* b = reinterpret_cast<half_t*>(row) + ((col >> 4) << 5) + (col & 15);
+  *reinterpret_cast<half8*>(b) = hi;
+  *reinterpret_cast<half8*>(b + 16) = lo;
+}
+
 // Chan merge of (nb, mb, M2b) into (na, ma, M2a)
 __device__ __forceinline__ void chan_merge(float& na, float& ma, float& m2a, float nb, float mb, float m2b) {
   if (nb == 0.f) return;
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
           if (p.silu) y = y / (1.0f + __expf(-y));
           v[u][j] = y;
         }
-        store8<YT>(Y + (size_t)(row + u * RL) * p.ldy + vc * 8, v[u]);
+        store8r<YT>(Y + (size_t)(row + u * RL) * p.ldy, vc * 8, v[u]);
       }
     }
     for (; row < row1; row += RL) {
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
         if (p.silu) y = y / (1.0f + __expf(-y));
         v[j] = y;
       }
-      store8<YT>(Y + (size_t)row * p.ldy + vc * 8, v);
+      store8r<YT>(Y + (size_t)row * p.ldy, vc * 8, v);
     }
   }
 }
@@ -337,7 +351,11 @@ void launch_groupnorm(const GroupNormParams& pin, hipStream_t s) {
   if (p.x_dt == DT_F16 && p.y_dt == DT_F16) GN_APPLY(half_t, half_t);
   else if (p.x_dt == DT_F32 && p.y_dt == DT_F16) GN_APPLY(float, half_t);
   else if (p.x_dt == DT_F32 && p.y_dt == DT_F32) GN_APPLY(float, float);
-  else GN_APPLY(half_t, float);
+  else if (p.x_dt == DT_F32 && p.y_dt == DT_HL) {
+    if ((p.C & 15) != 0 || (p.ldy & 15) != 0) throw std::runtime_error("groupnorm: HL16 output needs C % 16 == 0 rows");
+    GN_APPLY(float, hlout_t);
+  } else if (p.x_dt == DT_F16 && p.y_dt == DT_F32) GN_APPLY(half_t, float);
+  else throw std::runtime_error("groupnorm: unsupported dtype pair");
 #undef GN_APPLY
 }
 

@@ -76,6 +76,15 @@ Vae::Vae(const VaeCfg& cfg, int compute_dt, WeightSource* dec_src, WeightSource*
 }
 Vae::~Vae() {}
 
+// GEMM operand view of a residual-stream tensor: the split-operand mode keeps the stream in fp32 and stages (hi, lo) f16 pairs,
+// so the few convolutions that read the stream directly (nin_shortcut, up- / downsampler) get an HL16 copy; other modes read x
+static Act as_operand(Exec& ex, const Act& x, size_t rows, int C) {
+  if (ex.cdt != DT_HL || x.dt == DT_HL) return x;
+  Act o = ex.alloc(rows, C, DT_HL);
+  if (!ex.dry) launch_f32_to_hl(x.p, x.ld, o.p, o.ld, rows, C, ex.s);
+  return o;
+}
+
 void Vae::res_block(Exec& ex, const VaeResW& w, const Act& x, int B, int H, int W, const Act& out) {
   // ResnetBlock::forward autoencoder/mod.rs:500-516
   const size_t mk = ex.act->mark();
@@ -83,12 +92,12 @@ void Vae::res_block(Exec& ex, const VaeResW& w, const Act& x, int B, int H, int 
   const ConvGeom g3{B, H, W, H, W, 3, 1, 1, 0}, g1{B, H, W, H, W, 1, 1, 0, 0};
   Act gn1 = ex.alloc(M, w.cin, ex.cdt);
   run_groupnorm(ex, w.n1, x, B, H * W, gn1, true, cfg_.n_group);
-  Act h = ex.alloc(M, w.cout, ex.cdt);
+  Act h = ex.alloc(M, w.cout, ex.sdt);          // (read by a GroupNorm only: stays in the stream dtype)
   run_conv(ex, w.c1, gn1, w.cin, g3, h);
   Act gn2 = ex.alloc(M, w.cout, ex.cdt);
   run_groupnorm(ex, w.n2, h, B, H * W, gn2, true, cfg_.n_group);
   Epi e;
-  if (w.has_nin) { run_conv(ex, w.nin, x, w.cin, g1, out); e.R = out; }
+  if (w.has_nin) { run_conv(ex, w.nin, as_operand(ex, x, M, w.cin), w.cin, g1, out); e.R = out; }
   else e.R = x;
   run_conv(ex, w.c2, gn2, w.cout, g3, out, e);
   ex.act->reset(mk);
@@ -159,7 +168,9 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
     run_conv(ex, w.v, hn, C, g1, Act(nullptr, C, ex.cdt), ev);
     for (int b = 0; b < B; ++b) {
       Lin lk; lk.w = (char*)kbuf + (size_t)b * rows_k * C * dt_size(ex.cdt); lk.N = HW; lk.K = C; lk.Kpad = C; lk.Npad = rows_k; lk.cin = C;
-      Lin lv; lv.w = (char*)vt + (size_t)b * rows_v * kpad * dt_size(ex.cdt); lv.N = C; lv.K = HW; lv.Kpad = kpad; lv.Npad = rows_v; lv.cin = HW;
+      // (the P V contraction runs over the zero-padded key axis: P's columns and V^T's keys beyond HW are zeros, and whole k-tiles
+      // keep it on the direct-to-LDS pipeline -- the split-operand mode has no generic twin)
+      Lin lv; lv.w = (char*)vt + (size_t)b * rows_v * kpad * dt_size(ex.cdt); lv.N = C; lv.K = kpad; lv.Kpad = kpad; lv.Npad = rows_v; lv.cin = kpad;
       for (int q0 = 0; q0 < HW; q0 += QT) {
         const int nq = HW - q0 < QT ? HW - q0 : QT;
         const size_t row0 = ((size_t)b * HW + q0) * C * dt_size(ex.cdt);
@@ -178,7 +189,7 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
 void Vae::run_decode(Exec& ex, const Act& in, int n, int h, int w, const Act& out) {
   // Autoencoder::decode_latent :67-70 -> Decoder::forward :203-216 -> DecoderBlock::forward :306-324
   const size_t M0 = (size_t)n * h * w;
-  Act z = ex.alloc(M0, 4, ex.cdt);
+  Act z = ex.alloc(M0, 4, io_dt());            // (4-channel ends run as plain fp32 in the split-operand mode)
   run_conv(ex, post_quant_, in, 4, ConvGeom{n, h, w, h, w, 1, 1, 0, 0}, z);
   const int c0 = cfg_.dec.front().first;
   Act cur = ex.alloc(M0, c0, ex.sdt);
@@ -196,7 +207,7 @@ void Vae::run_decode(Exec& ex, const Act& in, int n, int h, int w, const Act& ou
     res_block(ex, b.r[1], a, n, h, w, bb);
     if (b.has_up) {
       res_block(ex, b.r[2], bb, n, h, w, a);
-      run_conv(ex, b.up, a, co, ConvGeom{n, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next);
+      run_conv(ex, b.up, as_operand(ex, a, M, co), co, ConvGeom{n, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next);
       h *= 2; w *= 2;
     } else {
       res_block(ex, b.r[2], bb, n, h, w, next);
@@ -230,7 +241,7 @@ void Vae::run_encode(Exec& ex, const Act& in, int n, int H, int W, const Act& ou
       Act bb = ex.alloc(M, co, ex.sdt);
       res_block(ex, b.r[1], a, n, h, w, bb);
       // PaddedConv2d(pad left 0, right 1, top 0, bottom 1), stride 2 (:229-238, :384-407)
-      run_conv(ex, b.down, bb, co, ConvGeom{n, h, w, h2, w2, 3, 2, 0, 0}, next);
+      run_conv(ex, b.down, as_operand(ex, bb, M, co), co, ConvGeom{n, h, w, h2, w2, 3, 2, 0, 0}, next);
     } else {
       res_block(ex, b.r[1], a, n, h, w, next);
     }
@@ -242,7 +253,7 @@ void Vae::run_encode(Exec& ex, const Act& in, int n, int H, int W, const Act& ou
   const int cl = cfg_.enc.back().first;
   Act gn = ex.alloc(M, cl, ex.cdt);
   run_groupnorm(ex, e_norm_out_, cur, n, h * w, gn, true, cfg_.n_group);
-  Act e8 = ex.alloc(M, cfg_.enc_out, ex.cdt);
+  Act e8 = ex.alloc(M, cfg_.enc_out, io_dt());
   run_conv(ex, e_conv_out_, gn, cl, ConvGeom{n, h, w, h, w, 3, 1, 1, 0}, e8);
   run_conv(ex, quant_, e8, cfg_.enc_out, ConvGeom{n, h, w, h, w, 1, 1, 0, 0}, out);
 }
@@ -256,7 +267,7 @@ float* Vae::gn_workspace(Exec& ex, int n) {
 // two-pass execution: dry run sizes the arena, then the real run
 #define VAE_RUN(...)                                                                   \
   do {                                                                                 \
-    Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = cdt_; ex.act = &act_;                  \
+    Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = io_dt(); ex.act = &act_;               \
     act_.dry = true; act_.off = 0; act_.peak = 0; ex.dry = true;                       \
     __VA_ARGS__;                                                                       \
     const size_t peak = act_.peak;                                                     \
@@ -271,11 +282,11 @@ const float* Vae::decode(const float* latent, int n, int h, int w, hipStream_t s
   float* img = nullptr;
   VAE_RUN({
     ex.gn_partial = gn_workspace(ex, n);
-    Act in = ex.alloc((size_t)n * h * w, 4, cdt_);
+    Act in = ex.alloc((size_t)n * h * w, 4, io_dt());
     Act out = ex.alloc((size_t)n * h * w * 64, 3, DT_F32);
     img = (float*)out.p;
     if (!ex.dry)   // x * (1/scale_factor), stablediffusion/mod.rs:265
-      launch_nchw_to_nhwc(latent, 4 * h * w, in.p, cdt_, n, 4, h * w, 4, (float)(1.0 / cfg_.scale_factor), s);
+      launch_nchw_to_nhwc(latent, 4 * h * w, in.p, io_dt(), n, 4, h * w, 4, (float)(1.0 / cfg_.scale_factor), s);
     run_decode(ex, in, n, h, w, out);
   });
   return img;
@@ -292,9 +303,9 @@ void Vae::encode_nchw(const float* img, int n, int H, int W, float* latent_out, 
   SDXL_REQUIRE(has_enc_, "this Vae was created without encoder weights");
   VAE_RUN({
     ex.gn_partial = gn_workspace(ex, n);
-    Act in = ex.alloc((size_t)n * H * W, 3, cdt_);
+    Act in = ex.alloc((size_t)n * H * W, 3, io_dt());
     Act out = ex.alloc((size_t)n * (H / 8) * (W / 8), cfg_.enc_out, DT_F32);
-    if (!ex.dry) launch_nchw_to_nhwc(img, 3 * H * W, in.p, cdt_, n, 3, H * W, 3, 1.0f, s);
+    if (!ex.dry) launch_nchw_to_nhwc(img, 3 * H * W, in.p, io_dt(), n, 3, H * W, 3, 1.0f, s);
     run_encode(ex, in, n, H, W, out);
     if (!ex.dry)   // channels 0..4 (the mean) * scale_factor, autoencoder/mod.rs:63, stablediffusion/mod.rs:257-261
       launch_nhwc_to_nchw(out.p, DT_F32, cfg_.enc_out, latent_out, n, 4, (H / 8) * (W / 8), (float)cfg_.scale_factor, s);
@@ -304,9 +315,9 @@ void Vae::image_to_latent(const unsigned char* img_hwc, int n, int H, int W, flo
   SDXL_REQUIRE(has_enc_, "this Vae was created without encoder weights");
   VAE_RUN({
     ex.gn_partial = gn_workspace(ex, n);
-    Act in = ex.alloc((size_t)n * H * W, 3, cdt_);
+    Act in = ex.alloc((size_t)n * H * W, 3, io_dt());
     Act out = ex.alloc((size_t)n * (H / 8) * (W / 8), cfg_.enc_out, DT_F32);
-    if (!ex.dry) launch_from_u8_image(img_hwc, in.p, cdt_, 3, (size_t)n * H * W, s);
+    if (!ex.dry) launch_from_u8_image(img_hwc, in.p, io_dt(), 3, (size_t)n * H * W, s);
     run_encode(ex, in, n, H, W, out);
     if (!ex.dry)
       launch_nhwc_to_nchw(out.p, DT_F32, cfg_.enc_out, latent_out, n, 4, (H / 8) * (W / 8), (float)cfg_.scale_factor, s);

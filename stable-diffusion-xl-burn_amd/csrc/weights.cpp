@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 
 namespace sdxl {
 
@@ -121,7 +122,7 @@ size_t WeightBuilder::arena_bound(const std::vector<ParamSpec>& specs, int dt) {
   for (const ParamSpec& p : specs) {
     if (p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * round_up(p.shape[0], 64) * dt_size(dt) + 256;
     else if (p.kind == PK_CONV_W)
-      total += round_up(p.shape[0], 128) * round_up((size_t)p.shape[1] * p.shape[2] * p.shape[3], 64) * dt_size(dt) + 256;
+      total += round_up(p.shape[0], 128) * round_up((size_t)p.shape[1] * p.shape[2] * p.shape[3], 64) * dt_size(dt) + 768;   // (+ the DT_HL scale scalar)
     else total += round_up(p.numel(), 128) * sizeof(float) + 256;
     if (p.kind == PK_LINEAR_W || p.kind == PK_CONV_W) total += round_up(p.kind == PK_LINEAR_W ? p.shape[1] : p.shape[0], 128) * 4 + 256;
     if (p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * 4 + 256;   // column sums of LayerNorm-folded projections
@@ -247,13 +248,39 @@ Lin WeightBuilder::conv(const std::string& name) {
   const ParamSpec& s = spec(name + ".weight");
   Lin l; l.N = s.shape[0]; l.cin = s.shape[1]; l.ksize = s.shape[2];
   l.K = l.cin * l.ksize * l.ksize;
-  const int kt = dt == DT_F16 ? 64 : 32;
+  // split-operand models (DT_HL): the direct-to-LDS pipeline needs 32-channel k-tiles; the few layers without them (the 3- / 4- /
+  // 8-channel ends of the VAE) are packed and run as plain fp32 on the generic kernel
+  const int wdt = (dt == DT_HL && l.cin % 32 != 0) ? DT_F32 : dt;
+  if (wdt != dt) l.dt = wdt;
+  const int kt = wdt == DT_F16 ? 64 : 32;
   l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
-  void* w = arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
+  void* w = arena.alloc((size_t)l.Npad * l.Kpad * dt_size(wdt));
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   l.w = w; l.b = b;
+  float wscale = 1.f;
+  if (wdt == DT_HL) {
+    float* sc = (float*)arena.alloc(sizeof(float));     // (allocated on empty replicas too: identical arena layout)
+    l.acc_scale = sc;
+    // hi = f16(w * 2^e), lo = f16(w * 2^e - hi): with 2^e * max|w| in [2^13, 2^14) both halves of every weight down to 2^-11 of the
+    // largest stay f16-normal (22 significand bits); unscaled, |w| ~ 0.02 would push every lo into the subnormals (~20 bits).
+    // The factor is exact and the epilogue undoes it (IgemmParams::acc_scale).  The exponent is a function of the tensor only.
+    if (!src.empty()) {
+      launch_absmax(fetch(name + ".weight"), s.numel(), sc, st);
+      float h = 0.f;
+      SDXL_HIP(hipMemcpyAsync(&h, sc, sizeof(float), hipMemcpyDeviceToHost, st));
+      SDXL_HIP(hipStreamSynchronize(st));
+      int e = 0;
+      if (h > 0.f && std::isfinite(h)) { (void)std::frexp(h, &e); e = 14 - e; }       // h = m * 2^(14 - e), m in [0.5, 1) -> h * 2^e in [2^13, 2^14)
+      if (e > 24) e = 24;
+      if (e < -24) e = -24;
+      wscale = std::ldexp(1.0f, e);
+      const float inv = 1.0f / wscale;
+      SDXL_HIP(hipMemcpyAsync(sc, &inv, sizeof(float), hipMemcpyHostToDevice, st));
+      SDXL_HIP(hipStreamSynchronize(st));
+    }
+  }
   if (src.empty()) return l;
-  launch_pack_conv(fetch(name + ".weight"), w, dt, l.N, l.cin, l.ksize, l.Kpad, l.Npad, st);
+  launch_pack_conv(fetch(name + ".weight"), w, wdt, l.N, l.cin, l.ksize, l.Kpad, l.Npad, st, wscale);
   launch_pack_bias(fetch(name + ".bias"), b, l.N, l.Npad, 0, 0, st);
   return l;
 }
@@ -300,9 +327,10 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   SDXL_REQUIRE(!e.stat_out || (w.N % 64 == 0 && (e.n_split < 0 || e.n_split >= w.N) && e.act == 0), "row statistics need a plain N % 64 == 0 output");
   SDXL_REQUIRE(!e.ln_stat || w.cs, "ln_stat given but the weight is not LayerNorm-folded");
   SDXL_REQUIRE(!w.cs || e.ln_stat, "LayerNorm-folded weight used without row statistics");
-  SDXL_REQUIRE(!(ex.cdt == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
+  SDXL_REQUIRE(!((w.dt >= 0 ? w.dt : ex.cdt) == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
   if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize);
-  launch_igemm(p, ex.cdt, ex.s);
+  p.acc_scale = w.acc_scale;
+  launch_igemm(p, w.dt >= 0 ? w.dt : ex.cdt, ex.s);
   SDXL_HIP(hipGetLastError());     // a refused launch (bad grid / LDS attribute) must not pass silently
   if (ex.prof) ex.prof->end(ex.s);
   if (ex.fork_ev && ++ex.launches == ex.fork_after) SDXL_HIP(hipEventRecord(ex.fork_ev, ex.s));

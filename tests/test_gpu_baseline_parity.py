@@ -188,7 +188,7 @@ def test_decode_1024_matches_oracle(pkg, ctx):
     latent = seeded(1, 4, 128, 128, seed=121)
     assert np.allclose(checksum(latent), g["in_checksum"], rtol=1e-9)
     rep = {}
-    for name, dt in (("f32", pkg.DTYPE_F32), ("f16", pkg.DTYPE_F16)):
+    for name, dt in (("f32", pkg.DTYPE_F32), ("f32_split", pkg.DTYPE_F32_SPLIT), ("f16", pkg.DTYPE_F16)):
         ld = pkg.LatentDecoder(ctx, None, dt, seed=0)
         ld.decode_latent(latent.cuda())                                   # warm-up (plans, arena)
         torch.cuda.synchronize()
@@ -214,6 +214,10 @@ def test_decode_1024_matches_oracle(pkg, ctx):
     assert rep["f32"]["image_sub"]["max_abs"] <= IMG_ABS_F32 * max(1.0, rep["f32"]["image_sub"]["ref_max"])
     assert rep["f32"]["crops"]["max_abs"] <= IMG_ABS_F32 * max(1.0, rep["f32"]["crops"]["ref_max"])
     assert rep["f32"]["u8_max_diff"] <= 1
+    # the split-operand mode (3 f16 MFMAs per product on (hi, lo) operand pairs) must sit in the exact-fp32 class
+    assert rep["f32_split"]["image_sub"]["max_abs"] <= 1e-2 * IMG_ABS_F32 * max(1.0, rep["f32_split"]["image_sub"]["ref_max"]), rep["f32_split"]
+    assert rep["f32_split"]["crops"]["max_abs"] <= 1e-2 * IMG_ABS_F32 * max(1.0, rep["f32_split"]["crops"]["ref_max"])
+    assert rep["f32_split"]["u8_max_diff"] <= 1 and rep["f32_split"]["u8_frac_diff"] <= 2e-4
     assert rep["f16"]["image_sub"]["rel"] < F16_DECODE_REL
 
 
@@ -342,7 +346,7 @@ def test_encode_1024_matches_oracle(pkg, ctx):
     assert np.allclose(chk, g["in_checksum"], rtol=1e-12), "u8 test image differs from the fixture's: regenerate"
     ref = torch.from_numpy(g["latent"])
     rep = {}
-    for name, dt in (("f32", pkg.DTYPE_F32), ("f16", pkg.DTYPE_F16)):
+    for name, dt in (("f32", pkg.DTYPE_F32), ("f32_split", pkg.DTYPE_F32_SPLIT), ("f16", pkg.DTYPE_F16)):
         ld = pkg.LatentDecoder(ctx, None, dt, seed=0, with_encoder=True)
         out = ld.image_to_latent(pkg.RawImages(img.cuda(), 1024, 1024)).cpu()
         rep[name] = errs(out, ref)
@@ -350,6 +354,7 @@ def test_encode_1024_matches_oracle(pkg, ctx):
         print(f"image_to_latent 1024^2 {name} vs oracle: max-abs {rep[name]['max_abs']:.3e} rel {rep[name]['rel']:.3e} (|ref| {rep[name]['ref_max']:.3f})")
     REPORT["encode_1024_vs_oracle"] = rep
     assert rep["f32"]["max_abs"] <= LAT_ABS and rep["f32"]["rel"] < 1e-4, rep["f32"]
+    assert rep["f32_split"]["rel"] < 2e-5, rep["f32_split"]
     assert rep["f16"]["rel"] < 3.9e-3, rep["f16"]                            # measured 1.9e-3
 
 

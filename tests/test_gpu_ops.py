@@ -224,6 +224,39 @@ def test_conv2d(pkg, ctx, dtype, B, Cin, H, W, Cout, k, stride, pad, up):
     assert rel_err(out, ref) < TOL[dtype]
 
 
+SPLIT_CONVS = [  # B, Cin, H, W, Cout, k, stride, pad, upsample -- the VAE's shapes in small: Cin % 32 == 0
+    (1, 32, 8, 8, 32, 3, 1, 1, False),       # narrow output: wave tiles cut by N (staged epilogue)
+    (2, 64, 16, 16, 128, 3, 1, 1, False),
+    (1, 128, 32, 32, 256, 1, 1, 0, False),   # 1x1 (nin_shortcut, attention q / k / v / proj)
+    (1, 64, 16, 16, 64, 3, 2, 0, False),     # PaddedConv2d taps (stride 2, pad 0)
+    (1, 64, 8, 8, 64, 3, 1, 1, True),        # upsampler: nearest 2x in the gather
+    (1, 512, 16, 16, 512, 3, 1, 1, False),   # K = 4608: 144 k-tiles of 32
+    (3, 96, 9, 7, 160, 3, 1, 1, False),      # ragged rows / columns
+    (1, 128, 16, 16, 3, 3, 1, 1, False),     # conv_out: N = 3
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,pad,up", SPLIT_CONVS)
+def test_conv2d_split_operand(pkg, ctx, B, Cin, H, W, Cout, k, stride, pad, up):
+    """SDXL_DTYPE_F32_SPLIT as an operator: operands as (hi, lo) f16 pairs, a*w ~ ah*wh + al*wh + ah*wl on the f16 MFMA, fp32
+    accumulation -- must sit in the fp32 class against an fp64 reference.  Inputs span 5 decades (values whose lo half is an f16
+    subnormal included) and the weights are small (|w| ~ 0.02 / sqrt(fan-in): without the packing's power-of-two scale their lo
+    halves would all be subnormal)."""
+    g = torch.Generator().manual_seed(16)
+    x = seeded(B, Cin, H, W, seed=13) * torch.pow(10.0, torch.rand(B, Cin, 1, 1, generator=g) * 5.0 - 4.0)
+    w = 0.02 * seeded(Cout, Cin, k, k, seed=14) / math.sqrt(Cin * k * k)
+    b = 0.01 * seeded(Cout, seed=15)
+    xi = OM.upsample_nearest2x(x) if up else x
+    ref = F.conv2d(xi.double(), w.double(), b.double(), stride=stride, padding=pad)
+    out = pkg.conv2d(ctx, x.cuda(), w.cuda(), b.cuda(), stride, pad, up, pkg.DTYPE_F32_SPLIT).cpu().double()
+    out32 = pkg.conv2d(ctx, x.cuda(), w.cuda(), b.cuda(), stride, pad, up, pkg.DTYPE_F32).cpu().double()
+    assert out.shape == ref.shape
+    e = float((out - ref).abs().max() / ref.abs().max())
+    e32 = float((out32 - ref).abs().max() / ref.abs().max())
+    print(f"conv2d split-operand {(B, Cin, H, W, Cout, k, stride, pad, up)}: rel err vs fp64 {e:.3e} (exact-fp32 MFMA: {e32:.3e})")
+    assert e < 2e-6, e
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("B,Nq,Nk,C,heads,masked", [
     (1, 64, 64, 64, 1, False), (2, 256, 256, 128, 2, False), (2, 300, 77, 640, 10, False),   # cross-attn Nk=77
