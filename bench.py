@@ -372,7 +372,7 @@ def main():
     ap.add_argument("--n-steps", type=int, default=None, help="--n-diffusion-steps of the reference CLI (30 -> 31 iterations)")
     ap.add_argument("--cfg", type=float, default=None)
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res"])
-    ap.add_argument("--vae-dtype", default="f32", choices=["f16", "f32", "f32_split"],
+    ap.add_argument("--vae-dtype", default="f32_split", choices=["f16", "f32", "f32_split"],
                     help="arithmetic of the VAE legs; the reference decodes in f32 (src/bin/sample/main.rs:121,271-278): f32 = exact-fp32 "
                          "MFMA, f32_split = fp32-class results from three f16 MFMAs per product on (hi, lo) operand pairs")
     ap.add_argument("--pipeline-decode", action="store_true",

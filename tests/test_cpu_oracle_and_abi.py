@@ -439,3 +439,51 @@ def test_special_token_literal_follows_the_reference_regex(tok):
     assert t.encode("a <|startoftext|>", False, False) == [320, 49406]
     ids = t.encode("-<|startoftext|>", False, False)
     assert 49406 not in ids and t.decode(ids).replace(" ", "") == "-<|startoftext|>"
+
+
+def _ref_dump(name):
+    import numpy as np
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref", name + ".npy")
+    return np.load(f) if os.path.exists(f) else None
+
+
+def test_oracle_matches_reference_dumps():
+    """Golden vectors produced by the REAL reference (oracle/_ref_recipe: its loaders + UNet / Encoder / Decoder forwards on the
+    arb_tensor probes of src/bin/test/main.rs:51-54,128-162, run on a box with cargo) pin the oracle when they are committed under
+    tests/golden/ref/.  Until then the oracle stays "parity unpinned" and this test skips."""
+    import numpy as np
+    import pytest
+    import torch
+    from oracle import config as OC, model as OM
+    got = {k: _ref_dump(k) for k in ("unet_out", "encoder_out", "decoder_out")}
+    if all(v is None for v in got.values()):
+        pytest.skip("no reference dumps committed (tests/golden/ref/ is empty): see oracle/_ref_recipe/README.md")
+    ucfg, vcfg = OC.tiny_config(), OC.tiny_vae_config()
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())   # noqa: E731
+    if got["unet_out"] is not None:
+        W = OM.to_torch(OC.synth_weights(OC.unet_param_specs(ucfg), 0))
+        out = OM.unet_forward(ucfg, W, torch.from_numpy(OC.arb_tensor(1, 4, 8, 8)), torch.tensor([1]),
+                              torch.from_numpy(OC.arb_tensor(1, 1, ucfg.context_dim)), torch.from_numpy(OC.arb_tensor(1, ucfg.adm_in_channels)))
+        assert rel(out.numpy().reshape(-1), got["unet_out"].reshape(-1)) < 1e-5
+    if got["encoder_out"] is not None:
+        W = OM.to_torch(OC.synth_weights(OC.vae_encoder_param_specs(vcfg), 0))
+        out = OM.vae_encoder_forward(vcfg, W, torch.from_numpy(OC.arb_tensor(1, 3, 16, 16)))
+        assert rel(out.numpy().reshape(-1), got["encoder_out"].reshape(-1)) < 1e-5
+    if got["decoder_out"] is not None:
+        W = OM.to_torch(OC.synth_weights(OC.vae_decoder_param_specs(vcfg), 0))
+        out = OM.vae_decoder_forward(vcfg, W, torch.from_numpy(OC.arb_tensor(1, 4, 4, 4)))
+        assert rel(out.numpy().reshape(-1), got["decoder_out"].reshape(-1)) < 1e-5
+
+
+def test_ref_recipe_exports_the_reference_tree(tmp_path):
+    """the pin recipe's exporter writes what the reference's loaders read (python/save.py conventions): spot checks"""
+    import numpy as np
+    from oracle._ref_recipe import export_params as EP
+    EP.main(str(tmp_path))
+    rd = lambda *p: np.load(os.path.join(str(tmp_path), *p))   # noqa: E731
+    assert rd("params_unet", "input_blocks", "0", "stride.npy").tolist() == [2.0, 1.0, 1.0]          # [len, values]: (1, 1)
+    assert rd("params_unet", "input_blocks", "0", "n_channels_in.npy").tolist() == [1.0, 4.0]
+    assert rd("params_vae", "encoder", "n_block.npy").tolist() == [1.0, 4.0]
+    assert rd("params_vae", "encoder", "blocks", "0", "downsampler", "padding.npy").tolist() == [4.0, 0.0, 1.0, 0.0, 1.0]
+    assert rd("params_vae", "encoder", "blocks", "0", "downsampler", "conv", "stride.npy").tolist() == [2.0, 2.0, 2.0]
+    assert rd("params_vae", "decoder", "norm_out", "n_group.npy").tolist() == [1.0, 32.0]

@@ -14,7 +14,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 pkg = ge.load_package()
 ctx = pkg.Context(0)
-g = np.load("tests/golden/fullsize_decode1024.npz")
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fullsize_decode1024.npz"))
 latent = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(121)).cuda()
 names = sys.argv[1:] or ["f32", "f32_split", "f16"]
 dts = {"f32": pkg.DTYPE_F32, "f32_split": pkg.DTYPE_F32_SPLIT, "f16": pkg.DTYPE_F16}
