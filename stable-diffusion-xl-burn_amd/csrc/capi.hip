@@ -63,9 +63,12 @@ void dtypes(int dtype, int& cdt, int& sdt) {
     case SDXL_DTYPE_F32: cdt = DT_F32; sdt = DT_F32; break;
     case SDXL_DTYPE_F16: cdt = DT_F16; sdt = DT_F16; break;
     case SDXL_DTYPE_F16_F32RES: cdt = DT_F16; sdt = DT_F32; break;
-    case SDXL_DTYPE_F32_SPLIT: throw Error("SDXL_DTYPE_F32_SPLIT is a VAE precision (sdxl_vae_create*)");
+    case SDXL_DTYPE_F32_SPLIT: cdt = DT_HL; sdt = DT_F32; break;   // UNet / Diffuser / VAE only (no_split() guards the rest)
     default: throw Error("unknown dtype");
   }
+}
+void no_split(int cdt, const char* what) {
+  if (cdt == DT_HL) throw Error(std::string("SDXL_DTYPE_F32_SPLIT is not available for ") + what);
 }
 void vae_dtype(int dtype, int& cdt) {     // the VAE additionally takes the split-operand fp32-class mode
   int sdt;
@@ -418,7 +421,7 @@ int sdxl_qkv_attention(sdxl_ctx* ctx, void* stream, const float* q, const float*
   SDXL_REQUIRE(n_head > 0 && n_state % n_head == 0, "State size must be a multiple of head size");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_qkv_attention");
   const int d = n_state / n_head;
   const size_t es = dt_size(cdt);
   Tmp tmp;
@@ -501,7 +504,7 @@ int sdxl_clip_param_spec(const sdxl_clip_config* cfg, int index, const char** na
 static int clip_create_impl(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, WeightSource& src, sdxl_clip** out) {
   SDXL_REQUIRE(ctx && out, "bad argument");
   use(ctx);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "the CLIP text encoders");
   sdxl_clip* h = new sdxl_clip();
   h->ctx = ctx;
   try { h->c = new ClipText(to_ccfg(cfg), cdt, sdt, src, ctx->stream); } catch (...) { delete h; throw; }
@@ -813,7 +816,7 @@ int sdxl_group_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* ga
   SDXL_REQUIRE(C % 8 == 0 && n_group <= 256, "unsupported GroupNorm shape");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_group_norm");
   Tmp tmp;
   void* xi = tmp.get((size_t)B * HW * C * dt_size(sdt));
   void* yo = tmp.get((size_t)B * HW * C * dt_size(cdt));
@@ -834,7 +837,7 @@ int sdxl_layer_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* ga
   SDXL_REQUIRE(C % 8 == 0, "unsupported LayerNorm width");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_layer_norm");
   Tmp tmp;
   void* xi = tmp.get((size_t)rows * C * dt_size(sdt));
   void* yo = tmp.get((size_t)rows * C * dt_size(cdt));
@@ -900,7 +903,7 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   SDXL_REQUIRE(!geglu || (N % 32 == 0), "GEGLU width must be a multiple of 32");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_linear");
   const int kt = cdt == DT_F16 ? 64 : 32;
   Lin l; l.N = N; l.K = K; l.cin = K; l.ksize = 1; l.Kpad = (int)round_up(K, kt); l.Npad = (int)round_up(N, 128);
   Tmp tmp;
@@ -926,7 +929,7 @@ int sdxl_layer_norm_linear(sdxl_ctx* ctx, void* stream, const float* x, const fl
   SDXL_REQUIRE(K % 64 == 0, "LayerNorm width must be a multiple of 64");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_layer_norm_linear");
   // the model's own builder does the packing / folding: a five-entry parameter list over a device-side flat buffer
   std::vector<ParamSpec> specs(5);
   specs[0].name = "lin.weight"; specs[0].shape = {K, N}; specs[0].kind = PK_LINEAR_W;

@@ -442,13 +442,13 @@ __global__ void absmax_kernel(const float* src, size_t n, unsigned* out) {
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
 }
-void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s) {
-  (void)hipMemsetAsync(out_dev, 0, sizeof(float), s);
+void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s, bool accumulate) {
+  if (!accumulate) (void)hipMemsetAsync(out_dev, 0, sizeof(float), s);
   const unsigned blocks = (unsigned)std::min<size_t>(1024, (n + 255) / 256);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, src, n, reinterpret_cast<unsigned*>(out_dev));
 }
 __global__ void pack_linear_kernel(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu,
-                                   int n_offset, const float* kscale) {
+                                   int n_offset, const float* kscale, float wscale) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)Npad * Kpad) return;
   const int np = i / Kpad;
@@ -458,14 +458,15 @@ __global__ void pack_linear_kernel(const float* src, void* dst, int dt, int K, i
     const int n = geglu ? geglu_unpermute(np, N) : np;
     v = src[(size_t)k * N + n];
     if (kscale) v *= kscale[k];       // LayerNorm gamma folded into the projection (W' = diag(gamma) W)
+    v *= wscale;                      // power of two (DT_HL packing), 1 otherwise
   }
   st_f(dst, ((size_t)n_offset + np) * Kpad + k, dt, v);
 }
 void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu, int n_offset,
-                        hipStream_t s, const float* kscale) {
+                        hipStream_t s, const float* kscale, float wscale) {
   const size_t total = (size_t)Npad * Kpad;
   hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, K, N, Kpad, Npad, geglu, n_offset,
-                     kscale);
+                     kscale, wscale);
 }
 // cs[r] = sum_k packed[r][k] over the ROUNDED packed values (what the MFMA really multiplies), one wave per packed row
 __global__ void colsum_packed_kernel(const void* wp, int dt, int Kpad, int nrows, float* cs) {

@@ -139,8 +139,10 @@ struct WeightBuilder {
   const ParamSpec& spec(const std::string& name, size_t* idx = nullptr) const;
   bool has(const std::string& name) const { return index.count(name) != 0; }
   const float* fetch(const std::string& name);            // canonical fp32 tensor in tmp
-  Lin linear(const std::string& name, bool geglu = false);                  // name.weight [K,N] (+ name.bias)
-  Lin fused_linear(const std::vector<std::string>& names);                  // concatenated along N (same K)
+  // dt_override >= 0: pack in that dtype whatever the model's (the GEMV weights of a split-operand model stay fp32)
+  Lin linear(const std::string& name, bool geglu = false, int dt_override = -1);   // name.weight [K,N] (+ name.bias)
+  Lin fused_linear(const std::vector<std::string>& names, int dt_override = -1);   // concatenated along N (same K)
+  float hl_scale(Lin& l, const std::vector<std::string>& weight_names);     // DT_HL packing: power-of-two factor, inverse into the arena
   // the same with the preceding LayerNorm(gamma, beta) folded into weight / bias / column sums
   Lin linear_ln(const std::string& name, bool geglu, const std::string& norm);
   Lin fused_linear_ln(const std::vector<std::string>& names, const std::string& norm);
@@ -208,6 +210,7 @@ struct Epi {
 };
 bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());   // true: e.gn_part was filled
 bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());
+Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C);    // HL16 copy of an fp32 stream tensor for a split-operand GEMM (else x)
 void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups = 32);
 void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y);
 
@@ -235,6 +238,10 @@ class UNet {
   void* unet_in(int B, int H, int W);     // ensures the plan exists
   float* eps_out() { return eps_; }
   int compute_dt() const { return cdt_; }
+  // dtype of the NHWC input the sampler writes (unet_in) and of the attention operands: the compute dtype, except that the
+  // split-operand mode (DT_HL GEMM operands) keeps the 4-channel input and q / k / V^T in plain fp32
+  int input_dt() const { return cdt_ == DT_HL ? DT_F32 : cdt_; }
+  int attn_dt() const { return cdt_ == DT_HL ? DT_F32 : cdt_; }
   void set_use_graph(bool g) { use_graph_ = g; }
   // per-handle option: run the two entries of a batch-2 forward (the CFG pair) as two concurrent batch-1 chains on two
   // streams, the second released after `release_offset` GEMM launches of the first; bit-identical results

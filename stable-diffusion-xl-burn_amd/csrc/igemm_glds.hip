@@ -1119,12 +1119,18 @@ bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s) {
 // Returns false for shapes the generic kernel must take (none in the VAE: its Cin % 32 != 0 layers are packed fp32).
 bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
   if (!g_zero_pages[current_device()]) return false;
-  if (p.act != 0 || p.ln_stat || p.stat_out || p.xa_k || p.gn_part) return false;
+  if (p.act > 1 || p.ln_stat || p.stat_out || p.xa_k || p.gn_part) return false;
   if (p.a_dt != DT_HL || (p.Cin % 32) != 0 || (p.lda % 4) != 0 || (p.Kpad % 32) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
-  if (p.n_split < p.N && p.n_split != 0) return false;                 // plain or fully transposed outputs only
-  if (p.c_dt == DT_HL && ((p.N & 7) != 0 || (p.n_split >= p.N && ((p.ldc & 15) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0)))) return false;
-  if (p.c_dt == DT_HL && p.n_split < p.N && ((p.ct_ld & 15) != 0 || (p.rpb & 7) != 0 || (p.M % 8) != 0)) return false;
+  if (p.n_split < p.N && (p.n_split & 3) != 0) return false;
+  if (p.c_dt == DT_HL) {
+    // HL16 outputs are written as whole 8-column (8-key) pieces: plain outputs with aligned rows, or a fully transposed one
+    // (the VAE's V^T) whose batch entries are whole pieces; mixed / ragged splits go out as fp32 (the UNet's q | k | V^T)
+    if (p.n_split < p.N && p.n_split != 0) return false;
+    const int nout = p.act == 1 ? (p.N >> 1) : p.N;
+    if (p.n_split >= p.N && ((nout & 7) != 0 || (p.ldc & 15) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0)) return false;
+    if (p.n_split < p.N && ((p.ct_ld & 15) != 0 || (p.rpb & 7) != 0 || (p.M % 8) != 0)) return false;
+  }
   if (p.ebias && (p.ebias_ld & 3) != 0) return false;
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   const long t256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);

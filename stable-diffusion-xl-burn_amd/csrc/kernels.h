@@ -208,14 +208,15 @@ void launch_from_u8_image(const unsigned char* src, void* dst, int dt, int ldd, 
 void launch_synth_fill(float* dst, size_t numel, uint64_t key, float scale, float mean, hipStream_t s);
 // canonical Linear [K][N] fp32 (burn layout) -> packed [Npad][Kpad] (dt); optional GEGLU interleave
 void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int Kpad, int Npad, int geglu,
-                        int n_offset, hipStream_t s, const float* kscale = nullptr);   // kscale[k]: LayerNorm gamma fold
+                        int n_offset, hipStream_t s, const float* kscale = nullptr,    // kscale[k]: LayerNorm gamma fold
+                        float wscale = 1.0f);                                          // power-of-two factor of the DT_HL packing
 // LayerNorm fold helpers: column sums of the packed (rounded) weight rows; beta . W + bias in canonical column order
 void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s);
 void launch_beta_dot(const float* w, const float* beta, const float* bias, float* out, int K, int N, hipStream_t s);
 // canonical conv [Cout][Cin][kh][kw] fp32 -> packed [Npad][Kpad], k = (kh*kw_idx)*Cin + c
 void launch_pack_conv(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad,
                       hipStream_t s, float wscale = 1.0f);   // wscale: power-of-two factor of the DT_HL packing (undone by IgemmParams::acc_scale)
-void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s);   // *out_dev = max |src[i]|
+void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s, bool accumulate = false);   // *out_dev = max(|src[i]|[, *out_dev])
 // bias vector permuted the same way as GEGLU-packed columns (fp32 -> fp32)
 void launch_pack_bias(const float* src, float* dst, int N, int Npad, int geglu, int n_offset, hipStream_t s);
 

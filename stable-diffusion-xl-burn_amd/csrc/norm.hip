@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
       v[j] = (v[j] - mean) * rstd * g0[j] + b0[j];
       v[4 + j] = (v[4 + j] - mean) * rstd * g1[j] + b1[j];
     }
-    store8<YT>(y + vc * 8, v);
+    store8r<YT>(y, vc * 8, v);
   }
 }
 
@@ -448,13 +448,19 @@ __global__ __launch_bounds__(256) void layernorm_cached_kernel(const LayerNormPa
         o[j] = (v[i][j] - mean) * rstd * g0[j] + b0[j];
         o[4 + j] = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
       }
-      store8<YT>(y + vc * 8, o);
+      store8r<YT>(y, vc * 8, o);
     }
   }
 }
 
 void launch_layernorm(const LayerNormParams& p, hipStream_t s) {
   dim3 g((p.rows + 3) / 4);
+  if (p.y_dt == DT_HL) {     // split-operand output (fp32 rows in): the GEMM operand format of the fp32-class mode
+    if (p.x_dt != DT_F32 || (p.C & 15) != 0 || (p.ldy & 15) != 0) throw std::runtime_error("layernorm: HL16 output needs fp32 input and C % 16 == 0 rows");
+    if (p.C <= 8 * 64 * 3) hipLaunchKernelGGL((layernorm_cached_kernel<float, hlout_t, 3>), g, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((layernorm_kernel<float, hlout_t>), g, dim3(256), 0, s, p);
+    return;
+  }
   if (p.C <= 8 * 64 * 3) {
     if (p.x_dt == DT_F16 && p.y_dt == DT_F16) hipLaunchKernelGGL((layernorm_cached_kernel<half_t, half_t, 3>), g, dim3(256), 0, s, p);
     else if (p.x_dt == DT_F32 && p.y_dt == DT_F16) hipLaunchKernelGGL((layernorm_cached_kernel<float, half_t, 3>), g, dim3(256), 0, s, p);

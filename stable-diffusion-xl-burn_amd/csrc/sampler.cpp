@@ -115,7 +115,7 @@ void Diffuser::diffuse(float* latent, const Conditioning& c, int step_start, int
   p.table = table_; p.step_idx = step_idx_;
   p.n = n; p.HW = HW; p.use_cfg = single ? 0 : 1;
   p.ref = reference; p.mask = mask; p.step_noise = step_noise; p.n_steps_total = iters;
-  p.unet_in = unet_in; p.in_dt = u.compute_dt(); p.in_ld = uc.in_channels; p.in_rep = single ? 1 : 2;
+  p.unet_in = unet_in; p.in_dt = u.input_dt(); p.in_ld = uc.in_channels; p.in_rep = single ? 1 : 2;
   p.t_out = t_dev_;
   launch_ddim_step(p, 0, s);
 

@@ -75,7 +75,7 @@ void gemv(Exec& ex, const Lin& w, const float* x, int ldx, float* y, int ldy, in
           const float* yadd = nullptr) {
   if (ex.dry) return;
   GemvParams p{};
-  p.X = x; p.ldx = ldx; p.W = w.w; p.w_dt = ex.cdt; p.Kpad = w.Kpad; p.bias = w.b;
+  p.X = x; p.ldx = ldx; p.W = w.w; p.w_dt = w.dt >= 0 ? w.dt : ex.cdt; p.Kpad = w.Kpad; p.bias = w.b;
   p.Y = y; p.ldy = ldy; p.Yadd = yadd; p.Bm = Bm; p.N = w.N; p.K = w.K;
   p.silu_in = silu_in; p.silu_out = silu_out;
   if (ex.prof) ex.prof->begin(Profiler::OTHER, 2.0 * Bm * (double)w.N * w.K, ex.s);
@@ -87,10 +87,14 @@ void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, 
   if (ex.dry) return;
   AttnParams p{};
   p.Q = q.p; p.ldq = q.ld; p.K = k.p; p.ldk = k.ld; p.Vt = vt; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
-  p.dt = ex.cdt; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+  // (the split-operand mode runs the attention on fp32 tensors: q / k / V^T / o all carry q's dtype)
+  p.dt = q.dt; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
   if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0);
   launch_attention_d64(p, ex.s);
-  SDXL_HIP(hipGetLastError());
+  {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) throw Error(std::string("attention launch failed (") + hipGetErrorString(le) + "): Nq=" + std::to_string(Nq) + " Nk=" + std::to_string(Nk) + " dt=" + std::to_string(p.dt));
+  }
   if (ex.prof) ex.prof->end(ex.s);
 }
 }  // namespace
@@ -98,7 +102,7 @@ void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, 
 UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st)
     : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt) {
   SDXL_REQUIRE(cfg.n_head_channels == 64, "this engine's fused attention kernel is specialised for 64 channels per head");
-  SDXL_REQUIRE(!(compute_dt == DT_F32 && stream_dt != DT_F32), "f32 compute implies an f32 residual stream");
+  SDXL_REQUIRE(!((compute_dt == DT_F32 || compute_dt == DT_HL) && stream_dt != DT_F32), "f32 / split-operand compute implies an f32 residual stream");
   SDXL_REQUIRE(cfg.model_channels % 32 == 0, "GroupNorm(32) needs model_channels % 32 == 0");
   fuse_ln_ = compute_dt == DT_F16 && stream_dt == DT_F16;
   build_weights(src, st);
@@ -114,10 +118,11 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
   const std::vector<ParamSpec> specs = unet_param_specs(cfg_);
   warena_.reserve(WeightBuilder::arena_bound(specs, cdt_));
   WeightBuilder wb(specs, src, warena_, cdt_, st);
-  lin1_t_ = wb.linear("lin1_time_embed");
-  lin2_t_ = wb.linear("lin2_time_embed");
-  lin1_l_ = wb.linear("lin1_label_embed");
-  lin2_l_ = wb.linear("lin2_label_embed");
+  const int gv = cdt_ == DT_HL ? DT_F32 : -1;     // the M <= 8 GEMV weights of a split-operand model are packed fp32
+  lin1_t_ = wb.linear("lin1_time_embed", false, gv);
+  lin2_t_ = wb.linear("lin2_time_embed", false, gv);
+  lin1_l_ = wb.linear("lin1_label_embed", false, gv);
+  lin2_l_ = wb.linear("lin2_label_embed", false, gv);
   std::vector<BlockDesc> inp, out; BlockDesc mid;
   unet_block_plan(cfg_, inp, mid, out);
   std::vector<std::string> emb_names;
@@ -143,7 +148,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
   for (size_t i = 0; i < out.size(); ++i) out_.push_back(load_block("output_blocks." + std::to_string(i), out[i]));
   norm_out_ = wb.norm("norm_out");
   conv_out_ = wb.conv("conv_out");
-  embcat_ = wb.fused_linear(emb_names);
+  embcat_ = wb.fused_linear(emb_names, gv);
   emb_total_ = emb_off;
   SDXL_HIP(hipStreamSynchronize(st));
   // execution order of the spatial transformers (for the K/V caches)
@@ -157,16 +162,18 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
   SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
   const int vt_ld = (int)round_up(n_ctx, 64);
   const bool pack_xa = cdt_ == DT_F16 && n_ctx <= 96;   // operand-order copies for the fused cross-attention epilogue
+  const int kvdt = attn_dt();                           // dtype of the K / V^T caches (fp32 in the split-operand mode)
   const int emb = 4 * cfg_.model_channels;
   if (B != ctx_B_ || n_ctx != n_ctx_) {
     // (re)allocate the caches; captured graphs hold these addresses
     if (graph_) { (void)hipGraphExecDestroy(graph_); graph_ = nullptr; plan_runs_ = 0; }
     size_t bytes = 1 << 16;
     for (const STW* st : st_list_)
-      bytes += st->blocks.size() * (round_up((size_t)B * n_ctx * st->C * dt_size(cdt_), 256) +
-                                    round_up((size_t)B * st->C * vt_ld * dt_size(cdt_), 256) +
+      bytes += st->blocks.size() * (round_up((size_t)B * n_ctx * st->C * dt_size(kvdt), 256) +
+                                    round_up((size_t)B * st->C * vt_ld * dt_size(kvdt), 256) +
                                     (pack_xa ? round_up(xattn_pack_bytes(B, st->C), 256) : 0) + 768);
     bytes += 3 * round_up((size_t)B * emb * sizeof(float), 256);
+    if (cdt_ == DT_HL) bytes += round_up((size_t)B * n_ctx * cfg_.context_dim * 4, 256) + 256;   // HL16 copy of the context
     ctx_arena_.reserve(bytes);
     ctx_arena_.off = 0;
     SDXL_HIP(hipMemsetAsync(ctx_arena_.base, 0, bytes, s));   // V^T key padding must be zero
@@ -175,8 +182,8 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
       std::vector<KV> v;
       for (size_t j = 0; j < st->blocks.size(); ++j) {
         KV kv;
-        kv.k = ctx_arena_.alloc((size_t)B * n_ctx * st->C * dt_size(cdt_));
-        kv.vt = ctx_arena_.alloc((size_t)B * st->C * vt_ld * dt_size(cdt_));
+        kv.k = ctx_arena_.alloc((size_t)B * n_ctx * st->C * dt_size(kvdt));
+        kv.vt = ctx_arena_.alloc((size_t)B * st->C * vt_ld * dt_size(kvdt));
         if (pack_xa) kv.xa = ctx_arena_.alloc(xattn_pack_bytes(B, st->C));
         v.push_back(kv);
       }
@@ -186,15 +193,19 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
     ctx_B_ = B; n_ctx_ = n_ctx; vt_ld_ctx_ = vt_ld;
   }
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &ctx_arena_;
-  const Act ctx((void*)context, cfg_.context_dim, DT_F32);
+  const size_t m0 = ctx_arena_.mark();
+  Act ctx((void*)context, cfg_.context_dim, DT_F32);
+  if (cdt_ == DT_HL && !st_list_.empty() && !st_list_[0]->blocks.empty())      // one HL16 copy of the context for all 70 projections
+    ctx = hl_operand(ex, st_list_[0]->blocks[0].kv2, ctx, (size_t)B * n_ctx, cfg_.context_dim);
   for (size_t si = 0; si < st_list_.size(); ++si) {
     const STW* st = st_list_[si];
     for (size_t j = 0; j < st->blocks.size(); ++j) {
       Epi e; e.n_split = st->C; e.Ct = kv_[si][j].vt; e.ct_rows = st->C; e.ct_ld = vt_ld; e.rpb = n_ctx;
-      run_linear(ex, st->blocks[j].kv2, ctx, B * n_ctx, Act(kv_[si][j].k, st->C, cdt_), e);
+      run_linear(ex, st->blocks[j].kv2, ctx, B * n_ctx, Act(kv_[si][j].k, st->C, kvdt), e);
       if (kv_[si][j].xa) launch_xattn_pack(kv_[si][j].k, kv_[si][j].vt, kv_[si][j].xa, B, st->C, n_ctx, vt_ld, s);
     }
   }
+  ctx_arena_.reset(m0);
   // label embedding MLP (unet/mod.rs:464-466); scratch after the caches
   const size_t m = ctx_arena_.mark();
   float* l1 = (float*)ctx_arena_.alloc((size_t)B * emb * sizeof(float));
@@ -215,14 +226,14 @@ const float* UNet::res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, 
   const bool tiles256 = gn_from_producer_ && HW % 256 == 0;
   Act gn1 = ex.alloc(M, w.cin, ex.cdt);
   run_groupnorm(ex, w.norm_in, x, B, HW, gn1, true);
-  Act h = ex.alloc(M, w.cout, ex.cdt);
+  Act h = ex.alloc(M, w.cout, ex.cdt == DT_HL ? ex.sdt : ex.cdt);     // (read by a GroupNorm only: fp32 in the split-operand mode)
   Epi e1; e1.ebias = ex.ebias + w.emb_off; e1.ebias_ld = emb_total_;
   if (tiles256) e1.gn_part = (float*)ex.act->alloc(M / 256 * (size_t)w.cout * 2 * sizeof(float));
   if (run_conv(ex, w.conv_in, gn1, w.cin, g3, h, e1)) { h.gn_part = e1.gn_part; h.gn_rt = HW / 256; }
   Act gn2 = ex.alloc(M, w.cout, ex.cdt);
   run_groupnorm(ex, w.norm_out, h, B, HW, gn2, true);
   Epi e2;
-  if (w.has_skip) { run_conv(ex, w.skip, x, w.cin, g1, out); e2.R = out; }
+  if (w.has_skip) { run_conv(ex, w.skip, hl_operand(ex, w.skip, x, M, w.cin), w.cin, g1, out); e2.R = out; }
   else e2.R = x;
   if (tiles256) e2.gn_part = out_gn_part;
   const bool produced = run_conv(ex, w.conv_out, gn2, w.cout, g3, out, e2);
@@ -238,9 +249,10 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   SDXL_REQUIRE(C == w.heads * 64, "head dim must be 64");
   const int npad = (int)round_up(HW, 64);
   // cross-attention caches of this run's batch entries (dry runs carry null caches)
-  auto kv_k = [&](int s_, size_t j) { char* k = (char*)kv_[s_][j].k; return (void*)(k ? k + (size_t)ex.b0 * n_ctx_ * C * dt_size(ex.cdt) : k); };
+  const int adt = attn_dt();      // q / k / V^T / attention output: the compute dtype, fp32 in the split-operand mode
+  auto kv_k = [&](int s_, size_t j) { char* k = (char*)kv_[s_][j].k; return (void*)(k ? k + (size_t)ex.b0 * n_ctx_ * C * dt_size(adt) : k); };
   auto kv_xa = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].xa; return (const void*)(v ? v + xattn_pack_bytes(ex.b0, C) : v); };
-  auto kv_vt = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].vt; return (const void*)(v ? v + (size_t)ex.b0 * C * vt_ld_ctx_ * dt_size(ex.cdt) : v); };
+  auto kv_vt = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].vt; return (const void*)(v ? v + (size_t)ex.b0 * C * vt_ld_ctx_ * dt_size(adt) : v); };
   Act gn = ex.alloc(M, C, ex.cdt);
   run_groupnorm(ex, w.norm, x, B, HW, gn, false);
   Act t = ex.alloc(M, C, ex.sdt);
@@ -252,12 +264,15 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   int stp = 0;
   { Epi ep; ep.stat_out = w.blocks.empty() ? nullptr : stbuf[stp]; run_linear(ex, w.proj_in, gn, (int)M, t, ep); }
   Act ln = ex.alloc(M, C, ex.cdt);
-  Act qk = ex.alloc(M, 2 * C, ex.cdt);
-  void* vt = ex.act->alloc((size_t)B * C * npad * dt_size(ex.cdt));
+  Act qk = ex.alloc(M, 2 * C, adt);
+  void* vt = ex.act->alloc((size_t)B * C * npad * dt_size(adt));
   Act ao = ex.alloc(M, C, ex.cdt);
-  Act q = ex.alloc(M, C, ex.cdt);
+  Act q = ex.alloc(M, C, adt);
   Act gg = ex.alloc(M, 4 * C, ex.cdt);
-  if (npad != HW && !ex.dry) launch_fill_zero(vt, (size_t)B * C * npad * dt_size(ex.cdt), ex.s);
+  // split-operand mode: the attention runs on fp32 tensors (exact-fp32 MFMA kernel); its output becomes the HL16 operand `ao`
+  Act ao32 = ex.cdt == DT_HL ? ex.alloc(M, C, DT_F32) : ao;
+  auto ao_ready = [&]() { if (ex.cdt == DT_HL && !ex.dry) launch_f32_to_hl(ao32.p, ao32.ld, ao.p, ao.ld, M, C, ex.s); };
+  if (npad != HW && !ex.dry) launch_fill_zero(vt, (size_t)B * C * npad * dt_size(adt), ex.s);
   if (fuse_ln_) {
     // LayerNorms folded into the consuming GEMMs: every producer of the residual stream t also accumulates the row
     // (sum, sum^2) its consumer needs, so no LayerNorm kernel runs and t is read by the projections directly
@@ -293,7 +308,8 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_layernorm(ex, b.n1, t, (int)M, ln);
     Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW;
     run_linear(ex, b.qkv, ln, (int)M, qk, eq);
-    attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
+    attention(ex, qk, qk.cols(C), vt, npad, ao32, B, w.heads, HW, HW);
+    ao_ready();
     Epi er; er.R = t; er.rpb = HW;
     run_linear(ex, b.out1, ao, (int)M, t, er);
     run_layernorm(ex, b.n2, t, (int)M, ln);
@@ -303,7 +319,8 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       run_linear(ex, b.q2, ln, (int)M, ao, e2q);
     } else {
       run_linear(ex, b.q2, ln, (int)M, q);
-      attention(ex, q, Act(kv_k(si, j), C, ex.cdt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
+      attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_);
+      ao_ready();
     }
     run_linear(ex, b.out2, ao, (int)M, t, er);
     run_layernorm(ex, b.n3, t, (int)M, ln);
@@ -312,7 +329,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_linear(ex, b.ff, gg, (int)M, t, er);
   }
   Epi eo; eo.R = x; eo.rpb = HW;
-  run_linear(ex, w.proj_out, t, (int)M, x, eo);
+  run_linear(ex, w.proj_out, hl_operand(ex, w.proj_out, t, M, C), (int)M, x, eo);
   ex.act->reset(mk);
 }
 
@@ -326,7 +343,7 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
   float* embv = emb_ + (size_t)b0 * emb;
   float* ebias = ebias_ + (size_t)b0 * emb_total_;
   const float* label_emb = label_emb_ ? label_emb_ + (size_t)b0 * emb : nullptr;
-  void* in = (char*)in_ + (size_t)b0 * H * W * cfg_.in_channels * dt_size(cdt_);
+  void* in = (char*)in_ + (size_t)b0 * H * W * cfg_.in_channels * dt_size(input_dt());
   float* eps = eps_ + (size_t)b0 * H * W * cfg_.out_channels;
   ex.ebias = ebias; ex.b0 = b0;
   ex.gn_partial = gn_partial_ + (size_t)b0 * groupnorm_workspace_floats(1, 32);
@@ -357,7 +374,7 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
     cat[j] = ex.alloc((size_t)B * hs_h[i] * hs_w[i], out_[j].d.c_in, ex.sdt);
   }
   // --- input blocks (:474-477)
-  Act cur(in, cfg_.in_channels, ex.cdt);
+  Act cur(in, cfg_.in_channels, input_dt());
   int h = H, w = W, cur_c = cfg_.in_channels;
   int si = 0;
   for (int i = 0; i < n_in; ++i) {
@@ -365,10 +382,10 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
     const int j = n_in - 1 - i;
     const Act dest = cat[j].cols(cx[j]);
     switch (b.d.kind) {
-      case BK_CONV: run_conv(ex, b.conv, cur, cur_c, ConvGeom{B, h, w, h, w, 3, 1, 1, 0}, dest); break;
+      case BK_CONV: run_conv(ex, b.conv, hl_operand(ex, b.conv, cur, (size_t)B * h * w, cur_c), cur_c, ConvGeom{B, h, w, h, w, 3, 1, 1, 0}, dest); break;
       case BK_DOWN: {
         const int h2 = (h - 1) / 2 + 1, w2 = (w - 1) / 2 + 1;
-        run_conv(ex, b.conv, cur, cur_c, ConvGeom{B, h, w, h2, w2, 3, 2, 1, 0}, dest);
+        run_conv(ex, b.conv, hl_operand(ex, b.conv, cur, (size_t)B * h * w, cur_c), cur_c, ConvGeom{B, h, w, h2, w2, 3, 2, 1, 0}, dest);
         h = h2; w = w2;
         break;
       }
@@ -414,7 +431,7 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
       res_block(ex, b.res, cat[j], B, h, w, dest);
     }
     if (up) {   // Upsample::forward :742-752 -- nearest 2x fused into the conv gather
-      run_conv(ex, b.conv, dest, b.d.c_out, ConvGeom{B, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next);
+      run_conv(ex, b.conv, hl_operand(ex, b.conv, dest, (size_t)B * h * w, b.d.c_out), b.d.c_out, ConvGeom{B, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next);
       h *= 2; w *= 2;
     }
     ex.act->reset(mk);
@@ -442,7 +459,7 @@ void UNet::ensure_plan(int B, int H, int W) {
   pB_ = B; pH_ = H; pW_ = W;
   const int mc = cfg_.model_channels, emb = 4 * mc;
   auto persist = [&]() {
-    in_ = act_.alloc((size_t)B * H * W * cfg_.in_channels * dt_size(cdt_));
+    in_ = act_.alloc((size_t)B * H * W * cfg_.in_channels * dt_size(input_dt()));
     eps_ = (float*)act_.alloc((size_t)B * H * W * cfg_.out_channels * sizeof(float));
     temb_ = (float*)act_.alloc((size_t)B * mc * sizeof(float));
     g1_ = (float*)act_.alloc((size_t)B * emb * sizeof(float));
@@ -564,7 +581,7 @@ void UNet::forward_nchw(const float* x, const int* timesteps, const float* conte
                         int H, int W, float* out, hipStream_t s) {
   ensure_plan(B, H, W);
   set_context(context, n_ctx, label, B, s);
-  launch_nchw_to_nhwc(x, cfg_.in_channels * H * W, in_, cdt_, B, cfg_.in_channels, H * W, cfg_.in_channels, 1.0f, s);
+  launch_nchw_to_nhwc(x, cfg_.in_channels * H * W, in_, input_dt(), B, cfg_.in_channels, H * W, cfg_.in_channels, 1.0f, s);
   launch_i32_to_f32(timesteps, tconv_, B, s);
   forward(B, H, W, tconv_, 1, s);
   launch_nhwc_to_nchw(eps_, DT_F32, cfg_.out_channels, out, B, cfg_.out_channels, H * W, 1.0f, s);

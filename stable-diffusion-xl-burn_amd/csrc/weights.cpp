@@ -120,7 +120,7 @@ WeightBuilder::~WeightBuilder() { if (tmp) (void)hipFree(tmp); if (tmp2) (void)h
 size_t WeightBuilder::arena_bound(const std::vector<ParamSpec>& specs, int dt) {
   size_t total = 1 << 20;
   for (const ParamSpec& p : specs) {
-    if (p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * round_up(p.shape[0], 64) * dt_size(dt) + 256;
+    if (p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * round_up(p.shape[0], 64) * dt_size(dt) + 768;   // (+ the DT_HL scale scalar)
     else if (p.kind == PK_CONV_W)
       total += round_up(p.shape[0], 128) * round_up((size_t)p.shape[1] * p.shape[2] * p.shape[3], 64) * dt_size(dt) + 768;   // (+ the DT_HL scale scalar)
     else total += round_up(p.numel(), 128) * sizeof(float) + 256;
@@ -140,21 +140,47 @@ const float* WeightBuilder::fetch(const std::string& name) {
   src.fetch(s, i, tmp, st);
   return tmp;
 }
-Lin WeightBuilder::linear(const std::string& name, bool geglu) {
+// Split-operand packing (DT_HL): hi = f16(w * 2^e), lo = f16(w * 2^e - hi).  With 2^e * max|w| in [2^13, 2^14) both halves of every
+// weight down to 2^-11 of the largest stay f16-normal (22 significand bits); unscaled, |w| ~ 0.02 would push every lo into the
+// subnormals (~20 bits).  The factor is exact, a function of the tensor(s) only, and the GEMM epilogue undoes it with the device
+// scalar this returns through l.acc_scale (it lives in the arena, so replicas receive it with the weights).
+float WeightBuilder::hl_scale(Lin& l, const std::vector<std::string>& weight_names) {
+  float* sc = (float*)arena.alloc(sizeof(float));     // (allocated on empty replicas too: identical arena layout)
+  l.acc_scale = sc;
+  if (src.empty()) return 1.f;
+  SDXL_HIP(hipMemsetAsync(sc, 0, sizeof(float), st));
+  for (const std::string& n : weight_names) launch_absmax(fetch(n), spec(n).numel(), sc, st, true);
+  float h = 0.f;
+  SDXL_HIP(hipMemcpyAsync(&h, sc, sizeof(float), hipMemcpyDeviceToHost, st));
+  SDXL_HIP(hipStreamSynchronize(st));
+  int e = 0;
+  if (h > 0.f && std::isfinite(h)) { (void)std::frexp(h, &e); e = 14 - e; }       // h = m * 2^(14 - e), m in [0.5, 1) -> h * 2^e in [2^13, 2^14)
+  e = e > 24 ? 24 : (e < -24 ? -24 : e);
+  const float wscale = std::ldexp(1.0f, e), inv = 1.0f / wscale;
+  SDXL_HIP(hipMemcpyAsync(sc, &inv, sizeof(float), hipMemcpyHostToDevice, st));
+  SDXL_HIP(hipStreamSynchronize(st));
+  return wscale;
+}
+
+Lin WeightBuilder::linear(const std::string& name, bool geglu, int dt_override) {
   const ParamSpec& s = spec(name + ".weight");
   Lin l; l.K = s.shape[0]; l.N = s.shape[1]; l.ksize = 1; l.cin = l.K;
-  const int kt = dt == DT_F16 ? 64 : 32;
+  // dt_override: the GEMV weights of a split-operand model stay fp32; K % 32 != 0 cannot go through the HL pipeline either
+  const int wdt = dt_override >= 0 ? dt_override : ((dt == DT_HL && l.K % 32 != 0) ? DT_F32 : dt);
+  if (wdt != dt) l.dt = wdt;
+  const int kt = wdt == DT_F16 ? 64 : 32;
   l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
-  void* w = arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
+  void* w = arena.alloc((size_t)l.Npad * l.Kpad * dt_size(wdt));
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   l.w = w; l.b = b;
+  const float wscale = wdt == DT_HL ? hl_scale(l, {name + ".weight"}) : 1.f;
   if (src.empty()) return l;
-  launch_pack_linear(fetch(name + ".weight"), w, dt, l.K, l.N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st);
+  launch_pack_linear(fetch(name + ".weight"), w, wdt, l.K, l.N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st, nullptr, wscale);
   const float* bsrc = has(name + ".bias") ? fetch(name + ".bias") : nullptr;
   launch_pack_bias(bsrc, b, l.N, l.Npad, geglu ? 1 : 0, 0, st);
   return l;
 }
-Lin WeightBuilder::fused_linear(const std::vector<std::string>& names) {
+Lin WeightBuilder::fused_linear(const std::vector<std::string>& names, int dt_override) {
   Lin l; l.ksize = 1;
   int ntot = 0;
   for (const std::string& n : names) {
@@ -164,19 +190,27 @@ Lin WeightBuilder::fused_linear(const std::vector<std::string>& names) {
     ntot += s.shape[1];
   }
   l.N = ntot; l.cin = l.K;
-  const int kt = dt == DT_F16 ? 64 : 32;
+  const int wdt = dt_override >= 0 ? dt_override : ((dt == DT_HL && l.K % 32 != 0) ? DT_F32 : dt);
+  if (wdt != dt) l.dt = wdt;
+  const int kt = wdt == DT_F16 ? 64 : 32;
   l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
-  char* w = (char*)arena.alloc((size_t)l.Npad * l.Kpad * dt_size(dt));
+  char* w = (char*)arena.alloc((size_t)l.Npad * l.Kpad * dt_size(wdt));
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   l.w = w; l.b = b;
+  float wscale = 1.f;
+  if (wdt == DT_HL) {     // ONE factor for the concatenated matrix (one accumulator scale per GEMM)
+    std::vector<std::string> wn;
+    for (const std::string& n : names) wn.push_back(n + ".weight");
+    wscale = hl_scale(l, wn);
+  }
   if (src.empty()) return l;
-  SDXL_HIP(hipMemsetAsync(w, 0, (size_t)l.Npad * l.Kpad * dt_size(dt), st));
+  SDXL_HIP(hipMemsetAsync(w, 0, (size_t)l.Npad * l.Kpad * dt_size(wdt), st));
   SDXL_HIP(hipMemsetAsync(b, 0, (size_t)l.Npad * sizeof(float), st));
   int off = 0;
   for (const std::string& n : names) {
     const ParamSpec& s = spec(n + ".weight");
     const int N = s.shape[1];
-    launch_pack_linear(fetch(n + ".weight"), w, dt, l.K, N, l.Kpad, N, 0, off, st);   // exactly N rows at row offset
+    launch_pack_linear(fetch(n + ".weight"), w, wdt, l.K, N, l.Kpad, N, 0, off, st, nullptr, wscale);   // exactly N rows at row offset
     const float* bsrc = has(n + ".bias") ? fetch(n + ".bias") : nullptr;
     launch_pack_bias(bsrc, b, N, N, 0, off, st);
     off += N;
@@ -257,28 +291,7 @@ Lin WeightBuilder::conv(const std::string& name) {
   void* w = arena.alloc((size_t)l.Npad * l.Kpad * dt_size(wdt));
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   l.w = w; l.b = b;
-  float wscale = 1.f;
-  if (wdt == DT_HL) {
-    float* sc = (float*)arena.alloc(sizeof(float));     // (allocated on empty replicas too: identical arena layout)
-    l.acc_scale = sc;
-    // hi = f16(w * 2^e), lo = f16(w * 2^e - hi): with 2^e * max|w| in [2^13, 2^14) both halves of every weight down to 2^-11 of the
-    // largest stay f16-normal (22 significand bits); unscaled, |w| ~ 0.02 would push every lo into the subnormals (~20 bits).
-    // The factor is exact and the epilogue undoes it (IgemmParams::acc_scale).  The exponent is a function of the tensor only.
-    if (!src.empty()) {
-      launch_absmax(fetch(name + ".weight"), s.numel(), sc, st);
-      float h = 0.f;
-      SDXL_HIP(hipMemcpyAsync(&h, sc, sizeof(float), hipMemcpyDeviceToHost, st));
-      SDXL_HIP(hipStreamSynchronize(st));
-      int e = 0;
-      if (h > 0.f && std::isfinite(h)) { (void)std::frexp(h, &e); e = 14 - e; }       // h = m * 2^(14 - e), m in [0.5, 1) -> h * 2^e in [2^13, 2^14)
-      if (e > 24) e = 24;
-      if (e < -24) e = -24;
-      wscale = std::ldexp(1.0f, e);
-      const float inv = 1.0f / wscale;
-      SDXL_HIP(hipMemcpyAsync(sc, &inv, sizeof(float), hipMemcpyHostToDevice, st));
-      SDXL_HIP(hipStreamSynchronize(st));
-    }
-  }
+  const float wscale = wdt == DT_HL ? hl_scale(l, {name + ".weight"}) : 1.f;
   if (src.empty()) return l;
   launch_pack_conv(fetch(name + ".weight"), w, wdt, l.N, l.cin, l.ksize, l.Kpad, l.Npad, st, wscale);
   launch_pack_bias(fetch(name + ".bias"), b, l.N, l.Npad, 0, 0, st);
@@ -331,10 +344,25 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize);
   p.acc_scale = w.acc_scale;
   launch_igemm(p, w.dt >= 0 ? w.dt : ex.cdt, ex.s);
-  SDXL_HIP(hipGetLastError());     // a refused launch (bad grid / LDS attribute) must not pass silently
+  {   // a refused launch (bad grid / LDS attribute) must not pass silently
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess)
+      throw Error(std::string("implicit-GEMM launch failed (") + hipGetErrorString(le) + "): M=" + std::to_string(p.M) + " N=" + std::to_string(p.N) +
+                  " K=" + std::to_string(p.K) + " ksize=" + std::to_string(p.ksize) + " a_dt=" + std::to_string(p.a_dt) + " c_dt=" + std::to_string(p.c_dt) +
+                  " compute=" + std::to_string(w.dt >= 0 ? w.dt : ex.cdt) + " act=" + std::to_string(p.act) + " n_split=" + std::to_string(p.n_split));
+  }
   if (ex.prof) ex.prof->end(ex.s);
   if (ex.fork_ev && ++ex.launches == ex.fork_after) SDXL_HIP(hipEventRecord(ex.fork_ev, ex.s));
   return p.gn_part != nullptr;
+}
+// GEMM operand view of a residual-stream tensor: the split-operand mode keeps the stream in fp32 and stages (hi, lo) f16 pairs, so
+// GEMMs that read the stream directly (skip / nin_shortcut 1x1 convs, up- / downsamplers, proj_out) get an HL16 copy; other modes
+// -- and layers whose weights were packed fp32 (w.dt) -- read x itself
+Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C) {
+  if (ex.cdt != DT_HL || x.dt != DT_F32 || w.dt == DT_F32) return x;
+  Act o = ex.alloc(rows, C, DT_HL);
+  if (!ex.dry) launch_f32_to_hl(x.p, x.ld, o.p, o.ld, rows, C, ex.s);
+  return o;
 }
 bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e) {
   ConvGeom g{1, M, 1, M, 1, 1, 1, 0, 0};
@@ -354,7 +382,10 @@ void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const 
   SDXL_REQUIRE(!x.gn_part || x.gn_rt * 256 == HW, "producer GroupNorm statistics do not cover the tensor");
   if (ex.prof) ex.prof->begin(Profiler::GROUPNORM, 0.0, ex.s);
   launch_groupnorm(p, ex.s);
-  SDXL_HIP(hipGetLastError());
+  {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) throw Error(std::string("GroupNorm launch failed (") + hipGetErrorString(le) + "): C=" + std::to_string(p.C) + " HW=" + std::to_string(p.HW) + " y_dt=" + std::to_string(p.y_dt));
+  }
   if (ex.prof) ex.prof->end(ex.s);
 }
 void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y) {
@@ -364,6 +395,10 @@ void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& 
   p.gamma = n.gamma; p.beta = n.beta; p.rows = rows; p.C = n.C; p.eps = 1e-5f; p.eps_ptr = n.eps;
   if (ex.prof) ex.prof->begin(Profiler::LAYERNORM, 0.0, ex.s);
   launch_layernorm(p, ex.s);
+  {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) throw Error(std::string("LayerNorm launch failed (") + hipGetErrorString(le) + "): C=" + std::to_string(p.C) + " rows=" + std::to_string(p.rows) + " y_dt=" + std::to_string(p.y_dt));
+  }
   if (ex.prof) ex.prof->end(ex.s);
 }
 

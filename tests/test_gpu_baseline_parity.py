@@ -171,7 +171,8 @@ def test_unet_forward_1024_matches_oracle(pkg, ctx):
     ref = torch.from_numpy(g["out"])
     rep = {}
     outs = {}
-    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f16", pkg.DTYPE_F16, F16_FWD_REL), ("f16_f32res", pkg.DTYPE_F16_F32RES, F16RES_FWD_REL)):
+    for name, dt, tol in (("f32", pkg.DTYPE_F32, F32_FWD_REL), ("f32_split", pkg.DTYPE_F32_SPLIT, F32_FWD_REL), ("f16", pkg.DTYPE_F16, F16_FWD_REL),
+                          ("f16_f32res", pkg.DTYPE_F16_F32RES, F16RES_FWD_REL)):
         u = pkg.UNet(ctx, cfg, dt, seed=0)
         outs[name] = u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu()
         rep[name] = errs(outs[name], ref)
@@ -229,7 +230,7 @@ def test_config2_trajectory_parity_and_drift(pkg, ctx):
     n_it = pkg.step_count(30)
     assert n_it == 31
     trajs, secs = {}, {}
-    for name, dt in (("f32", pkg.DTYPE_F32), ("f16", pkg.DTYPE_F16), ("f16_f32res", pkg.DTYPE_F16_F32RES)):
+    for name, dt in (("f32", pkg.DTYPE_F32), ("f32_split", pkg.DTYPE_F32_SPLIT), ("f16", pkg.DTYPE_F16), ("f16_f32res", pkg.DTYPE_F16_F32RES)):
         d = pkg.Diffuser(ctx, cfg, dt, seed=0)
         trace = torch.zeros(n_it, 1, 4, 128, 128, device="cuda")
         d.set_trace(trace)
@@ -256,6 +257,13 @@ def test_config2_trajectory_parity_and_drift(pkg, ctx):
               f"engine {secs['f32']:.1f} s vs oracle {rep['oracle_seconds']:.0f} s")
         for j, s in enumerate(steps):
             assert rep["f32_vs_oracle"][str(s)]["max_abs"] <= lat_bound(ref_traj[j]), (s, rep["f32_vs_oracle"][str(s)])
+        # the split-operand mode (fp32 stream, (hi, lo) f16 GEMM operands, fp32 attention) against the SAME oracle trajectory and bar
+        rep["f32_split_vs_oracle"] = {str(s): errs(trajs["f32_split"][s], ref_traj[j]) for j, s in enumerate(steps)}
+        rep["f32_split_vs_oracle"]["final"] = errs(trajs["f32_split"][-1], torch.from_numpy(g["latent"]))
+        fs = rep["f32_split_vs_oracle"]["final"]
+        print(f"config 2 (31 steps, CFG 7.5) F32_SPLIT engine vs oracle: final max-abs {fs['max_abs']:.3e} rel {fs['rel']:.3e}; engine {secs['f32_split']:.1f} s")
+        for j, s in enumerate(steps):
+            assert rep["f32_split_vs_oracle"][str(s)]["max_abs"] <= lat_bound(ref_traj[j]), (s, rep["f32_split_vs_oracle"][str(s)])
     for name in ("f16", "f16_f32res"):
         per = [errs(trajs[name][k], trajs["f32"][k]) for k in range(n_it)]
         rep[name + "_vs_f32"] = per

@@ -21,15 +21,17 @@ pytestmark = pytest.mark.gpu
 
 # f16-operand bounds: <= 2x the largest value measured for the class (profiles/r02_gpu_tests_final.log: forward 1.4e-3 on 16^2 /
 # 2.3e-3 on 32^2 inputs; F16_F32RES 1.2e-3), so a 2x regression fails
-FWD_TOL = {0: 1e-4, 1: 4.5e-3, 2: 2.5e-3}
-EPS_TOL = {0: 1e-4, 1: 6e-3, 2: 6e-3}    # the low-variance per-norm-eps probe (measured 1.2e-5 / 2.9e-3 / 2.7e-3)
+# dtype 3 = SDXL_DTYPE_F32_SPLIT: fp32 residual stream, GEMM operands as (hi, lo) f16 pairs (3 MFMAs per product), fp32 attention --
+# held to the strict mode's bounds
+FWD_TOL = {0: 1e-4, 1: 4.5e-3, 2: 2.5e-3, 3: 1e-4}
+EPS_TOL = {0: 1e-4, 1: 6e-3, 2: 6e-3, 3: 1e-4}    # the low-variance per-norm-eps probe (measured 1.2e-5 / 2.9e-3 / 2.7e-3)
 LAT_ABS_F32 = 1e-3           # north_star: latents within 1e-3 of the fp32 CPU reference (strict-parity mode)
 LAT_REL_F16 = 7.5e-3         # fp16-operand modes: max-abs error relative to max|latent|; measured 3.0e-3 (4 CFG-7.5 steps) and 3.8e-3
                              # (5-step inpainting) on the tiny net -> <= 2x measured
 
 
 def lat_tol(dtype, ref):
-    return LAT_ABS_F32 if dtype == 0 else LAT_REL_F16 * float(ref.abs().max())
+    return LAT_ABS_F32 if dtype in (0, 3) else LAT_REL_F16 * float(ref.abs().max())
 
 
 def _cond(ocfg, n, res, n_ctx=9, refiner=False, seed=30):
@@ -52,7 +54,7 @@ def _pkg_cond(pkg, c, res, refiner=False):
                             resolution=res)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("which", ["tiny", "tiny_refiner"])
 def test_unet_forward(pkg, ctx, dtype, which):
     ocfg = OC.tiny_config() if which == "tiny" else OC.tiny_refiner_config()
@@ -79,7 +81,7 @@ def test_unet_forward(pkg, ctx, dtype, which):
     assert torch.equal(out2, outs[0]), "synthetic device weights differ from the oracle's"
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 def test_unet_forward_per_norm_eps(pkg, ctx, dtype):
     # eps is a per-module value in the reference's dumps (groupnorm/load.rs:19, layernorm/load.rs:17), not a global 1e-5:
     # low-variance inputs make the difference visible.  Every GroupNorm / LayerNorm (stand-alone kernels AND the folded
@@ -174,7 +176,7 @@ def test_fused_cross_attention_matches_two_kernel_path(pkg, ctx):
     assert e_f < FWD_TOL[1] and e_p < FWD_TOL[1] and e_fp < 4e-3
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 def test_unet_forward_batch_independence(pkg, ctx, dtype):
     # the engine batches the CFG pair; per-sample results must not depend on what else is in the batch
     ocfg = OC.tiny_config()
@@ -187,7 +189,7 @@ def test_unet_forward_batch_independence(pkg, ctx, dtype):
         assert torch.equal(one[0], both[i])
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("n,n_steps,cfg_scale", [(1, 4, 7.5), (2, 8, 1.0)])
 def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
     ocfg = OC.tiny_config()
@@ -206,7 +208,7 @@ def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
     assert torch.equal(out, out2), "trajectory is not deterministic"
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 3])
 def test_refine_latent(pkg, ctx, dtype):
     ocfg = OC.tiny_refiner_config()
     res = (64, 64)
@@ -220,7 +222,7 @@ def test_refine_latent(pkg, ctx, dtype):
     assert e < lat_tol(dtype, ref)
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 3])
 def test_sample_latent_with_inpainting(pkg, ctx, dtype):
     ocfg = OC.tiny_config()
     res = (64, 64)
@@ -350,7 +352,7 @@ def test_errors_are_reported_not_fatal(pkg, ctx):
                   torch.zeros(1, 3, ocfg.context_dim).cuda(), torch.zeros(1, ocfg.adm_in_channels).cuda())
 
 
-@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dtype", [1, 0, 3])
 def test_empty_replica_receives_weight_arena(pkg, ctx, dtype):
     """the multi-GPU replica path on one GPU: a model created `empty` (identical arena layout, no contents) must reproduce
     the source model bit for bit once the packed arena has been copied in through the zero-copy tensor view -- exactly what
