@@ -21,6 +21,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDXL_MEASURE_LIB=1 (tools/ only): the measurement build (`build.py --measure`: A/B partners, measurement modes, timeline stamps)
 LIB_PATH = os.path.join(_HERE, "lib", "libsdxl_mi355_measure.so" if os.environ.get("SDXL_MEASURE_LIB") == "1" else "libsdxl_mi355.so")
+if os.environ.get("SDXL_LIB_PATH"):      # tools/ only: an explicitly named build of the same library (A/B of two commits on one box)
+    LIB_PATH = os.environ["SDXL_LIB_PATH"]
 
 DTYPE_F32 = 0        # strict parity: fp32 storage + exact fp32 MFMA
 DTYPE_F16 = 1        # fp16 storage / MFMA operands, fp32 accumulate

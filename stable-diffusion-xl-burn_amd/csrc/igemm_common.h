@@ -15,6 +15,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+// Wave-uniform read-only vectors (column sums, biases): eight floats through the SCALAR cache (s_load_dwordx8) instead of a
+// 64-lane VMEM request whose lanes all ask for the same 16 bytes.  `ptr` must be wave-uniform and 4-byte aligned; the memory is
+// never written by the running kernel (constant address space).
+__device__ __forceinline__ f32x8 uniform_load8(const float* ptr) {
+  const unsigned long long a = (unsigned long long)(uintptr_t)ptr;
+  const unsigned long long u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+  return *(const __attribute__((address_space(4))) f32x8*)(uintptr_t)u;
+}
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Split-operand element (DT_HL): a logical fp32 value x travels as TWO f16 numbers, hi = f16(x) and lo = f16(x - hi), i.e. 22
@@ -858,17 +867,21 @@ __device__ __forceinline__ void xattn_inplace(const IgemmParams& p, f32x16 (&acc
                                               float (&lnA)[TM], float (&lnC)[TM], const void* zeros,
                                               const half8 (&kf)[3][4], const half8 (&vf)[2][6]) {
   if (nw >= p.N) return;                                              // zero-padded weight columns: nothing is stored
-  const int fr = lane & 31, fh = lane >> 5;
-  const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
+  const int fh = lane >> 5;
   const int nctx = p.xa_nctx;
-  f32x4 cz[2][4], bz[2][4];                                          // folded-LayerNorm column sums, bias (beta W of the folded norm)
+  // folded-LayerNorm column sums and bias (beta W of the folded norm) of this wave's 64 columns: wave-uniform, so they come
+  // through the scalar cache, eight columns per s_load; a lane keeps the four of its half (fh)
+  f32x4 cz[2][4], bz[2][4];
+  const float* zf = reinterpret_cast<const float*>(zeros);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int nb = nw + j * 32 + 8 * q + 4 * fh;
-      cz[j][q] = *(p.ln_stat ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
-      bz[j][q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
+      const int nbu = nw + j * 32 + 8 * q;
+      const f32x8 c8 = uniform_load8(p.ln_stat ? p.ln_cs + nbu : zf);
+      const f32x8 b8 = uniform_load8(p.bias ? p.bias + nbu : zf);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { cz[j][q][r] = fh ? c8[4 + r] : c8[r]; bz[j][q][r] = fh ? b8[4 + r] : b8[r]; }
     }
   const float sc = p.xa_scale * 1.44269504088896340736f;             // p = exp2(s - m)
 #pragma unroll

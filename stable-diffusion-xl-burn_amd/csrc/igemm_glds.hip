@@ -343,14 +343,18 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       if constexpr (ph < 0 || q % 3 == ph) {
         if constexpr (LIN) {
           // saddr form: global_load_lds_dwordx4 voffset, sbase -- M0 = LDS byte address of this wave's 1-KiB piece
+          // (hand-written, so the hazards are ours to keep: an LDS-DMA instruction must not issue in the wait state right behind
+          // the SALU write of M0 -- it would take the PREVIOUS piece's LDS address -- and a VMEM instruction needs 5 wait
+          // states behind a VALU write (v_readlane / v_readfirstlane restore) of its scalar base; s_mov + s_nop 3 covers both.
+          // The compiler's hazard recogniser does this for the builtin form and does not look inside inline asm.)
           if constexpr (q < AJ) {
             const unsigned m = lds0 + buf * STAGE + wave * 1024 + q * (NW * 1024), vo = aoff[q];
             const unsigned long long sb = abase;      // (asm operands do not capture into the generic lambda by themselves)
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(vo), "s"(sb) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(vo), "s"(sb) : "memory");
           } else if (q - AJ < BJ - 1 || lastb) {
             const unsigned m = lds0 + buf * STAGE + BM * 128 + wave * 1024 + (q - AJ) * (NW * 1024), vo = woff[q - AJ];
             const unsigned long long sb = wbase;
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(vo), "s"(sb) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(vo), "s"(sb) : "memory");
           }
         } else if constexpr (q < AJ) {
           __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(la + q * (NW * 1024)), 16, 0, 0);
@@ -467,6 +471,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   if constexpr (LN_COOP) lnc.finish(p, m0, ln_coef);
   if (!ln_coop) ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
   if (NPRO <= nk) wait_tiles(std::integral_constant<int, NPRO - 1>{}); else wait_vmcnt<0>();
+  // finish()'s ds_write of the row coefficients must have LANDED before the barrier releases their readers: a raw s_barrier
+  // carries no wait of its own, and a wave whose tile 0 is already there reaches it a few cycles behind the write
+  if constexpr (LN_COOP) wait_lgkmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -779,6 +786,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   lnc.finish(p, m0, ln_coef);
   if (!ln_coop) ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
   if (NS <= nk) wait_tiles(std::integral_constant<int, NS - 1>{}); else wait_vmcnt<0>();
+  wait_lgkmcnt<0>();                             // the coefficients' ds_write has landed (raw s_barrier waits for nothing)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
