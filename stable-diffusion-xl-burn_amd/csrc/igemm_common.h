@@ -24,6 +24,12 @@ __device__ __forceinline__ f32x8 uniform_load8(const float* ptr) {
   const unsigned long long u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
   return *(const __attribute__((address_space(4))) f32x8*)(uintptr_t)u;
 }
+// the four values of this lane's half (fh = lane >> 5) of the eight columns from `nbu` of a per-column vector; a null / absent
+// vector reads the zero page.  Vectors are padded to Npad, so the eight-column read never leaves the array.
+__device__ __forceinline__ f32x4 col_vec4(const float* arr, bool present, int nbu, int fh, const void* zeros) {
+  const f32x8 c = uniform_load8(present ? arr + nbu : reinterpret_cast<const float*>(zeros));
+  return fh ? f32x4{c[4], c[5], c[6], c[7]} : f32x4{c[0], c[1], c[2], c[3]};
+}
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Split-operand element (DT_HL): a logical fp32 value x travels as TWO f16 numbers, hi = f16(x) and lo = f16(x - hi), i.e. 22
@@ -311,13 +317,15 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       f32x4 bz[NQ], cz[NQ], gz[NQ], gc[NQ], ez[TM][NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int nb = nt + 8 * q + 4 * fh;        // packed column of element r = 0 (bias arrays are padded to Npad)
+        const int nbu = nt + 8 * q;                // wave-uniform part: the weight-side vectors come through the scalar cache
+        const int nb = nbu + 4 * fh;               // packed column of element r = 0 (bias arrays are padded to Npad)
         const bool ok = nb < p.N;                  // columns of the zero-padded weight rows: nothing to add, never stored
-        bz[q] = *((p.bias && ok) ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
-        cz[q] = *((p.ln_stat && ok) ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
+        const bool oku = nbu < p.N;
+        bz[q] = col_vec4(p.bias, p.bias && oku, nbu, fh, zeros);
+        cz[q] = col_vec4(p.ln_cs, p.ln_stat && oku, nbu, fh, zeros);
         if constexpr (GEGLU) {
-          gz[q] = *((p.bias && ok) ? reinterpret_cast<const f32x4*>(p.bias + nb + 16) : zv);
-          gc[q] = *((p.ln_stat && ok) ? reinterpret_cast<const f32x4*>(p.ln_cs + nb + 16) : zv);
+          gz[q] = col_vec4(p.bias, p.bias && oku, nbu + 16, fh, zeros);
+          gc[q] = col_vec4(p.ln_cs, p.ln_stat && oku, nbu + 16, fh, zeros);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -350,10 +358,10 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       f32x4 bz[4], cz[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int nb = nw + j * 32 + 8 * q + 4 * fh;
-        const bool ok = nb < p.N;
-        bz[q] = *((p.bias && ok) ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
-        cz[q] = *((p.ln_stat && ok) ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
+        const int nbu = nw + j * 32 + 8 * q;
+        const bool oku = nbu < p.N;
+        bz[q] = col_vec4(p.bias, p.bias && oku, nbu, fh, zeros);
+        cz[q] = col_vec4(p.ln_cs, p.ln_stat && oku, nbu, fh, zeros);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -686,12 +694,12 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, const 
     f32x4 bz[NQ], cz[NQ], gz[NQ], gc[NQ], ez[TM][NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int nb = nt + 8 * q + 4 * fh;
-      bz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
-      cz[q] = *(p.ln_stat ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
+      const int nbu = nt + 8 * q, nb = nbu + 4 * fh;      // weight-side vectors: wave-uniform, through the scalar cache
+      bz[q] = col_vec4(p.bias, p.bias != nullptr, nbu, fh, zeros);
+      cz[q] = col_vec4(p.ln_cs, p.ln_stat != nullptr, nbu, fh, zeros);
       if constexpr (GEGLU) {
-        gz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb + 16) : zv);
-        gc[q] = *(p.ln_stat ? reinterpret_cast<const f32x4*>(p.ln_cs + nb + 16) : zv);
+        gz[q] = col_vec4(p.bias, p.bias != nullptr, nbu + 16, fh, zeros);
+        gc[q] = col_vec4(p.ln_cs, p.ln_stat != nullptr, nbu + 16, fh, zeros);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -872,16 +880,13 @@ __device__ __forceinline__ void xattn_inplace(const IgemmParams& p, f32x16 (&acc
   // folded-LayerNorm column sums and bias (beta W of the folded norm) of this wave's 64 columns: wave-uniform, so they come
   // through the scalar cache, eight columns per s_load; a lane keeps the four of its half (fh)
   f32x4 cz[2][4], bz[2][4];
-  const float* zf = reinterpret_cast<const float*>(zeros);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int nbu = nw + j * 32 + 8 * q;
-      const f32x8 c8 = uniform_load8(p.ln_stat ? p.ln_cs + nbu : zf);
-      const f32x8 b8 = uniform_load8(p.bias ? p.bias + nbu : zf);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { cz[j][q][r] = fh ? c8[4 + r] : c8[r]; bz[j][q][r] = fh ? b8[4 + r] : b8[r]; }
+      cz[j][q] = col_vec4(p.ln_cs, p.ln_stat != nullptr, nbu, fh, zeros);
+      bz[j][q] = col_vec4(p.bias, p.bias != nullptr, nbu, fh, zeros);
     }
   const float sc = p.xa_scale * 1.44269504088896340736f;             // p = exp2(s - m)
 #pragma unroll
