@@ -317,15 +317,13 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       f32x4 bz[NQ], cz[NQ], gz[NQ], gc[NQ], ez[TM][NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int nbu = nt + 8 * q;                // wave-uniform part: the weight-side vectors come through the scalar cache
-        const int nb = nbu + 4 * fh;               // packed column of element r = 0 (bias arrays are padded to Npad)
+        const int nb = nt + 8 * q + 4 * fh;        // packed column of element r = 0 (bias arrays are padded to Npad)
         const bool ok = nb < p.N;                  // columns of the zero-padded weight rows: nothing to add, never stored
-        const bool oku = nbu < p.N;
-        bz[q] = col_vec4(p.bias, p.bias && oku, nbu, fh, zeros);
-        cz[q] = col_vec4(p.ln_cs, p.ln_stat && oku, nbu, fh, zeros);
+        bz[q] = *((p.bias && ok) ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
+        cz[q] = *((p.ln_stat && ok) ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
         if constexpr (GEGLU) {
-          gz[q] = col_vec4(p.bias, p.bias && oku, nbu + 16, fh, zeros);
-          gc[q] = col_vec4(p.ln_cs, p.ln_stat && oku, nbu + 16, fh, zeros);
+          gz[q] = *((p.bias && ok) ? reinterpret_cast<const f32x4*>(p.bias + nb + 16) : zv);
+          gc[q] = *((p.ln_stat && ok) ? reinterpret_cast<const f32x4*>(p.ln_cs + nb + 16) : zv);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -358,10 +356,10 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
       f32x4 bz[4], cz[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int nbu = nw + j * 32 + 8 * q;
-        const bool oku = nbu < p.N;
-        bz[q] = col_vec4(p.bias, p.bias && oku, nbu, fh, zeros);
-        cz[q] = col_vec4(p.ln_cs, p.ln_stat && oku, nbu, fh, zeros);
+        const int nb = nw + j * 32 + 8 * q + 4 * fh;
+        const bool ok = nb < p.N;
+        bz[q] = *((p.bias && ok) ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
+        cz[q] = *((p.ln_stat && ok) ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -694,12 +692,12 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, const 
     f32x4 bz[NQ], cz[NQ], gz[NQ], gc[NQ], ez[TM][NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int nbu = nt + 8 * q, nb = nbu + 4 * fh;      // weight-side vectors: wave-uniform, through the scalar cache
-      bz[q] = col_vec4(p.bias, p.bias != nullptr, nbu, fh, zeros);
-      cz[q] = col_vec4(p.ln_cs, p.ln_stat != nullptr, nbu, fh, zeros);
+      const int nb = nt + 8 * q + 4 * fh;
+      bz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
+      cz[q] = *(p.ln_stat ? reinterpret_cast<const f32x4*>(p.ln_cs + nb) : zv);
       if constexpr (GEGLU) {
-        gz[q] = col_vec4(p.bias, p.bias != nullptr, nbu + 16, fh, zeros);
-        gc[q] = col_vec4(p.ln_cs, p.ln_stat != nullptr, nbu + 16, fh, zeros);
+        gz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb + 16) : zv);
+        gc[q] = *(p.ln_stat ? reinterpret_cast<const f32x4*>(p.ln_cs + nb + 16) : zv);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -878,7 +876,8 @@ __device__ __forceinline__ void xattn_inplace(const IgemmParams& p, f32x16 (&acc
   const int fh = lane >> 5;
   const int nctx = p.xa_nctx;
   // folded-LayerNorm column sums and bias (beta W of the folded norm) of this wave's 64 columns: wave-uniform, so they come
-  // through the scalar cache, eight columns per s_load; a lane keeps the four of its half (fh)
+  // through the scalar cache, eight columns per s_load; a lane keeps the four of its half (fh).  (The other epilogues keep the
+  // 64-lane VMEM form of these vectors: scalar loads there measured +0.6 ms per UNet step -- SMEM waits are all-or-nothing.)
   f32x4 cz[2][4], bz[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
