@@ -35,20 +35,22 @@ SHAPES = [  # name, B, H, W, Cin, Cout, production variant, timeline variant, (B
     ("attn_out 2048x1280 K1280", 2, 32, 32, 1280, 1280, 45, 145, (96, 128, 6)),
     ("qkv 2048x3840 K1280", 2, 32, 32, 1280, 3840, 35, 135, (256, 128, 8)),
     ("ff_out64 8192x640 K2560", 2, 64, 64, 2560, 640, 35, 135, (256, 128, 8)),
+    ("conv64 640 3x3 K5760", 2, 64, 64, 640, 640, 35, 135, (256, 128, 8), 3),
+    ("conv128 320 3x3 K2880", 2, 128, 128, 320, 320, 35, 135, (256, 128, 8), 3),
 ]
 
 
-def run(name, B, H, W, Cin, Cout, vprod, vtl, tile):
+def run(name, B, H, W, Cin, Cout, vprod, vtl, tile, ksize=1):
     bm, bn, nw = tile
     M = B * H * W
     nwg = ((M + bm - 1) // bm) * ((Cout + bn - 1) // bn)
     pkg.debug_set("igemm_variant", vprod)
     L.sdxl_debug_timeline(None)
-    us_prod = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, 1, False, 20) * 1e3
+    us_prod = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, ksize, False, 20) * 1e3
     buf = torch.zeros(nwg * nw * TLW, dtype=torch.int32, device="cuda")
     L.sdxl_debug_timeline(ctypes.c_void_p(buf.data_ptr()))
     pkg.debug_set("igemm_variant", vtl)
-    us_tl = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, 1, False, 20) * 1e3     # the buffer holds the LAST launch's stamps
+    us_tl = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, ksize, False, 20) * 1e3     # the buffer holds the LAST launch's stamps
     torch.cuda.synchronize()
     L.sdxl_debug_timeline(None)
     t = buf.cpu().numpy().astype(np.uint32).reshape(nwg, nw, TLW).astype(np.int64)
@@ -68,7 +70,7 @@ def run(name, B, H, W, Cin, Cout, vprod, vtl, tile):
     loop = d(T3, T2)
     P1, P2, P3, P4, E1 = (t[:, :, i] for i in (8, 9, 10, 11, 12))
     st = lambda x: dict(mean=float(x.mean()), p50=float(np.median(x)), p90=float(np.percentile(x, 90)), max=float(x.max()))   # noqa: E731
-    rep = dict(shape=name, M=M, N=Cout, K=Cin, tile=f"{bm}x{bn}", workgroups=nwg, waves=nw, k_tiles=nk,
+    rep = dict(shape=name, M=M, N=Cout, K=Cin * ksize * ksize, tile=f"{bm}x{bn}", workgroups=nwg, waves=nw, k_tiles=nk,
                us_production=us_prod, us_with_stamps=us_tl,
                dispatch_ramp=st(ramp), prologue_issue=st(d(T1, T0)), first_tile_wait=st(d(T2, T1)),
                prologue_parts=dict(kernel_args=st(d(P1, T0)), dma_geometry=st(d(P2, P1)), first_tap_pointers=st(d(P3, P2)),
