@@ -619,6 +619,202 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Split-operand variant (SDXL_DTYPE_F32_SPLIT): fp32-class attention on the f16 matrix pipe.  Q and O are fp32; K [B][Nk][C] and
+// V^T [B][C][vt_ld] arrive in the HL16 format of the split-operand GEMMs (every 16 logical elements of a row = 16 hi halfs |
+// 16 lo halfs, x = hi + lo to ~2^-22: launch_f32_to_hl), so a row of 64 d (or 64 keys) is 256 bytes = 16 chunks of 16 bytes,
+// chunk 4g+{0,1} = hi of group g, 4g+{2,3} = lo.  Schedule of variant 2 (S^T = K Q^T, deferred max, P stays in registers as the
+// B operand of O^T = V^T P^T), with every product as three MFMAs:  a_hi b_hi + a_hi b_lo + a_lo b_hi  (lo x lo is below fp32
+// rounding).  Q is scaled by scale*log2(e) in fp32 and split once per wave; P = exp2(S - m) is split after the exponential, times 2^11:
+// with thousands of keys most probabilities are ~1e-4 and their lo halves would fall into the f16 subnormals (measured: 9e-5 rel
+// on 4096 keys without the scale, 5e-7 with it).
+// Tiles of 64 keys: 16 KiB of K + 16 KiB of V^T per slot, TWO slots (64 KiB -> two blocks per CU), one barrier per tile.
+__global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p, const void* zeros) {
+  constexpr int KV = 64, TILE = 64 * 256;
+  constexpr float THR = 4.0f;          // P = exp2(S - m) <= 16
+  constexpr float PSC = 2048.0f;       // P travels as P * 2^11 (<= 2^15): the lo halves of small probabilities stay out of the f16 subnormals
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V^T tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, h = lane >> 5;
+  const int nqb = (p.Nq + 127) / 128;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bh = bid / nqb, qb = bid - bh * nqb;
+  const int b = bh / p.H, hd = bh - b * p.H;
+  const int q0 = qb * 128 + wave * 32;
+  const float* Qg = reinterpret_cast<const float*>(p.Q) + (size_t)b * p.Nq * p.ldq + hd * 64;
+  const half_t* Kg = reinterpret_cast<const half_t*>(p.K) + ((size_t)b * p.Nk * p.ldk + hd * 64) * 2;          // row stride 2 * ldk halfs
+  const half_t* Vg = reinterpret_cast<const half_t*>(p.Vt) + ((size_t)b * p.H + hd) * 64 * (size_t)(2 * p.vt_ld);   // row stride 2 * vt_ld halfs
+  const float sc = p.scale * 1.44269504088896340736f;
+
+  // Q fragments (B operand of S^T): query = q0 + fr, d = ks*16 + h*8 .. +7, scaled in fp32, then (hi, lo)
+  half8 qh[4], ql[4];
+  {
+    const int q = q0 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, c = a;
+      if (q < p.Nq) {
+        const float* qp = Qg + (size_t)q * p.ldq + ks * 16 + h * 8;
+        a = *reinterpret_cast<const f32x4*>(qp); c = *reinterpret_cast<const f32x4*>(qp + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x0 = a[e] * sc, x1 = c[e] * sc;
+        asm("" : "+v"(x0)); asm("" : "+v"(x1));      // pinned in fp32: hi and lo must come from the SAME rounded product (store_hl8)
+        const half_t h0 = (half_t)x0, h1 = (half_t)x1;
+        qh[ks][e] = h0; ql[ks][e] = (half_t)(x0 - (float)h0);
+        qh[ks][4 + e] = h1; ql[ks][4 + e] = (half_t)(x1 - (float)h1);
+      }
+    }
+  }
+  // DMA geometry: a 1-KiB piece = 4 rows x 16 chunks (lane -> row lane>>4, slot lane&15); wave w stages rows [16w, 16w+16) of K
+  // and of V^T, four pieces each.  LDS slot c of row r holds source chunk c ^ (r & 7): rows 256 bytes apart spread over the banks.
+  const int prow = lane >> 4, pslot = lane & 15;
+  auto stage = [&](int t, int buf) {
+    const int k0 = t * KV;
+    char* lk = smem + buf * 2 * TILE + wave * 4096;
+    char* lv = lk + TILE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 16 + j * 4 + prow;
+      const int chunk = pslot ^ (row & 7);
+      const int key = k0 + row;
+      const half_t* ks = key < p.Nk ? Kg + (size_t)key * (2 * p.ldk) + chunk * 8 : reinterpret_cast<const half_t*>(zeros);
+      __builtin_amdgcn_global_load_lds((agptr_t)ks, (alptr_t)(lk + j * 1024), 16, 0, 0);
+      const half_t* vs = Vg + (size_t)row * (2 * p.vt_ld) + 2 * k0 + chunk * 8;      // rows zero padded to vt_ld (multiple of 64 keys)
+      __builtin_amdgcn_global_load_lds((agptr_t)vs, (alptr_t)(lv + j * 1024), 16, 0, 0);
+    }
+  };
+  int rowoff[2], rsw[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) { const int row = u * 32 + fr; rowoff[u] = row * 256; rsw[u] = row & 7; }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m = 0.f, l = 0.f;
+  f32x16 minit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
+  const int nt = (p.Nk + KV - 1) / KV;
+  stage(0, 0);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own pieces of tile t landed
+    __builtin_amdgcn_s_barrier();                              // everyone's pieces landed; everyone is done with tile t-1
+    asm volatile("" ::: "memory");
+    if (t + 1 < nt) stage(t + 1, cur ^ 1);
+    const char* kb = smem + cur * 2 * TILE;
+    const char* vb = kb + TILE;
+    // ---- S^T - m: three MFMAs per 16-deep product
+    f32x16 sv[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const half8 khi = *reinterpret_cast<const half8*>(kb + rowoff[u] + (((4 * ks + h) ^ rsw[u]) << 4));
+        const half8 klo = *reinterpret_cast<const half8*>(kb + rowoff[u] + (((4 * ks + 2 + h) ^ rsw[u]) << 4));
+        sv[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qh[ks], ks == 0 ? minit : sv[u], 0, 0, 0);
+        sv[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, ql[ks], sv[u], 0, 0, 0);
+        sv[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qh[ks], sv[u], 0, 0, 0);
+      }
+    if (t == nt - 1 && (p.Nk & 63) != 0) {                      // key tail (wave-uniform branch)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * KV + u * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= p.Nk) sv[u][r] = -INFINITY;
+    }
+    float lmax = sv[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) lmax = fmaxf(lmax, sv[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lmax = fmaxf(lmax, sv[1][r]);
+    if (t == 0 || __any(lmax > THR)) {                          // rare after the first tiles; wave-uniform
+      const float pm = fmaxf(lmax, __shfl_xor(lmax, 32));
+      const float delta = t == 0 ? pm : fmaxf(pm, 0.f);
+      const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+      m = t == 0 ? delta : m + delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) minit[r] = -m;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[u][r] -= delta;
+    }
+    // ---- P = exp2(S - m) as (hi, lo) B fragments: k-step s4 = u*2 + hf holds registers 8*hf .. 8*hf+7 of key tile u
+    half8 ph[4], pl[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float ls = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(sv[u][8 * hf + e]);
+          ls += pe;
+          float ps = pe * PSC;
+          asm("" : "+v"(ps));
+          const half_t hi = (half_t)ps;
+          ph[u * 2 + hf][e] = hi;
+          pl[u * 2 + hf][e] = (half_t)(ps - (float)hi);
+        }
+        l += ls;
+      }
+    // ---- O^T += V^T P^T: k-step s4 = the 16 keys of HL16 group s4 in the order {4h..4h+3, 8+4h..8+4h+3}
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const char* vr = vb + rowoff[dt] + 8 * h;
+        const i32x2 a0 = *reinterpret_cast<const i32x2*>(vr + (((4 * s4 + 0) ^ rsw[dt]) << 4));
+        const i32x2 a1 = *reinterpret_cast<const i32x2*>(vr + (((4 * s4 + 1) ^ rsw[dt]) << 4));
+        const i32x2 b0 = *reinterpret_cast<const i32x2*>(vr + (((4 * s4 + 2) ^ rsw[dt]) << 4));
+        const i32x2 b1 = *reinterpret_cast<const i32x2*>(vr + (((4 * s4 + 3) ^ rsw[dt]) << 4));
+        const half8 vhi = __builtin_bit_cast(half8, i32x4{a0[0], a0[1], a1[0], a1[1]});
+        const half8 vlo = __builtin_bit_cast(half8, i32x4{b0[0], b0[1], b1[0], b1[1]});
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, ph[s4], o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, pl[s4], o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, ph[s4], o[dt], 0, 0, 0);
+      }
+    cur ^= 1;
+  }
+  // ---- normalise, park per wave in LDS ([query][d] fp32: 16 chunks of 16 bytes per row, swizzled by query & 15), store whole rows
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / (l * PSC);
+  __syncthreads();
+  char* ob = smem + wave * 8192;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      // registers 4g..4g+3 of o[dt] = d 32dt + 8g + 4h + {0..3} of query fr
+      const f32x4 v = f32x4{o[dt][g * 4] * inv, o[dt][g * 4 + 1] * inv, o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv};
+      const int chunk = dt * 8 + g * 2 + h;
+      *reinterpret_cast<f32x4*>(ob + fr * 256 + ((chunk ^ (fr & 15)) << 4)) = v;
+    }
+  float* Og = reinterpret_cast<float*>(p.O) + (size_t)b * p.Nq * p.ldo + hd * 64;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 4 + (lane >> 4), piece = lane & 15;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ob + row * 256 + ((piece ^ (row & 15)) << 4));
+    const int q = q0 + row;
+    if (q < p.Nq) *reinterpret_cast<f32x4*>(Og + (size_t)q * p.ldo + piece * 4) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // f16 variant "key split" (variant 6): variant 2 for grids that leave most SIMDs with ONE wave.
 //   Self-attention at 32^2 (Nq = Nk = 1024, 40 batch-heads) is 320 blocks of 128 queries = 1280 waves on 1024 SIMDs: a wave
 //   alone on its SIMD runs QK^T (MFMA), softmax (VALU, the longer part) and PV (MFMA) strictly in turn, and the SIMDs that
@@ -1239,6 +1435,25 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
     }
     hipLaunchKernelGGL(attn_d64_kernel<float>, grid, dim3(256), lds, s, p);
   }
+}
+
+// split-operand attention (attn_d64_hl_kernel): Q / O fp32, K / V^T in HL16.  Returns false when the shape / alignment needs the
+// fp32 kernel (masked attention, unaligned rows).
+bool launch_attention_d64_hl(const AttnParams& p, hipStream_t s) {
+  const int dev = attn_device();
+  const void* zeros = g_attn_zeros[dev];
+  if (!zeros || p.mask) return false;
+  if ((p.ldq & 3) != 0 || (p.ldo & 3) != 0 || (p.ldk & 15) != 0 || (p.vt_ld & 63) != 0 || p.vt_ld < (int)(((p.Nk + 63) / 64) * 64)) return false;
+  if (((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) | reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) != 0) return false;
+  constexpr int lds = 2 * 2 * 64 * 256;
+  static bool set[kMaxDev] = {};
+  if (!set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_d64_hl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      throw std::runtime_error("attention: hipFuncSetAttribute failed");
+    set[dev] = true;
+  }
+  hipLaunchKernelGGL(attn_d64_hl_kernel, dim3(((p.Nq + 127) / 128) * p.B * p.H), dim3(256), lds, s, p, zeros);
+  return true;
 }
 
 // one wide head (d = 512, f16, no mask): see attn_hd_kernel.  Returns false when the shape / alignment needs the unfused path.

@@ -421,8 +421,32 @@ int sdxl_qkv_attention(sdxl_ctx* ctx, void* stream, const float* q, const float*
   SDXL_REQUIRE(n_head > 0 && n_state % n_head == 0, "State size must be a multiple of head size");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_qkv_attention");
+  int cdt, sdt; dtypes(dtype, cdt, sdt);
   const int d = n_state / n_head;
+  if (cdt == DT_HL) {
+    // split-operand mode: Q / O stay fp32, K and V^T go through the HL16 format of the split GEMMs (attn_d64_hl_kernel)
+    SDXL_REQUIRE(d == 64 && !mask, "sdxl_qkv_attention: the split-operand mode covers unmasked head-dim-64 attention");
+    const int npad = (int)round_up(Nk, 64);
+    Tmp tmp;
+    void* kh = tmp.get((size_t)B * Nk * n_state * 4);
+    float* vt32 = (float*)tmp.get((size_t)B * n_state * npad * 4);
+    void* vth = tmp.get((size_t)B * n_state * npad * 4);
+    launch_f32_to_hl(k, n_state, kh, n_state, (size_t)B * Nk, n_state, s);
+    launch_fill_zero(vt32, (size_t)B * n_state * npad * 4, s);
+    for (int b = 0; b < B; ++b) {
+      const size_t tot = (size_t)Nk * n_state;
+      hipLaunchKernelGGL(transpose_pad_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, v + (size_t)b * Nk * n_state, n_state,
+                         Nk, n_state, (char*)vt32 + (size_t)b * n_state * npad * 4, DT_F32, npad);
+    }
+    launch_f32_to_hl(vt32, npad, vth, npad, (size_t)B * n_state, npad, s);
+    AttnParams p{};
+    p.Q = q; p.ldq = n_state; p.K = kh; p.ldk = n_state; p.Vt = vth; p.vt_ld = npad; p.O = out; p.ldo = n_state;
+    p.dt = DT_HL; p.B = B; p.H = n_head; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+    SDXL_REQUIRE(launch_attention_d64_hl(p, s), "split-operand attention kernel refused an aligned shape");
+    SDXL_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
+  no_split(cdt, "sdxl_qkv_attention");
   const size_t es = dt_size(cdt);
   Tmp tmp;
   if (d == 64 || (d == 512 && cdt == DT_F16 && !mask)) {

@@ -46,7 +46,14 @@ template <> struct is_hl<hl16_t> { static constexpr bool value = true; };
 __device__ __forceinline__ void store_hl8(void* row_base, int n0, const float (&w)[8]) {
   half8 hi, lo;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { hi[e] = (half_t)w[e]; lo[e] = (half_t)(w[e] - (float)hi[e]); }
+  for (int e = 0; e < 8; ++e) {
+    // the value is pinned in its fp32 form first: otherwise the compiler may fuse the multiply / fma that produced it into the
+    // f16 conversion (v_fma_mixlo_f16: ONE rounding of the exact result) for hi while lo is taken against the doubly rounded
+    // value, and near a tie the two disagree by a whole f16 ulp of hi (found with one-hot operands: tools/attn_split_err.py)
+    float x = w[e];
+    asm("" : "+v"(x));
+    hi[e] = (half_t)x; lo[e] = (half_t)(x - (float)hi[e]);
+  }
   half_t* b = reinterpret_cast<half_t*>(row_base) + ((n0 >> 4) << 5) + (n0 & 15);
   *reinterpret_cast<half8*>(b) = hi;
   *reinterpret_cast<half8*>(b + 16) = lo;

@@ -127,6 +127,10 @@ struct AttnParams {
   const float* mask; int ldmask;   // optional additive [Nq][Nk] fp32 (0 / -inf), null in UNet/VAE
 };
 void launch_attention_d64(const AttnParams& p, hipStream_t s);
+// split-operand (fp32-class) head-dim-64 attention: Q / O fp32 (ldq / ldo in floats), K [B][Nk] rows and Vt [B][H*64][vt_ld] rows in
+// HL16 (ldk / vt_ld in LOGICAL elements: a row is 2 * ld halfs), no mask; vt_ld a multiple of 64 keys, zero beyond Nk.  Returns false
+// when the shape / alignment needs launch_attention_d64 on fp32 tensors.
+bool launch_attention_d64_hl(const AttnParams& p, hipStream_t s);
 // the same contraction for ONE wide head of 512 channels (VAE mid block): flash kernel, scores never materialised; Q/K/O rows
 // hold the heads at columns h*512, Vt is [B][H*512][vt_ld] with zero columns up to a multiple of 32 keys.  f16, no mask;
 // returns false when the shape / alignment needs the unfused path.  p.scale = d^-1/2.

@@ -48,7 +48,11 @@ template <typename YT> __device__ __forceinline__ void store8r(YT* row, int col,
 template <> __device__ __forceinline__ void store8r<hlout_t>(hlout_t* row, int col, const float (&v)[8]) {
   half8 hi, lo;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { hi[j] = (half_t)v[j]; lo[j] = (half_t)(v[j] - (float)hi[j]); }
+  for (int j = 0; j < 8; ++j) {
+    float x = v[j];
+    asm("" : "+v"(x));          // one fp32 value for both halves (see store_hl8, igemm_common.h)
+    hi[j] = (half_t)x; lo[j] = (half_t)(x - (float)hi[j]);
+  }
   half_t* b = reinterpret_cast<half_t*>(row) + ((col >> 4) << 5) + (col & 15);
   *reinterpret_cast<half8*>(b) = hi;
   *reinterpret_cast<half8*>(b + 16) = lo;

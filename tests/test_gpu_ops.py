@@ -272,6 +272,32 @@ def test_qkv_attention(pkg, ctx, dtype, B, Nq, Nk, C, heads, masked):
     assert rel_err(out, ref) < (1e-4 if dtype == 0 else 6e-3)
 
 
+@pytest.mark.parametrize("B,Nq,Nk,C,heads", [(1, 64, 64, 64, 1), (2, 256, 256, 128, 2), (2, 300, 77, 640, 10), (1, 1024, 1024, 1280, 20),
+                                             (1, 130, 200, 64, 1), (2, 64, 1, 64, 1), (1, 33, 192, 64, 1), (2, 4096, 4096, 128, 2)])
+def test_qkv_attention_split_operand(pkg, ctx, B, Nq, Nk, C, heads):
+    # SDXL_DTYPE_F32_SPLIT: fp32 Q / O, K and V^T as (hi, lo) f16 pairs, three MFMAs per product (attn_d64_hl_kernel) -- held to the
+    # strict mode's bound against a float64 reference; ragged query blocks, key tails (Nk = 77, 1, 200), several heads / entries
+    q, k, v = seeded(B, Nq, C, seed=16), seeded(B, Nk, C, seed=17), seeded(B, Nk, C, seed=18)
+    ref = OM.qkv_attention(q.double(), k.double(), v.double(), None, heads)
+    out = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, heads, 3)
+    e = rel_err(out.double(), ref)
+    print(f"split-operand attention B={B} Nq={Nq} Nk={Nk} C={C}: rel err {e:.3e}")
+    assert e < 5e-6
+    out2 = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, heads, 3)
+    assert torch.equal(out, out2)
+
+
+def test_qkv_attention_split_operand_rescale(pkg, ctx):
+    B, N, C = 1, 320, 64
+    q, k, v = seeded(B, N, C, seed=19), seeded(B, N, C, seed=20), seeded(B, N, C, seed=21)
+    k[0, 200] = q[0, 3] * 6.0
+    k[0, 290] = q[0, 77] * 2.5
+    k[0, 10] = q[0, 130] * 9.0
+    ref = OM.qkv_attention(q.double(), k.double(), v.double(), None, 1)
+    out = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, 1, 3)
+    assert rel_err(out.double(), ref) < 5e-6
+
+
 @pytest.mark.parametrize("dtype,variant", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 6)])
 def test_qkv_attention_online_softmax_rescale(pkg, ctx, dtype, variant):
     # keys far above the rest in LATE tiles force the running-max rescale branch (guide rule 26): for the deferred-max
