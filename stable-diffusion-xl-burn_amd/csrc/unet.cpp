@@ -97,6 +97,20 @@ void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, 
   }
   if (ex.prof) ex.prof->end(ex.s);
 }
+// split-operand mode: q / o fp32, K [B][Nk][ldk] and V^T [B][H*64][vt_ld] in HL16 (attn_d64_hl_kernel)
+void attention_hl(Exec& ex, const Act& q, const void* kh, int ldk, const void* vth, int vt_ld, const Act& o, int B, int H, int Nq, int Nk) {
+  if (ex.dry) return;
+  AttnParams p{};
+  p.Q = q.p; p.ldq = q.ld; p.K = kh; p.ldk = ldk; p.Vt = vth; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
+  p.dt = DT_HL; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+  if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0);
+  if (!launch_attention_d64_hl(p, ex.s)) throw Error("split-operand attention: unsupported shape / alignment (Nq=" + std::to_string(Nq) + " Nk=" + std::to_string(Nk) + ")");
+  {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) throw Error(std::string("split-operand attention launch failed (") + hipGetErrorString(le) + ")");
+  }
+  if (ex.prof) ex.prof->end(ex.s);
+}
 }  // namespace
 
 UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st)
@@ -174,6 +188,11 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
                                     (pack_xa ? round_up(xattn_pack_bytes(B, st->C), 256) : 0) + 768);
     bytes += 3 * round_up((size_t)B * emb * sizeof(float), 256);
     if (cdt_ == DT_HL) bytes += round_up((size_t)B * n_ctx * cfg_.context_dim * 4, 256) + 256;   // HL16 copy of the context
+    if (cdt_ == DT_HL) {   // fp32 scratch of one block's K / V^T projection: the caches themselves are HL16 (what the attention kernel reads)
+      size_t mx = 0;
+      for (const STW* st : st_list_) mx = std::max(mx, round_up((size_t)B * n_ctx * st->C * 4, 256) + round_up((size_t)B * st->C * vt_ld * 4, 256));
+      bytes += mx + 512;
+    }
     ctx_arena_.reserve(bytes);
     ctx_arena_.off = 0;
     SDXL_HIP(hipMemsetAsync(ctx_arena_.base, 0, bytes, s));   // V^T key padding must be zero
@@ -200,6 +219,18 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
   for (size_t si = 0; si < st_list_.size(); ++si) {
     const STW* st = st_list_[si];
     for (size_t j = 0; j < st->blocks.size(); ++j) {
+      if (cdt_ == DT_HL) {
+        const size_t ms = ctx_arena_.mark();
+        void* k32 = ctx_arena_.alloc((size_t)B * n_ctx * st->C * 4);
+        void* vt32 = ctx_arena_.alloc((size_t)B * st->C * vt_ld * 4);
+        launch_fill_zero(vt32, (size_t)B * st->C * vt_ld * 4, s);                     // V^T key padding must be zero
+        Epi e; e.n_split = st->C; e.Ct = vt32; e.ct_rows = st->C; e.ct_ld = vt_ld; e.rpb = n_ctx;
+        run_linear(ex, st->blocks[j].kv2, ctx, B * n_ctx, Act(k32, st->C, DT_F32), e);
+        launch_f32_to_hl(k32, st->C, kv_[si][j].k, st->C, (size_t)B * n_ctx, st->C, s);
+        launch_f32_to_hl(vt32, vt_ld, kv_[si][j].vt, vt_ld, (size_t)B * st->C, vt_ld, s);
+        ctx_arena_.reset(ms);
+        continue;
+      }
       Epi e; e.n_split = st->C; e.Ct = kv_[si][j].vt; e.ct_rows = st->C; e.ct_ld = vt_ld; e.rpb = n_ctx;
       run_linear(ex, st->blocks[j].kv2, ctx, B * n_ctx, Act(kv_[si][j].k, st->C, kvdt), e);
       if (kv_[si][j].xa) launch_xattn_pack(kv_[si][j].k, kv_[si][j].vt, kv_[si][j].xa, B, st->C, n_ctx, vt_ld, s);
@@ -273,6 +304,10 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   Act ao32 = ex.cdt == DT_HL ? ex.alloc(M, C, DT_F32) : ao;
   auto ao_ready = [&]() { if (ex.cdt == DT_HL && !ex.dry) launch_f32_to_hl(ao32.p, ao32.ld, ao.p, ao.ld, M, C, ex.s); };
   if (npad != HW && !ex.dry) launch_fill_zero(vt, (size_t)B * C * npad * dt_size(adt), ex.s);
+  // split-operand mode: the attention kernel takes K and V^T in HL16 (same bytes as fp32); q and the output stay fp32
+  const bool hl_attn = ex.cdt == DT_HL;
+  void* kh = hl_attn ? ex.act->alloc(M * (size_t)C * 4) : nullptr;
+  void* vth = hl_attn ? ex.act->alloc((size_t)B * C * npad * 4) : nullptr;
   if (fuse_ln_) {
     // LayerNorms folded into the consuming GEMMs: every producer of the residual stream t also accumulates the row
     // (sum, sum^2) its consumer needs, so no LayerNorm kernel runs and t is read by the projections directly
@@ -308,7 +343,13 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_layernorm(ex, b.n1, t, (int)M, ln);
     Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW;
     run_linear(ex, b.qkv, ln, (int)M, qk, eq);
-    attention(ex, qk, qk.cols(C), vt, npad, ao32, B, w.heads, HW, HW);
+    if (hl_attn) {
+      if (!ex.dry) {
+        launch_f32_to_hl(qk.cols(C).p, qk.ld, kh, C, M, C, ex.s);
+        launch_f32_to_hl(vt, npad, vth, npad, (size_t)B * C, npad, ex.s);
+      }
+      attention_hl(ex, qk, kh, C, vth, npad, ao32, B, w.heads, HW, HW);
+    } else attention(ex, qk, qk.cols(C), vt, npad, ao32, B, w.heads, HW, HW);
     ao_ready();
     Epi er; er.R = t; er.rpb = HW;
     run_linear(ex, b.out1, ao, (int)M, t, er);
@@ -319,7 +360,8 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       run_linear(ex, b.q2, ln, (int)M, ao, e2q);
     } else {
       run_linear(ex, b.q2, ln, (int)M, q);
-      attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_);
+      if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_);   // caches are HL16 (set_context)
+      else attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_);
       ao_ready();
     }
     run_linear(ex, b.out2, ao, (int)M, t, er);
