@@ -804,6 +804,28 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
       const int chunk = dt * 8 + g * 2 + h;
       *reinterpret_cast<f32x4*>(ob + fr * 256 + ((chunk ^ (fr & 15)) << 4)) = v;
     }
+  if (p.o_dt == DT_HL) {        // the out-projection's operand format: 8 consecutive d per lane -> hi / lo octets of an HL16 group
+    half_t* Oh = reinterpret_cast<half_t*>(p.O) + ((size_t)b * p.Nq * p.ldo + hd * 64) * 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), piece = lane & 7;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(ob + row * 256 + (((2 * piece) ^ (row & 15)) << 4));
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(ob + row * 256 + (((2 * piece + 1) ^ (row & 15)) << 4));
+      half8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (half_t)v0[e]; lo[e] = (half_t)(v0[e] - (float)hi[e]);
+        hi[4 + e] = (half_t)v1[e]; lo[4 + e] = (half_t)(v1[e] - (float)hi[4 + e]);
+      }
+      const int q = q0 + row;
+      if (q < p.Nq) {
+        half_t* dst = Oh + (size_t)q * (2 * p.ldo) + (piece >> 1) * 32 + (piece & 1) * 8;
+        *reinterpret_cast<half8*>(dst) = hi;
+        *reinterpret_cast<half8*>(dst + 16) = lo;
+      }
+    }
+    return;
+  }
   float* Og = reinterpret_cast<float*>(p.O) + (size_t)b * p.Nq * p.ldo + hd * 64;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
@@ -1443,6 +1465,7 @@ bool launch_attention_d64_hl(const AttnParams& p, hipStream_t s) {
   const int dev = attn_device();
   const void* zeros = g_attn_zeros[dev];
   if (!zeros || p.mask) return false;
+  if (p.o_dt != DT_F32 && (p.o_dt != DT_HL || (p.ldo & 15) != 0)) return false;
   if ((p.ldq & 3) != 0 || (p.ldo & 3) != 0 || (p.ldk & 15) != 0 || (p.vt_ld & 63) != 0 || p.vt_ld < (int)(((p.Nk + 63) / 64) * 64)) return false;
   if (((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) | reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) != 0) return false;
   constexpr int lds = 2 * 2 * 64 * 256;

@@ -103,6 +103,7 @@ void attention_hl(Exec& ex, const Act& q, const void* kh, int ldk, const void* v
   AttnParams p{};
   p.Q = q.p; p.ldq = q.ld; p.K = kh; p.ldk = ldk; p.Vt = vth; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
   p.dt = DT_HL; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+  p.o_dt = o.dt == DT_HL ? DT_HL : DT_F32;
   if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0);
   if (!launch_attention_d64_hl(p, ex.s)) throw Error("split-operand attention: unsupported shape / alignment (Nq=" + std::to_string(Nq) + " Nk=" + std::to_string(Nk) + ")");
   {
@@ -300,9 +301,9 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   Act ao = ex.alloc(M, C, ex.cdt);
   Act q = ex.alloc(M, C, adt);
   Act gg = ex.alloc(M, 4 * C, ex.cdt);
-  // split-operand mode: the attention runs on fp32 tensors (exact-fp32 MFMA kernel); its output becomes the HL16 operand `ao`
-  Act ao32 = ex.cdt == DT_HL ? ex.alloc(M, C, DT_F32) : ao;
-  auto ao_ready = [&]() { if (ex.cdt == DT_HL && !ex.dry) launch_f32_to_hl(ao32.p, ao32.ld, ao.p, ao.ld, M, C, ex.s); };
+  // (split-operand mode: attention_hl writes the out-projection's HL16 operand `ao` itself)
+  const Act ao32 = ao;
+  auto ao_ready = [&]() {};
   if (npad != HW && !ex.dry) launch_fill_zero(vt, (size_t)B * C * npad * dt_size(adt), ex.s);
   // split-operand mode: the attention kernel takes K and V^T in HL16 (same bytes as fp32); q and the output stay fp32
   const bool hl_attn = ex.cdt == DT_HL;
@@ -348,9 +349,8 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
         launch_f32_to_hl(qk.cols(C).p, qk.ld, kh, C, M, C, ex.s);
         launch_f32_to_hl(vt, npad, vth, npad, (size_t)B * C, npad, ex.s);
       }
-      attention_hl(ex, qk, kh, C, vth, npad, ao32, B, w.heads, HW, HW);
-    } else attention(ex, qk, qk.cols(C), vt, npad, ao32, B, w.heads, HW, HW);
-    ao_ready();
+      attention_hl(ex, qk, kh, C, vth, npad, ao, B, w.heads, HW, HW);       // writes the out-projection's HL16 operand directly
+    } else { attention(ex, qk, qk.cols(C), vt, npad, ao32, B, w.heads, HW, HW); ao_ready(); }
     Epi er; er.R = t; er.rpb = HW;
     run_linear(ex, b.out1, ao, (int)M, t, er);
     run_layernorm(ex, b.n2, t, (int)M, ln);
@@ -360,9 +360,8 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       run_linear(ex, b.q2, ln, (int)M, ao, e2q);
     } else {
       run_linear(ex, b.q2, ln, (int)M, q);
-      if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_);   // caches are HL16 (set_context)
-      else attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_);
-      ao_ready();
+      if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);   // caches are HL16 (set_context)
+      else { attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_); ao_ready(); }
     }
     run_linear(ex, b.out2, ao, (int)M, t, er);
     run_layernorm(ex, b.n3, t, (int)M, ln);
