@@ -658,8 +658,15 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
     for (int ks = 0; ks < 4; ++ks) {
       f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, c = a;
       if (q < p.Nq) {
-        const float* qp = Qg + (size_t)q * p.ldq + ks * 16 + h * 8;
-        a = *reinterpret_cast<const f32x4*>(qp); c = *reinterpret_cast<const f32x4*>(qp + 4);
+        if (p.q_dt == DT_HL) {      // the projection wrote q as HL16: x = hi + lo (22 significant bits), scaled and split again below
+          const half_t* qp = reinterpret_cast<const half_t*>(p.Q) + (((size_t)b * p.Nq + q) * p.ldq + hd * 64) * 2 + ks * 32 + h * 8;
+          const half8 hi = *reinterpret_cast<const half8*>(qp), lo = *reinterpret_cast<const half8*>(qp + 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[e] = (float)hi[e] + (float)lo[e]; c[e] = (float)hi[4 + e] + (float)lo[4 + e]; }
+        } else {
+          const float* qp = Qg + (size_t)q * p.ldq + ks * 16 + h * 8;
+          a = *reinterpret_cast<const f32x4*>(qp); c = *reinterpret_cast<const f32x4*>(qp + 4);
+        }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1466,6 +1473,7 @@ bool launch_attention_d64_hl(const AttnParams& p, hipStream_t s) {
   const void* zeros = g_attn_zeros[dev];
   if (!zeros || p.mask) return false;
   if (p.o_dt != DT_F32 && (p.o_dt != DT_HL || (p.ldo & 15) != 0)) return false;
+  if (p.q_dt != DT_F32 && (p.q_dt != DT_HL || (p.ldq & 15) != 0)) return false;
   if ((p.ldq & 3) != 0 || (p.ldo & 3) != 0 || (p.ldk & 15) != 0 || (p.vt_ld & 63) != 0 || p.vt_ld < (int)(((p.Nk + 63) / 64) * 64)) return false;
   if (((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) | reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) != 0) return false;
   constexpr int lds = 2 * 2 * 64 * 256;

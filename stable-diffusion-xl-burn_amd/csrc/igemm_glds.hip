@@ -1132,12 +1132,13 @@ bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
   if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
   if (p.n_split < p.N && (p.n_split & 3) != 0) return false;
   if (p.c_dt == DT_HL) {
-    // HL16 outputs are written as whole 8-column (8-key) pieces: plain outputs with aligned rows, or a fully transposed one
-    // (the VAE's V^T) whose batch entries are whole pieces; mixed / ragged splits go out as fp32 (the UNet's q | k | V^T)
-    if (p.n_split < p.N && p.n_split != 0) return false;
+    // HL16 outputs are written as whole 8-column (8-key) pieces: plain outputs with aligned rows, a fully transposed one (the
+    // VAE's V^T) whose batch entries are whole pieces, or a split at a multiple of 128 columns (the UNet's q | k | V^T: a wave
+    // tile is then wholly on one side); ragged splits go out as fp32
+    if (p.n_split < p.N && p.n_split != 0 && ((p.n_split & 127) != 0 || p.act != 0)) return false;
     const int nout = p.act == 1 ? (p.N >> 1) : p.N;
-    if (p.n_split >= p.N && ((nout & 7) != 0 || (p.ldc & 15) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0)) return false;
-    if (p.n_split < p.N && ((p.ct_ld & 15) != 0 || (p.rpb & 7) != 0 || (p.M % 8) != 0)) return false;
+    if (p.n_split != 0 && ((nout & 7) != 0 || (p.ldc & 15) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0)) return false;
+    if (p.n_split < p.N && ((p.ct_ld & 15) != 0 || (p.rpb & 7) != 0 || (p.M % 8) != 0 || (reinterpret_cast<uintptr_t>(p.Ct) & 15) != 0)) return false;
   }
   if (p.ebias && (p.ebias_ld & 3) != 0) return false;
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);

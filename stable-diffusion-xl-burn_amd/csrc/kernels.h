@@ -125,6 +125,7 @@ struct AttnParams {
   int B, H, Nq, Nk;
   float scale;                 // 1/sqrt(d)
   const float* mask; int ldmask;   // optional additive [Nq][Nk] fp32 (0 / -inf), null in UNet/VAE
+  int q_dt = 0;                // split-operand kernel only: DT_F32 (0) or DT_HL -- Q rows in HL16 (ldq in logical elements)
   int o_dt = 0;                // split-operand kernel only: DT_F32 (0) or DT_HL -- O written as HL16 rows (ldo in logical elements), the next GEMM's operand
 };
 void launch_attention_d64(const AttnParams& p, hipStream_t s);

@@ -104,6 +104,7 @@ void attention_hl(Exec& ex, const Act& q, const void* kh, int ldk, const void* v
   p.Q = q.p; p.ldq = q.ld; p.K = kh; p.ldk = ldk; p.Vt = vth; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
   p.dt = DT_HL; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
   p.o_dt = o.dt == DT_HL ? DT_HL : DT_F32;
+  p.q_dt = q.dt == DT_HL ? DT_HL : DT_F32;
   if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0);
   if (!launch_attention_d64_hl(p, ex.s)) throw Error("split-operand attention: unsupported shape / alignment (Nq=" + std::to_string(Nq) + " Nk=" + std::to_string(Nk) + ")");
   {
@@ -296,10 +297,14 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   int stp = 0;
   { Epi ep; ep.stat_out = w.blocks.empty() ? nullptr : stbuf[stp]; run_linear(ex, w.proj_in, gn, (int)M, t, ep); }
   Act ln = ex.alloc(M, C, ex.cdt);
-  Act qk = ex.alloc(M, 2 * C, adt);
+  // (split-operand mode: the projections write q | k and V^T as HL16 -- 4 bytes per element like fp32 -- what attention_hl reads)
+  // (HL16 pieces are 8 keys wide: token counts that are not multiples of 8 -- tiny test nets -- go through fp32 + a conversion)
+  const bool hl_direct = ex.cdt == DT_HL && HW % 8 == 0 && (2 * C) % 128 == 0;
+  const int qdt = hl_direct ? DT_HL : adt;
+  Act qk = ex.alloc(M, 2 * C, qdt);
   void* vt = ex.act->alloc((size_t)B * C * npad * dt_size(adt));
   Act ao = ex.alloc(M, C, ex.cdt);
-  Act q = ex.alloc(M, C, adt);
+  Act q = ex.alloc(M, C, qdt);
   Act gg = ex.alloc(M, 4 * C, ex.cdt);
   // (split-operand mode: attention_hl writes the out-projection's HL16 operand `ao` itself)
   const Act ao32 = ao;
@@ -307,8 +312,8 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   if (npad != HW && !ex.dry) launch_fill_zero(vt, (size_t)B * C * npad * dt_size(adt), ex.s);
   // split-operand mode: the attention kernel takes K and V^T in HL16 (same bytes as fp32); q and the output stay fp32
   const bool hl_attn = ex.cdt == DT_HL;
-  void* kh = hl_attn ? ex.act->alloc(M * (size_t)C * 4) : nullptr;
-  void* vth = hl_attn ? ex.act->alloc((size_t)B * C * npad * 4) : nullptr;
+  void* kh = hl_attn && !hl_direct ? ex.act->alloc(M * (size_t)C * 4) : nullptr;
+  void* vth = hl_attn && !hl_direct ? ex.act->alloc((size_t)B * C * npad * 4) : nullptr;
   if (fuse_ln_) {
     // LayerNorms folded into the consuming GEMMs: every producer of the residual stream t also accumulates the row
     // (sum, sum^2) its consumer needs, so no LayerNorm kernel runs and t is read by the projections directly
@@ -344,13 +349,15 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_layernorm(ex, b.n1, t, (int)M, ln);
     Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW;
     run_linear(ex, b.qkv, ln, (int)M, qk, eq);
-    if (hl_attn) {
+    if (hl_attn && hl_direct) attention_hl(ex, qk, qk.cols(C).p, qk.ld, vt, npad, ao, B, w.heads, HW, HW);   // q | k and V^T are HL16; writes the out-projection's operand
+    else if (hl_attn) {
       if (!ex.dry) {
         launch_f32_to_hl(qk.cols(C).p, qk.ld, kh, C, M, C, ex.s);
         launch_f32_to_hl(vt, npad, vth, npad, (size_t)B * C, npad, ex.s);
       }
-      attention_hl(ex, qk, kh, C, vth, npad, ao, B, w.heads, HW, HW);       // writes the out-projection's HL16 operand directly
-    } else { attention(ex, qk, qk.cols(C), vt, npad, ao32, B, w.heads, HW, HW); ao_ready(); }
+      attention_hl(ex, qk, kh, C, vth, npad, ao, B, w.heads, HW, HW);
+    }
+    else { attention(ex, qk, qk.cols(C), vt, npad, ao32, B, w.heads, HW, HW); ao_ready(); }
     Epi er; er.R = t; er.rpb = HW;
     run_linear(ex, b.out1, ao, (int)M, t, er);
     run_layernorm(ex, b.n2, t, (int)M, ln);
