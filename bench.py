@@ -333,7 +333,7 @@ def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str):
         out[f"config2_{prec}_vs_oracle_final_max_abs"], out[f"config2_{prec}_vs_oracle_final_rel"] = a, r
         strict = {}
         for tag, dtv, what in (("f32", pkg.DTYPE_F32, "SDXL_DTYPE_F32 UNet (exact-fp32 MFMA) + the timed VAE"),
-                               ("f32_split", pkg.DTYPE_F32_SPLIT, "SDXL_DTYPE_F32_SPLIT UNet (fp32 stream, (hi, lo) f16 GEMM operands x 3 MFMAs, fp32 attention) + the timed VAE")):
+                               ("f32_split", pkg.DTYPE_F32_SPLIT, "SDXL_DTYPE_F32_SPLIT UNet (fp32 stream, (hi, lo) f16 operands x 3 MFMAs in the GEMMs and in the attention) + the timed VAE")):
             if prec == tag:
                 continue
             d32 = pkg.Diffuser(ctx, cfg, dtv, seed=0)
@@ -378,7 +378,7 @@ def main():
     ap.add_argument("--cfg", type=float, default=None)
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res", "f32_split"],
                     help="UNet arithmetic: f16 (the reference's GPU precision, src/bin/sample/main.rs:122), f16_f32res, f32 (exact-fp32 MFMA: the strict-parity "
-                         "mode) or f32_split (fp32-class: fp32 stream, (hi, lo) f16 GEMM operands with three MFMAs per product, fp32 attention)")
+                         "mode) or f32_split (fp32-class: fp32 stream, (hi, lo) f16 operands with three MFMAs per product in the GEMMs and in the attention)")
     ap.add_argument("--vae-dtype", default="f32_split", choices=["f16", "f32", "f32_split"],
                     help="arithmetic of the VAE legs; the reference decodes in f32 (src/bin/sample/main.rs:121,271-278): f32 = exact-fp32 "
                          "MFMA, f32_split = fp32-class results from three f16 MFMAs per product on (hi, lo) operand pairs")
