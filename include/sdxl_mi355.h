@@ -39,10 +39,12 @@ enum {
   SDXL_DTYPE_F32 = 0,       /* strict-parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)      */
   SDXL_DTYPE_F16 = 1,       /* fp16 storage + fp16 MFMA operands, fp32 accumulation/statistics/softmax           */
   SDXL_DTYPE_F16_F32RES = 2,/* fp16 MFMA operands, fp32 residual stream                                         */
-  SDXL_DTYPE_F32_SPLIT = 3  /* VAE only (sdxl_vae_create*): fp32 storage of the residual stream, GEMM operands as (hi, lo) f16 pairs and
-                             * three f16 MFMAs per product (a*w ~ ah*wh + al*wh + ah*wl, 22-bit significands, fp32 accumulation):
-                             * fp32-class results -- the reference decodes in f32, src/bin/sample/main.rs:121,271-278 -- at a third
-                             * of the f16 matrix rate instead of the 1/16 of the exact-fp32 MFMA                                   */
+  SDXL_DTYPE_F32_SPLIT = 3  /* fp32-class results on the f16 matrix pipe (UNet / Diffuser, VAE, sdxl_conv2d, sdxl_qkv_attention with unmasked
+                             * head-dim-64 attention): fp32 storage of the residual stream, GEMM and attention operands as (hi, lo) f16
+                             * pairs and three f16 MFMAs per product (a*w ~ ah*wh + al*wh + ah*wl, 22-bit significands, fp32
+                             * accumulation) -- the reference decodes in f32, src/bin/sample/main.rs:121,271-278 -- at a third of the
+                             * f16 matrix rate instead of the 1/16 of the exact-fp32 MFMA.  Measured: 2.3e-4 on the 31-step latent
+                             * of config 2 against the CPU oracle (SDXL_DTYPE_F32: 3.9e-4) at 2.7x the speed of SDXL_DTYPE_F32      */
 };
 
 /* UNetConfig (src/model/unet/mod.rs:59-69) + DiffuserConfig.is_refiner (src/model/stablediffusion/mod.rs:269-278) */
@@ -143,7 +145,8 @@ int sdxl_unet_set_fused_cross_attention(sdxl_unet* u, int enabled);
 int sdxl_unet_set_gn_from_producer(sdxl_unet* u, int enabled);
 
 /* ---- Backend::qkv_attention (src/backend.rs:4-19; generic body :88-128, LibTorch override :32-79)
- * q [B,Nq,n_head*d], k,v [B,Nk,n_head*d], mask additive [Nq,Nk] or NULL, out [B,Nq,n_head*d]; fp32 device tensors */
+ * q [B,Nq,n_head*d], k,v [B,Nk,n_head*d], mask additive [Nq,Nk] or NULL, out [B,Nq,n_head*d]; fp32 device tensors.
+ * dtype SDXL_DTYPE_F32_SPLIT: d = 64 and mask == NULL only (the UNet's attention), anything else is refused with an error. */
 int sdxl_qkv_attention(sdxl_ctx* ctx, void* stream, const float* q, const float* k, const float* v, const float* mask,
                        int B, int Nq, int Nk, int n_state, int n_head, int dtype, float* out);
 /* Backend::attn_decoder_mask (src/backend.rs:130-136): writes the [n,n] causal mask (0 / -inf) */
