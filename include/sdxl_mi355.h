@@ -39,7 +39,7 @@ enum {
   SDXL_DTYPE_F32 = 0,       /* strict-parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)      */
   SDXL_DTYPE_F16 = 1,       /* fp16 storage + fp16 MFMA operands, fp32 accumulation/statistics/softmax           */
   SDXL_DTYPE_F16_F32RES = 2,/* fp16 MFMA operands, fp32 residual stream                                         */
-  SDXL_DTYPE_F32_SPLIT = 3  /* fp32-class results on the f16 matrix pipe (UNet / Diffuser, VAE, sdxl_conv2d, sdxl_qkv_attention with unmasked
+  SDXL_DTYPE_F32_SPLIT = 3  /* fp32-class results on the f16 matrix pipe (UNet / Diffuser, VAE, sdxl_conv2d, sdxl_linear, sdxl_qkv_attention with unmasked
                              * head-dim-64 attention): fp32 storage of the residual stream, GEMM and attention operands as (hi, lo) f16
                              * pairs and three f16 MFMAs per product (a*w ~ ah*wh + al*wh + ah*wl, 22-bit significands, fp32
                              * accumulation) -- the reference decodes in f32, src/bin/sample/main.rs:121,271-278 -- at a third of the

@@ -927,17 +927,37 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   SDXL_REQUIRE(!geglu || (N % 32 == 0), "GEGLU width must be a multiple of 32");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_linear");
+  int cdt, sdt;
+  if (dtype == SDXL_DTYPE_F32_SPLIT) { cdt = DT_HL; sdt = DT_HL; }   // split-operand GEMM as an operator: HL16 operands (incl. the GEGLU epilogue)
+  else dtypes(dtype, cdt, sdt);
+  SDXL_REQUIRE(cdt != DT_HL || K % 32 == 0, "SDXL_DTYPE_F32_SPLIT linear layers need K % 32 == 0");
   const int kt = cdt == DT_F16 ? 64 : 32;
   Lin l; l.N = N; l.K = K; l.cin = K; l.ksize = 1; l.Kpad = (int)round_up(K, kt); l.Npad = (int)round_up(N, 128);
   Tmp tmp;
   void* wp = tmp.get((size_t)l.Npad * l.Kpad * dt_size(cdt));
   float* bp = (float*)tmp.get((size_t)l.Npad * sizeof(float));
   void* xi = tmp.get((size_t)M * K * dt_size(sdt));
-  launch_pack_linear(weight, wp, cdt, K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, s);
+  float wscale = 1.f;
+  if (cdt == DT_HL) {     // power-of-two weight scale from max |w|, exactly as WeightBuilder::linear
+    float* sc = (float*)tmp.get(256);
+    launch_absmax(weight, (size_t)K * N, sc, s);
+    float h = 0.f;
+    SDXL_HIP(hipMemcpyAsync(&h, sc, sizeof(float), hipMemcpyDeviceToHost, s));
+    SDXL_HIP(hipStreamSynchronize(s));
+    int e = 0;
+    if (h > 0.f && std::isfinite(h)) { (void)std::frexp(h, &e); e = 14 - e; }
+    e = e > 24 ? 24 : (e < -24 ? -24 : e);
+    wscale = std::ldexp(1.0f, e);
+    const float inv = 1.0f / wscale;
+    SDXL_HIP(hipMemcpyAsync(sc, &inv, sizeof(float), hipMemcpyHostToDevice, s));
+    SDXL_HIP(hipStreamSynchronize(s));
+    l.acc_scale = sc;
+  }
+  launch_pack_linear(weight, wp, cdt, K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, s, nullptr, wscale);
   launch_pack_bias(bias, bp, N, l.Npad, geglu ? 1 : 0, 0, s);
   l.w = wp; l.b = bp;
-  launch_copy_rows(x, DT_F32, K, xi, sdt, K, M, K, s);
+  if (cdt == DT_HL) launch_f32_to_hl(x, K, xi, K, (size_t)M, K, s);
+  else launch_copy_rows(x, DT_F32, K, xi, sdt, K, M, K, s);
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
   give_splitk_ws(ex, tmp, 1, M, N, s);
   Epi e; e.act = geglu ? 1 : 0;

@@ -173,6 +173,21 @@ def test_linear(pkg, ctx, dtype, M, K, N):
     assert rel_err(out, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,K,N,geglu", [(77, 128, 192, False), (256, 320, 1280, False), (1000, 640, 96, False), (64, 2816, 1280, False),
+                                           (2048, 1280, 1280, False), (256, 640, 5120, True), (300, 1280, 10240, True), (130, 64, 128, True)])
+def test_linear_split_operand(pkg, ctx, M, K, N, geglu):
+    # SDXL_DTYPE_F32_SPLIT as an operator: HL16 operands, three MFMAs per product, incl. the exact-erf GEGLU epilogue (unet/mod.rs:942-956)
+    x = seeded(M, K, seed=7).double()
+    w = (seeded(K, N, seed=8) / math.sqrt(K)).double()
+    b = (0.1 * seeded(N, seed=9)).double()
+    y = x @ w + b
+    ref = y[:, :N // 2] * torch.nn.functional.gelu(y[:, N // 2:]) if geglu else y
+    out = pkg.linear(ctx, x.float().cuda(), w.float().cuda(), b.float().cuda(), geglu, 3)
+    e = rel_err(out.double(), ref)
+    print(f"linear split-operand M={M} K={K} N={N} geglu={geglu}: rel err vs fp64 {e:.3e}")
+    assert e < 5e-6
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_asymmetric_identity(pkg, ctx, dtype):
     # A = I with an asymmetric B catches a transposed / mis-mapped MFMA C layout (guide rule 16)
