@@ -142,6 +142,25 @@ def run_unet1024_f16w(cfg, W):
                         in_checksum=checksum(i["x"], i["ctx"], i["y"]), oracle_seconds=np.array([dt]))
 
 
+def run_config2_f16w(cfg, W):
+    """BASELINE configs[1] (the benchmarked trajectory of make_golden_fullsize.run_config2, same seeded inputs) with every parameter
+    rounded to IEEE f16 first -- the weights a real SDXL record holds (HalfPrecisionSettings, src/bin/sample/main.rs:37).  Not part of
+    the default set (about 25 minutes of oracle time): `python -m oracle.make_golden_r3 config2_f16w`."""
+    from oracle.make_golden_fullsize import config2_inputs
+    i = config2_inputs(cfg)
+    W16 = {k: (v if k.endswith(".eps") else v.half().float()) for k, v in W.items()}
+    cond = OP.Conditioning(i["uctx"], None, i["ctx"], None, i["uy"], None, i["y"], None, (1024, 1024))
+    trace = []
+    t0 = time.time()
+    lat = OP.Diffuser(cfg, W16, OC.alphas_cumprod()).sample_latent(cond, 7.5, 30, i["noise"], trace)
+    dt = time.time() - t0
+    keep = (0, 15, 30)
+    print(f"[golden] config 2 with f16-representable weights: 31-step sample_latent {dt:.1f} s, |latent|max {float(lat.abs().max()):.2f}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "fullsize_config2_f16w.npz"), steps=np.array(keep), traj=np.stack([trace[k].numpy() for k in keep]),
+                        latent=lat.numpy(), in_checksum=checksum(*i.values()), oracle_seconds=np.array([dt]),
+                        oracle_threads=np.array([torch.get_num_threads()]))
+
+
 def main():
     what = set(sys.argv[1:]) or {"refiner1024", "refine1024", "encode1024", "inpaint1024", "unet1024_f16w"}
     os.makedirs(OUT, exist_ok=True)
@@ -159,8 +178,10 @@ def main():
         if "refine1024" in what:
             run_refine1024(cfg, W)
         del W
-    if what & {"inpaint1024", "unet1024_f16w"}:
+    if what & {"inpaint1024", "unet1024_f16w", "config2_f16w"}:
         cfg, W = base_weights()
+        if "config2_f16w" in what:
+            run_config2_f16w(cfg, W)
         if "unet1024_f16w" in what:
             run_unet1024_f16w(cfg, W)
         if "inpaint1024" in what:

@@ -153,6 +153,7 @@ int sdxl_debug_set(const char* key, int value) {
   if (std::strcmp(key, "igemm_variant") == 0) igemm_set_variant(value);
   else if (std::strcmp(key, "attn_variant") == 0) attention_set_variant(value);
   else if (std::strcmp(key, "igemm_epilogue_staged") == 0) igemm_set_epilogue_staged(value);
+  else if (std::strcmp(key, "hl_weights_exact") == 0) igemm_set_hl_weights_exact(value);
 #ifdef SDXL_MEASURE
   else if (std::strcmp(key, "igemm_unrolled") == 0) igemm_set_unrolled(value);
   else if (std::strcmp(key, "no_cfg") == 0) g_debug_no_cfg = value != 0;
@@ -907,6 +908,7 @@ int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
     const float inv = 1.0f / wscale;
     SDXL_HIP(hipMemcpyAsync(sc, &inv, sizeof(float), hipMemcpyHostToDevice, s));
     SDXL_HIP(hipStreamSynchronize(s));
+    launch_f16_exact(weight, (size_t)Cout * l.K, wscale, sc + 1, s);      // exact-f16 weights: the kernel leaves out the w_lo MFMAs
     l.acc_scale = sc;
   }
   launch_pack_conv(weight, wp, cdt, Cout, Cin, ksize, l.Kpad, l.Npad, s, wscale);
@@ -951,6 +953,7 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
     const float inv = 1.0f / wscale;
     SDXL_HIP(hipMemcpyAsync(sc, &inv, sizeof(float), hipMemcpyHostToDevice, s));
     SDXL_HIP(hipStreamSynchronize(s));
+    launch_f16_exact(weight, (size_t)K * N, wscale, sc + 1, s);      // exact-f16 weights: the kernel leaves out the w_lo MFMAs
     l.acc_scale = sc;
   }
   launch_pack_linear(weight, wp, cdt, K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, s, nullptr, wscale);

@@ -255,6 +255,24 @@ __global__ void f32_to_hl_kernel(const float* src, int lds_, half_t* dst, int ld
   *reinterpret_cast<half8*>(dp) = hi;
   *reinterpret_cast<half8*>(dp + 16) = lo;
 }
+// one flag per weight matrix: 1.0f while every scaled element is exactly one f16 value (the reference's records are f16:
+// HalfPrecisionSettings, src/bin/sample/main.rs:37), 0.0f as soon as one is not
+__global__ void f16_exact_kernel(const float* src, size_t n, float wscale, float* exact) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (size_t i = i0; i < n; i += stride) {
+    float x = src[i] * wscale;
+    asm("" : "+v"(x));
+    bad |= (float)(half_t)x != x;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *exact = 0.0f;        // (benign race: every writer stores the same value)
+}
+void launch_f16_exact(const float* src, size_t n, float wscale, float* exact, hipStream_t s, bool accumulate) {
+  if (!accumulate) { const float one = 1.0f; (void)hipMemcpyAsync(exact, &one, sizeof(float), hipMemcpyHostToDevice, s); (void)hipStreamSynchronize(s); }
+  if (n == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(f16_exact_kernel, dim3(blocks), dim3(256), 0, s, src, n, wscale, exact);
+}
 void launch_f32_to_hl(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, hipStream_t s) {
   if ((C & 15) != 0 || (lds_ & 3) != 0 || (ldd & 15) != 0) throw std::runtime_error("f32_to_hl: C % 16 == 0 rows with aligned strides only");
   const size_t total = rows * (size_t)(C / 8);

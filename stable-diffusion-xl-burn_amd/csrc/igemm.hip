@@ -348,11 +348,14 @@ static std::atomic<int> g_igemm_variant_a{0};   // test hook (sdxl_debug_set "ig
 void igemm_set_variant(int v) { g_igemm_variant_a = v; }
 static std::atomic<int> g_igemm_epi_staged{0};
 void igemm_set_epilogue_staged(int v) { g_igemm_epi_staged = v; }
+static std::atomic<int> g_hl_wexact{1};
+void igemm_set_hl_weights_exact(int v) { g_hl_wexact = v; }
 
 void launch_igemm(const IgemmParams& pin, int compute_dt, hipStream_t s) {
   if (pin.M <= 0 || pin.N <= 0) return;
   IgemmParams p = pin;
   p.epi_staged = g_igemm_epi_staged.load();
+  p.hl_wexact_ok = g_hl_wexact.load();
   const int g_igemm_variant = g_igemm_variant_a.load();
   if (compute_dt == DT_F16 && g_igemm_variant >= 0 && launch_igemm_glds(p, g_igemm_variant, s)) return;
   if (compute_dt == DT_F16 && g_igemm_variant > 0 && launch_igemm_glds(p, 0, s)) return;   // forced tile refused the shape

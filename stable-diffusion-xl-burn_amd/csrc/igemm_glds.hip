@@ -416,16 +416,18 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   };
   // split-operand MFMAs.  CROSS = false: hi x hi of fragment set SH (TM*TN MFMAs); CROSS = true: the two cross terms
   // w_hi x a_lo and w_lo x a_hi of the pair (SH, SL) (2*TM*TN MFMAs).  DMA pieces PH go behind the first MFMA, as above.
-  auto mma_hl = [&](auto SHI, auto SLO, auto CROSS, int buf, auto PH, bool more) {
+  // WX = every packed weight of this layer is ONE f16 (its lo half is zero: what a real SDXL record holds): the w_lo x a_hi
+  // MFMAs would add exact zeros and are left out, as are the ds_reads of the weights' lo fragments -- bit-identical results.
+  auto mma_hl = [&](auto SHI, auto SLO, auto CROSS, auto WXT, int buf, auto PH, bool more) {
     if constexpr (HL) {
       constexpr int sh = decltype(SHI)::value, sl = decltype(SLO)::value, ph = decltype(PH)::value;
-      constexpr bool cross = decltype(CROSS)::value;
+      constexpr bool cross = decltype(CROSS)::value, wx = decltype(WXT)::value;
       auto one = [&](auto X) {
         constexpr int x = decltype(X)::value, i = x / TN, j = x % TN;
         if constexpr (!cross) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[sh][j], fA[sh][i], acc[i][j], 0, 0, 0);
         else {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[sh][j], fA[sl][i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[sl][j], fA[sh][i], acc[i][j], 0, 0, 0);
+          if constexpr (!wx) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[sl][j], fA[sh][i], acc[i][j], 0, 0, 0);
         }
       };
       one(std::integral_constant<int, 0>{});
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float lnA[TM], lnC[TM];
+  bool hl_wexact = false;        // split-operand launches: every packed weight is one f16 (its lo half is zero)
   const bool ln_coop = LN_COOP && p.ln_slots <= 24;
   if constexpr (LN_COOP) lnc.finish(p, m0, ln_coef);
   if (!ln_coop) ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
@@ -488,6 +491,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     const float sc = p.acc_scale ? *p.acc_scale : 1.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) { lnA[i] = sc; lnC[i] = 0.f; }
+    // (readfirstlane: the compiler must SEE that the choice is wave-uniform -- as a vector condition it runs both k-loops one after
+    // the other under complementary EXEC masks, and MFMAs, barriers and the M0-addressed DMA do not honour EXEC)
+    const int wx = (p.acc_scale && p.hl_wexact_ok && p.acc_scale[1] != 0.f) ? 1 : 0;
+    hl_wexact = __builtin_amdgcn_readfirstlane(wx) != 0;
   }
   ldfrag(0, 0, I0{});
   // The k-loop is unrolled by the ring depth: ring slots become compile-time constants, so every
@@ -506,16 +513,21 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       fa[q][kk] = (basea ^ (kk << 5)) + (PERSLOT ? q * STAGE : q * 65536u);
       fb[q][kk] = (baseb ^ (kk << 5)) + (PERSLOT ? q * STAGE : q * 65536u);
     }
-  auto ldf = [&](auto SO, auto KK, auto SET) {
+  auto ldf = [&](auto SO, auto KK, auto SET, auto NOB) {          // NOB: leave out the weight fragments (split-operand lo sets of exact-f16 weights)
     constexpr unsigned so = decltype(SO)::value;
     constexpr int kk = decltype(KK)::value, set = decltype(SET)::value;
+    constexpr bool nob = decltype(NOB)::value;
     constexpr int hi = PERSLOT ? (int)(so / STAGE) : (so >= 65536u ? 1 : 0);
     constexpr unsigned lo = PERSLOT ? 0u : so - hi * 65536u;
     static_assert(lo + (TM - 1) * 4096 < 65536u && lo + (TN - 1) * 4096 < 65536u, "fragment immediate out of range");
     static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<lo + decltype(I)::value * 4096, frag_t>(fa[hi][kk]); });
-    static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<lo + decltype(J)::value * 4096, frag_t>(fb[hi][kk]); });
+    if constexpr (!nob) static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<lo + decltype(J)::value * 4096, frag_t>(fb[hi][kk]); });
   };
-  auto ktile = [&](int kt, auto CUR) {
+  using NB0 = std::false_type;
+  auto ktile = [&](int kt, auto CUR, auto WXT) {
+    constexpr bool wx = decltype(WXT)::value;
+    using WX = std::integral_constant<bool, wx>;
+    constexpr int NFL = wx ? TM : NF;          // ds_reads of a lo fragment set
     constexpr int c = decltype(CUR)::value;
     constexpr int nslot = (c + 1) % NS, fl = (c + NS - 1) % NS;
     using SO = std::integral_constant<unsigned, (unsigned)c * STAGE>;
@@ -524,15 +536,15 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     if constexpr (HL) {
       // one 32-deep k-tile = the pairs (hi0, lo0) and (hi1, lo1) in sets 0..3; set 0 was requested behind the previous barrier
       using F = std::false_type; using Tt = std::true_type;
-      ldf(SO{}, I1{}, I1{});
+      ldf(SO{}, I1{}, I1{}, WX{});
+      wait_lgkmcnt<NFL>();
+      mma_hl(I0{}, I0{}, F{}, WX{}, fl, I0{}, more);      // w_hi0 x a_hi0
+      ldf(SO{}, I2{}, I2{}, NB0{});
       wait_lgkmcnt<NF>();
-      mma_hl(I0{}, I0{}, F{}, fl, I0{}, more);            // w_hi0 x a_hi0
-      ldf(SO{}, I2{}, I2{});
-      wait_lgkmcnt<NF>();
-      mma_hl(I0{}, I1{}, Tt{}, fl, I1{}, more);           // w_hi0 x a_lo0 + w_lo0 x a_hi0
-      ldf(SO{}, I3{}, I3{});
-      wait_lgkmcnt<NF>();
-      mma_hl(I2{}, I2{}, F{}, fl, I2{}, more);            // w_hi1 x a_hi1
+      mma_hl(I0{}, I1{}, Tt{}, WX{}, fl, I1{}, more);     // w_hi0 x a_lo0 (+ w_lo0 x a_hi0)
+      ldf(SO{}, I3{}, I3{}, WX{});
+      wait_lgkmcnt<NFL>();
+      mma_hl(I2{}, I2{}, F{}, WX{}, fl, I2{}, more);      // w_hi1 x a_hi1
       if (more) tile_done();
       if (kt + 1 < nk) {
         if (more) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
@@ -540,20 +552,20 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        ldf(SN{}, I0{}, I0{});
+        ldf(SN{}, I0{}, I0{}, NB0{});
       } else {
         wait_lgkmcnt<0>();
       }
-      mma_hl(I2{}, I3{}, Tt{}, fl, I3{}, false);          // w_hi1 x a_lo1 + w_lo1 x a_hi1
+      mma_hl(I2{}, I3{}, Tt{}, WX{}, fl, I3{}, false);    // w_hi1 x a_lo1 (+ w_lo1 x a_hi1)
       return;
     }
-    ldf(SO{}, I1{}, I1{});
+    ldf(SO{}, I1{}, I1{}, NB0{});
     wait_lgkmcnt<NF>();
     mma(I0{}, fl, I0{}, more);
-    ldf(SO{}, I2{}, I0{});
+    ldf(SO{}, I2{}, I0{}, NB0{});
     wait_lgkmcnt<NF>();
     mma(I1{}, fl, I1{}, more);
-    ldf(SO{}, I3{}, I1{});
+    ldf(SO{}, I3{}, I1{}, NB0{});
     wait_lgkmcnt<NF>();
     mma(I0{}, fl, I2{}, more);
     if (more) tile_done();
@@ -563,15 +575,23 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      ldf(SN{}, I0{}, I0{});
+      ldf(SN{}, I0{}, I0{}, NB0{});
     } else {
       wait_lgkmcnt<0>();
     }
     mma(I1{}, fl, I3{}, false);
   };
   int kt = 0;
-  for (; kt + NS <= nk; kt += NS) static_for<NS>([&](auto S) { ktile(kt + decltype(S)::value, S); });
-  static_for<NS - 1>([&](auto S) { if (kt + decltype(S)::value < nk) ktile(kt + decltype(S)::value, S); });
+  auto kloop = [&](auto WXT) {
+    for (; kt + NS <= nk; kt += NS) static_for<NS>([&](auto S) { ktile(kt + decltype(S)::value, S, WXT); });
+    static_for<NS - 1>([&](auto S) { if (kt + decltype(S)::value < nk) ktile(kt + decltype(S)::value, S, WXT); });
+  };
+  if constexpr (HL) {
+    // two copies of the k-loop: the compiler moves the first fragments (asm ds_reads it believes complete) into each copy's
+    // registers at the loop entry -- they must have LANDED before that (one LDS latency per launch)
+    wait_lgkmcnt<0>();
+    if (hl_wexact) kloop(std::true_type{}); else kloop(std::false_type{});       // wave-uniform: a device scalar next to the weight scale
+  } else kloop(std::false_type{});
   __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring: it becomes the staging area
   asm volatile("" ::: "memory");
   if constexpr (BN == 128) {

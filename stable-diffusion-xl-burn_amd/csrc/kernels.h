@@ -57,8 +57,9 @@ struct IgemmParams {
   // GroupNorm statistics of the stored output, from the epilogue (256x128 kernel; igemm_gn_part_ok): gn_part[M/256][N] (mean, M2)
   // of every column over the 256 rows of a tile -- the consumer's GroupNorm merges row tiles and channels (norm.hip, chan_part)
   float* gn_part;
-  const float* acc_scale;  // DT_HL compute: the packed weights carry a power-of-two factor (exact); device scalar 1 / factor the epilogue multiplies the
+  const float* acc_scale;   /* [0] = 1 / weight scale, [1] != 0: every packed weight is exactly one f16 (lo halves all zero) */  // DT_HL compute: the packed weights carry a power-of-two factor (exact); device scalar 1 / factor the epilogue multiplies the
                            // accumulators by (lives in the weight arena, so replicas that receive the arena by broadcast need no host copy); null = 1
+  int hl_wexact_ok; // A/B knob (sdxl_debug_set "hl_weights_exact", default 1): split-operand launches may leave out the w_lo MFMAs when acc_scale[1] says every weight is one f16
   int epi_staged;   // A/B knob (sdxl_debug_set "igemm_epilogue_staged"): 1 = LDS-staged epilogue everywhere, 0 = direct row-per-lane where it applies
 };
 bool igemm_gn_part_ok(const IgemmParams& p);
@@ -73,6 +74,7 @@ size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max);   // sla
 constexpr int kSplitkCounters = 4096;                                // arrival counters a plan must provide (zeroed once)
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
+void igemm_set_hl_weights_exact(int v); // A/B: 0 keeps all three MFMAs per product even where the packed weights are exact f16 values
 void igemm_set_epilogue_staged(int v);   // A/B: 1 forces the LDS-staged epilogue (default 0: direct row-per-lane epilogue on whole wave tiles)
 void igemm_set_unrolled(int v);   // auto selection: pipelined kernels with the k-loop unrolled by the ring depth (default on)
 #ifdef SDXL_MEASURE
@@ -171,6 +173,9 @@ void launch_nhwc_to_nchw(const void* src, int dt, int lds, float* dst, int B, in
 void launch_copy_rows(const void* src, int sdt, int lds, void* dst, int ddt, int ldd, int rows, int C, hipStream_t s);
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 // fp32 rows -> split-operand HL16 rows (C % 16 == 0, row strides in logical elements, dst stride % 16 == 0)
+// exact[0] = 1.0f if every x * wscale of src[0..n) is exactly one f16 value (the packed lo halves are all zero), else 0.0f;
+// `accumulate`: AND with the value already there (several tensors of one fused matrix)
+void launch_f16_exact(const float* src, size_t n, float wscale, float* exact, hipStream_t s, bool accumulate = false);
 void launch_f32_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows, int C, hipStream_t s);
 void launch_round_f16(float* p, size_t n, hipStream_t s);   // p[i] = float(half(p[i])): parameters as a HalfPrecisionSettings record holds them
 void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s);

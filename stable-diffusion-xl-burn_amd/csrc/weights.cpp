@@ -145,10 +145,10 @@ const float* WeightBuilder::fetch(const std::string& name) {
 // subnormals (~20 bits).  The factor is exact, a function of the tensor(s) only, and the GEMM epilogue undoes it with the device
 // scalar this returns through l.acc_scale (it lives in the arena, so replicas receive it with the weights).
 float WeightBuilder::hl_scale(Lin& l, const std::vector<std::string>& weight_names) {
-  float* sc = (float*)arena.alloc(sizeof(float));     // (allocated on empty replicas too: identical arena layout)
+  float* sc = (float*)arena.alloc(2 * sizeof(float));     // [0] 1 / factor, [1] "every weight is one f16" (allocated on empty replicas too: identical arena layout)
   l.acc_scale = sc;
   if (src.empty()) return 1.f;
-  SDXL_HIP(hipMemsetAsync(sc, 0, sizeof(float), st));
+  SDXL_HIP(hipMemsetAsync(sc, 0, 2 * sizeof(float), st));
   for (const std::string& n : weight_names) launch_absmax(fetch(n), spec(n).numel(), sc, st, true);
   float h = 0.f;
   SDXL_HIP(hipMemcpyAsync(&h, sc, sizeof(float), hipMemcpyDeviceToHost, st));
@@ -159,6 +159,10 @@ float WeightBuilder::hl_scale(Lin& l, const std::vector<std::string>& weight_nam
   const float wscale = std::ldexp(1.0f, e), inv = 1.0f / wscale;
   SDXL_HIP(hipMemcpyAsync(sc, &inv, sizeof(float), hipMemcpyHostToDevice, st));
   SDXL_HIP(hipStreamSynchronize(st));
+  // real SDXL records hold f16 parameters: where every scaled weight of the matrix is exactly one f16 the lo halves are zero and the
+  // kernel leaves out a third of its MFMAs (igemm_glds.hip, WX).  (gamma-folded weights never qualify: the split mode does not fold.)
+  bool first = true;
+  for (const std::string& n : weight_names) { launch_f16_exact(fetch(n), spec(n).numel(), wscale, sc + 1, st, !first); first = false; }
   return wscale;
 }
 

@@ -188,6 +188,25 @@ def test_linear_split_operand(pkg, ctx, M, K, N, geglu):
     assert e < 5e-6
 
 
+@pytest.mark.parametrize("M,K,N,geglu", [(256, 320, 1280, False), (2048, 1280, 1280, False), (300, 1280, 10240, True)])
+def test_linear_split_operand_exact_f16_weights(pkg, ctx, M, K, N, geglu):
+    # weights that ARE f16 values (what a real SDXL record holds, src/bin/sample/main.rs:37): the packed lo halves are zero and the
+    # kernel leaves out the w_lo x a_hi MFMAs -- the result must be bit-identical to the three-MFMA form, and as accurate
+    x = seeded(M, K, seed=7)
+    w = (seeded(K, N, seed=8) / math.sqrt(K)).half().float()
+    b = 0.1 * seeded(N, seed=9)
+    y = x.double() @ w.double() + b.double()
+    ref = y[:, :N // 2] * torch.nn.functional.gelu(y[:, N // 2:]) if geglu else y
+    out = pkg.linear(ctx, x.cuda(), w.cuda(), b.cuda(), geglu, 3)
+    pkg.debug_set("hl_weights_exact", 0)
+    try:
+        out3 = pkg.linear(ctx, x.cuda(), w.cuda(), b.cuda(), geglu, 3)
+    finally:
+        pkg.debug_set("hl_weights_exact", 1)
+    assert torch.equal(out, out3), "two-MFMA form differs from the three-MFMA form on exact-f16 weights"
+    assert rel_err(out.double(), ref) < 5e-6
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_asymmetric_identity(pkg, ctx, dtype):
     # A = I with an asymmetric B catches a transposed / mis-mapped MFMA C layout (guide rule 16)

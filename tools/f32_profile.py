@@ -4,7 +4,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package(); ctx = pkg.Context(0)
 cfg = pkg.sdxl_base_config()
 name = sys.argv[1] if len(sys.argv) > 1 else "f32"
-d = pkg.Diffuser(ctx, cfg, {"f32": pkg.DTYPE_F32, "f16": pkg.DTYPE_F16, "f16_f32res": pkg.DTYPE_F16_F32RES, "f32_split": pkg.DTYPE_F32_SPLIT}[name], seed=0)
+d = pkg.Diffuser(ctx, cfg, {"f32": pkg.DTYPE_F32, "f16": pkg.DTYPE_F16, "f16_f32res": pkg.DTYPE_F16_F32RES, "f32_split": pkg.DTYPE_F32_SPLIT}[name], seed=(pkg.SEED_F16_WEIGHTS if os.environ.get("F16W") == "1" else 0))
 g = torch.Generator(device="cuda").manual_seed(1)
 r = lambda *s: torch.randn(*s, device="cuda", generator=g)
 cond = pkg.Conditioning(context_full=r(1, 77, cfg.context_dim), channel_context=r(1, cfg.adm_in_channels), unconditional_context_full=r(77, cfg.context_dim),
