@@ -487,3 +487,28 @@ def test_ref_recipe_exports_the_reference_tree(tmp_path):
     assert rd("params_vae", "encoder", "blocks", "0", "downsampler", "padding.npy").tolist() == [4.0, 0.0, 1.0, 0.0, 1.0]
     assert rd("params_vae", "encoder", "blocks", "0", "downsampler", "conv", "stride.npy").tolist() == [2.0, 2.0, 2.0]
     assert rd("params_vae", "decoder", "norm_out", "n_group.npy").tolist() == [1.0, 32.0]
+
+
+def test_production_gemm_assembly_has_no_async_read_hazard(tmp_path):
+    """tools/asm_lint.py over the device assembly of the production GEMM translation unit: no instruction may read or overwrite the
+    destination registers of a hand-written asynchronous `ds_read_b128` before a counted `s_waitcnt lgkmcnt` covers it.  (The compiler
+    believes an inline-asm output complete when the statement ends; it broke the split-operand kernel exactly this way when that kernel
+    grew a second copy of its k-loop.)  Takes about two minutes of hipcc."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_lint
+    src = os.path.join(ROOT, "stable-diffusion-xl-burn_amd", "csrc", "igemm_glds.hip")
+    out = str(tmp_path / "igemm_glds.s")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out,
+                        "-Wno-unused-function"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    findings = asm_lint.lint(out)
+    assert not findings, "\n".join(findings[:10])
+    # the lint must see the kernels it is meant to check
+    text = open(out).read()
+    assert text.count("ds_read_b128") > 500 and "igemm_pipe_kernel" in text

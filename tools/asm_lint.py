@@ -1,0 +1,105 @@
+"""Lint of the device assembly for the hazard the hand-written asynchronous LDS reads carry.
+
+The pipelined GEMM kernels issue their fragment reads as inline-asm `ds_read_b128` and wait for them with hand-counted
+`s_waitcnt lgkmcnt(N)`.  The compiler believes an asm output is complete the moment the statement ends, so it is free to read (copy,
+spill, use) or overwrite the destination registers BEFORE the data has landed -- it did exactly that when a kernel grew a second copy
+of its k-loop (register moves at the loop entry).  This script replays the LGKM queue over the generated code:
+
+  * every inline-asm `ds_read*` (between ;;#ASMSTART / ;;#ASMEND) enters the in-order queue with its destination registers;
+    compiler-issued LDS / SMEM operations enter it too (they count in lgkmcnt; SMEM returns out of order, so only lgkmcnt(0) clears a
+    queue that holds one);
+  * `s_waitcnt lgkmcnt(N)` retires all but the N youngest entries;
+  * any instruction that reads or writes a register of a still-pending inline-asm read is reported (except another LDS read that
+    only overwrites it: LDS returns in order, so the younger data lands last -- that is how the compiler recycles the registers of
+    fragment reads whose results a tail copy of the loop never uses);
+  * the queue is dropped at labels (join points: the other predecessors are checked on their own paths).
+
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -x hip --cuda-device-only -S csrc/igemm_glds.hip -o /tmp/glds.s
+    python tools/asm_lint.py /tmp/glds.s            -> exit status 1 if anything is reported
+"""
+import re
+import sys
+
+REG = re.compile(r"\b([vs])(?:\[(\d+):(\d+)\]|(\d+)\b)")
+NO_DST = ("global_store", "buffer_store", "flat_store", "scratch_store", "ds_write", "s_cbranch", "s_branch", "s_barrier", "s_nop", "s_waitcnt",
+          "s_endpgm", "s_setprio", "s_sleep", "s_cmp", "s_bitcmp", "global_load_lds", "buffer_wbl2", "buffer_inv", "s_sendmsg", "s_setreg")
+
+
+def regs(op):
+    out = set()
+    for m in REG.finditer(op):
+        kind = m.group(1)
+        if m.group(4) is not None:
+            out.add((kind, int(m.group(4))))
+        else:
+            out.update((kind, r) for r in range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def lint(path):
+    findings, kernel, in_asm, queue = [], None, False, []      # queue entries: dict(dst=set, asm=bool, smem=bool, line=int, text=str)
+    for ln, raw in enumerate(open(path), 1):
+        line = raw.strip()
+        if not line:
+            continue
+        if line.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if line.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if line.startswith(";") or line.startswith("."):
+            if re.match(r"\.LBB\d+_\d+:", line):
+                queue = []
+            continue
+        if re.match(r"^[A-Za-z_][\w$.]*:", line):            # function label
+            kernel, queue = line.split(":")[0], []
+            continue
+        code = line.split(";")[0].strip()
+        if not code:
+            continue
+        parts = code.split(None, 1)
+        mn, ops = parts[0], [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        if mn == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", code)
+            if m:
+                n = int(m.group(1))
+                if any(e["smem"] for e in queue):
+                    if n == 0:
+                        queue = []
+                else:
+                    queue = queue[len(queue) - n:] if n else []
+            continue
+        if mn == "s_endpgm":
+            queue = []
+            continue
+        has_dst = not mn.startswith(NO_DST)
+        written = regs(ops[0]) if (has_dst and ops) else set()
+        read = set().union(*[regs(o) for o in (ops[1:] if has_dst else ops)]) if ops else set()
+        is_lds_read = mn.startswith(("ds_read", "ds_bpermute", "ds_swizzle", "ds_permute"))
+        for e in queue:
+            # (an LDS read that only OVERWRITES a pending destination is consistent: LDS returns in order, the younger data lands last)
+            hit = (read & e["dst"]) | (set() if is_lds_read else (written & e["dst"]))
+            if e["asm"] and hit:
+                what = "reads" if read & e["dst"] else "overwrites"
+                findings.append(f"{kernel}: line {ln}: `{code}` {what} {sorted(r for r in (read | written) & e['dst'])[:4]} of the inline-asm "
+                                f"`{e['text']}` (line {e['line']}) before any lgkmcnt wait covers it")
+                break
+        if mn.startswith(("ds_read", "ds_bpermute", "ds_swizzle", "ds_permute")):
+            queue.append(dict(dst=written, asm=in_asm, smem=False, line=ln, text=code))
+        elif mn.startswith(("ds_write", "ds_add", "ds_max", "ds_min", "ds_or", "ds_and")):
+            queue.append(dict(dst=set(), asm=in_asm, smem=False, line=ln, text=code))
+        elif mn.startswith(("s_load", "s_buffer_load", "s_memtime", "s_memrealtime")):
+            queue.append(dict(dst=set(), asm=in_asm, smem=True, line=ln, text=code))
+    return findings
+
+
+if __name__ == "__main__":
+    bad = []
+    for p in sys.argv[1:]:
+        f = lint(p)
+        print(f"{p}: {len(f)} finding(s)")
+        for x in f[:40]:
+            print("  " + x)
+        bad += f
+    sys.exit(1 if bad else 0)
