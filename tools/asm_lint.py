@@ -13,6 +13,8 @@ of its k-loop (register moves at the loop entry).  This s
     only overwrites it: LDS returns in order, so the younger data lands last -- that is how the compiler recycles the registers of
     fragment reads whose results a tail copy of the loop never uses);
   * the queue is dropped at labels (join points: the other predecessors are checked on their own paths).
+Second rule: an LDS-DMA instruction (`global_load_lds_*`) must not issue directly behind a write of M0 (the compiler's hazard
+recogniser guarantees that for the builtin form, not inside inline asm).
 
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -x hip --cuda-device-only -S csrc/igemm_glds.hip -o /tmp/glds.s
     python tools/asm_lint.py /tmp/glds.s            -> exit status 1 if anything is reported
@@ -37,7 +39,7 @@ def regs(op):
 
 
 def lint(path):
-    findings, kernel, in_asm, queue = [], None, False, []      # queue entries: dict(dst=set, asm=bool, smem=bool, line=int, text=str)
+    findings, kernel, in_asm, queue, prev_writes_m0 = [], None, False, [], False      # queue entries: dict(dst=set, asm=bool, smem=bool, line=int, text=str)
     for ln, raw in enumerate(open(path), 1):
         line = raw.strip()
         if not line:
@@ -73,6 +75,11 @@ def lint(path):
         if mn == "s_endpgm":
             queue = []
             continue
+        # second rule: an LDS-DMA instruction must not issue in the wait state right behind a write of M0
+        if mn.startswith("global_load_lds") or (mn.startswith("buffer_load") and " lds" in code):
+            if prev_writes_m0:
+                findings.append(f"{kernel}: line {ln}: `{code}` issues directly behind a write of M0 (one wait state is required)")
+        prev_writes_m0 = bool(ops) and ops[0] == "m0" and mn.startswith("s_")
         has_dst = not mn.startswith(NO_DST)
         written = regs(ops[0]) if (has_dst and ops) else set()
         read = set().union(*[regs(o) for o in (ops[1:] if has_dst else ops)]) if ops else set()
