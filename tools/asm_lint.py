@@ -13,6 +13,7 @@ of its k-loop (register moves at the loop entry).  This s
     only overwrites it: LDS returns in order, so the younger data lands last -- that is how the compiler recycles the registers of
     fragment reads whose results a tail copy of the loop never uses);
   * the queue is dropped at labels (join points: the other predecessors are checked on their own paths).
+Third rule: no `s_barrier` while an LDS write of the wave is still in the queue (a raw barrier carries no wait of its own).
 Second rule: an LDS-DMA instruction (`global_load_lds_*`) must not issue directly behind a write of M0 (the compiler's hazard
 recogniser guarantees that for the builtin form, not inside inline asm).
 
@@ -52,7 +53,7 @@ def lint(path):
             continue
         if line.startswith(";") or line.startswith("."):
             if re.match(r"\.LBB\d+_\d+:", line):
-                queue = []
+                queue = [e for e in queue if e.get("write")]       # (a pending LDS write stays pending whichever path joins here)
             continue
         if re.match(r"^[A-Za-z_][\w$.]*:", line):            # function label
             kernel, queue = line.split(":")[0], []
@@ -71,6 +72,13 @@ def lint(path):
                         queue = []
                 else:
                     queue = queue[len(queue) - n:] if n else []
+            continue
+        # third rule: a raw s_barrier waits for nothing -- an LDS write of this wave that is still in the queue may not have landed when
+        # the barrier releases its readers
+        if mn == "s_barrier":
+            w = next((e for e in queue if e.get("write")), None)
+            if w:
+                findings.append(f"{kernel}: line {ln}: s_barrier with the LDS write `{w['text']}` (line {w['line']}) still pending: no lgkmcnt wait between them")
             continue
         if mn == "s_endpgm":
             queue = []
@@ -95,7 +103,7 @@ def lint(path):
         if mn.startswith(("ds_read", "ds_bpermute", "ds_swizzle", "ds_permute")):
             queue.append(dict(dst=written, asm=in_asm, smem=False, line=ln, text=code))
         elif mn.startswith(("ds_write", "ds_add", "ds_max", "ds_min", "ds_or", "ds_and")):
-            queue.append(dict(dst=set(), asm=in_asm, smem=False, line=ln, text=code))
+            queue.append(dict(dst=set(), asm=in_asm, smem=False, line=ln, text=code, write=True))
         elif mn.startswith(("s_load", "s_buffer_load", "s_memtime", "s_memrealtime")):
             queue.append(dict(dst=set(), asm=in_asm, smem=True, line=ln, text=code))
     return findings
