@@ -307,8 +307,6 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   Act q = ex.alloc(M, C, qdt);
   Act gg = ex.alloc(M, 4 * C, ex.cdt);
   // (split-operand mode: attention_hl writes the out-projection's HL16 operand `ao` itself)
-  const Act ao32 = ao;
-  auto ao_ready = [&]() {};
   if (npad != HW && !ex.dry) launch_fill_zero(vt, (size_t)B * C * npad * dt_size(adt), ex.s);
   // split-operand mode: the attention kernel takes K and V^T in HL16 (same bytes as fp32); q and the output stay fp32
   const bool hl_attn = ex.cdt == DT_HL;
@@ -357,7 +355,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       }
       attention_hl(ex, qk, kh, C, vth, npad, ao, B, w.heads, HW, HW);
     }
-    else { attention(ex, qk, qk.cols(C), vt, npad, ao32, B, w.heads, HW, HW); ao_ready(); }
+    else attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
     Epi er; er.R = t; er.rpb = HW;
     run_linear(ex, b.out1, ao, (int)M, t, er);
     run_layernorm(ex, b.n2, t, (int)M, ln);
@@ -368,7 +366,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     } else {
       run_linear(ex, b.q2, ln, (int)M, q);
       if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);   // caches are HL16 (set_context)
-      else { attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_); ao_ready(); }
+      else attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
     }
     run_linear(ex, b.out2, ao, (int)M, t, er);
     run_layernorm(ex, b.n3, t, (int)M, ln);
