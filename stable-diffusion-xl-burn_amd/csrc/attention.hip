@@ -14,6 +14,7 @@
 // next tile's global loads issued before the MFMAs, one barrier per tile.  fp32 running max / sum / accumulators.
 // T = _Float16 uses v_mfma_f32_16x16x32_f16, T = float uses v_mfma_f32_16x16x4_f32 (strict-parity mode).
 #include "kernels.h"
+#include <algorithm>
 #include <atomic>
 #include <stdexcept>
 
@@ -432,28 +433,22 @@ __global__ __launch_bounds__(256, 2) void attn_d64_f16_kernel(const AttnParams p
 //   * O is normalised, parked in LDS per wave and written as whole 128-byte rows.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// 1-D grid, XCD-aware: hardware block b runs on XCD b % 8; remap so that every XCD owns a CONTIGUOUS range of logical ids =
+// whole heads (all query blocks of a head), i.e. a head's K / V^T (2 x Nk x 128 B) is fetched into ONE XCD's L2 and re-read
+// there by its query blocks, instead of every XCD streaming every head from the Infinity Cache.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// body of variant 2: the block's four waves take the 128 queries [128 qb, 128 qb + 128) of batch entry b, head hd
 template <int NS>
-// launch bound 2 waves/SIMD: with a 256-register budget hipcc keeps the MFMA accumulators in VGPRs; at the default
-// bound it parks S and O in AGPRs and pays ~240 v_accvgpr_read/write per 64-key tile around the softmax (measured: VALU
-// active 1370 cycles per wave-tile, 2.7x the MFMA time)
-__global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p, const void* zeros) {
+__device__ __forceinline__ void attn_d64_v2_body(const AttnParams& p, const void* zeros, char* smem, int b, int hd, int qb) {
   constexpr int KV = 64, TILE = 64 * 128;
   constexpr float THR = 8.0f;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, h = lane >> 5;
-  // 1-D grid, XCD-aware: hardware block b runs on XCD b % 8; remap so that every XCD owns a CONTIGUOUS range of logical
-  // ids = whole heads (all query blocks of a head), i.e. a head's K / V^T (2 x Nk x 128 B) is fetched into ONE XCD's L2
-  // and re-read there by its Nq/128 query blocks, instead of every XCD streaming every head from the Infinity Cache.
-  const int nqb = (p.Nq + 127) / 128;
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int bh = bid / nqb, qb = bid - bh * nqb;
-  const int b = bh / p.H, hd = bh - b * p.H;
   const int q0 = qb * 128 + wave * 32;
   const half_t* Qg = reinterpret_cast<const half_t*>(p.Q) + (size_t)b * p.Nq * p.ldq + hd * 64;
   const half_t* Kg = reinterpret_cast<const half_t*>(p.K) + (size_t)b * p.Nk * p.ldk + hd * 64;
@@ -616,6 +611,19 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p,
     const int q = q0 + row;
     if (q < p.Nq) *reinterpret_cast<i32x4*>(Og + (size_t)q * p.ldo + piece * 8) = v;
   }
+}
+
+template <int NS>
+// launch bound 2 waves/SIMD: with a 256-register budget hipcc keeps the MFMA accumulators in VGPRs; at the default
+// bound it parks S and O in AGPRs and pays ~240 v_accvgpr_read/write per 64-key tile around the softmax (measured: VALU
+// active 1370 cycles per wave-tile, 2.7x the MFMA time)
+__global__ __launch_bounds__(256, 2) void attn_d64_v2_kernel(const AttnParams p, const void* zeros) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][K tile | V^T tile]
+  const int nqb = (p.Nq + 127) / 128;
+  const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int bh = bid / nqb, qb = bid - bh * nqb;
+  const int b = bh / p.H;
+  attn_d64_v2_body<NS>(p, zeros, smem, b, bh - b * p.H, qb);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -853,23 +861,21 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
 //   worst SIMD 3 half-units instead of 2 whole ones).  The ring, the DMA pieces and the barriers are variant 2's.  At the end
 //   the odd-half waves park (m, l, O) in the dead ring and the even-half waves merge:  O = O0 2^(m0-m) + O1 2^(m1-m).
 //   Needs Nk % 64 == 0 (no key tail inside a half) -- the launcher sends everything else to variant 2.
-__global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p, const void* zeros) {
+//   KP = 4 is the same body one step finer (the small blocks of attn_d64_mix_kernel): a block is ONE 32-query sub-tile and its
+//   four waves are key QUARTERS = {tile parity} x {key half}: a wave computes on every other 64-key tile only (it still stages
+//   its DMA pieces and takes the barrier of every tile), and wave 0 merges three partners.
+template <int KP>
+__device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void* zeros, char* smem, int b, int hd, int qb) {
+  static_assert(KP == 2 || KP == 4, "key parts per query sub-tile");
   constexpr int KV = 64, TILE = 64 * 128, NS = 3;
   constexpr float THR = 8.0f;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qs = wave & 1, kp = wave >> 1;
+  const int qs = KP == 2 ? (wave & 1) : 0, kp = KP == 2 ? (wave >> 1) : wave;      // query sub-tile, key part
+  const int kh = KP == 2 ? kp : (kp & 1), tp = kp >> 1;                             // key half inside a tile; (KP = 4) tile parity
   const int fr = lane & 31, h = lane >> 5;
-  const int nqb = (p.Nq + 63) / 64;
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int bh = bid / nqb, qb = bid - bh * nqb;
-  const int b = bh / p.H, hd = bh - b * p.H;
-  const int q0 = qb * 64 + qs * 32;
+  const int q0 = qb * (KP == 2 ? 64 : 32) + qs * 32;
+  (void)zeros;
   const half_t* Qg = reinterpret_cast<const half_t*>(p.Q) + (size_t)b * p.Nq * p.ldq + hd * 64;
   const half_t* Kg = reinterpret_cast<const half_t*>(p.K) + (size_t)b * p.Nk * p.ldk + hd * 64;
   const half_t* Vg = reinterpret_cast<const half_t*>(p.Vt) + ((size_t)b * p.H + hd) * 64 * p.vt_ld;
@@ -902,8 +908,8 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
       __builtin_amdgcn_global_load_lds((agptr_t)vs, (alptr_t)(lv + j * 1024), 16, 0, 0);
     }
   };
-  // fragment byte offsets inside a tile: K rows kp*32 + fr; V^T rows dt*32 + fr, keys of this wave's half
-  const int krow = kp * 32 + fr;
+  // fragment byte offsets inside a tile: K rows kh*32 + fr; V^T rows dt*32 + fr, keys of this wave's half
+  const int krow = kh * 32 + fr;
   const int koff = krow * 128 + ((h ^ ((krow >> 1) & 7)) << 4);   // chunk of k-step ks: ^ (ks << 5)
   const int voff[2] = {fr * 128, (32 + fr) * 128};
   const int vsw[2] = {(fr ^ (fr >> 3)) & 7, ((32 + fr) ^ ((32 + fr) >> 3)) & 7};
@@ -930,6 +936,9 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
     if (t + NS - 1 < nt) stage(t + NS - 1, cur == 0 ? NS - 1 : cur - 1);
     const char* kb = smem + cur * 2 * TILE;
     const char* vb = kb + TILE;
+    cur = cur == NS - 1 ? 0 : cur + 1;
+    if (KP == 4 && (t & 1) != tp) continue;                    // the other parity's tile (wave-uniform)
+    const bool first = KP == 2 ? t == 0 : t == tp;             // this wave's first tile sets the reference
     // ---- S^T - m for this wave's 32 keys
     f32x16 sv;
 #pragma unroll
@@ -940,11 +949,11 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
     float lmax = sv[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) lmax = fmaxf(lmax, sv[r]);
-    if (t == 0 || __any(lmax > THR)) {
+    if (first || __any(lmax > THR)) {
       const float pm = fmaxf(lmax, __shfl_xor(lmax, 32));
-      const float delta = t == 0 ? pm : fmaxf(pm, 0.f);
-      const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
-      m = t == 0 ? delta : m + delta;
+      const float delta = first ? pm : fmaxf(pm, 0.f);
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+      m = first ? delta : m + delta;
 #pragma unroll
       for (int r = 0; r < 16; ++r) minit[r] = -m;
       l *= alpha;
@@ -970,10 +979,10 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
       l += ls;
       pf[hf] = hh;
     }
-    // ---- O^T += V^T P^T: k-step hf covers keys kp*32 + 16*hf + {4h..4h+3, 8+4h..8+4h+3}
+    // ---- O^T += V^T P^T: k-step hf covers keys kh*32 + 16*hf + {4h..4h+3, 8+4h..8+4h+3}
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      const int base = kp * 32 + hf * 16;
+      const int base = kh * 32 + hf * 16;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const int b1 = (base + 4 * h) * 2, b2 = b1 + 16;
@@ -983,13 +992,16 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, vf), pf[hf], o[dt], 0, 0, 0);
       }
     }
-    cur = cur == NS - 1 ? 0 : cur + 1;
   }
   l += __shfl_xor(l, 32);
-  // ---- merge the two key halves of each query sub-tile through the dead ring: [qs][34][64 lanes] floats at smem + 0
+  if (KP == 4 && tp >= nt) m = -INFINITY;       // (a wave that saw no tile of its parity: weight 0 in the merge; the launcher asks Nk >= 128)
+  // ---- merge the key parts of each query sub-tile through the dead ring: parked images of [34][64 lanes] floats at smem + 0
+  //      (KP = 2: one per query sub-tile; KP = 4: the three partners of wave 0)
+  constexpr int NPARK = KP == 2 ? 2 : 3, NMERGE = KP == 2 ? 1 : 3;
   __syncthreads();
-  float* mb = reinterpret_cast<float*>(smem) + qs * (34 * 64) + lane;
-  if (kp == 1) {
+  float* mbase = reinterpret_cast<float*>(smem) + lane;
+  if (kp != 0) {
+    float* mb = mbase + (KP == 2 ? qs : kp - 1) * (34 * 64);
     mb[0] = m; mb[64] = l;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -997,19 +1009,31 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
       for (int r = 0; r < 16; ++r) mb[(2 + dt * 16 + r) * 64] = o[dt][r];
   }
   __syncthreads();
-  if (kp == 1) return;
+  if (kp != 0) return;
   {
-    const float m1 = mb[0], l1 = mb[64];
-    const float mm = fmaxf(m, m1);
-    const float a0 = __builtin_amdgcn_exp2f(m - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
-    l = l * a0 + l1 * a1;
+    const float* mb = mbase + (KP == 2 ? qs : 0) * (34 * 64);
+    float mm = m;
+#pragma unroll
+    for (int j = 0; j < NMERGE; ++j) mm = fmaxf(mm, mb[j * (34 * 64)]);
+    const float a0 = __builtin_amdgcn_exp2f(m - mm);
+    l *= a0;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] = o[dt][r] * a0 + mb[(2 + dt * 16 + r) * 64] * a1;
+      for (int r = 0; r < 16; ++r) o[dt][r] *= a0;
+#pragma unroll
+    for (int j = 0; j < NMERGE; ++j) {
+      const float* mj = mb + j * (34 * 64);
+      const float aj = __builtin_amdgcn_exp2f(mj[0] - mm);
+      l += mj[64] * aj;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] += mj[(2 + dt * 16 + r) * 64] * aj;
+    }
   }
   const float inv = 1.0f / l;
-  char* ob = smem + 24576 + qs * 4096;          // behind the merge buffers (2 x 8704 B)
+  char* ob = smem + ((NPARK * 8704 + 4095) & ~4095) + qs * 4096;          // behind the parked images (8704 B each)
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -1026,6 +1050,56 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
     const i32x4 v = *reinterpret_cast<const i32x4*>(ob + row * 128 + ((piece ^ (row & 7)) << 4));
     const int q = q0 + row;
     if (q < p.Nq) *reinterpret_cast<i32x4*>(Og + (size_t)q * p.ldo + piece * 8) = v;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p, const void* zeros) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][K tile | V^T tile]
+  const int nqb = (p.Nq + 63) / 64;
+  const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int bh = bid / nqb, qb = bid - bh * nqb;
+  const int b = bh / p.H;
+  attn_d64_ks_body<2>(p, zeros, smem, b, bh - b * p.H, qb);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// f16 "mixed block sizes" (variants 7 / 8): one launch of LARGE blocks followed by SMALL blocks of half their queries.
+//   Self-attention of the CFG pair is 640 equal blocks at both levels (64^2: 128-query blocks of variant 2; 32^2: 64-query
+//   blocks of the key-split variant) on 256 CUs with room for three blocks each: half the CUs carry three blocks, the other half
+//   two, and the launch lasts as long as the CUs with three.  Here the heads of a batch entry are divided 4 : 1 -- the first
+//   4/5 of the heads run in large blocks, the rest in small ones (half the queries per block, each wave half the work) -- so
+//   that the pair is 512 large + 256 small blocks = two large and one small per CU, 2.5 units of work on every SIMD.
+//     LEVEL 0: large = variant 2 (128 queries), small = key split (64 queries, waves = 2 query sub-tiles x 2 key halves)
+//     LEVEL 1: large = key split (64 queries),  small = key quarters (32 queries, waves = 4 key parts)
+//   Large blocks come first in every XCD's dispatch order; every XCD owns contiguous ranges of both kinds (whole heads where
+//   the counts allow).  Which kernel body a (head, query) runs through depends on the head index and the shape of ONE batch
+//   entry only, so an entry comes out bit-identical alone, in the CFG pair or in a larger batch.
+template <int LEVEL>
+__global__ __launch_bounds__(256, 2) void attn_d64_mix_kernel(const AttnParams p, const void* zeros, int big_heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][K tile | V^T tile]
+  constexpr int QL = LEVEL == 0 ? 128 : 64, QS = QL / 2;
+  const int nql = (p.Nq + QL - 1) / QL, nqs = (p.Nq + QS - 1) / QS;
+  const int NL = p.B * big_heads * nql, NSM = p.B * (p.H - big_heads) * nqs;       // large / small blocks of the launch
+  int bid = blockIdx.x;
+  bool large;
+  if (((NL | NSM) & 7) == 0) {            // per XCD: its large blocks first, then its small ones
+    const int xcd = bid & 7, idx = bid >> 3, nlx = NL >> 3;
+    large = idx < nlx;
+    bid = large ? xcd * nlx + idx : xcd * (NSM >> 3) + (idx - nlx);
+  } else {
+    large = bid < NL;
+    if (!large) bid -= NL;
+  }
+  if (large) {
+    const int per = big_heads * nql;
+    const int b = bid / per, r = bid - b * per, hd = r / nql, qb = r - hd * nql;
+    if constexpr (LEVEL == 0) attn_d64_v2_body<3>(p, zeros, smem, b, hd, qb);
+    else attn_d64_ks_body<2>(p, zeros, smem, b, hd, qb);
+  } else {
+    const int per = (p.H - big_heads) * nqs;
+    const int b = bid / per, r = bid - b * per, hs = r / nqs, qb = r - hs * nqs;
+    if constexpr (LEVEL == 0) attn_d64_ks_body<2>(p, zeros, smem, b, big_heads + hs, qb);
+    else attn_d64_ks_body<4>(p, zeros, smem, b, big_heads + hs, qb);
   }
 }
 
@@ -1414,7 +1488,7 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
   const bool aligned = ((p.ldq | p.ldk | p.vt_ld | p.ldo) & 7) == 0 &&
                        ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
                          reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) == 0;
-  if (p.dt == DT_F16 && (g_attn_variant == 0 || (g_attn_variant >= 2 && g_attn_variant <= 6)) && g_attn_zero && aligned && !p.mask) {
+  if (p.dt == DT_F16 && (g_attn_variant == 0 || (g_attn_variant >= 2 && g_attn_variant <= 9)) && g_attn_zero && aligned && !p.mask) {
     // 3-slot ring = 48 KiB per block -> three blocks per CU: the 640 blocks of the 64^2 level run as ONE round (a 4-slot
     // ring admits two per CU, a second half-empty round: 147 us vs 126 us measured); variant 3 keeps the 4-slot ring for A/B
     const dim3 g1(grid.x * grid.y);
@@ -1423,7 +1497,25 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
     // The choice must not depend on the batch size: a batch entry has to come out bit-identical whether it runs alone or
     // next to others (tests/test_gpu_fullsize.py, split-CFG chains), so it is made on one batch entry's grid (query blocks x heads).
     const bool ks_ok = (p.Nk % 64) == 0 && p.Nk >= 128;
-    if (ks_ok && (g_attn_variant == 6 || (g_attn_variant == 0 && (int)grid.x * p.H < 256))) {
+    const bool ks_pick = ks_ok && (g_attn_variant == 6 || ((g_attn_variant == 0 || g_attn_variant == 9) && (int)grid.x * p.H < 256));
+    // mixed block sizes (attn_d64_mix_kernel): the first 4/5 of the heads in 128-query blocks, the rest in 64-query key-split
+    // blocks -- two large + one small block per CU for the CFG pair at 64^2 (121 -> 107 us; alone 78 -> 64 us, two pairs 210 ->
+    // 218 us: profiles/r03_attention_block_balance.txt).  Like the pick above a function of one batch entry's shape only.
+    // Level 1 (64-query + 32-query key-quarter blocks for the 32^2 shapes) measured no gain (23.2 -> 23.3 us) and is not picked.
+    // Forced: 7 = level 0, 8 = level 1; 9 = the automatic choice without mixing (A/B).
+    int mix = -1;
+    if (ks_ok && g_attn_variant == 7) mix = 0;
+    else if (ks_ok && g_attn_variant == 8) mix = 1;
+    else if (ks_ok && g_attn_variant == 0 && !ks_pick && p.H % 5 == 0) mix = 0;
+    if (mix >= 0) {
+      const int big_heads = p.H >= 2 ? std::max(1, p.H * 4 / 5) : 0;
+      const int ql = mix == 0 ? 128 : 64;
+      const int nl = p.B * big_heads * ((p.Nq + ql - 1) / ql), nsm = p.B * (p.H - big_heads) * ((p.Nq + ql / 2 - 1) / (ql / 2));
+      if (mix == 0) hipLaunchKernelGGL(attn_d64_mix_kernel<0>, dim3(nl + nsm), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero, big_heads);
+      else hipLaunchKernelGGL(attn_d64_mix_kernel<1>, dim3(nl + nsm), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero, big_heads);
+      return;
+    }
+    if (ks_pick) {
       hipLaunchKernelGGL(attn_d64_ks_kernel, dim3(((p.Nq + 63) / 64) * p.B * p.H), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
       return;
     }

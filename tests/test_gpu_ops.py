@@ -332,7 +332,7 @@ def test_qkv_attention_split_operand_rescale(pkg, ctx):
     assert rel_err(out.double(), ref) < 5e-6
 
 
-@pytest.mark.parametrize("dtype,variant", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 6)])
+@pytest.mark.parametrize("dtype,variant", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 6), (1, 7), (1, 8)])
 def test_qkv_attention_online_softmax_rescale(pkg, ctx, dtype, variant):
     # keys far above the rest in LATE tiles force the running-max rescale branch (guide rule 26): for the deferred-max
     # f16 kernel both the "exceeds the threshold" path (spikes) and the "stays below it" path (all other tiles) run
@@ -374,9 +374,12 @@ def test_qkv_attention_wide_head_flash_rescale(pkg, ctx):
     assert rel_err(out, ref) < 6e-3
 
 
-@pytest.mark.parametrize("variant", [1, 2, 6])     # 6 = key-split kernel (64-query blocks, waves = query sub-tile x key half)
+# 6 = key-split kernel (64-query blocks, waves = query sub-tile x key half); 7 / 8 = mixed block sizes (the first 4/5 of the heads in
+# 128- / 64-query blocks, the rest in 64-query key-split / 32-query key-quarter blocks: attn_d64_mix_kernel)
+@pytest.mark.parametrize("variant", [1, 2, 6, 7, 8])
 @pytest.mark.parametrize("B,Nq,Nk,C,heads", [(2, 256, 256, 128, 2), (2, 300, 77, 640, 10), (1, 1024, 1024, 1280, 20),
-                                             (1, 130, 200, 64, 1), (2, 64, 1, 64, 1), (2, 100, 128, 128, 2), (1, 33, 192, 64, 1)])
+                                             (1, 130, 200, 64, 1), (2, 64, 1, 64, 1), (2, 100, 128, 128, 2), (1, 33, 192, 64, 1),
+                                             (2, 300, 320, 320, 5), (3, 1000, 192, 640, 10)])
 def test_qkv_attention_f16_variants(pkg, ctx, variant, B, Nq, Nk, C, heads):
     q, k, v = seeded(B, Nq, C, seed=16), seeded(B, Nk, C, seed=17), seeded(B, Nk, C, seed=18)
     ref = OM.qkv_attention(q, k, v, None, heads)
@@ -386,6 +389,34 @@ def test_qkv_attention_f16_variants(pkg, ctx, variant, B, Nq, Nk, C, heads):
     finally:
         pkg.debug_set("attn_variant", 0)
     assert rel_err(out, ref) < 6e-3
+
+
+@pytest.mark.parametrize("variant,heads,N,B", [(7, 10, 384, 3), (8, 20, 320, 3), (0, 10, 3328, 2), (0, 20, 256, 3)])
+def test_qkv_attention_mixed_block_sizes_are_their_bodies(pkg, ctx, variant, heads, N, B):
+    # attn_d64_mix_kernel only re-assigns (head, query block) to blocks: the first 4/5 of the heads must come out bit-identical to
+    # the large-block kernel alone (7: variant 2, 8: key split), at level 0 the rest bit-identical to the key-split kernel alone; and
+    # a batch entry must not depend on its neighbours (the head split is a function of one entry's shape).  Variant 0 = the automatic
+    # choice: mixed at (10 heads, 3328 queries) -- 26 x 10 >= 256 blocks of 128 queries per entry --, key split alone at (20, 256)
+    C = 64 * heads
+    q, k, v = seeded(B, N, C, seed=31), seeded(B, N, C, seed=32), seeded(B, N, C, seed=33)
+
+    def run(var, sl=slice(None)):
+        pkg.debug_set("attn_variant", var)
+        try:
+            return pkg.qkv_attention(ctx, q[sl].cuda(), k[sl].cuda(), v[sl].cuda(), None, heads, 1)
+        finally:
+            pkg.debug_set("attn_variant", 0)
+
+    out = run(variant)
+    assert rel_err(out, OM.qkv_attention(q, k, v, None, heads)) < 6e-3
+    assert torch.equal(run(variant, slice(1, 2)), out[1:2])
+    big = 64 * (heads * 4 // 5)
+    if variant == 0 and N < 3328:
+        assert torch.equal(out, run(6))
+    else:
+        assert torch.equal(out[..., :big], run(6 if variant == 8 else 2)[..., :big])
+        if variant != 8:
+            assert torch.equal(out[..., big:], run(6)[..., big:])
 
 
 def test_attn_decoder_mask(pkg, ctx):
