@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
 int groupnorm_nsplit(int B, int HW, int C) {
   (void)B; (void)C;
   int n = HW / 32;       // >= 32 rows per block; up to kGnMaxSplit row splits x B blocks keep all 256 CUs streaming
-  if (n < 1) n = 1;      // (512 splits = 4 workgroups per CU measured no faster: 29.8 vs 29.0 us per GroupNorm)
+  if (n < 1) n = 1;      // (512 splits = 4 workgroups per CU measured no faster: 29.8 vs 29.0 us per GroupNorm; nor do 8-row
+                         //  blocks at 32^2, 128 x B blocks instead of 32 x B: GroupNorm class 1.215 vs 1.216 ms per step, r03 g17)
   if (n > kGnMaxSplit) n = kGnMaxSplit;
   return n;
 }
