@@ -442,7 +442,10 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
 }
 
 // body of variant 2: the block's four waves take the 128 queries [128 qb, 128 qb + 128) of batch entry b, head hd
-template <int NS>
+// PRIO = 2: the softmax / PV phase of a wave runs at raised issue priority (s_setprio), the score MFMAs at base priority -- with three
+// waves per SIMD in different phases the exp-heavy phase is the one that must not wait (measured, profiles/r03_attention_block_balance.txt:
+// 113.4 -> 111.1 us at 64^2, key split 22.0 -> 21.6 us at 32^2, mixed blocks 101.2 -> 99.8 us; raising the MFMA phase instead: no change)
+template <int NS, int PRIO = 2>
 __device__ __forceinline__ void attn_d64_v2_body(const AttnParams& p, const void* zeros, char* smem, int b, int hd, int qb) {
   constexpr int KV = 64, TILE = 64 * 128;
   constexpr float THR = 8.0f;
@@ -468,20 +471,35 @@ __device__ __forceinline__ void attn_d64_v2_body(const AttnParams& p, const void
       qf[ks] = v;
     }
   }
-  // DMA geometry: wave w stages tile rows [16w, 16w+16) of K and of V^T, two 1-KiB pieces each
+  // DMA geometry: wave w stages tile rows [16w, 16w+16) of K and of V^T, two 1-KiB pieces each.  A lane's source chunk is a
+  // loop-invariant 32-bit byte offset from the tile's (wave-uniform) base -- the per-tile address work is one 64-bit add per piece
+  // (profiles/r03_attention_pmc.txt: the 64-bit multiply-adds and the per-lane tail select that used to sit here were ~20 VALU
+  // instructions of every tile in a kernel whose VALU is the busiest unit)
   const int lrow = lane >> 3, slot = lane & 7;
+  unsigned kofs[2], vofs[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wave * 16 + j * 8 + lrow;
+    kofs[j] = (unsigned)(row * p.ldk + (slot ^ ((row >> 1) & 7)) * 8) * 2u;
+    vofs[j] = (unsigned)(row * p.vt_ld + (slot ^ ((row ^ (row >> 3)) & 7)) * 8) * 2u;      // rows zero padded to vt_ld
+  }
   auto stage = [&](int t, int buf) {
     const int k0 = t * KV;
     char* lk = smem + buf * 2 * TILE + wave * 2048;
     char* lv = lk + TILE;
+    const char* kt = reinterpret_cast<const char*>(Kg + (size_t)k0 * p.ldk);
+    const char* vt = reinterpret_cast<const char*>(Vg + k0);
+    const char* ks[2] = {kt + kofs[0], kt + kofs[1]};
+    if (k0 + KV > p.Nk) {                                        // key tail (wave-uniform, last tile only): rows past Nk read zeros
+      asm volatile("" ::: "memory");                             // (keeps the selects out of the full tiles' path)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (k0 + wave * 16 + j * 8 + lrow >= p.Nk) ks[j] = reinterpret_cast<const char*>(zeros);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int row = wave * 16 + j * 8 + lrow;
-      const int key = k0 + row;
-      const half_t* ks = key < p.Nk ? Kg + (size_t)key * p.ldk + (slot ^ ((row >> 1) & 7)) * 8 : reinterpret_cast<const half_t*>(zeros);
-      __builtin_amdgcn_global_load_lds((agptr_t)ks, (alptr_t)(lk + j * 1024), 16, 0, 0);
-      const half_t* vs = Vg + (size_t)row * p.vt_ld + k0 + (slot ^ ((row ^ (row >> 3)) & 7)) * 8;   // rows zero padded to vt_ld
-      __builtin_amdgcn_global_load_lds((agptr_t)vs, (alptr_t)(lv + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((agptr_t)ks[j], (alptr_t)(lk + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((agptr_t)(vt + vofs[j]), (alptr_t)(lv + j * 1024), 16, 0, 0);
     }
   };
   // fragment byte offsets inside a tile
@@ -520,6 +538,7 @@ __device__ __forceinline__ void attn_d64_v2_body(const AttnParams& p, const void
     const char* kb = smem + cur * 2 * TILE;
     const char* vb = kb + TILE;
     // ---- S^T - m
+    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
     f32x16 sv[2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -528,18 +547,23 @@ __device__ __forceinline__ void attn_d64_v2_body(const AttnParams& p, const void
         const half8 kf = *reinterpret_cast<const half8*>(kb + (koff[u] ^ (ks << 5)));
         sv[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? minit : sv[u], 0, 0, 0);
       }
+    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(2);
     if (t == nt - 1 && (p.Nk & 63) != 0) {                      // key tail (wave-uniform branch)
+      asm volatile("" ::: "memory");                            // a real branch: as selects this was 32 v_cndmask in EVERY tile
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (t * KV + u * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= p.Nk) sv[u][r] = -INFINITY;
     }
-    float lmax = sv[0][0];
+    // (four independent chains: as one chain the 16 v_max3 are each other's operands and the wave issues nothing else meanwhile)
+    float lm[4] = {sv[0][0], sv[0][8], sv[1][0], sv[1][8]};
 #pragma unroll
-    for (int r = 1; r < 16; ++r) lmax = fmaxf(lmax, sv[0][r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lmax = fmaxf(lmax, sv[1][r]);
+    for (int r = 1; r < 8; ++r) {
+      lm[0] = fmaxf(lm[0], sv[0][r]); lm[1] = fmaxf(lm[1], sv[0][8 + r]);
+      lm[2] = fmaxf(lm[2], sv[1][r]); lm[3] = fmaxf(lm[3], sv[1][8 + r]);
+    }
+    const float lmax = fmaxf(fmaxf(lm[0], lm[1]), fmaxf(lm[2], lm[3]));
     if (t == 0 || __any(lmax > THR)) {                          // rare after the first tiles; wave-uniform
       const float pm = fmaxf(lmax, __shfl_xor(lmax, 32));
       const float delta = t == 0 ? pm : fmaxf(pm, 0.f);         // never lower the reference
@@ -740,17 +764,21 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
         sv[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qh[ks], sv[u], 0, 0, 0);
       }
     if (t == nt - 1 && (p.Nk & 63) != 0) {                      // key tail (wave-uniform branch)
+      asm volatile("" ::: "memory");                            // a real branch: as selects this was 32 v_cndmask in EVERY tile
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (t * KV + u * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= p.Nk) sv[u][r] = -INFINITY;
     }
-    float lmax = sv[0][0];
+    // (four independent chains: as one chain the 16 v_max3 are each other's operands and the wave issues nothing else meanwhile)
+    float lm[4] = {sv[0][0], sv[0][8], sv[1][0], sv[1][8]};
 #pragma unroll
-    for (int r = 1; r < 16; ++r) lmax = fmaxf(lmax, sv[0][r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lmax = fmaxf(lmax, sv[1][r]);
+    for (int r = 1; r < 8; ++r) {
+      lm[0] = fmaxf(lm[0], sv[0][r]); lm[1] = fmaxf(lm[1], sv[0][8 + r]);
+      lm[2] = fmaxf(lm[2], sv[1][r]); lm[3] = fmaxf(lm[3], sv[1][8 + r]);
+    }
+    const float lmax = fmaxf(fmaxf(lm[0], lm[1]), fmaxf(lm[2], lm[3]));
     if (t == 0 || __any(lmax > THR)) {                          // rare after the first tiles; wave-uniform
       const float pm = fmaxf(lmax, __shfl_xor(lmax, 32));
       const float delta = t == 0 ? pm : fmaxf(pm, 0.f);
@@ -864,7 +892,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
 //   KP = 4 is the same body one step finer (the small blocks of attn_d64_mix_kernel): a block is ONE 32-query sub-tile and its
 //   four waves are key QUARTERS = {tile parity} x {key half}: a wave computes on every other 64-key tile only (it still stages
 //   its DMA pieces and takes the barrier of every tile), and wave 0 merges three partners.
-template <int KP>
+template <int KP, int PRIO = 2>
 __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void* zeros, char* smem, int b, int hd, int qb) {
   static_assert(KP == 2 || KP == 4, "key parts per query sub-tile");
   constexpr int KV = 64, TILE = 64 * 128, NS = 3;
@@ -895,17 +923,23 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
   }
   // DMA geometry (as variant 2): wave w stages tile rows [16w, 16w+16) of K and of V^T, two 1-KiB pieces each
   const int lrow = lane >> 3, slot = lane & 7;
+  unsigned kofs[2], vofs[2];                   // loop-invariant byte offsets of this lane's source chunks from the tile bases
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wave * 16 + j * 8 + lrow;
+    kofs[j] = (unsigned)(row * p.ldk + (slot ^ ((row >> 1) & 7)) * 8) * 2u;
+    vofs[j] = (unsigned)(row * p.vt_ld + (slot ^ ((row ^ (row >> 3)) & 7)) * 8) * 2u;
+  }
   auto stage = [&](int t, int buf) {
     const int k0 = t * KV;
     char* lk = smem + buf * 2 * TILE + wave * 2048;
     char* lv = lk + TILE;
+    const char* kt = reinterpret_cast<const char*>(Kg + (size_t)k0 * p.ldk);
+    const char* vt = reinterpret_cast<const char*>(Vg + k0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int row = wave * 16 + j * 8 + lrow;
-      const half_t* ksrc = Kg + (size_t)(k0 + row) * p.ldk + (slot ^ ((row >> 1) & 7)) * 8;
-      __builtin_amdgcn_global_load_lds((agptr_t)ksrc, (alptr_t)(lk + j * 1024), 16, 0, 0);
-      const half_t* vs = Vg + (size_t)row * p.vt_ld + k0 + (slot ^ ((row ^ (row >> 3)) & 7)) * 8;
-      __builtin_amdgcn_global_load_lds((agptr_t)vs, (alptr_t)(lv + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((agptr_t)(kt + kofs[j]), (alptr_t)(lk + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((agptr_t)(vt + vofs[j]), (alptr_t)(lv + j * 1024), 16, 0, 0);
     }
   };
   // fragment byte offsets inside a tile: K rows kh*32 + fr; V^T rows dt*32 + fr, keys of this wave's half
@@ -940,15 +974,18 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
     if (KP == 4 && (t & 1) != tp) continue;                    // the other parity's tile (wave-uniform)
     const bool first = KP == 2 ? t == 0 : t == tp;             // this wave's first tile sets the reference
     // ---- S^T - m for this wave's 32 keys
+    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
     f32x16 sv;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const half8 kf = *reinterpret_cast<const half8*>(kb + (koff ^ (ks << 5)));
       sv = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? minit : sv, 0, 0, 0);
     }
-    float lmax = sv[0];
+    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(2);
+    float lm[2] = {sv[0], sv[8]};                 // (two independent chains, see variant 2)
 #pragma unroll
-    for (int r = 1; r < 16; ++r) lmax = fmaxf(lmax, sv[r]);
+    for (int r = 1; r < 8; ++r) { lm[0] = fmaxf(lm[0], sv[r]); lm[1] = fmaxf(lm[1], sv[8 + r]); }
+    const float lmax = fmaxf(lm[0], lm[1]);
     if (first || __any(lmax > THR)) {
       const float pm = fmaxf(lmax, __shfl_xor(lmax, 32));
       const float delta = first ? pm : fmaxf(pm, 0.f);
@@ -1053,13 +1090,14 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
   }
 }
 
+template <int PRIO = 2>
 __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p, const void* zeros) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][K tile | V^T tile]
   const int nqb = (p.Nq + 63) / 64;
   const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
   const int bh = bid / nqb, qb = bid - bh * nqb;
   const int b = bh / p.H;
-  attn_d64_ks_body<2>(p, zeros, smem, b, bh - b * p.H, qb);
+  attn_d64_ks_body<2, PRIO>(p, zeros, smem, b, bh - b * p.H, qb);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1074,7 +1112,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
 //   Large blocks come first in every XCD's dispatch order; every XCD owns contiguous ranges of both kinds (whole heads where
 //   the counts allow).  Which kernel body a (head, query) runs through depends on the head index and the shape of ONE batch
 //   entry only, so an entry comes out bit-identical alone, in the CFG pair or in a larger batch.
-template <int LEVEL>
+template <int LEVEL, int PRIO = 2>
 __global__ __launch_bounds__(256, 2) void attn_d64_mix_kernel(const AttnParams p, const void* zeros, int big_heads) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][K tile | V^T tile]
   constexpr int QL = LEVEL == 0 ? 128 : 64, QS = QL / 2;
@@ -1093,13 +1131,13 @@ __global__ __launch_bounds__(256, 2) void attn_d64_mix_kernel(const AttnParams p
   if (large) {
     const int per = big_heads * nql;
     const int b = bid / per, r = bid - b * per, hd = r / nql, qb = r - hd * nql;
-    if constexpr (LEVEL == 0) attn_d64_v2_body<3>(p, zeros, smem, b, hd, qb);
-    else attn_d64_ks_body<2>(p, zeros, smem, b, hd, qb);
+    if constexpr (LEVEL == 0) attn_d64_v2_body<3, PRIO>(p, zeros, smem, b, hd, qb);
+    else attn_d64_ks_body<2, PRIO>(p, zeros, smem, b, hd, qb);
   } else {
     const int per = (p.H - big_heads) * nqs;
     const int b = bid / per, r = bid - b * per, hs = r / nqs, qb = r - hs * nqs;
-    if constexpr (LEVEL == 0) attn_d64_ks_body<2>(p, zeros, smem, b, big_heads + hs, qb);
-    else attn_d64_ks_body<4>(p, zeros, smem, b, big_heads + hs, qb);
+    if constexpr (LEVEL == 0) attn_d64_ks_body<2, PRIO>(p, zeros, smem, b, big_heads + hs, qb);
+    else attn_d64_ks_body<4, PRIO>(p, zeros, smem, b, big_heads + hs, qb);
   }
 }
 
@@ -1516,7 +1554,7 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
       return;
     }
     if (ks_pick) {
-      hipLaunchKernelGGL(attn_d64_ks_kernel, dim3(((p.Nq + 63) / 64) * p.B * p.H), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
+      hipLaunchKernelGGL(attn_d64_ks_kernel<2>, dim3(((p.Nq + 63) / 64) * p.B * p.H), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
       return;
     }
 #ifdef SDXL_MEASURE
