@@ -318,7 +318,10 @@ int groupnorm_nsplit(int B, int HW, int C) {
   (void)B; (void)C;
   int n = HW / 32;       // >= 32 rows per block; up to kGnMaxSplit row splits x B blocks keep all 256 CUs streaming
   if (n < 1) n = 1;      // (512 splits = 4 workgroups per CU measured no faster: 29.8 vs 29.0 us per GroupNorm; nor do 8-row
-                         //  blocks at 32^2, 128 x B blocks instead of 32 x B: GroupNorm class 1.215 vs 1.216 ms per step, r03 g17)
+                         //  blocks at 32^2, 128 x B blocks instead of 32 x B: GroupNorm class 1.215 vs 1.216 ms per step, r03 g17;
+                         //  nor does a one-launch kernel that keeps a whole (entry, group) slab of the 32^2 level in the registers
+                         //  of one 512-thread workgroup -- 64 workgroups, statistics + apply: 1.199 vs 1.213 ms per step,
+                         //  profiles/r03_gn_onepass_ab.txt; 40..160-byte row segments per group do not coalesce)
   if (n > kGnMaxSplit) n = kGnMaxSplit;
   return n;
 }
