@@ -190,7 +190,10 @@ __global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams
 //   * WGM = waves along M (4: 4x2 wave grid, 8: 8x1 -- the 256x160 tile, 3: the 6-wave 96x128 tile).  BN need not be a
 //     multiple of 64: the weight tile's BN/8 eight-row pieces are dealt round-robin, waves below REM carry one more piece
 //     and wait on their own count.
-template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false>
+//   * S2 ("two k-tiles per rendezvous", rings of >= 4 slots): the vmcnt wait + s_barrier run in every SECOND k-tile only and cover the
+//     next TWO tiles; the DMA lead is one tile shorter (tile kt + NS - 2 goes into the slot of tile kt - 2, which the last barrier
+//     -- in tile kt - 1 or kt - 2 -- has freed).  Half the rendezvous of a launch for one tile less in flight.
+template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
   kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();   // every argument line in flight at once (one wait instead of five)
   typedef typename PipeElem<T>::frag frag_t;
@@ -443,7 +446,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   using IALL = std::integral_constant<int, -1>;
-  constexpr int NPRO = NS - 1;                 // tiles staged by the prologue
+  constexpr int LEAD = S2 ? NS - 2 : NS - 1;   // tile kt + LEAD is issued during tile kt
+  constexpr int NPRO = LEAD;                   // tiles staged by the prologue
+  static_assert(!S2 || (NS >= 4 && !HL), "two tiles per rendezvous: ring of >= 4 slots, f16 / f32 elements");
 
   // fused cross-attention, one-MFMA-row wave tiles: the 24 context fragments (96 VGPRs -- these kernels have the room) are
   // requested BEFORE the first DMA piece, so they are the oldest entries of the in-order vmcnt queue and ride under the
@@ -473,7 +478,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   const bool ln_coop = LN_COOP && p.ln_slots <= 24;
   if constexpr (LN_COOP) lnc.finish(p, m0, ln_coef);
   if (!ln_coop) ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
-  if (NPRO <= nk) wait_tiles(std::integral_constant<int, NPRO - 1>{}); else wait_vmcnt<0>();
+  // (S2: the first rendezvous covers tiles 0 AND 1)
+  if (NPRO <= nk) wait_tiles(std::integral_constant<int, NPRO - (S2 ? 2 : 1)>{}); else wait_vmcnt<0>();
   // finish()'s ds_write of the row coefficients must have LANDED before the barrier releases their readers: a raw s_barrier
   // carries no wait of its own, and a wave whose tile 0 is already there reaches it a few cycles behind the write
   if constexpr (LN_COOP) wait_lgkmcnt<0>();
@@ -529,10 +535,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     using WX = std::integral_constant<bool, wx>;
     constexpr int NFL = wx ? TM : NF;          // ds_reads of a lo fragment set
     constexpr int c = decltype(CUR)::value;
-    constexpr int nslot = (c + 1) % NS, fl = (c + NS - 1) % NS;
+    constexpr int nslot = (c + 1) % NS, fl = (c + NS - (S2 ? 2 : 1)) % NS;      // fl: the slot tile kt + LEAD goes into
     using SO = std::integral_constant<unsigned, (unsigned)c * STAGE>;
     using SN = std::integral_constant<unsigned, (unsigned)nslot * STAGE>;
-    const bool more = kt + NS - 1 < nk;
+    const bool more = kt + LEAD < nk;
     if constexpr (HL) {
       // one 32-deep k-tile = the pairs (hi0, lo0) and (hi1, lo1) in sets 0..3; set 0 was requested behind the previous barrier
       using F = std::false_type; using Tt = std::true_type;
@@ -570,12 +576,20 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     mma(I0{}, fl, I2{}, more);
     if (more) tile_done();
     if (kt + 1 < nk) {
-      if (more) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      ldf(SN{}, I0{}, I0{}, NB0{});
+      if (!S2 || (kt & 1)) {
+        // own pieces of the next tile (S2: the next two) landed, then the rendezvous; tiles beyond may stay in flight
+        if (more) wait_tiles(std::integral_constant<int, LEAD - (S2 ? 2 : 1)>{}); else wait_vmcnt<0>();
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ldf(SN{}, I0{}, I0{}, NB0{});
+      } else {
+        // S2, even tile: tile kt + 1 was covered by the rendezvous of tile kt - 1 (or the prologue's) -- no wait, no barrier
+        ldf(SN{}, I0{}, I0{}, NB0{});
+        wait_lgkmcnt<NF>();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
       wait_lgkmcnt<0>();
     }
@@ -897,18 +911,18 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_pages[dev]);
 }
 
-template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false>
+template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)pipe_lds_total(NS * (BM + BN) * 128, 0);   // ring + LayerNorm coefficients
   static bool attr_set[kMaxDev] = {};
   const int dev = current_device();
-  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA>, lds, attr_set, dev);
+  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2>, lds, attr_set, dev);
   const int sk = (BN == 128 && p.splitk > 1) ? p.splitk : 1;
   if (sk > 1 && (size_t)tilesM * tilesN * sk * BM * BN * 4 > p.splitk_ws_bytes) throw std::runtime_error("igemm: split-K workspace too small");
   IgemmParams q = p;
   q.splitk = sk;
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
 }
 
 static void launch_wide(const IgemmParams& p, hipStream_t s) {
@@ -1106,6 +1120,10 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 44: launch_pipe<128, 128, 5, 4, 8>(psk, s); break;   // 5-slot ring = all 160 KiB of LDS: 4 tiles in flight
     case 45: launch_pipe<96, 128, 5, 3, 6>(psk, s); break;    // 6 waves (3 x 2), 96-row tile: M = 2048 x N = 1280 -> 220 workgroups
     case 46: launch_pipe<96, 128, 4, 3, 6>(psk, s); break;
+    // 45 with ONE rendezvous per two k-tiles (S2).  Alone, on L2-resident operands, 2 - 4 % faster on every shape of the step; inside
+    // the step, where the weights stream in cold, the tile less in flight costs more than the rendezvous saved: GEMM class 20.95 -
+    // 21.04 vs 20.76 - 20.82 ms on one box (profiles/r03_two_tiles_per_rendezvous.txt).  Kept as the A/B partner, not selected.
+    case 47: launch_pipe<96, 128, 5, 3, 6, half_t, false, true>(psk, s); break;
     case 49:                                                                // 4 waves 4x1 (32x160 wave tiles): N = 640 at 64^2 -> exactly 256 tiles
       if (p.N % 160 != 0 || p.stat_out) return false;
       launch_pipe<128, 160, 3, 4, 4>(psk, s); break;

@@ -455,7 +455,7 @@ def test_conv_split_k_matches_batch_entries(pkg, ctx):
 # ring slots, ragged M / N tiles, GEGLU pairs, 3x3 taps with halo zero-fill, stride 2 and the fused nearest-2x gather
 # production kernels (what the auto selection launches) -- always built; the A/B partners and dead-end experiments exist only
 # in a measure build (`build.py --measure`) and are exercised when the loaded library is one
-IGEMM_VARIANTS = [4, 6, 26, 35, 36, 38, 44, 45, 46, 49]
+IGEMM_VARIANTS = [4, 6, 26, 35, 36, 38, 44, 45, 46, 47, 49]
 IGEMM_MEASURE_VARIANTS = [40, 41, 42, 43, 1, 8, 10, 11, 12, 13, 14, 15, 16, 19, 20, 21, 22, 23, 24, 25, 33, 34, 37]
 
 
