@@ -247,6 +247,38 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
 
   // ---- DMA geometry: piece j of this wave covers tile rows (j*8 + wave)*8 .. +7; lane -> (row, slot)
   const int lrow = lane >> 3, slot = lane & 7;
+  // weight rows first: they need no pixel arithmetic, and inside a UNet step the weights are the operand that arrives cold (the
+  // activations were written by the previous launch) -- tile 0's weight pieces go out BEFORE the activation geometry below is
+  // worked out (~1.5 k cycles earlier).  The in-order vmcnt accounting is unchanged: tile 0's pieces are still this wave's oldest.
+  // Measured on the bench line, two libraries on one box: 23.30 / 23.27 -> 23.23 / 23.24 ms per step (profiles/r03_weights_first_ab.txt).
+  const T* wptr[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int row = (j * NW + wave) * 8 + lrow;
+    wptr[j] = reinterpret_cast<const T*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * CE;
+  }
+  // this workgroup's k-tiles [kbeg, kbeg + nk) of the Kpad / KT of the contraction (split-K: slice `slice` of SK)
+  const int nk_all = p.Kpad / KT;
+  const int kbeg = SK > 1 ? (int)((long)slice * nk_all / SK) : 0;
+  const int nk = SK > 1 ? (int)((long)(slice + 1) * nk_all / SK) - kbeg : nk_all;
+  if (kbeg > 0) {
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) wptr[j] += kbeg * KT;
+  }
+  constexpr bool B0_EARLY = !LIN;      // (the scalar-base form of the fused cross-attention projections keeps the plain order)
+  if constexpr (B0_EARLY) {
+    if (nk > 0) {
+      char* lb0 = smem + BM * 128 + wave * 1024;       // ring slot 0
+      static_for<BJ>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        if (j < BJ - 1 || lastb) {
+          __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(lb0 + j * (NW * 1024)), 16, 0, 0);
+          wptr[j] += KT;
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   const int HWo = p.Hout * p.Wout;
   const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
   // (prologue cost, tools/timeline_probe.py: the two integer divisions per tile row below took 1.5 - 2.7 k cycles of every launch.
@@ -272,24 +304,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     }
   }
   const T* Ag = reinterpret_cast<const T*>(p.A);
-  const T* wptr[BJ];
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) {
-    const int row = (j * NW + wave) * 8 + lrow;
-    wptr[j] = reinterpret_cast<const T*>(p.W) + (size_t)(n0 + row) * p.Kpad + (slot ^ ((row >> 1) & 7)) * CE;
-  }
-  // this workgroup's k-tiles [kbeg, kbeg + nk) of the Kpad / KT of the contraction (split-K: slice `slice` of SK)
-  const int nk_all = p.Kpad / KT;
-  const int kbeg = SK > 1 ? (int)((long)slice * nk_all / SK) : 0;
-  const int nk = SK > 1 ? (int)((long)(slice + 1) * nk_all / SK) - kbeg : nk_all;
   const T* aptr[AJ];
   int aadv[AJ];
   int s_c0 = 0, s_dy = 0, s_dx = 0;
   if (kbeg > 0) {   // start the tap walk inside the contraction
     const int e0 = kbeg * KT, tap = e0 / p.Cin;
     s_c0 = e0 - tap * p.Cin; s_dy = tap / p.ksize; s_dx = tap - s_dy * p.ksize;
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) wptr[j] += e0;
   }
   auto retap = [&]() {
     if (lin_rows) {       // one tap, rows are contiguous K-runs: no bounds / pixel arithmetic
@@ -343,7 +363,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     char* lb = la + BM * 128;
     static_for<PER>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
-      if constexpr (ph < 0 || q % 3 == ph) {
+      if constexpr (ph == -1 || (ph >= 0 && q % 3 == ph) || (ph == -3 && q < AJ)) {      // -1: all pieces; -3: the activation pieces only
         if constexpr (LIN) {
           // saddr form: global_load_lds_dwordx4 voffset, sbase -- M0 = LDS byte address of this wave's 1-KiB piece
           // (hand-written, so the hazards are ours to keep: an LDS-DMA instruction must not issue in the wait state right behind
@@ -446,6 +466,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   using IALL = std::integral_constant<int, -1>;
+  using IAONLY = std::integral_constant<int, -3>;
   constexpr int LEAD = S2 ? NS - 2 : NS - 1;   // tile kt + LEAD is issued during tile kt
   constexpr int NPRO = LEAD;                   // tiles staged by the prologue
   static_assert(!S2 || (NS >= 4 && !HL), "two tiles per rendezvous: ring of >= 4 slots, f16 / f32 elements");
@@ -465,7 +486,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   // ---- prologue: tiles 0 .. NPRO-1 in flight, wait for tile 0 only
 #pragma unroll
   for (int s = 0; s < NPRO; ++s)
-    if (s < nk) { issue(s, IALL{}); tile_done(); }
+    if (s < nk) {
+      if (B0_EARLY && s == 0) issue(0, IAONLY{}); else issue(s, IALL{});      // (tile 0's weight pieces are already on their way)
+      tile_done();
+    }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
