@@ -46,11 +46,13 @@ def run(name, B, H, W, Cin, Cout, vprod, vtl, tile, ksize=1):
     nwg = ((M + bm - 1) // bm) * ((Cout + bn - 1) // bn)
     pkg.debug_set("igemm_variant", vprod)
     L.sdxl_debug_timeline(None)
-    us_prod = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, ksize, False, 20) * 1e3
+    # COLD=1: rotate through > 256 MB of weight copies, so every launch streams its weights from HBM as it does inside a UNet step
+    flags = 8 if os.environ.get("COLD") == "1" else 0
+    us_prod = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, ksize, flags, 20) * 1e3
     buf = torch.zeros(nwg * nw * TLW, dtype=torch.int32, device="cuda")
     L.sdxl_debug_timeline(ctypes.c_void_p(buf.data_ptr()))
     pkg.debug_set("igemm_variant", vtl)
-    us_tl = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, ksize, False, 20) * 1e3     # the buffer holds the LAST launch's stamps
+    us_tl = pkg.bench_igemm(ctx, B, H, W, Cin, Cout, ksize, flags, 20) * 1e3     # the buffer holds the LAST launch's stamps
     torch.cuda.synchronize()
     L.sdxl_debug_timeline(None)
     t = buf.cpu().numpy().astype(np.uint32).reshape(nwg, nw, TLW).astype(np.int64)
