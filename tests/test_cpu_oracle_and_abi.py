@@ -512,3 +512,11 @@ def test_production_gemm_assembly_has_no_async_read_hazard(tmp_path):
     # the lint must see the kernels it is meant to check
     text = open(out).read()
     assert text.count("ds_read_b128") > 500 and "igemm_pipe_kernel" in text
+    # the attention translation unit (raw barriers, LDS-DMA rings, hand-counted vmcnt waits) under the same rules
+    src2, out2 = os.path.join(ROOT, "stable-diffusion-xl-burn_amd", "csrc", "attention.hip"), str(tmp_path / "attention.s")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "--cuda-device-only", "-S", src2, "-o", out2,
+                        "-Wno-unused-function"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    findings = asm_lint.lint(out2)
+    assert not findings, "\n".join(findings[:10])
+    assert "attn_d64_mix_kernel" in open(out2).read()
