@@ -19,7 +19,7 @@ OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsdxl_mi355.so")
 ARCH = "gfx950"
-SOURCES = ["igemm.hip", "igemm_glds.hip", "igemm_measure.hip", "norm.hip", "attention.hip", "elementwise.hip", "capi.hip",
+SOURCES = ["igemm.hip", "igemm_glds.hip", "igemm_wreg.hip", "igemm_measure.hip", "norm.hip", "attention.hip", "elementwise.hip", "capi.hip",
            "specs.cpp", "weights.cpp", "unet.cpp", "vae.cpp", "sampler.cpp", "clip.cpp", "comm.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]

@@ -94,6 +94,14 @@ struct Tmp {   // scoped device scratch for the single-op entry points
   ~Tmp() { for (void* p : ptrs) (void)hipFree(p); }
   void* get(size_t bytes) { void* p = nullptr; SDXL_HIP(hipMalloc(&p, bytes ? bytes : 16)); ptrs.push_back(p); return p; }
 };
+// fragment-order image of a plain f16 linear / 1x1 weight for the single-op entry points (what WeightBuilder::attach_wfrag does
+// for the models): the operators then run the same kernel selection as the models
+static void tmp_wfrag(Lin& l, int cdt, bool geglu, Tmp& tmp, hipStream_t s) {
+  if (cdt != DT_F16 || geglu || l.ksize != 1 || l.N % 128 != 0 || l.K != l.Kpad || l.Kpad % 64 != 0 || l.Kpad < 128 || l.cs || l.acc_scale) return;
+  void* wf = tmp.get((size_t)l.Npad * l.Kpad * 2);
+  launch_repack_wfrag(l.w, wf, l.Npad, l.Kpad, s);
+  l.wf = wf;
+}
 // the single-op entry points run the same kernel selection as the models, split-K included (f16 compute only)
 void give_splitk_ws(Exec& ex, Tmp& tmp, int batch, int rows_per_entry, int n, hipStream_t s) {
   if (ex.cdt != DT_F16) return;
@@ -154,6 +162,7 @@ int sdxl_debug_set(const char* key, int value) {
   else if (std::strcmp(key, "attn_variant") == 0) attention_set_variant(value);
   else if (std::strcmp(key, "igemm_epilogue_staged") == 0) igemm_set_epilogue_staged(value);
   else if (std::strcmp(key, "hl_weights_exact") == 0) igemm_set_hl_weights_exact(value);
+  else if (std::strcmp(key, "igemm_wreg") == 0) igemm_set_wreg(value);
 #ifdef SDXL_MEASURE
   else if (std::strcmp(key, "igemm_unrolled") == 0) igemm_set_unrolled(value);
   else if (std::strcmp(key, "no_cfg") == 0) g_debug_no_cfg = value != 0;
@@ -198,6 +207,7 @@ int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, 
   launch_pack_bias(bsrc, bp, Cout, l.Npad, (geglu & 1) ? 1 : 0, 0, s);
   launch_copy_rows(xsrc, DT_F32, Cin, xi, DT_F16, Cin, (int)M, Cin, s);
   l.w = wp; l.b = bp;
+  tmp_wfrag(l, DT_F16, (geglu & 1) != 0, tmp, s);
   Exec ex; ex.s = s; ex.cdt = DT_F16; ex.sdt = DT_F16;
   give_splitk_ws(ex, tmp, B, H * W, Cout, s);
   const bool ln_in = (geglu & 2) != 0, st_out = (geglu & 4) != 0, cold = (geglu & 8) != 0;
@@ -205,6 +215,7 @@ int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, 
   // cold mode: rotate through enough copies of the weight (> 256 MB Infinity Cache) that every launch streams it from HBM,
   // as in the model where each of the ~500 weights is touched once per step
   std::vector<void*> wcopies(1, wp);
+  std::vector<const void*> wfcopies(1, l.wf);
   if (cold) {
     const size_t wbytes = (size_t)l.Npad * l.Kpad * 2;
     const int nc = (int)std::min<size_t>(96, (size_t)(320u << 20) / wbytes + 1);
@@ -212,6 +223,9 @@ int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, 
       void* c = tmp.get(wbytes);
       SDXL_HIP(hipMemcpyAsync(c, wp, wbytes, hipMemcpyDeviceToDevice, s));
       wcopies.push_back(c);
+      void* cf = nullptr;
+      if (l.wf) { cf = tmp.get(wbytes); SDXL_HIP(hipMemcpyAsync(cf, l.wf, wbytes, hipMemcpyDeviceToDevice, s)); }
+      wfcopies.push_back(cf);
     }
   }
   Epi e; e.act = geglu ? 1 : 0;
@@ -235,6 +249,7 @@ int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, 
   SDXL_HIP(hipEventRecord(a, s));
   for (int i = 0; i < iters; ++i) {
     l.w = wcopies[(size_t)i % wcopies.size()];
+    l.wf = wfcopies[(size_t)i % wfcopies.size()];
     run_conv(ex, l, Act(xi, Cin, DT_F16), Cin, g, out, e);
   }
   SDXL_HIP(hipEventRecord(b, s));
@@ -914,6 +929,7 @@ int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   launch_pack_conv(weight, wp, cdt, Cout, Cin, ksize, l.Kpad, l.Npad, s, wscale);
   launch_pack_bias(bias, bp, Cout, l.Npad, 0, 0, s);
   l.w = wp; l.b = bp;
+  tmp_wfrag(l, cdt, false, tmp, s);
   launch_nchw_to_nhwc(x, Cin * H * W, xi, sdt, B, Cin, H * W, Cin, 1.0f, s);     // (st_f handles the HL16 layout: Cin % 16 == 0 rows)
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
   give_splitk_ws(ex, tmp, B, Ho * Wo, Cout, s);
@@ -959,6 +975,7 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   launch_pack_linear(weight, wp, cdt, K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, s, nullptr, wscale);
   launch_pack_bias(bias, bp, N, l.Npad, geglu ? 1 : 0, 0, s);
   l.w = wp; l.b = bp;
+  tmp_wfrag(l, cdt, geglu != 0, tmp, s);
   if (cdt == DT_HL) launch_f32_to_hl(x, K, xi, K, (size_t)M, K, s);
   else launch_copy_rows(x, DT_F32, K, xi, sdt, K, M, K, s);
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
@@ -1016,6 +1033,7 @@ int sdxl_layer_norm_linear(sdxl_ctx* ctx, void* stream, const float* x, const fl
     }
     launch_pack_linear(eye, ip, DT_F16, K, K, id.Kpad, id.Npad, 0, 0, s);
     id.w = ip; id.b = nullptr;
+    tmp_wfrag(id, DT_F16, false, tmp, s);    // (C % 128 == 0: the identity runs on the weights-in-registers kernel, pair-exchanged row statistics)
     void* x16 = tmp.get((size_t)M * K * 2);
     launch_copy_rows(x, DT_F32, K, x16, DT_F16, K, M, K, s);
     float* stat = (float*)tmp.get((size_t)M * (K / 64) * 2 * sizeof(float));
@@ -1082,6 +1100,7 @@ int sdxl_ln_query_cross_attention(sdxl_ctx* ctx, void* stream, const float* x, c
   }
   launch_pack_linear(eye, ip, DT_F16, C, C, id.Kpad, id.Npad, 0, 0, s);
   id.w = ip; id.b = nullptr;
+  tmp_wfrag(id, DT_F16, false, tmp, s);    // (C % 128 == 0: the identity runs on the weights-in-registers kernel, pair-exchanged row statistics)
   void* x16 = tmp.get((size_t)M * C * 2);
   void* xi = tmp.get((size_t)M * C * 2);
   launch_copy_rows(x, DT_F32, C, x16, DT_F16, C, M, C, s);

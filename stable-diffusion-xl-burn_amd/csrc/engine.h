@@ -112,6 +112,7 @@ struct FlatSourceF16 : WeightSource {   // flat IEEE-f16 buffer (host or device)
 
 struct Lin {        // packed dense weight: [Npad][Kpad] compute dtype + fp32 bias [Npad]
   const void* w = nullptr; const float* b = nullptr;
+  const void* wf = nullptr;        // f16 linear layers / 1x1 convs with N % 128 == 0: the same weights in MFMA fragment order (igemm_wreg.hip)
   int N = 0, K = 0, Kpad = 0, Npad = 0, ksize = 1, cin = 0;
   // LayerNorm folded in (linear_ln / fused_linear_ln): w = diag(gamma) W, b = beta W + bias, cs = column sums of the
   // packed rows; the GEMM then takes the RAW rows plus their per-64-column (mean, M2) statistics -- see IgemmParams::ln_stat
@@ -149,6 +150,7 @@ struct WeightBuilder {
   Lin fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu);
   float* tmp2 = nullptr; size_t tmp2_numel = 0;   // scratch for folded biases (device)
   Lin conv(const std::string& name);                                        // name.weight [Cout,Cin,k,k] + bias
+  void attach_wfrag(Lin& l, bool fill);    // second image of a plain f16 linear / 1x1 weight in fragment order (arena; no-op for other layers)
   NormW norm(const std::string& name);
 };
 

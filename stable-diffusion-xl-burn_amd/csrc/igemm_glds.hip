@@ -1084,6 +1084,7 @@ void launch_xattn_pack(const void* K, const void* Vt, void* out, int B, int C, i
                      reinterpret_cast<const half_t*>(Vt), reinterpret_cast<half8*>(out), B, C, nctx, vt_ld);
 }
 
+bool launch_igemm_wreg(const IgemmParams& p, int variant, hipStream_t s);   // igemm_wreg.hip
 bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   if (!g_zero_pages[current_device()]) return false;
   if (p.act > 1) return false;   // GELU / QuickGELU epilogues (CLIP MLP, once per prompt) live in the generic kernel
@@ -1117,6 +1118,10 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     if (!igemm_gn_part_ok(p)) throw std::runtime_error("igemm: GroupNorm statistics requested from a shape the 256x128 epilogue does not take");
     variant = 0;            // (a forced test variant must not drop the statistics)
   }
+  // plain linear layers / 1x1 convs whose weights also exist in fragment order: the weights-in-registers kernel (igemm_wreg.hip).
+  // The rule is static per layer (never the batch), so its k-summation order (even + odd k-tiles) is what such a layer always gets.
+  if ((variant == 0 || (variant >= 60 && variant <= 62)) && launch_igemm_wreg(psk, variant, s)) return true;
+  if (variant >= 60 && variant <= 62) return false;
   if (variant == 0 && igemm_splitk_slices(p) > 1) {
     // long contractions over a small output (FF-out and the 32^2 convs of the CFG pair: M = 2048, N = 1280 is 80 tiles of
     // 256x128 on 256 CUs): three k-slices per tile fill the chip with the tile shape that moves the fewest bytes per flop

@@ -1,0 +1,477 @@
+// Linear-layer GEMM with the weights streamed STRAIGHT INTO REGISTERS (round 4).
+//
+// Why a third structure next to igemm_pipe_kernel / igemm_wide_kernel.  The timeline of the 96x128 pipe kernel (the M = 2048 x
+// N = 1280 linears: 257 launches of a UNet step) shows a k-tile of 1279 cycles for 384 cycles of matrix-pipe work: six waves on
+// four SIMDs (two SIMDs carry twice the MFMAs), both operands staged through LDS (3 ds_read_b128 per 2 MFMAs) and a rendezvous
+// of all waves per 64-deep k-tile with nothing else resident on the CU to fill it (140 KiB of LDS per workgroup).  Here:
+//   * the WEIGHTS never touch LDS.  They are re-packed once at model build in MFMA A-operand order (launch_repack_wfrag: per
+//     32-column block and 64-deep k-tile four 1-KiB fragments, lane l = weight row l&31, k = 16 kk + 8 (l>>5) .. +7), so a wave
+//     streams its own 32 columns as ONE contiguous run with plain `global_load_dwordx4` (1 KiB per instruction, whole lines), L + 1
+//     k-tiles deep in registers.  A weight fragment is private to its wave: no barrier, no LDS bytes, no ds_read for this operand.
+//   * only the ACTIVATIONS go through LDS (global_load_lds, the pipe kernel's swizzled 128-byte rows): BM x 128 B per k-tile, so
+//     a ring slot is 8 - 16 KiB instead of 28 - 48 and the ring is L + 1 = 4 - 5 tiles deep per k-group.
+//   * wave tile = BM rows x 32 columns (TM = BM / 32 accumulator tiles): TM ds_read_b128 per TM MFMAs, every wave of a group on
+//     its own SIMD with the same work (no 6-waves-on-4-SIMDs imbalance).
+//   * TWO k-groups per workgroup (waves 0-3: even k-tiles, waves 4-7: odd k-tiles of the SAME output tile): two waves per SIMD
+//     that share nothing but the barrier -- what "two workgroups per CU" would give, on grids of < 256 workgroups that can never
+//     be two per CU.  The groups' fp32 partial sums meet once, through LDS, in the fixed order (even + odd): bit-reproducible,
+//     independent of BM and of the batch (the selection rule is static per layer, so an entry is bit-identical alone or batched).
+// Hand-kept invariants (the compiler sees neither the asm loads nor the DMA completion):
+//   * VMEM queue of a wave, per (virtual) iteration i: W(i + L) x 4, then the wave's PP activation pieces of tile i + L, in that
+//     order, iff tile i + L exists.  Returns are in order, so every wait is a constant: with d = tiles left in the group,
+//     W(j) has landed at  vmcnt(PP + min(L - 1, d - 1) * U),  the wave's pieces of tile j + 1 at  vmcnt(min(L - 1, max(d - 2, 0)) * U),
+//     U = PP + 4.
+//   * slot / register stage of tile j = j % (L + 1); tile j + L goes into the stage of tile j - 1, which the barrier of
+//     iteration j - 1 (activations) and the last MFMAs of iteration j - 1 (weights) have freed.
+//   * one s_barrier per iteration, between the third and the fourth kk-step: before it the wave's own pieces of tile j + 1 have
+//     landed and all its reads of tile j are complete (lgkmcnt(0)).
+// tools/asm_lint.py checks the asm-load rule (no instruction touches the destination of a pending asm global_load before a
+// counted vmcnt wait covers it) on the device assembly of this file.
+#include "igemm_common.h"
+#include <atomic>
+
+namespace sdxl {
+
+// weight fragment load.  Inline asm: the compiler's own vmcnt bookkeeping of a plain load is exact in straight-line code only -- at
+// the loop header it falls back to vmcnt(0) in front of the first MFMA, which serialises the whole prefetch -- so these loads
+// are waited for by hand like the DMA pieces (counts in the file header; tools/asm_lint.py replays the queue over the assembly).
+template <int OFF> __device__ __forceinline__ half8 wreg_gload128(const half_t* ptr) {
+  half8 v;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(ptr), "n"(OFF));
+  return v;
+}
+
+// [Npad][Kpad] row-major packed weights (f16, k contiguous) -> fragment order: 16-byte unit ((nb * nk + kt) * 4 + kk) * 64 + lane
+// = row nb * 32 + (lane & 31), 16-byte chunk kt * 8 + kk * 2 + (lane >> 5)
+__global__ void repack_wfrag_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int nblocks, int nk) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)nblocks * nk * 256;
+  if (i >= total) return;
+  const int lane = (int)(i & 63), kk = (int)((i >> 6) & 3);
+  const size_t t = i >> 8;
+  const int kt = (int)(t % nk);
+  const int nb = (int)(t / nk);
+  dst[i] = src[(size_t)(nb * 32 + (lane & 31)) * (nk * 8) + kt * 8 + kk * 2 + (lane >> 5)];
+}
+void launch_repack_wfrag(const void* w, void* wf, int Npad, int Kpad, hipStream_t s) {
+  const int nblocks = Npad / 32, nk = Kpad / 64;
+  const size_t total = (size_t)nblocks * nk * 256;
+  hipLaunchKernelGGL(repack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(w),
+                     reinterpret_cast<f32x4*>(wf), nblocks, nk);
+}
+
+// direct row-per-lane epilogue of a BM x 32 wave tile (igemm_epilogue_rows with one column tile), plus the row statistics of
+// the stored values for the next folded LayerNorm: a 64-column statistics slot spans the wave PAIR (w, w ^ 1), so the slot's pivot
+// (its first stored value, held by the even wave) and the odd wave's half of the sums cross through LDS.  The arithmetic -- per
+// 8-column piece shifted sums, pieces paired across the lane halves, (p0 + p1) + (p2 + p3) per 32 columns, even + odd -- is the
+// tree of igemm_epilogue_rows / the staged epilogue, so the (mean, M2) bits do not depend on which kernel produced the rows.
+// Called by ALL waves of the workgroup (two barriers when p.stat_out); `active` = this wave holds a finished tile.
+template <int TM>
+__device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM], int mw, int nw, int lane, int w,
+                                              bool active, float* xch, const void* zeros) {
+  const int fr = lane & 31, fh = lane >> 5;
+  const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
+  half8 hv[TM][2];
+  int m[TM];
+  bool mok[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { m[i] = mw + i * 32 + fr; mok[i] = m[i] < p.M; }
+  if (active) {
+    int bidx[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) bidx[i] = (p.ebias && mok[i]) ? m[i] / p.rpb : 0;
+    const bool r16 = p.R && p.r_dt == DT_F16, r32 = p.R && p.r_dt == DT_F32;
+    half8 rh[TM][2];
+    f32x4 rf[TM][2][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int n0 = nw + t * 16 + 8 * fh;
+        const size_t o = (size_t)(mok[i] ? m[i] : 0) * p.ldr + n0;
+        rh[i][t] = *((r16 && mok[i]) ? reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.R) + o) : reinterpret_cast<const half8*>(zeros));
+        if (r32) {
+          rf[i][t][0] = *(mok[i] ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o) : zv);
+          rf[i][t][1] = *(mok[i] ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o + 4) : zv);
+        }
+      }
+    f32x4 bz[4], ez[TM][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nb = nw + 8 * q + 4 * fh;
+      bz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ez[i][q] = *(p.ebias ? reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx[i] * p.ebias_ld + nb) : zv);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q][r] = acc[i][q * 4 + r];
+        v[q] = v[q] + bz[q] + ez[i][q];
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float wv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * t][r]), __float_as_uint(v[2 * t + 1][r]), false, false);
+          wv[r] = __uint_as_float(sw[0]);
+          wv[4 + r] = __uint_as_float(sw[1]);
+        }
+        if (r16) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wv[e] += (float)rh[i][t][e];
+        } else if (r32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { wv[e] += rf[i][t][0][e]; wv[4 + e] += rf[i][t][1][e]; }
+        }
+        const int n0 = nw + t * 16 + 8 * fh;
+        if (p.c_dt == DT_F16) {
+          half8 h;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] = (half_t)wv[e];
+          if (mok[i]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.C) + (size_t)m[i] * p.ldc + n0) = h;
+          hv[i][t] = h;
+        } else if (mok[i]) {
+          float* cp = reinterpret_cast<float*>(p.C) + (size_t)m[i] * p.ldc + n0;
+          *reinterpret_cast<f32x4*>(cp) = f32x4{wv[0], wv[1], wv[2], wv[3]};
+          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{wv[4], wv[5], wv[6], wv[7]};
+        }
+      }
+    }
+  }
+  if (!p.stat_out) return;          // (kernel argument: uniform over the workgroup; the launcher admits stat_out with f16 outputs only)
+  // ---- row statistics of the stored (rounded) values, slot = the 64 columns of the wave pair (w & ~1, w | 1)
+  const int pair = w >> 1;
+  const bool odd = (w & 1) != 0;
+  float* xpiv = xch + pair * (TM * 32);                  // [pair][row]
+  float* xsum = xch + 2 * (TM * 32) + pair * (TM * 64);  // [pair][row][2]
+  float piv[TM];
+  if (active && !odd) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      piv[i] = __shfl((float)hv[i][0][0], fr);           // the slot's first stored value (lanes 0..31 of the even wave hold it)
+      if (fh == 0) xpiv[i * 32 + fr] = piv[i];
+    }
+  }
+  wait_lgkmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float A1[TM], A2[TM];
+  if (active) {
+    if (odd) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) piv[i] = xpiv[i * 32 + fr];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float s1[2], s2[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        s1[t] = 0.f; s2[t] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)hv[i][t][e] - piv[i]; s1[t] += d; s2[t] = fmaf(d, d, s2[t]); }
+        s1[t] += __shfl_xor(s1[t], 32); s2[t] += __shfl_xor(s2[t], 32);
+      }
+      A1[i] = s1[0] + s1[1]; A2[i] = s2[0] + s2[1];
+      if (odd && fh == 0) { xsum[(i * 32 + fr) * 2] = A1[i]; xsum[(i * 32 + fr) * 2 + 1] = A2[i]; }
+    }
+  }
+  wait_lgkmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (active && !odd && fh == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float s1 = A1[i] + xsum[(i * 32 + fr) * 2];
+      const float s2 = A2[i] + xsum[(i * 32 + fr) * 2 + 1];
+      if (mok[i]) {
+        float* dst = p.stat_out + ((size_t)(nw >> 6) * p.M + m[i]) * 2;
+        dst[0] = piv[i] + s1 * (1.0f / 64.0f);
+        dst[1] = fmaxf(s2 - s1 * s1 * (1.0f / 64.0f), 0.f);
+      }
+    }
+  }
+}
+
+template <int BM, int L>
+__global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, const void* zeros) {
+  kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();
+  constexpr int NG = 2;                       // k-groups per workgroup
+  constexpr int NSG = L + 1;                  // ring slots / weight register stages per group
+  constexpr int TM = BM / 32;                 // accumulator tiles per wave (wave tile BM x 32)
+  constexpr int PP = BM / 32;                 // activation DMA pieces (8 rows x 128 B) per wave and k-tile
+  constexpr int U = PP + 4;                   // VMEM operations per wave and k-tile
+  constexpr int NOPS = U;
+  constexpr int SLOT = BM * 128;              // bytes per ring slot
+  constexpr int RING = NSG * SLOT;            // bytes per group
+  constexpr int KSTEP = 64 * NG;              // elements between a group's consecutive k-tiles
+  static_assert(BM % 32 == 0 && TM >= 2 && TM <= 4, "wave tile: 64 / 96 / 128 rows");
+  static_assert((NSG - 1) * SLOT + (TM - 1) * 4096 < 65536, "fragment offsets must fit the ds_read immediate");
+  static_assert(PP + (L - 1) * U < 64 && L >= 2, "vmcnt is 6 bits");
+  static_assert(NOPS <= 3 * TM, "one VMEM operation per MFMA gap before the rendezvous");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, w = wave & 3;
+
+  const int tilesM = (p.M + BM - 1) / BM;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  // an XCD (private L2) owns a run of consecutive remapped ids = all row tiles of a few weight column tiles: the weight panel of
+  // a column tile is read from HBM by one XCD only and its row tiles find it in that L2
+  const int tn = bid / tilesM, tm = bid - tn * tilesM;
+  const int m0 = tm * BM, n0 = tn * 128;
+  const int nk = p.Kpad >> 6;
+  const int nkg = (nk - g + 1) >> 1;          // k-tiles of this group: g, g + 2, ...
+
+  // ---- weight stream: this wave's 32 columns, fragment order, contiguous over k
+  const half_t* wp = reinterpret_cast<const half_t*>(p.Wf) + ((size_t)((n0 >> 5) + w) * nk + g) * 2048 + lane * 8;
+  half8 Wr[NSG][4];
+  auto loadW = [&](auto S, auto KK) {
+    constexpr int s = decltype(S)::value, kk = decltype(KK)::value;
+    Wr[s][kk] = wreg_gload128<kk * 1024>(wp);
+    if constexpr (kk == 3) wp += NG * 2048;
+  };
+  // ---- activation pieces: piece q of this wave = tile rows (4 q + w) * 8 .. + 7 of the group's k-tile; lane -> (row, 16-byte slot)
+  const half_t* Ag = reinterpret_cast<const half_t*>(p.A);
+  const half_t* aptr[PP];
+  int aadv[PP];
+  char* const ring = smem + g * RING;
+  auto setupA = [&]() {
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {
+      const int row = (q * 4 + w) * 8 + (lane >> 3);
+      const int m = m0 + row;
+      const bool ok = m < p.M;
+      aptr[q] = ok ? Ag + (size_t)m * p.lda + g * 64 + (((lane & 7) ^ ((row >> 1) & 7)) << 3) : reinterpret_cast<const half_t*>(zeros);
+      aadv[q] = ok ? KSTEP : 0;
+    }
+  };
+  auto pieceA = [&](auto S, auto Q) {
+    constexpr int s = decltype(S)::value, q = decltype(Q)::value;
+    __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(ring + s * SLOT + (q * 4 + w) * 1024), 16, 0, 0);
+    aptr[q] += aadv[q];
+  };
+  // operation x of a k-tile's VMEM sequence: 0..3 weight fragments, 4.. activation pieces
+  auto vmem_op = [&](auto S, auto X) {
+    constexpr int x = decltype(X)::value;
+    if constexpr (x < 4) loadW(S, X);
+    else pieceA(S, std::integral_constant<int, x - 4>{});
+  };
+
+  const int fr = lane & 31, fh = lane >> 5;
+  unsigned fa[4];
+  {
+    const unsigned basea = lds0 + g * RING + fr * 128 + ((fh ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fa[kk] = basea ^ (kk << 5);
+  }
+  half8 fA[2][TM];
+  auto ldsA = [&](auto SET, auto S, auto KK) {
+    constexpr int set = decltype(SET)::value, s = decltype(S)::value, kk = decltype(KK)::value;
+    static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<s * SLOT + decltype(I)::value * 4096>(fa[kk]); });
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+  // Slot rotation.  Everything below is straight-line code with compile-time slots, register stages and wait counts: the LAST
+  // tile of a group always sits in slot L, so the final L tiles ("drain": nothing left to issue, the waits shrink with the tiles
+  // left) are one static sequence over slots 1 .. L, the steady tiles before them are whole passes over slots 1, 2, .., L, 0
+  // behind one partial pass, and only the prologue (and that partial pass) is entered by the run-time first slot s0.
+  const int s0 = ((L - (nkg - 1)) % NSG + NSG) % NSG;         // slot of tile 0
+  const int ns = nkg > L ? nkg - L : 0;                       // steady tiles (tile j + L exists)
+
+  // ---- prologue = virtual iterations -L .. -1: W(i), pieces(i) for the first L tiles into slots s0 + i.  Tile 0's weights go
+  // out before the activation geometry is worked out (inside a UNet step the weights are the operand that arrives cold from HBM).
+  static_for<NSG>([&](auto C) {
+    constexpr int c = decltype(C)::value;
+    if (s0 == c && nkg > 0) static_for<4>([&](auto KK) { loadW(C, KK); });
+  });
+  setupA();
+  static_for<NSG>([&](auto C) {
+    constexpr int c = decltype(C)::value;
+    if (s0 == c) {
+      static_for<L>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        using SI = std::integral_constant<int, (c + i) % NSG>;
+        if (i < nkg) {
+          if constexpr (i > 0) static_for<4>([&](auto KK) { loadW(SI{}, KK); });
+          static_for<PP>([&](auto Q) { pieceA(SI{}, Q); });
+        }
+      });
+    }
+  });
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // rendezvous of virtual iteration -1: own pieces of tile 0 landed (tiles 1 .. min(L, nkg) - 1 may stay in flight), then everybody's
+  if (nkg >= L) wait_vmcnt<(L - 1) * U>();
+  else static_for<L - 1>([&](auto D) { constexpr int dd = decltype(D)::value + 1; if (nkg == dd) wait_vmcnt<(dd - 1) * U>(); });
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<NSG>([&](auto C) { if (s0 == decltype(C)::value && nkg > 0) ldsA(I0{}, C, I0{}); });
+  __builtin_amdgcn_sched_barrier(0);
+
+  // TM MFMAs of kk-step KK from fragment set SET; steady tiles put VMEM operations X0 .. of tile j + L behind MFMAs 0, 1, ...
+  auto mma = [&](auto SET, auto S, auto KK, auto SF, auto X0) {
+    constexpr int set = decltype(SET)::value, s = decltype(S)::value, kk = decltype(KK)::value, x0 = decltype(X0)::value;
+    static_for<TM>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[s][kk], fA[set][i], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (x0 >= 0 && x0 + i < NOPS) {
+        vmem_op(SF, std::integral_constant<int, x0 + i>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  };
+  using NOX = std::integral_constant<int, -1>;
+  // one k-tile in slot S.  D = 0: steady (more than L tiles left: tile j + L is issued, constant waits); D = 1 .. L: drain tile
+  // with D tiles left, itself included
+  auto ktile = [&](auto S, auto DD) {
+    constexpr int c = decltype(S)::value, cn = (c + 1) % NSG, cf = (c + L) % NSG, D = decltype(DD)::value;
+    constexpr bool steady = D == 0;
+    using SF = std::integral_constant<int, cf>;
+    using SN = std::integral_constant<int, cn>;
+    using X0 = std::integral_constant<int, steady ? 0 : -1>;
+    using X1 = std::integral_constant<int, steady ? TM : -1>;
+    using X2 = std::integral_constant<int, steady ? 2 * TM : -1>;
+    ldsA(I1{}, S, I1{});
+    wait_vmcnt<steady ? PP + (L - 1) * U : PP + (D - 1) * U>();        // W(j) has landed
+    wait_lgkmcnt<TM>();
+    mma(I0{}, S, I0{}, SF{}, X0{});
+    ldsA(I0{}, S, I2{});
+    wait_lgkmcnt<TM>();
+    mma(I1{}, S, I1{}, SF{}, X1{});
+    ldsA(I1{}, S, I3{});
+    wait_lgkmcnt<TM>();
+    mma(I0{}, S, I2{}, SF{}, X2{});
+    if constexpr (steady || D > 1) {
+      wait_vmcnt<steady ? (L - 1) * U : (D - 2) * U>();                // own pieces of tile j + 1 have landed
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      ldsA(I0{}, SN{}, I0{});
+    } else {
+      wait_lgkmcnt<0>();
+    }
+    mma(I1{}, S, I3{}, SF{}, NOX{});
+  };
+  using STEADY = std::integral_constant<int, 0>;
+  if (ns > 0) {
+    // first (partial) pass: slots s0, s0 + 1, .., L, 0 -- then whole passes 1, .., L, 0
+    const int first = s0 == 0 ? 1 : NSG - s0 + 1;
+    static_for<L>([&](auto C) { constexpr int c = decltype(C)::value + 1; if (s0 != 0 && s0 <= c) ktile(std::integral_constant<int, c>{}, STEADY{}); });
+    ktile(I0{}, STEADY{});
+    for (int pass = (ns - first) / NSG; pass > 0; --pass) {
+      static_for<L>([&](auto C) { ktile(std::integral_constant<int, decltype(C)::value + 1>{}, STEADY{}); });
+      ktile(I0{}, STEADY{});
+    }
+  }
+  // drain: D = L .. 1 tiles left, slots 1 .. L (groups with fewer than L tiles enter in the middle)
+  static_for<L>([&](auto X) {
+    constexpr int D = L - decltype(X)::value;
+    if (D <= nkg) ktile(std::integral_constant<int, L + 1 - D>{}, std::integral_constant<int, D>{});
+  });
+  // odd k-tile count: group 1 has one tile -- and one rendezvous -- less; barrier counts must match across the workgroup
+  if ((nk & 1) && g == 1) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();                    // both rings are dead: they become the exchange area
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- the two groups' partial sums meet in LDS: group 1 parks its accumulators (lane-linear 16-byte pieces), group 0 adds them
+  // (even k-tiles + odd k-tiles: one fixed order) and runs the epilogue
+  f32x4* xr = reinterpret_cast<f32x4*>(smem) + (size_t)w * (TM * 4 * 64) + lane;
+  if (g == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xr[(i * 4 + q) * 64] = f32x4{acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+  }
+  wait_lgkmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o = xr[(i * 4 + q) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][4 * q + r] += o[r];
+      }
+  }
+  float* xch = reinterpret_cast<float*>(smem + 4 * TM * 4096);      // statistics exchange: behind the accumulator exchange area
+  wreg_epilogue<TM>(p, acc, m0, n0 + w * 32, lane, w, g == 0, xch, zeros);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static std::atomic<int> g_wreg_enable{1};
+void igemm_set_wreg(int v) { g_wreg_enable = v; }
+
+template <int BM, int L>
+static void launch_wreg_t(const IgemmParams& p, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * (L + 1) * BM * 128;
+  static_assert(lds >= (size_t)4 * (BM / 32) * 4096 + (size_t)6 * BM * 4, "exchange areas must fit the dead rings");
+  static bool attr_set[kIgemmMaxDev] = {};
+  const int dev = igemm_current_device();
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wreg_kernel<BM, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      throw std::runtime_error("igemm_wreg: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    attr_set[dev] = true;
+  }
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = p.N / 128;
+  hipLaunchKernelGGL((igemm_wreg_kernel<BM, L>), dim3(tilesM * tilesN), dim3(512), lds, s, p, igemm_zero_page());
+}
+
+// shapes this kernel takes: plain f16 linear layers / 1x1 convolutions whose weights were also packed in fragment order
+bool igemm_wreg_ok(const IgemmParams& p) {
+  if (!p.Wf || !igemm_zero_page()) return false;
+  if (p.a_dt != DT_F16 || (p.c_dt != DT_F16 && p.c_dt != DT_F32)) return false;
+  if (p.ksize != 1 || p.stride != 1 || p.up != 0 || p.pad != 0 || p.Hin != p.Hout || p.Win != p.Wout) return false;
+  if (p.N % 128 != 0 || p.Cin != p.K || p.K != p.Kpad || p.Kpad % 64 != 0 || p.Kpad < 128) return false;
+  if (p.act != 0 || p.n_split < p.N || p.xa_k || p.gn_part || p.ln_stat || p.acc_scale) return false;
+  if ((p.lda & 7) != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
+  if ((p.ldc & 7) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0) return false;
+  if (p.R && ((p.ldr & 7) != 0 || (reinterpret_cast<uintptr_t>(p.R) & 15) != 0)) return false;
+  if (p.ebias && (p.ebias_ld & 3) != 0) return false;
+  if (p.stat_out && p.c_dt != DT_F16) return false;
+  return true;
+}
+// variant 0: rows per tile from the grid it makes on 256 CUs (the k-summation order does not depend on it); 60 / 61 / 62 force
+// 96 / 128 / 64 rows
+bool launch_igemm_wreg(const IgemmParams& p, int variant, hipStream_t s) {
+  if (!igemm_wreg_ok(p)) return false;
+  if (variant == 0 && !g_wreg_enable.load()) return false;
+  int bm = variant == 60 ? 96 : variant == 61 ? 128 : variant == 62 ? 64 : 0;
+  if (!bm) {
+    double best = 1e300;
+    for (int c : {64, 96, 128}) {
+      const long tiles = (long)((p.M + c - 1) / c) * (p.N / 128);
+      const double cost = (double)((tiles + 255) / 256) * (c + 40);
+      if (cost < best) { best = cost; bm = c; }
+    }
+  }
+  if (bm == 64) launch_wreg_t<64, 4>(p, s);
+  else if (bm == 96) launch_wreg_t<96, 4>(p, s);
+  else launch_wreg_t<128, 3>(p, s);
+  return true;
+}
+
+}  // namespace sdxl

@@ -22,6 +22,8 @@ static inline size_t dt_size(int dt) { return dt == DT_F16 ? 2 : 4; }
 struct IgemmParams {
   const void* A;        // source activations [B][Hin][Win] rows of lda elements (dtype a_dt)
   const void* W;        // packed weights [Npad][Kpad] in compute dtype, K order = (tap, cin), zero padded
+  const void* Wf;       // optional: the same f16 weights in MFMA fragment order (launch_repack_wfrag) -- linear layers / 1x1 convs the
+                        // weights-in-registers kernel may take (igemm_wreg.hip); null = not packed that way
   int a_dt;             // dtype of A in memory (DT_F16 / DT_F32); converted to compute dtype while staging
   int B, Hin, Win, Cin, lda;
   int Hout, Wout;       // M = B*Hout*Wout
@@ -73,6 +75,11 @@ int igemm_splitk_slices(const IgemmParams& p);                       // 1 or 3: 
 size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max);   // slab bytes a plan must provide
 constexpr int kSplitkCounters = 4096;                                // arrival counters a plan must provide (zeroed once)
 void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
+// [Npad][Kpad] f16 row-major packed weights -> fragment order (same bytes): per 32-row block and 64-deep k-tile four 1-KiB MFMA
+// A-operand fragments, contiguous over k -- what igemm_wreg_kernel streams straight into registers.  Npad % 32 == 0, Kpad % 64 == 0.
+void launch_repack_wfrag(const void* w, void* wf, int Npad, int Kpad, hipStream_t s);
+bool igemm_wreg_ok(const IgemmParams& p);   // shapes the weights-in-registers kernel takes (plain f16 linear / 1x1, N % 128 == 0, Wf set)
+void igemm_set_wreg(int v);      // A/B knob (sdxl_debug_set "igemm_wreg"): 0 = the auto selection never picks the weights-in-registers kernel
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
 void igemm_set_hl_weights_exact(int v); // A/B: 0 keeps all three MFMAs per product even where the packed weights are exact f16 values
 void igemm_set_epilogue_staged(int v);   // A/B: 1 forces the LDS-staged epilogue (default 0: direct row-per-lane epilogue on whole wave tiles)

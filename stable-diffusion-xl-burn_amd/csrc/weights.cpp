@@ -126,6 +126,9 @@ size_t WeightBuilder::arena_bound(const std::vector<ParamSpec>& specs, int dt) {
     else total += round_up(p.numel(), 128) * sizeof(float) + 256;
     if (p.kind == PK_LINEAR_W || p.kind == PK_CONV_W) total += round_up(p.kind == PK_LINEAR_W ? p.shape[1] : p.shape[0], 128) * 4 + 256;
     if (p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * 4 + 256;   // column sums of LayerNorm-folded projections
+    // fragment-order image of the f16 linear / 1x1 weights (attach_wfrag)
+    if (dt == DT_F16 && p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * round_up(p.shape[0], 64) * 2 + 256;
+    if (dt == DT_F16 && p.kind == PK_CONV_W && p.shape[2] == 1) total += round_up(p.shape[0], 128) * round_up((size_t)p.shape[1], 64) * 2 + 256;
   }
   return total;
 }
@@ -166,6 +169,16 @@ float WeightBuilder::hl_scale(Lin& l, const std::vector<std::string>& weight_nam
   return wscale;
 }
 
+// Plain f16 linear layers / 1x1 convolutions whose width is a multiple of 128 keep a second image of the packed weights in MFMA
+// fragment order: the weights-in-registers GEMM (igemm_wreg.hip) streams it straight into VGPRs.  Same bytes, same arena (so a
+// replica receives it with the weight broadcast); allocated on empty replicas too (identical arena layout).
+void WeightBuilder::attach_wfrag(Lin& l, bool fill) {
+  const int wdt = l.dt >= 0 ? l.dt : dt;
+  if (wdt != DT_F16 || l.ksize != 1 || l.N % 128 != 0 || l.K != l.Kpad || l.Kpad % 64 != 0 || l.Kpad < 128 || l.cs || l.acc_scale) return;
+  void* wf = arena.alloc((size_t)l.Npad * l.Kpad * 2);
+  l.wf = wf;
+  if (fill) launch_repack_wfrag(l.w, wf, l.Npad, l.Kpad, st);
+}
 Lin WeightBuilder::linear(const std::string& name, bool geglu, int dt_override) {
   const ParamSpec& s = spec(name + ".weight");
   Lin l; l.K = s.shape[0]; l.N = s.shape[1]; l.ksize = 1; l.cin = l.K;
@@ -178,10 +191,11 @@ Lin WeightBuilder::linear(const std::string& name, bool geglu, int dt_override) 
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   l.w = w; l.b = b;
   const float wscale = wdt == DT_HL ? hl_scale(l, {name + ".weight"}) : 1.f;
-  if (src.empty()) return l;
+  if (src.empty()) { if (!geglu) attach_wfrag(l, false); return l; }
   launch_pack_linear(fetch(name + ".weight"), w, wdt, l.K, l.N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st, nullptr, wscale);
   const float* bsrc = has(name + ".bias") ? fetch(name + ".bias") : nullptr;
   launch_pack_bias(bsrc, b, l.N, l.Npad, geglu ? 1 : 0, 0, st);
+  if (!geglu) attach_wfrag(l, true);
   return l;
 }
 Lin WeightBuilder::fused_linear(const std::vector<std::string>& names, int dt_override) {
@@ -296,9 +310,10 @@ Lin WeightBuilder::conv(const std::string& name) {
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   l.w = w; l.b = b;
   const float wscale = wdt == DT_HL ? hl_scale(l, {name + ".weight"}) : 1.f;
-  if (src.empty()) return l;
+  if (src.empty()) { attach_wfrag(l, false); return l; }
   launch_pack_conv(fetch(name + ".weight"), w, wdt, l.N, l.cin, l.ksize, l.Kpad, l.Npad, st, wscale);
   launch_pack_bias(fetch(name + ".bias"), b, l.N, l.Npad, 0, 0, st);
+  attach_wfrag(l, true);
   return l;
 }
 NormW WeightBuilder::norm(const std::string& name) {
@@ -320,7 +335,7 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   if (ex.dry) return false;
   SDXL_REQUIRE(cin == w.cin, "run_conv: channel mismatch");
   IgemmParams p{};
-  p.A = a.p; p.W = w.w; p.a_dt = a.dt;
+  p.A = a.p; p.W = w.w; p.Wf = w.wf; p.a_dt = a.dt;
   p.B = g.B; p.Hin = g.Hin; p.Win = g.Win; p.Cin = cin; p.lda = a.ld;
   p.Hout = g.Hout; p.Wout = g.Wout;
   p.ksize = g.ksize; p.stride = g.stride; p.pad = g.pad; p.up = g.up;

@@ -525,3 +525,67 @@ def test_igemm_variants_unet(pkg, ctx, igemm_variant, variant):
     u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), 1, seed=0)
     out = u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu()
     assert rel_err(out, ref) < 4.5e-3          # <= 2x the measured class (test_gpu_models.FWD_TOL)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# weights-in-registers GEMM (igemm_wreg.hip): plain f16 linear layers with N % 128 == 0, K % 64 == 0, K >= 128.  Variants 60 / 61 / 62
+# force 96 / 128 / 64 rows per tile.  Shapes: fewer k-tiles per group than the prefetch depth (K = 128 .. 512), odd k-tile counts (the
+# two k-groups carry different tile counts), ragged M tails, the UNet's own shapes, long contractions.
+WREG_SHAPES = [(300, 640, 640), (2048, 1280, 1280), (100, 128, 128), (4096, 320, 640), (96, 192, 256), (1000, 5120, 1280),
+               (33, 2560, 384), (257, 256, 128), (511, 448, 256), (64, 576, 128), (130, 704, 384), (2048, 1344, 256)]
+
+
+@pytest.mark.parametrize("variant", [60, 61, 62])
+def test_igemm_wreg_linear(pkg, ctx, igemm_variant, variant):
+    igemm_variant(variant)
+    for (M, K, N) in WREG_SHAPES:
+        x = seeded(M, K, seed=40)
+        w = seeded(K, N, seed=41) / math.sqrt(K)
+        b = 0.1 * seeded(N, seed=42)
+        ref = x @ w + b
+        out = pkg.linear(ctx, x.cuda(), w.cuda(), b.cuda(), False, 1)
+        e = rel_err(out, ref)
+        assert e < TOL[1], f"variant {variant} M={M} K={K} N={N}: rel err {e}"
+
+
+def test_igemm_wreg_exact_and_tile_independent(pkg, ctx, igemm_variant):
+    # small-integer operands: every product and every partial sum is exact in f16 x f16 -> f32, so ANY kernel must return the same
+    # bits -- a stale fragment register or a tile read before it landed shows up as a wrong integer.  And on general data the three
+    # tile heights of the weights-in-registers kernel share one k-summation order (even k-tiles + odd k-tiles): bit-identical.
+    g = torch.Generator().manual_seed(3)
+    for (M, K, N) in WREG_SHAPES:
+        xi = torch.randint(-4, 5, (M, K), generator=g).float()
+        wi = torch.randint(-3, 4, (K, N), generator=g).float()
+        bi = torch.randint(-8, 9, (N,), generator=g).float()
+        ref = xi @ wi + bi
+        x = seeded(M, K, seed=40)
+        w = seeded(K, N, seed=41) / math.sqrt(K)
+        outs = []
+        for variant in (60, 61, 62, 0):
+            igemm_variant(variant)
+            for rep in range(2):
+                o = pkg.linear(ctx, xi.cuda(), wi.cuda(), bi.cuda(), False, 1).cpu()
+                assert torch.equal(o, ref), f"variant {variant} M={M} K={K} N={N}: {(o != ref).sum().item()} wrong integers"
+            if variant:
+                outs.append(pkg.linear(ctx, x.cuda(), w.cuda(), None, False, 1))
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), f"M={M} K={K} N={N}: tile heights differ"
+
+
+def test_igemm_wreg_row_statistics_match_the_pipe_kernels(pkg, ctx):
+    # the statistics a producer leaves for the next folded LayerNorm must not depend on the kernel that produced the rows: the
+    # identity projection's output is exact, so the folded-LayerNorm consumer sees bit-identical statistics -- and returns
+    # bit-identical results -- with the weights-in-registers kernel (wave-pair exchange of pivot and sums) on or off
+    for (M, K, N) in [(300, 1280, 1280), (2048, 640, 640), (96, 128, 256)]:
+        x = (seeded(M, K, seed=11) * 1.5 + 0.3).half().float()
+        gamma, beta = 1 + 0.1 * seeded(K, seed=5), 0.1 * seeded(K, seed=6)
+        w = seeded(K, N, seed=8) / math.sqrt(K)
+        outs = []
+        for on in (1, 0):
+            pkg.debug_set("igemm_wreg", on)
+            try:
+                outs.append(pkg.layer_norm_linear(ctx, x.cuda(), gamma.cuda(), beta.cuda(), w.cuda(), None, 1e-5, False, 1))
+            finally:
+                pkg.debug_set("igemm_wreg", 1)
+        ref = OM.layer_norm(x, gamma, beta, 1e-5) @ w
+        assert rel_err(outs[0], ref) < TOL[1]
+        assert torch.equal(outs[0], outs[1]), f"M={M} K={K} N={N}: row statistics differ between the producers"

@@ -17,6 +17,14 @@ Third rule: no `s_barrier` while an LDS write of the wave is still in the queue 
 Second rule: an LDS-DMA instruction (`global_load_lds_*`) must not issue directly behind a write of M0 (the compiler's hazard
 recogniser guarantees that for the builtin form, not inside inline asm).
 
+Fourth rule (round 4, igemm_wreg.hip): the same replay for the VM queue.  The weights-in-registers GEMM issues its weight fragments as
+inline-asm `global_load_dwordx4` and waits for them with hand-counted `s_waitcnt vmcnt(N)`; every VMEM operation (loads, LDS-DMA,
+stores, atomics) enters the in-order queue, asm loads with their destination registers, `vmcnt(N)` retires all but the N youngest,
+and any instruction that touches a pending asm destination is reported (a younger VMEM load that only overwrites it is consistent:
+returns are in order).  Unlike the LGKM queue this one survives labels -- the weights stay in flight across loop back edges: at a
+label reached by fall-through the state is kept, behind an unconditional branch it is the state of the first forward branch to that
+label, and every backward branch replays its loop body once with the state it arrives with (the steady state of the k-loop).
+
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -x hip --cuda-device-only -S csrc/igemm_glds.hip -o /tmp/glds.s
     python tools/asm_lint.py /tmp/glds.s            -> exit status 1 if anything is reported
 """
@@ -109,10 +117,113 @@ def lint(path):
     return findings
 
 
+VMEM = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "flat_load", "flat_store",
+        "flat_atomic", "scratch_load", "scratch_store")
+
+
+def lint_vm(path):
+    """fourth rule: pending inline-asm global loads vs hand-counted vmcnt (see the module docstring)"""
+    funcs, cur, in_asm = [], None, False
+    for ln, raw in enumerate(open(path), 1):
+        line = raw.strip()
+        if not line:
+            continue
+        if line.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if line.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"(\.LBB\d+_\d+):", line)
+        if m:
+            if cur is not None:
+                cur["ins"].append(dict(label=m.group(1), line=ln))
+            continue
+        if line.startswith(";") or line.startswith("."):
+            continue
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m:
+            cur = dict(name=m.group(1), ins=[])
+            funcs.append(cur)
+            continue
+        code = line.split(";")[0].strip()
+        if code and cur is not None:
+            parts = code.split(None, 1)
+            cur["ins"].append(dict(mn=parts[0], ops=[o.strip() for o in parts[1].split(",")] if len(parts) > 1 else [], code=code, line=ln, asm=in_asm))
+    findings = []
+    for f in funcs:
+        ins = f["ins"]
+        if not any(i.get("asm") and i.get("mn", "").startswith("global_load") for i in ins):
+            continue
+        label_at = {i["label"]: k for k, i in enumerate(ins) if "label" in i}
+        saved, replayed, seen = {}, set(), set()
+
+        def step(k, q):
+            i = ins[k]
+            mn, ops, code = i["mn"], i["ops"], i["code"]
+            if mn == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", code)
+                if m:
+                    n = int(m.group(1))
+                    del q[:max(0, len(q) - n)]
+                return
+            has_dst = not mn.startswith(NO_DST)
+            written = regs(ops[0]) if (has_dst and ops) else set()
+            read = set().union(*[regs(o) for o in (ops[1:] if has_dst else ops)]) if ops else set()
+            is_vm = mn.startswith(VMEM)
+            is_vm_load = is_vm and "_load" in mn and "lds" not in mn
+            for e in q:
+                hit = (read & e["dst"]) | (set() if is_vm_load else (written & e["dst"]))
+                if e["asm"] and hit:
+                    key = (i["line"], e["line"])
+                    if key not in seen:
+                        seen.add(key)
+                        what = "reads" if read & e["dst"] else "overwrites"
+                        findings.append(f"{f['name']}: line {i['line']}: `{code}` {what} {sorted(hit)[:4]} of the inline-asm `{e['text']}` "
+                                        f"(line {e['line']}) before any vmcnt wait covers it")
+                    break
+            if is_vm:
+                q.append(dict(dst=written if (is_vm_load and i["asm"]) else set(), asm=i["asm"] and is_vm_load, line=i["line"], text=code))
+
+        def walk(k0, k1, q, top):
+            k, fall = k0, True
+            while k < k1:
+                i = ins[k]
+                if "label" in i:
+                    if not fall:
+                        q[:] = [dict(e) for e in saved.get(i["label"], [])]
+                    fall = True
+                    k += 1
+                    continue
+                if not fall:
+                    k += 1
+                    continue
+                mn = i["mn"]
+                if mn in ("s_endpgm", "s_setpc_b64"):
+                    fall = False
+                elif mn == "s_branch" or mn.startswith("s_cbranch"):
+                    tgt = i["ops"][0] if i["ops"] else None
+                    if tgt in label_at:
+                        if label_at[tgt] > k:
+                            saved.setdefault(tgt, [dict(e) for e in q])
+                        elif top and k not in replayed:
+                            replayed.add(k)
+                            q2 = [dict(e) for e in q]
+                            walk(label_at[tgt], k, q2, False)
+                    if mn == "s_branch":
+                        fall = False
+                else:
+                    step(k, q)
+                k += 1
+
+        walk(0, len(ins), [], True)
+    return findings
+
+
 if __name__ == "__main__":
     bad = []
     for p in sys.argv[1:]:
-        f = lint(p)
+        f = lint(p) + lint_vm(p)
         print(f"{p}: {len(f)} finding(s)")
         for x in f[:40]:
             print("  " + x)
