@@ -197,7 +197,10 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
   }
 }
 
-template <int BM, int L>
+// MODE (measure builds, forced variants 63 ..): 0 production; knock-outs that time one resource alone (results are garbage):
+// 1 no MFMAs, 2 operand pointers frozen (every fetch after the first hits the L1 / L2: same instruction stream, no fabric traffic),
+// 3 no VMEM at all in the k-loop, 4 no k-loop barriers; 5 = production arithmetic with the other XCD ownership (row tiles)
+template <int BM, int L, int MODE = 0>
 __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, const void* zeros) {
   kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();
   constexpr int NG = 2;                       // k-groups per workgroup
@@ -229,7 +232,8 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   }
   // an XCD (private L2) owns a run of consecutive remapped ids = all row tiles of a few weight column tiles: the weight panel of
   // a column tile is read from HBM by one XCD only and its row tiles find it in that L2
-  const int tn = bid / tilesM, tm = bid - tn * tilesM;
+  int tn = bid / tilesM, tm = bid - tn * tilesM;
+  if constexpr (MODE == 5) { const int tilesN = p.N >> 7; tm = bid / tilesN; tn = bid - tm * tilesN; }
   const int m0 = tm * BM, n0 = tn * 128;
   const int nk = p.Kpad >> 6;
   const int nkg = (nk - g + 1) >> 1;          // k-tiles of this group: g, g + 2, ...
@@ -237,10 +241,11 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   // ---- weight stream: this wave's 32 columns, fragment order, contiguous over k
   const half_t* wp = reinterpret_cast<const half_t*>(p.Wf) + ((size_t)((n0 >> 5) + w) * nk + g) * 2048 + lane * 8;
   half8 Wr[NSG][4];
+  if constexpr (MODE == 3) { static_for<NSG>([&](auto S_) { static_for<4>([&](auto K_) { Wr[decltype(S_)::value][decltype(K_)::value] = half8{1, 1, 1, 1, 1, 1, 1, 1}; }); }); }
   auto loadW = [&](auto S, auto KK) {
     constexpr int s = decltype(S)::value, kk = decltype(KK)::value;
-    Wr[s][kk] = wreg_gload128<kk * 1024>(wp);
-    if constexpr (kk == 3) wp += NG * 2048;
+    if constexpr (MODE != 3) Wr[s][kk] = wreg_gload128<kk * 1024>(wp);
+    if constexpr (kk == 3 && MODE != 2) wp += NG * 2048;
   };
   // ---- activation pieces: piece q of this wave = tile rows (4 q + w) * 8 .. + 7 of the group's k-tile; lane -> (row, 16-byte slot)
   const half_t* Ag = reinterpret_cast<const half_t*>(p.A);
@@ -259,8 +264,8 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   };
   auto pieceA = [&](auto S, auto Q) {
     constexpr int s = decltype(S)::value, q = decltype(Q)::value;
-    __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(ring + s * SLOT + (q * 4 + w) * 1024), 16, 0, 0);
-    aptr[q] += aadv[q];
+    if constexpr (MODE != 3) __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(ring + s * SLOT + (q * 4 + w) * 1024), 16, 0, 0);
+    if constexpr (MODE != 2) aptr[q] += aadv[q];
   };
   // operation x of a k-tile's VMEM sequence: 0..3 weight fragments, 4.. activation pieces
   auto vmem_op = [&](auto S, auto X) {
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     constexpr int set = decltype(SET)::value, s = decltype(S)::value, kk = decltype(KK)::value, x0 = decltype(X0)::value;
     static_for<TM>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[s][kk], fA[set][i], acc[i], 0, 0, 0);
+      if constexpr (MODE != 1) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[s][kk], fA[set][i], acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (x0 >= 0 && x0 + i < NOPS) {
         vmem_op(SF, std::integral_constant<int, x0 + i>{});
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     if constexpr (steady || D > 1) {
       wait_vmcnt<steady ? (L - 1) * U : (D - 2) * U>();                // own pieces of tile j + 1 have landed
       wait_lgkmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+      if constexpr (MODE != 4) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       ldsA(I0{}, SN{}, I0{});
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     if (D <= nkg) ktile(std::integral_constant<int, L + 1 - D>{}, std::integral_constant<int, D>{});
   });
   // odd k-tile count: group 1 has one tile -- and one rendezvous -- less; barrier counts must match across the workgroup
-  if ((nk & 1) && g == 1) __builtin_amdgcn_s_barrier();
+  if constexpr (MODE != 4) { if ((nk & 1) && g == 1) __builtin_amdgcn_s_barrier(); }
   __builtin_amdgcn_s_barrier();                    // both rings are dead: they become the exchange area
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -425,19 +430,19 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
 static std::atomic<int> g_wreg_enable{1};
 void igemm_set_wreg(int v) { g_wreg_enable = v; }
 
-template <int BM, int L>
+template <int BM, int L, int MODE = 0>
 static void launch_wreg_t(const IgemmParams& p, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (L + 1) * BM * 128;
   static_assert(lds >= (size_t)4 * (BM / 32) * 4096 + (size_t)6 * BM * 4, "exchange areas must fit the dead rings");
   static bool attr_set[kIgemmMaxDev] = {};
   const int dev = igemm_current_device();
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wreg_kernel<BM, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wreg_kernel<BM, L, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       throw std::runtime_error("igemm_wreg: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     attr_set[dev] = true;
   }
   const int tilesM = (p.M + BM - 1) / BM, tilesN = p.N / 128;
-  hipLaunchKernelGGL((igemm_wreg_kernel<BM, L>), dim3(tilesM * tilesN), dim3(512), lds, s, p, igemm_zero_page());
+  hipLaunchKernelGGL((igemm_wreg_kernel<BM, L, MODE>), dim3(tilesM * tilesN), dim3(512), lds, s, p, igemm_zero_page());
 }
 
 // shapes this kernel takes: plain f16 linear layers / 1x1 convolutions whose weights were also packed in fragment order
@@ -454,23 +459,40 @@ bool igemm_wreg_ok(const IgemmParams& p) {
   if (p.stat_out && p.c_dt != DT_F16) return false;
   return true;
 }
-// variant 0: rows per tile from the grid it makes on 256 CUs (the k-summation order does not depend on it); 60 / 61 / 62 force
-// 96 / 128 / 64 rows
+// variant 0: rows per tile from the grid it makes on 256 CUs (the k-summation order does not depend on it); 60 / 62 force 96 / 64
+// rows.  (A 128-row tile -- 64 accumulators + 4 weight stages + 2 x 4 fragments -- spilled fragment registers that were still in
+// flight and was 30 - 75 % slower than the 96-row tile on every shape of the step: removed, profiles/r04_wreg_first_ab.txt.)
 bool launch_igemm_wreg(const IgemmParams& p, int variant, hipStream_t s) {
   if (!igemm_wreg_ok(p)) return false;
-  if (variant == 0 && !g_wreg_enable.load()) return false;
-  int bm = variant == 60 ? 96 : variant == 61 ? 128 : variant == 62 ? 64 : 0;
+  if (variant == 0) {
+    if (!g_wreg_enable.load()) return false;
+    // where it pays (profiles/r04_wreg_first_ab.txt): grids of at most one round of 96-row tiles -- the 32^2 level of the UNet
+    // (220 workgroups: 16.0 vs 18.2 us out-projection, 42.4 vs 47.8 us FF-out, cold weights) and everything smaller; at the 64^2
+    // level (430 tiles) the 128x160 / 256x128 pipe kernels' whole-round grids win.  Evaluated on the CFG PAIR's shape (2 entries of
+    // rpb rows) whatever the actual batch: the two structures sum k in different orders, and an entry must come out bit-identical
+    // alone or batched.
+    const long rows = 2L * (p.rpb > 0 ? p.rpb : p.M);
+    if (((rows + 95) / 96) * (long)(p.N / 128) > 256) return false;
+  }
+#ifdef SDXL_MEASURE
+  if (variant >= 63 && variant <= 67) {     // knock-out timing modes of the 96-row kernel (garbage results except 67)
+    if (variant == 63) launch_wreg_t<96, 4, 1>(p, s); else if (variant == 64) launch_wreg_t<96, 4, 2>(p, s);
+    else if (variant == 65) launch_wreg_t<96, 4, 3>(p, s); else if (variant == 66) launch_wreg_t<96, 4, 4>(p, s);
+    else launch_wreg_t<96, 4, 5>(p, s);
+    return true;
+  }
+#endif
+  int bm = variant == 60 ? 96 : variant == 62 ? 64 : 0;
   if (!bm) {
     double best = 1e300;
-    for (int c : {64, 96, 128}) {
+    for (int c : {64, 96}) {
       const long tiles = (long)((p.M + c - 1) / c) * (p.N / 128);
       const double cost = (double)((tiles + 255) / 256) * (c + 40);
       if (cost < best) { best = cost; bm = c; }
     }
   }
   if (bm == 64) launch_wreg_t<64, 4>(p, s);
-  else if (bm == 96) launch_wreg_t<96, 4>(p, s);
-  else launch_wreg_t<128, 3>(p, s);
+  else launch_wreg_t<96, 4>(p, s);
   return true;
 }
 

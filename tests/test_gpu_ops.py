@@ -535,7 +535,7 @@ WREG_SHAPES = [(300, 640, 640), (2048, 1280, 1280), (100, 128, 128), (4096, 320,
                (33, 2560, 384), (257, 256, 128), (511, 448, 256), (64, 576, 128), (130, 704, 384), (2048, 1344, 256)]
 
 
-@pytest.mark.parametrize("variant", [60, 61, 62])
+@pytest.mark.parametrize("variant", [60, 62])
 def test_igemm_wreg_linear(pkg, ctx, igemm_variant, variant):
     igemm_variant(variant)
     for (M, K, N) in WREG_SHAPES:
@@ -561,14 +561,14 @@ def test_igemm_wreg_exact_and_tile_independent(pkg, ctx, igemm_variant):
         x = seeded(M, K, seed=40)
         w = seeded(K, N, seed=41) / math.sqrt(K)
         outs = []
-        for variant in (60, 61, 62, 0):
+        for variant in (60, 62, 0):
             igemm_variant(variant)
             for rep in range(2):
                 o = pkg.linear(ctx, xi.cuda(), wi.cuda(), bi.cuda(), False, 1).cpu()
                 assert torch.equal(o, ref), f"variant {variant} M={M} K={K} N={N}: {(o != ref).sum().item()} wrong integers"
             if variant:
                 outs.append(pkg.linear(ctx, x.cuda(), w.cuda(), None, False, 1))
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), f"M={M} K={K} N={N}: tile heights differ"
+        assert torch.equal(outs[0], outs[1]), f"M={M} K={K} N={N}: tile heights differ"
 
 
 def test_igemm_wreg_row_statistics_match_the_pipe_kernels(pkg, ctx):
