@@ -230,10 +230,15 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  // an XCD (private L2) owns a run of consecutive remapped ids = all row tiles of a few weight column tiles: the weight panel of
-  // a column tile is read from HBM by one XCD only and its row tiles find it in that L2
-  int tn = bid / tilesM, tm = bid - tn * tilesM;
-  if constexpr (MODE == 5) { const int tilesN = p.N >> 7; tm = bid / tilesN; tn = bid - tm * tilesN; }
+  // an XCD (private L2) owns a run of consecutive remapped ids = a few ROW tiles and sweeps every weight column tile under them:
+  // with M >= N (every shape this kernel is selected for) that is the ownership that brings fewer bytes into an XCD's L2 --
+  // (M / 8 + N) K instead of (N / 8 + M) K -- and the weights a second XCD asks for come out of the memory-side Infinity Cache,
+  // not out of HBM again.  Measured against column ownership (MODE 5) on the step's shapes, cold / warm weights: 16.0 / 14.2 vs
+  // 16.4 / 15.3 us (out-projection), 42.0 / 37.3 vs 42.7 / 39.2 us (FF-out), 142.8 / 123.7 vs 147.8 / 131.5 us at K = 20480
+  // (profiles/r04_wreg_knockout.txt).
+  const int tilesN = p.N >> 7;
+  int tm = bid / tilesN, tn = bid - tm * tilesN;
+  if constexpr (MODE == 5) { tn = bid / tilesM; tm = bid - tn * tilesM; }
   const int m0 = tm * BM, n0 = tn * 128;
   const int nk = p.Kpad >> 6;
   const int nkg = (nk - g + 1) >> 1;          // k-tiles of this group: g, g + 2, ...
@@ -338,6 +343,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     static_for<TM>([&](auto I) {
       constexpr int i = decltype(I)::value;
       if constexpr (MODE != 1) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[s][kk], fA[set][i], acc[i], 0, 0, 0);
+      else asm volatile("" ::"v"(Wr[s][kk]), "v"(fA[set][i]));      // (keeps the in-flight destination registers allocated up to here)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (x0 >= 0 && x0 + i < NOPS) {
         vmem_op(SF, std::integral_constant<int, x0 + i>{});

@@ -520,3 +520,29 @@ def test_production_gemm_assembly_has_no_async_read_hazard(tmp_path):
     findings = asm_lint.lint(out2)
     assert not findings, "\n".join(findings[:10])
     assert "attn_d64_mix_kernel" in open(out2).read()
+
+
+def test_weights_in_registers_gemm_assembly_has_no_async_load_hazard(tmp_path):
+    """the same lint over igemm_wreg.hip, plus its VM-queue rule: the weight fragments are inline-asm `global_load_dwordx4` with
+    hand-counted `s_waitcnt vmcnt`, so no instruction may touch a fragment register between its load and the wait that covers it (a
+    128-row build of this kernel spilled in-flight fragment registers to scratch -- wrong results on the GPU, four findings here)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_lint
+    src, out = os.path.join(ROOT, "stable-diffusion-xl-burn_amd", "csrc", "igemm_wreg.hip"), str(tmp_path / "igemm_wreg.s")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out,
+                        "-Wno-unused-function"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    findings = asm_lint.lint(out) + asm_lint.lint_vm(out)
+    assert not findings, "\n".join(findings[:10])
+    text = open(out).read()
+    assert "igemm_wreg_kernel" in text and text.count("global_load_dwordx4") > 100 and ".vgpr_spill_count: 0" in text
+    # the kernels must keep two waves per SIMD (<= 256 registers) without spilling
+    import re
+    for m in re.finditer(r"\.name:\s+(\S*igemm_wreg_kernel\S*).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", text, re.S):
+        assert int(m.group(2)) <= 256 and int(m.group(3)) == 0, m.group(0)[:200]

@@ -554,17 +554,21 @@ def test_igemm_wreg_exact_and_tile_independent(pkg, ctx, igemm_variant):
     # tile heights of the weights-in-registers kernel share one k-summation order (even k-tiles + odd k-tiles): bit-identical.
     g = torch.Generator().manual_seed(3)
     for (M, K, N) in WREG_SHAPES:
-        xi = torch.randint(-4, 5, (M, K), generator=g).float()
-        wi = torch.randint(-3, 4, (K, N), generator=g).float()
-        bi = torch.randint(-8, 9, (N,), generator=g).float()
-        ref = xi @ wi + bi
+        # (two data sets, alternating: what a stale register or LDS tile holds from the previous launch is then WRONG data)
+        sets = []
+        for _ in range(2):
+            xi = torch.randint(-4, 5, (M, K), generator=g).float()
+            wi = torch.randint(-3, 4, (K, N), generator=g).float()
+            bi = torch.randint(-8, 9, (N,), generator=g).float()
+            sets.append((xi.cuda(), wi.cuda(), bi.cuda(), xi @ wi + bi))
         x = seeded(M, K, seed=40)
         w = seeded(K, N, seed=41) / math.sqrt(K)
         outs = []
         for variant in (60, 62, 0):
             igemm_variant(variant)
-            for rep in range(2):
-                o = pkg.linear(ctx, xi.cuda(), wi.cuda(), bi.cuda(), False, 1).cpu()
+            for rep in range(4):
+                xi, wi, bi, ref = sets[rep & 1]
+                o = pkg.linear(ctx, xi, wi, bi, False, 1).cpu()
                 assert torch.equal(o, ref), f"variant {variant} M={M} K={K} N={N}: {(o != ref).sum().item()} wrong integers"
             if variant:
                 outs.append(pkg.linear(ctx, x.cuda(), w.cuda(), None, False, 1))

@@ -75,11 +75,15 @@ def lint(path):
             m = re.search(r"lgkmcnt\((\d+)\)", code)
             if m:
                 n = int(m.group(1))
-                if any(e["smem"] for e in queue):
-                    if n == 0:
-                        queue = []
+                if n == 0:
+                    queue = []
                 else:
-                    queue = queue[len(queue) - n:] if n else []
+                    # LDS operations return in order among themselves, SMEM in any order: lgkmcnt(N) leaves at most N operations
+                    # outstanding, hence at most N LDS operations -- the oldest LDS entries beyond that have landed whatever the
+                    # SMEM entries did; the SMEM entries themselves stay pending until lgkmcnt(0)
+                    lds = [e for e in queue if not e["smem"]]
+                    done = set(id(e) for e in lds[:max(0, len(lds) - n)])
+                    queue = [e for e in queue if id(e) not in done]
             continue
         # third rule: a raw s_barrier waits for nothing -- an LDS write of this wave that is still in the queue may not have landed when
         # the barrier releases its readers
@@ -156,7 +160,11 @@ def lint_vm(path):
         if not any(i.get("asm") and i.get("mn", "").startswith("global_load") for i in ins):
             continue
         label_at = {i["label"]: k for k, i in enumerate(ins) if "label" in i}
-        saved, replayed, seen = {}, set(), set()
+        loop_heads = set()
+        for k, i in enumerate(ins):
+            if i.get("mn", "").startswith(("s_cbranch", "s_branch")) and i["ops"] and i["ops"][0] in label_at and label_at[i["ops"][0]] < k:
+                loop_heads.add(i["ops"][0])
+        replayed, seen = set(), set()
 
         def step(k, q):
             i = ins[k]
@@ -185,33 +193,28 @@ def lint_vm(path):
             if is_vm:
                 q.append(dict(dst=written if (is_vm_load and i["asm"]) else set(), asm=i["asm"] and is_vm_load, line=i["line"], text=code))
 
+        # join points of forward branches drop the queue (as the LGKM rule does: which of the predecessors ran is not known, and a
+        # guessed one reports hazards on paths that cannot execute); a loop header keeps the state it is entered with, and every
+        # backward branch replays its body once with the state it arrives with -- the steady state of the k-loop
         def walk(k0, k1, q, top):
-            k, fall = k0, True
+            k = k0
             while k < k1:
                 i = ins[k]
                 if "label" in i:
-                    if not fall:
-                        q[:] = [dict(e) for e in saved.get(i["label"], [])]
-                    fall = True
-                    k += 1
-                    continue
-                if not fall:
+                    if i["label"] not in loop_heads or k != k0 and not top:
+                        q[:] = []
+                    elif i["label"] not in loop_heads:
+                        q[:] = []
                     k += 1
                     continue
                 mn = i["mn"]
-                if mn in ("s_endpgm", "s_setpc_b64"):
-                    fall = False
-                elif mn == "s_branch" or mn.startswith("s_cbranch"):
+                if mn in ("s_endpgm", "s_setpc_b64", "s_branch"):
+                    q[:] = []
+                elif mn.startswith("s_cbranch"):
                     tgt = i["ops"][0] if i["ops"] else None
-                    if tgt in label_at:
-                        if label_at[tgt] > k:
-                            saved.setdefault(tgt, [dict(e) for e in q])
-                        elif top and k not in replayed:
-                            replayed.add(k)
-                            q2 = [dict(e) for e in q]
-                            walk(label_at[tgt], k, q2, False)
-                    if mn == "s_branch":
-                        fall = False
+                    if tgt in label_at and label_at[tgt] < k and top and k not in replayed:
+                        replayed.add(k)
+                        walk(label_at[tgt] + 1, k, [dict(e) for e in q], False)
                 else:
                     step(k, q)
                 k += 1

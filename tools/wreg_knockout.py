@@ -14,6 +14,7 @@ for cold in (1, 0):
     for name, B, H, W, Cin, Cout in S:
         row = f"{name}     "
         for n, v in V:
+            print(f"[{name.strip()} {n}]", file=sys.stderr, flush=True)
             pkg.debug_set("igemm_variant", v)
             ms = min(pkg.bench_igemm(ctx, B, H, W, Cin, Cout, 1, 4 | (8 if cold else 0), 20) for _ in range(2))
             row += f"{ms*1e3:9.1f}"
