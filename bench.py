@@ -195,6 +195,7 @@ def cpu_baseline(res: int, budget_s: float = 30.0):
     scale = (res / 1024.0) ** 2
     tflop_image = (62 * TFLOP_PER_UNET_FWD_1024 + TFLOP_VAE_DECODE_1024) * scale
     return {"value": tf_per_s / tflop_image, "unit": "images/sec", "cores": threads, "kind": "port",
+            "method": "oracle, one UNet forward timed end to end, images/sec extrapolated by FLOPs",
             "sample": (f"ONE full oracle UNet::forward at {res}x{res} (B=1, {fwd_tf:.3f} TFLOP) timed end to end: {dt_:.1f} s = {tf_per_s:.3f} TFLOP/s on "
                        f"{threads} threads (host reports {os.cpu_count()} cpus, {cores} usable; output finite: {bool(torch.isfinite(out).all())}); "
                        f"images/sec = that rate over the {tflop_image:.1f} TFLOP of one image (31 CFG step pairs = 62 forwards + VAE decode)"),
@@ -244,7 +245,7 @@ def load_parity():
     STATIC part of the line's parity object -- what live_parity() below does not re-measure in this run"""
     out = {}
     try:
-        name = next(n for n in ("r03_parity_baseline.json", "r02_parity_baseline.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r04_parity_baseline.json", "r03_parity_baseline.json", "r02_parity_baseline.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as fh:
             r = json.load(fh)
         c1 = r.get("config1_f32_vs_oracle", {}).get("final")
@@ -628,7 +629,7 @@ def main():
     # HBM-side traffic of the same launches: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_step.py,
     # summarised by tools/pmc_traffic.py (gfx950 correction applied there); null when no committed summary exists
     traffic, traffic_src = None, None
-    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and args.dtype == "f16" and res == 1024:
             try:
@@ -660,7 +661,10 @@ def main():
                     cpu["value"] = cpu["tflops"] / tflop_image
                     cpu["sample"] += f"; rescaled to this config's {tflop_image:.1f} TFLOP per image"
         p50 = statistics.median(step_ms) if step_ms else None
-        parity, strict = load_parity(), None
+        # `live` (and `strict_f32`) are measured in THIS run; `committed_report` is the static summary of the parity tests' last
+        # recorded run under profiles/ -- context, not a measurement of this run
+        committed, strict = load_parity(), None
+        parity = {"committed_report": committed} if committed else None
         if args.config == 2 and res == 1024 and world == 1 and npc == 1 and not args.no_live_parity:
             try:
                 live, strict = live_parity(pkg, ctx, diffuser, decoder, args.dtype, args.vae_dtype)
@@ -681,7 +685,9 @@ def main():
                        "weights": "synthetic seeded (random-init SDXL-base architecture)",
                        "parallelism": f"replica x{world}, 1 prompt per GPU, weights broadcast once over RCCL",
                        "hipgraph": not args.no_graph, "split_cfg": bool(args.split_cfg), "fused_xattn": not args.unfused_xattn,
-                       "pipelined_decode": bool(pipelined), "prompts_per_call": npc},
+                       "pipelined_decode": bool(pipelined), "prompts_per_call": npc,
+                       # which build of the engine ran (SDXL_LIB_PATH / SDXL_MEASURE_LIB swap it: tools only) and the A/B knobs in force
+                       "library": os.path.relpath(pkg.LIB_PATH, ROOT), "debug_set": os.environ.get("SDXL_DEBUG_SET", "")},
             "images_per_sec_per_gpu": round(value / world, 4),
             "unet_step_ms_p50": None if p50 is None else round(p50, 3),
             "vae_dtype": args.vae_dtype, "decode_ms": round(decode_ms, 2),
