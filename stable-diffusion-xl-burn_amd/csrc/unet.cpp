@@ -295,7 +295,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   float* stbuf[2] = {nullptr, nullptr};
   if (fuse_ln_) for (int i = 0; i < 2; ++i) stbuf[i] = (float*)ex.act->alloc(M * (size_t)(C / 64) * 2 * sizeof(float));
   int stp = 0;
-  { Epi ep; ep.stat_out = w.blocks.empty() ? nullptr : stbuf[stp]; run_linear(ex, w.proj_in, gn, (int)M, t, ep); }
+  { Epi ep; ep.stat_out = w.blocks.empty() ? nullptr : stbuf[stp]; ep.rpb = HW; run_linear(ex, w.proj_in, gn, (int)M, t, ep); }   // (rpb: kernel selection looks at ONE entry's rows)
   Act ln = ex.alloc(M, C, ex.cdt);
   // (split-operand mode: the projections write q | k and V^T as HL16 -- 4 bytes per element like fp32 -- what attention_hl reads)
   // (HL16 pieces are 8 keys wide: token counts that are not multiples of 8 -- tiny test nets -- go through fp32 + a conversion)
