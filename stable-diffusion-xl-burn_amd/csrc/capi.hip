@@ -165,6 +165,7 @@ int sdxl_debug_set(const char* key, int value) {
   else if (std::strcmp(key, "igemm_wreg") == 0) igemm_set_wreg(value);
 #ifdef SDXL_MEASURE
   else if (std::strcmp(key, "igemm_unrolled") == 0) igemm_set_unrolled(value);
+  else if (std::strcmp(key, "xa_vec64") == 0) igemm_set_xa_vec64(value);
   else if (std::strcmp(key, "no_cfg") == 0) g_debug_no_cfg = value != 0;
 #endif
   else throw Error(std::string("unknown debug key ") + key);

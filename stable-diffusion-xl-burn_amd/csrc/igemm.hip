@@ -346,6 +346,8 @@ bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s);             // 
 bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s);              // igemm_glds.hip (split-operand fp32-class mode)
 static std::atomic<int> g_igemm_variant_a{0};   // test hook (sdxl_debug_set "igemm_variant"): -1 generic kernel only, 0 auto, >0 forced tile
 void igemm_set_variant(int v) { g_igemm_variant_a = v; }
+static std::atomic<int> g_xa_vec64{0};
+void igemm_set_xa_vec64(int v) { g_xa_vec64 = v; }
 static std::atomic<int> g_igemm_epi_staged{0};
 void igemm_set_epilogue_staged(int v) { g_igemm_epi_staged = v; }
 static std::atomic<int> g_hl_wexact{1};
@@ -355,6 +357,7 @@ void launch_igemm(const IgemmParams& pin, int compute_dt, hipStream_t s) {
   if (pin.M <= 0 || pin.N <= 0) return;
   IgemmParams p = pin;
   p.epi_staged = g_igemm_epi_staged.load();
+  p.xa_vec64 = g_xa_vec64.load();
   p.hl_wexact_ok = g_hl_wexact.load();
   const int g_igemm_variant = g_igemm_variant_a.load();
   if (compute_dt == DT_F16 && g_igemm_variant >= 0 && launch_igemm_glds(p, g_igemm_variant, s)) return;

@@ -891,6 +891,14 @@ __device__ __forceinline__ void xattn_inplace(const IgemmParams& p, f32x16 (&acc
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int nbu = nw + j * 32 + 8 * q;
+#ifdef SDXL_MEASURE
+      if (p.xa_vec64) {     // the ORIGINAL form: a 64-lane VMEM request whose lanes of one half all ask for the same 16 bytes (hazard experiment)
+        const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
+        cz[j][q] = *(p.ln_stat ? reinterpret_cast<const f32x4*>(p.ln_cs + nbu + 4 * fh) : zv);
+        bz[j][q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nbu + 4 * fh) : zv);
+        continue;
+      }
+#endif
       cz[j][q] = col_vec4(p.ln_cs, p.ln_stat != nullptr, nbu, fh, zeros);
       bz[j][q] = col_vec4(p.bias, p.bias != nullptr, nbu, fh, zeros);
     }

@@ -62,6 +62,8 @@ struct IgemmParams {
   const float* acc_scale;   /* [0] = 1 / weight scale, [1] != 0: every packed weight is exactly one f16 (lo halves all zero) */  // DT_HL compute: the packed weights carry a power-of-two factor (exact); device scalar 1 / factor the epilogue multiplies the
                            // accumulators by (lives in the weight arena, so replicas that receive the arena by broadcast need no host copy); null = 1
   int hl_wexact_ok; // A/B knob (sdxl_debug_set "hl_weights_exact", default 1): split-operand launches may leave out the w_lo MFMAs when acc_scale[1] says every weight is one f16
+  int xa_vec64;     // measure builds (sdxl_debug_set "xa_vec64"): the fused cross-attention epilogue reads its per-column vectors with the original 64-lane
+                    // VMEM loads instead of the scalar cache -- the hazard experiment of DESIGN 9.2 / 10.4
   int epi_staged;   // A/B knob (sdxl_debug_set "igemm_epilogue_staged"): 1 = LDS-staged epilogue everywhere, 0 = direct row-per-lane where it applies
 };
 bool igemm_gn_part_ok(const IgemmParams& p);
@@ -82,6 +84,7 @@ bool igemm_wreg_ok(const IgemmParams& p);   // shapes the weights-in-registers k
 void igemm_set_wreg(int v);      // A/B knob (sdxl_debug_set "igemm_wreg"): 0 = the auto selection never picks the weights-in-registers kernel
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
 void igemm_set_hl_weights_exact(int v); // A/B: 0 keeps all three MFMAs per product even where the packed weights are exact f16 values
+void igemm_set_xa_vec64(int v);          // measure builds: see IgemmParams::xa_vec64
 void igemm_set_epilogue_staged(int v);   // A/B: 1 forces the LDS-staged epilogue (default 0: direct row-per-lane epilogue on whole wave tiles)
 void igemm_set_unrolled(int v);   // auto selection: pipelined kernels with the k-loop unrolled by the ring depth (default on)
 #ifdef SDXL_MEASURE
