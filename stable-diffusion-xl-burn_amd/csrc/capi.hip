@@ -931,10 +931,17 @@ int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   launch_pack_bias(bias, bp, Cout, l.Npad, 0, 0, s);
   l.w = wp; l.b = bp;
   tmp_wfrag(l, cdt, false, tmp, s);
-  launch_nchw_to_nhwc(x, Cin * H * W, xi, sdt, B, Cin, H * W, Cin, 1.0f, s);     // (st_f handles the HL16 layout: Cin % 16 == 0 rows)
+  Act xa(xi, Cin, sdt);
+  if (cdt == DT_HL && l.acc_scale) {      // range-safe conversion, as the models convert their fp32 stream tensors (hl_operand)
+    float* x32 = (float*)tmp.get((size_t)B * H * W * Cin * sizeof(float));
+    float* sc = (float*)tmp.get(256);
+    launch_nchw_to_nhwc(x, Cin * H * W, x32, DT_F32, B, Cin, H * W, Cin, 1.0f, s);
+    launch_f32_to_hl_scaled(x32, Cin, xi, Cin, (size_t)B * H * W, Cin, sc, s);
+    xa.a_scale = sc + 1;
+  } else launch_nchw_to_nhwc(x, Cin * H * W, xi, sdt, B, Cin, H * W, Cin, 1.0f, s);     // (st_f handles the HL16 layout: Cin % 16 == 0 rows)
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
   give_splitk_ws(ex, tmp, B, Ho * Wo, Cout, s);
-  run_conv(ex, l, Act(xi, Cin, sdt), Cin, ConvGeom{B, H, W, Ho, Wo, ksize, stride, pad, upsample ? 1 : 0}, Act(yo, Cout, DT_F32));
+  run_conv(ex, l, xa, Cin, ConvGeom{B, H, W, Ho, Wo, ksize, stride, pad, upsample ? 1 : 0}, Act(yo, Cout, DT_F32));
   launch_nhwc_to_nchw(yo, DT_F32, Cout, out, B, Cout, Ho * Wo, 1.0f, s);
   SDXL_HIP(hipStreamSynchronize(s));
   API_END
@@ -977,12 +984,16 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   launch_pack_bias(bias, bp, N, l.Npad, geglu ? 1 : 0, 0, s);
   l.w = wp; l.b = bp;
   tmp_wfrag(l, cdt, geglu != 0, tmp, s);
-  if (cdt == DT_HL) launch_f32_to_hl(x, K, xi, K, (size_t)M, K, s);
-  else launch_copy_rows(x, DT_F32, K, xi, sdt, K, M, K, s);
+  Act xa(xi, K, sdt);
+  if (cdt == DT_HL) {      // range-safe conversion, as the models convert their fp32 stream tensors (hl_operand)
+    float* sc = (float*)tmp.get(256);
+    launch_f32_to_hl_scaled(x, K, xi, K, (size_t)M, K, sc, s);
+    xa.a_scale = sc + 1;
+  } else launch_copy_rows(x, DT_F32, K, xi, sdt, K, M, K, s);
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
   give_splitk_ws(ex, tmp, 1, M, N, s);
   Epi e; e.act = geglu ? 1 : 0;
-  run_linear(ex, l, Act(xi, K, sdt), M, Act(out, geglu ? N / 2 : N, DT_F32), e);
+  run_linear(ex, l, xa, M, Act(out, geglu ? N / 2 : N, DT_F32), e);
   SDXL_HIP(hipStreamSynchronize(s));
   API_END
 }

@@ -119,7 +119,7 @@ void launch_gemv(const GemvParams& pin, hipStream_t s) {
 // row softmax (one 256-thread block per row)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int lds_, void* P, int p_dt, int ldp, int n,
                                                            int npad, float scale, const float* mask, int ldmask,
-                                                           int mask_rows) {
+                                                           int mask_rows, float p_scale, float* p_scale_out) {
   __shared__ float red[8];
   const int row = blockIdx.x, tid = threadIdx.x;
   const float* s = S + (size_t)row * lds_;
@@ -138,16 +138,19 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int l
   if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
   __syncthreads();
   sum = red[4] + red[5] + red[6] + red[7];
-  const float inv = 1.0f / sum;
+  // p_scale (split-operand P V product, thousands of keys): probabilities ~1e-4 would put the lo halves of an HL16 P into the f16
+  // subnormals -- P is stored times a power of two and the P V GEMM undoes it through its accumulator scale (p_scale_out[0])
+  const float inv = p_scale / sum;
+  if (p_scale_out && row == 0 && tid == 0) { p_scale_out[0] = 1.0f / p_scale; p_scale_out[1] = 0.f; }
   for (int i = tid; i < npad; i += 256) {
     const float v = i < n ? expf(s[i] * scale + (mk ? mk[i] : 0.f) - mx) * inv : 0.f;
     st_f(P, (size_t)row * ldp + i, p_dt, v);
   }
 }
 void launch_softmax_rows(const float* S, int lds_, void* P, int p_dt, int ldp, int rows, int n, int npad, float scale,
-                         const float* mask, int ldmask, int mask_rows, hipStream_t s) {
+                         const float* mask, int ldmask, int mask_rows, hipStream_t s, float p_scale, float* p_scale_out) {
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, lds_, P, p_dt, ldp, n, npad, scale, mask,
-                     ldmask, mask_rows > 0 ? mask_rows : 1);
+                     ldmask, mask_rows > 0 ? mask_rows : 1, p_scale, p_scale_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -272,6 +275,62 @@ void launch_f16_exact(const float* src, size_t n, float wscale, float* exact, hi
   if (n == 0) return;
   const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
   hipLaunchKernelGGL(f16_exact_kernel, dim3(blocks), dim3(256), 0, s, src, n, wscale, exact);
+}
+// Range-safe conversion of an fp32 STREAM tensor (residual stream, VAE hidden state: magnitudes a model does not bound) into an HL16
+// GEMM operand: hi = f16(x) overflows to inf beyond 65504 (-> NaN out of the three-MFMA product) and below 6e-5 the lo half falls
+// into the f16 subnormals.  The tensor is therefore converted times the power of two 2^e that brings max|x| into [2^13, 2^14) -- exact,
+// the same rule the weights use (WeightBuilder::hl_scale) -- and the consuming GEMM undoes it through IgemmParams::a_scale.
+// scale_io[0] = max|x| (absmax_rows_kernel, float bits), scale_io[1] = 2^-e written here for the GEMM's epilogue.
+__global__ void absmax_rows_kernel(const float* src, int lds_, size_t rows, int C4, unsigned* out) {
+  float m = 0.f;
+  const size_t total = rows * (size_t)C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / C4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * lds_ + (i - r * C4) * 4);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns (NaN / inf sort on top)
+}
+__device__ __forceinline__ float hl_stream_scale(float absmax) {
+  if (!(absmax > 0.f) || !(absmax < INFINITY)) return 1.f;            // all-zero or non-finite tensors: nothing to rescue
+  int e;
+  (void)frexpf(absmax, &e);                                          // absmax = m 2^e, m in [0.5, 1)
+  e = 14 - e;
+  e = e > 60 ? 60 : (e < -60 ? -60 : e);
+  return ldexpf(1.0f, e);
+}
+__global__ void f32_to_hl_scaled_kernel(const float* src, int lds_, half_t* dst, int ldd, size_t rows, int C8, float* scale_io) {
+  const float sc = hl_stream_scale(scale_io[0]);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) scale_io[1] = 1.0f / sc;
+  if (i >= rows * C8) return;
+  const size_t r = i / C8;
+  const int c = (int)(i - r * C8) * 8;
+  const float* sp = src + r * lds_ + c;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+  half8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = a[e] * sc, y = b[e] * sc;                              // (pinned in fp32 first: see store_hl8)
+    asm("" : "+v"(x)); asm("" : "+v"(y));
+    hi[e] = (half_t)x; lo[e] = (half_t)(x - (float)hi[e]);
+    hi[4 + e] = (half_t)y; lo[4 + e] = (half_t)(y - (float)hi[4 + e]);
+  }
+  half_t* dp = dst + r * 2 * (size_t)ldd + ((c >> 4) << 5) + (c & 15);
+  *reinterpret_cast<half8*>(dp) = hi;
+  *reinterpret_cast<half8*>(dp + 16) = lo;
+}
+void launch_f32_to_hl_scaled(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s) {
+  if ((C & 15) != 0 || (lds_ & 3) != 0 || (ldd & 15) != 0) throw std::runtime_error("f32_to_hl: C % 16 == 0 rows with aligned strides only");
+  (void)hipMemsetAsync(scale_io, 0, 2 * sizeof(float), s);
+  const size_t t4 = rows * (size_t)(C / 4);
+  hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)std::min<size_t>(2048, (t4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
+                     rows, C / 4, reinterpret_cast<unsigned*>(scale_io));
+  const size_t total = rows * (size_t)(C / 8);
+  hipLaunchKernelGGL(f32_to_hl_scaled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
+                     reinterpret_cast<half_t*>(dst), ldd, rows, C / 8, scale_io);
 }
 void launch_f32_to_hl(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, hipStream_t s) {
   if ((C & 15) != 0 || (lds_ & 3) != 0 || (ldd & 15) != 0) throw std::runtime_error("f32_to_hl: C % 16 == 0 rows with aligned strides only");

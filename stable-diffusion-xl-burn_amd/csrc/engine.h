@@ -160,9 +160,10 @@ struct Act {
   // GroupNorm statistics of this tensor left behind by the GEMM that produced it (Epi::gn_part -> IgemmParams::gn_part):
   // [B][gn_rt][C] (mean, M2) per 256-row tile and channel.  A GroupNorm over exactly this tensor skips its statistics pass.
   const float* gn_part = nullptr; int gn_rt = 0;
+  const float* a_scale = nullptr;   // HL16 copy of an fp32 stream tensor (hl_operand): device scalar 2^-e the consuming GEMM multiplies back (IgemmParams::a_scale)
   Act() {}
   Act(void* p_, int ld_, int dt_) : p(p_), ld(ld_), dt(dt_) {}
-  Act cols(int c0) const { return Act((char*)p + (size_t)c0 * dt_size(dt), ld, dt); }   // (a column slice drops the statistics)
+  Act cols(int c0) const { Act a((char*)p + (size_t)c0 * dt_size(dt), ld, dt); a.a_scale = a_scale; return a; }   // (a column slice drops the statistics)
 };
 
 // per-kernel-class hipEvent profiler (eager runs only): live measurement of the dominant kernel for bench.py's roofline

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     }
   }
   if constexpr (HL) {   // split-operand weights are packed times a power of two (exact): the row coefficient of the epilogue undoes it
-    const float sc = p.acc_scale ? *p.acc_scale : 1.f;
+    const float sc = (p.acc_scale ? *p.acc_scale : 1.f) * (p.a_scale ? *p.a_scale : 1.f);       // both powers of two: exact
 #pragma unroll
     for (int i = 0; i < TM; ++i) { lnA[i] = sc; lnC[i] = 0.f; }
     // (readfirstlane: the compiler must SEE that the choice is wave-uniform -- as a vector condition it runs both k-loops one after

@@ -61,6 +61,7 @@ struct IgemmParams {
   float* gn_part;
   const float* acc_scale;   /* [0] = 1 / weight scale, [1] != 0: every packed weight is exactly one f16 (lo halves all zero) */  // DT_HL compute: the packed weights carry a power-of-two factor (exact); device scalar 1 / factor the epilogue multiplies the
                            // accumulators by (lives in the weight arena, so replicas that receive the arena by broadcast need no host copy); null = 1
+  const float* a_scale;     // DT_HL compute: device scalar 2^-e of an A operand converted by launch_f32_to_hl_scaled (null = 1); exact
   int hl_wexact_ok; // A/B knob (sdxl_debug_set "hl_weights_exact", default 1): split-operand launches may leave out the w_lo MFMAs when acc_scale[1] says every weight is one f16
   int xa_vec64;     // measure builds (sdxl_debug_set "xa_vec64"): the fused cross-attention epilogue reads its per-column vectors with the original 64-lane
                     // VMEM loads instead of the scalar cache -- the hazard experiment of DESIGN 9.2 / 10.4
@@ -155,7 +156,9 @@ void attention_set_variant(int v);     // -1: generic kernel only, 0: auto, 1: D
 // row softmax for the unfused attention path (VAE mid block, d=512, 1 head): P[r][:] = softmax(S[r][:]*scale + mask)
 // S fp32 [rows][lds] (scores from igemm), P in dtype p_dt [rows][ldp]; columns n..npad-1 of P are zero filled.
 void launch_softmax_rows(const float* S, int lds, void* P, int p_dt, int ldp, int rows, int n, int npad, float scale,
-                         const float* mask, int ldmask, int mask_rows, hipStream_t s);
+                         const float* mask, int ldmask, int mask_rows, hipStream_t s, float p_scale = 1.0f, float* p_scale_out = nullptr);
+// p_scale / p_scale_out: P is stored times the power of two p_scale and {1 / p_scale, 0} is left at p_scale_out -- the accumulator scale
+// (IgemmParams::acc_scale layout) of the split-operand P V product that consumes it
 
 // ---------------------------------------------------------------------------------------------------------
 // Small-M linear (GEMV): Y[b][n] = act_in(X[b][:]) . Wp[n][:] + bias[n]   (time/label/emb MLPs, M<=8)
@@ -187,6 +190,9 @@ void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 // `accumulate`: AND with the value already there (several tensors of one fused matrix)
 void launch_f16_exact(const float* src, size_t n, float wscale, float* exact, hipStream_t s, bool accumulate = false);
 void launch_f32_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows, int C, hipStream_t s);
+// the same for a tensor whose range the model does not bound (residual stream, VAE hidden state): converted times the power of two
+// that brings max|x| into [2^13, 2^14); scale_io (2 device floats) receives {max|x|, 2^-e} -- pass scale_io + 1 as IgemmParams::a_scale
+void launch_f32_to_hl_scaled(const void* src, int lds, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s);
 void launch_round_f16(float* p, size_t n, hipStream_t s);   // p[i] = float(half(p[i])): parameters as a HalfPrecisionSettings record holds them
 void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s);
 // CLIP text encoder (clip/mod.rs:99-105,139-147): x[b][t][:] = tok[ids[b][t]][:] + pos[t][:] (tables in dtype w_dt);

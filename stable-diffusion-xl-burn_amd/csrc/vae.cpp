@@ -145,6 +145,9 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
     const int QT = HW < 2048 ? HW : 2048;
     float* S = (float*)ex.act->alloc((size_t)QT * HW * sizeof(float));
     void* P = ex.act->alloc((size_t)QT * kpad * dt_size(ex.cdt));
+    // split-operand mode: P = softmax over up to 16 384 keys is ~6e-5 per entry -- stored times 2^12 so the lo halves of the HL16 image stay
+    // f16-normal; the P V product undoes it through its accumulator scale (attention.hip measured 9e-5 vs 5e-7 rel for the same trick)
+    float* pv_scale = ex.cdt == DT_HL ? (float*)ex.act->alloc(2 * sizeof(float)) : nullptr;
     if (!ex.dry) {
       launch_fill_zero(kbuf, (size_t)B * rows_k * C * dt_size(ex.cdt), ex.s);
       launch_fill_zero(vt, (size_t)B * rows_v * kpad * dt_size(ex.cdt), ex.s);
@@ -156,6 +159,15 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
                Act((char*)kbuf + (size_t)b * rows_k * C * dt_size(ex.cdt), C, ex.cdt));
     }
     Epi ev; ev.n_split = 0; ev.Ct = vt; ev.ct_rows = rows_v; ev.ct_ld = kpad; ev.rpb = HW;
+    if (ex.cdt == DT_HL && (HW % 8 != 0 || M % 8 != 0)) {
+      // HL16 rows are written as whole 8-key pieces: token counts that are not multiples of 8 (a 72 x 72 image: 9 x 9 latent) take the
+      // transposed V^T out as fp32 and convert it, as the UNet does for such shapes (no generic twin of the split-operand GEMM)
+      void* vt32 = ex.act->alloc((size_t)B * rows_v * kpad * sizeof(float));
+      if (!ex.dry) launch_fill_zero(vt32, (size_t)B * rows_v * kpad * sizeof(float), ex.s);
+      ev.Ct = vt32;
+      run_conv(ex, w.v, hn, C, g1, Act(nullptr, C, DT_F32), ev);
+      if (!ex.dry) launch_f32_to_hl(vt32, kpad, vt, kpad, (size_t)B * rows_v, kpad, ex.s);
+    } else
     run_conv(ex, w.v, hn, C, g1, Act(nullptr, C, ex.cdt), ev);
     for (int b = 0; b < B; ++b) {
       Lin lk; lk.w = (char*)kbuf + (size_t)b * rows_k * C * dt_size(ex.cdt); lk.N = HW; lk.K = C; lk.Kpad = C; lk.Npad = rows_k; lk.cin = C;
@@ -166,7 +178,8 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
         const int nq = HW - q0 < QT ? HW - q0 : QT;
         const size_t row0 = ((size_t)b * HW + q0) * C * dt_size(ex.cdt);
         run_linear(ex, lk, Act((char*)q.p + row0, C, ex.cdt), nq, Act(S, HW, DT_F32));
-        if (!ex.dry) launch_softmax_rows(S, HW, P, ex.cdt, kpad, nq, HW, kpad, scale, nullptr, 0, 0, ex.s);
+        if (!ex.dry) launch_softmax_rows(S, HW, P, ex.cdt, kpad, nq, HW, kpad, scale, nullptr, 0, 0, ex.s, pv_scale ? 4096.0f : 1.0f, pv_scale);
+        lv.acc_scale = pv_scale;
         run_linear(ex, lv, Act(P, kpad, ex.cdt), nq, Act((char*)o.p + row0, C, ex.cdt));
       }
     }

@@ -362,6 +362,7 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   SDXL_REQUIRE(!((w.dt >= 0 ? w.dt : ex.cdt) == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
   if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize);
   p.acc_scale = w.acc_scale;
+  p.a_scale = (w.dt >= 0 ? w.dt : ex.cdt) == DT_HL ? a.a_scale : nullptr;
   launch_igemm(p, w.dt >= 0 ? w.dt : ex.cdt, ex.s);
   {   // a refused launch (bad grid / LDS attribute) must not pass silently
     const hipError_t le = hipGetLastError();
@@ -380,7 +381,9 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
 Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C) {
   if (ex.cdt != DT_HL || x.dt != DT_F32 || w.dt == DT_F32) return x;
   Act o = ex.alloc(rows, C, DT_HL);
-  if (!ex.dry) launch_f32_to_hl(x.p, x.ld, o.p, o.ld, rows, C, ex.s);
+  float* sc = (float*)ex.act->alloc(2 * sizeof(float));      // {max|x|, 2^-e}: the stream's range is the model's, not ours
+  if (!ex.dry) launch_f32_to_hl_scaled(x.p, x.ld, o.p, o.ld, rows, C, sc, ex.s);
+  o.a_scale = sc + 1;
   return o;
 }
 bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e) {

@@ -388,3 +388,16 @@ def test_library_comm_single_rank(pkg, ctx):
     comm.bcast_buffer(buf)
     assert torch.equal(u.weight_arena_tensor(), before) and torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float32))
     assert pkg.bcast_plan(10_000_000, 8, 3) == (3 * 1249792, 1249792, 8 * 1249792, 10_000_000 - 8 * 1249792)
+
+
+def test_vae_split_operand_token_count_not_a_multiple_of_8(pkg, ctx):
+    # a 72 x 72 image: 9 x 9 latent, 81 tokens in the mid-block attention -- HL16 outputs are written as whole 8-key pieces, so the
+    # split-operand V^T goes out as fp32 and is converted (was: a runtime error while f32 / f16 decoded the same latent)
+    v = OC.tiny_vae_config()
+    Wd = OM.to_torch(OC.synth_weights(OC.vae_decoder_param_specs(v)))
+    latent = seeded(1, 4, 9, 9, seed=52) * 0.5
+    ref = OP.LatentDecoder(v, Wd).decode_latent(latent)
+    out = pkg.LatentDecoder(ctx, to_pkg_vcfg(pkg, v), 3, seed=0).decode_latent(latent.cuda()).cpu()
+    e = rel_err(out, ref)
+    print(f"vae decode 9x9 latent, split-operand: rel err {e:.3e}")
+    assert e < 5e-6

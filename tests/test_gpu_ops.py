@@ -593,3 +593,28 @@ def test_igemm_wreg_row_statistics_match_the_pipe_kernels(pkg, ctx):
         ref = OM.layer_norm(x, gamma, beta, 1e-5) @ w
         assert rel_err(outs[0], ref) < TOL[1]
         assert torch.equal(outs[0], outs[1]), f"M={M} K={K} N={N}: row statistics differ between the producers"
+
+
+@pytest.mark.parametrize("mag", [1e5, 3e7, 1e-6])
+def test_split_operand_operands_outside_the_f16_range(pkg, ctx, mag):
+    # the fp32 stream of a real model is not bounded by 65504 (the SDXL VAE's hidden state is the known case) and may sit far below
+    # f16's normal range: the HL16 conversion of such a tensor carries a power-of-two scale (launch_f32_to_hl_scaled) that the GEMM's
+    # epilogue undoes -- without it hi = f16(x) is inf (NaN out of the product) or the lo halves lose their bits
+    M, K, N = 300, 640, 256
+    x = seeded(M, K, seed=7) * mag
+    w = seeded(K, N, seed=8) / math.sqrt(K)
+    b = 0.1 * seeded(N, seed=9) * mag
+    ref = (x.double() @ w.double() + b.double()).float()
+    out = pkg.linear(ctx, x.cuda(), w.cuda(), b.cuda(), False, 3)
+    assert torch.isfinite(out).all()
+    e = rel_err(out, ref)
+    print(f"split-operand linear, |x| ~ {mag:g}: rel err {e:.3e}")
+    assert e < 4e-6
+    xc = seeded(1, 64, 20, 20, seed=43) * mag
+    wc = seeded(64, 64, 3, 3, seed=44) / math.sqrt(64 * 9)
+    bc = 0.1 * seeded(64, seed=45) * mag
+    refc = F.conv2d(xc.double(), wc.double(), bc.double(), padding=1).float()
+    outc = pkg.conv2d(ctx, xc.cuda(), wc.cuda(), bc.cuda(), 1, 1, False, 3)
+    ec = rel_err(outc, refc)
+    print(f"split-operand conv3x3, |x| ~ {mag:g}: rel err {ec:.3e}")
+    assert torch.isfinite(outc).all() and ec < 4e-6

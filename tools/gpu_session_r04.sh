@@ -19,6 +19,7 @@ for p in $PARTS; do
       [ -n "${AB_KNOB:-}" ] && python tools/launch_ab.py "$OUT/launches_${AB_KNOB}.csv" $OUT/launches_default.csv > $OUT/launch_ab.txt 2>&1 && tail -30 $OUT/launch_ab.txt;;
     clock) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/clock_probe.hip -o /tmp/clock_probe > $OUT/clock.txt 2>&1; timeout 60 /tmp/clock_probe >> $OUT/clock.txt 2>&1; cat $OUT/clock.txt;;
     rocprof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-live-parity > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err); find /tmp/rp -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats.csv \; ; head -30 $OUT/kernel_stats.csv;;
+    rocprof4) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp4 -o r -- python $GRAFT_REPO_ROOT/bench.py --config 4 --steps 1 --warmup 1 --no-cpu-baseline --no-live-parity > $GRAFT_REPO_ROOT/$OUT/rocprof_cfg4.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof_cfg4.err); find /tmp/rp4 -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats_cfg4.csv \; ; head -24 $OUT/kernel_stats_cfg4.csv;;
     trace) rm -rf /tmp/kt; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-live-parity > /dev/null 2>&1)
       f=$(find /tmp/kt -name '*kernel_trace*' | head -1)
       python tools/trace_step_summary.py $f > $OUT/step_kernels.txt 2>&1; python tools/trace_gaps.py $f $OUT/trace_gaps.json > /dev/null 2>&1; head -24 $OUT/step_kernels.txt;;
