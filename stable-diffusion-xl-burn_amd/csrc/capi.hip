@@ -180,6 +180,12 @@ int sdxl_debug_timeline(void* device_buf) {
   API_END
 }
 int sdxl_debug_timeline_words(void) { return igemm_timeline_words(); }
+// device buffer [workgroups][8][8] unsigned for the coarse s_memtime stamps of the wide (GEGLU) kernel; null switches it off
+int sdxl_debug_wide_timeline(void* device_buf) {
+  API_BEGIN
+  igemm_set_wide_timeline(device_buf);
+  API_END
+}
 #endif
 int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, int Cout, int ksize, int geglu, int iters,
                      float* avg_ms) {

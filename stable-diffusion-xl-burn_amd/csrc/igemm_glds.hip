@@ -727,8 +727,24 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
 // 16-lane ds_read_b128 service groups hit 16 distinct 16-byte slots of the 256-byte bank row.
 // Per k-tile: {frags kk=0 -> 10 MFMA} {frags kk=1 -> wait own pieces of tile kt+1 -> barrier -> 10 MFMA with the pieces of
 // tile kt+NS (slot just freed) issued between them}.  GEGLU epilogue only (staged through LDS in two 32-row passes).
+#ifdef SDXL_MEASURE
+// coarse s_memtime stamps of the wide kernel (tools/wide_timeline.py): [workgroup][wave][8] = entry, ring fill issued, tile 0 landed
+// (first barrier passed), k-loop done, ring dead (barrier), first / second epilogue pass issued, stores drained
+__device__ unsigned* g_wide_tl = nullptr;
+void igemm_set_wide_timeline(void* buf) {
+  unsigned* b = reinterpret_cast<unsigned*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_tl), &b, sizeof(b)) != hipSuccess) throw std::runtime_error("igemm: cannot set the wide-kernel timeline buffer");
+}
+#define WIDE_STAMP(i) do { wtl[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WIDE_STAMP(i) do { } while (0)
+#endif
 template <int NS>
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, const void* zeros) {
+#ifdef SDXL_MEASURE
+  unsigned wtl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  WIDE_STAMP(0);
   kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();   // every argument line in flight at once (one wait instead of five)
   constexpr int BM = 256, BN = 320, KT = 32;
   constexpr int WM = 64, WN = 160, TM = 2, TN = 5, NF = TM + TN;
@@ -839,6 +855,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
 #pragma unroll
   for (int s = 0; s < NS; ++s)
     if (s < nk) static_for<PER>([&](auto Q) { issue(s, Q); });
+  WIDE_STAMP(1);
   float lnA[TM], lnC[TM];
   const bool ln_coop = p.ln_slots <= 24;
   lnc.finish(p, m0, ln_coef);
@@ -848,6 +865,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  WIDE_STAMP(2);
   if (ln_coop) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -878,8 +896,10 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
     mma(cur, more);
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
+  WIDE_STAMP(3);
   __builtin_amdgcn_s_barrier();                  // ring dead -> staging area
   asm volatile("" ::: "memory");
+  WIDE_STAMP(4);
   if (p.act == 1) {
     // two passes of 32 rows: a full 64 x 80 fp32 staging region per wave would not fit next to seven others
     char* region = smem + wave * (32 * (WN / 2) * 4);
@@ -887,11 +907,21 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
       const float la1[1] = {lnA[0]}, lc1[1] = {lnC[0]};
       igemm_epilogue_staged_impl<1, TN, true>(p, acc0, m0 + wm * WM, n0 + wn * WN, lane, region, false, la1, lc1, zeros);
     }
+    WIDE_STAMP(5);
     {
       const float la1[1] = {lnA[1]}, lc1[1] = {lnC[1]};
       igemm_epilogue_staged_impl<1, TN, true>(p, acc1, m0 + wm * WM + 32, n0 + wn * WN, lane, region, false, la1, lc1, zeros);
     }
   }   // (the launcher only admits GEGLU projections)
+#ifdef SDXL_MEASURE
+  WIDE_STAMP(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WIDE_STAMP(7);
+  if (g_wide_tl && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_wide_tl[((size_t)blockIdx.x * 8 + wave) * 8 + i] = wtl[i];
+  }
+#endif
 }
 
 // Per-DEVICE state: the zero page the DMA reads halo / tail rows from lives on the device that launches, and the

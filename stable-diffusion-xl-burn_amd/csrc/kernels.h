@@ -89,7 +89,8 @@ void igemm_set_xa_vec64(int v);          // measure builds: see IgemmParams::xa_
 void igemm_set_epilogue_staged(int v);   // A/B: 1 forces the LDS-staged epilogue (default 0: direct row-per-lane epilogue on whole wave tiles)
 void igemm_set_unrolled(int v);   // auto selection: pipelined kernels with the k-loop unrolled by the ring depth (default on)
 #ifdef SDXL_MEASURE
-void igemm_set_timeline(void* device_buf);   // igemm_measure.hip: stamp buffer of the timeline kernel variants
+void igemm_set_timeline(void* device_buf);
+void igemm_set_wide_timeline(void* device_buf);   // igemm_glds.hip: [workgroups][8 waves][8] coarse stamps of the wide (GEGLU) kernel   // igemm_measure.hip: stamp buffer of the timeline kernel variants
 int igemm_timeline_words();
 #endif
 void igemm_glds_init();          // allocates the zero page the DMA fast path reads halo pixels from (call once per process)
