@@ -892,9 +892,28 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
 //   KP = 4 is the same body one step finer (the small blocks of attn_d64_mix_kernel): a block is ONE 32-query sub-tile and its
 //   four waves are key QUARTERS = {tile parity} x {key half}: a wave computes on every other 64-key tile only (it still stages
 //   its DMA pieces and takes the barrier of every tile), and wave 0 merges three partners.
+#ifdef SDXL_MEASURE
+// coarse s_memtime stamps of the key-split body (tools/attn_timeline.py): [workgroup][wave][8] = entry, Q loaded + first tiles issued,
+// k-loop done, merge done (key part 0 only), output stores issued; words 6 / 7 = s_memrealtime (100 MHz) at entry / exit
+__device__ unsigned* g_attn_tl = nullptr;
+void attention_set_timeline(void* buf) {
+  unsigned* b = reinterpret_cast<unsigned*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_tl), &b, sizeof(b)) != hipSuccess) throw std::runtime_error("attention: cannot set the timeline buffer");
+}
+#define ATTN_STAMP(i) do { atl[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define ATTN_DUMP() do { atl[7] = (unsigned)__builtin_amdgcn_s_memrealtime(); if (g_attn_tl && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) g_attn_tl[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i_] = atl[i_]; } } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#define ATTN_DUMP() do { } while (0)
+#endif
 template <int KP, int PRIO = 2>
 __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void* zeros, char* smem, int b, int hd, int qb) {
   static_assert(KP == 2 || KP == 4, "key parts per query sub-tile");
+#ifdef SDXL_MEASURE
+  unsigned atl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  atl[6] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
+  ATTN_STAMP(0);
   constexpr int KV = 64, TILE = 64 * 128, NS = 3;
   constexpr float THR = 8.0f;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -961,12 +980,14 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
     if (s0 < nt) stage(s0, s0);
+  ATTN_STAMP(1);
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
     if (t + NS - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (t == 0) ATTN_STAMP(2);
     if (t + NS - 1 < nt) stage(t + NS - 1, cur == 0 ? NS - 1 : cur - 1);
     const char* kb = smem + cur * 2 * TILE;
     const char* vb = kb + TILE;
@@ -1030,6 +1051,7 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
       }
     }
   }
+  ATTN_STAMP(3);
   l += __shfl_xor(l, 32);
   if (KP == 4 && tp >= nt) m = -INFINITY;       // (a wave that saw no tile of its parity: weight 0 in the merge; the launcher asks Nk >= 128)
   // ---- merge the key parts of each query sub-tile through the dead ring: parked images of [34][64 lanes] floats at smem + 0
@@ -1046,7 +1068,7 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
       for (int r = 0; r < 16; ++r) mb[(2 + dt * 16 + r) * 64] = o[dt][r];
   }
   __syncthreads();
-  if (kp != 0) return;
+  if (kp != 0) { ATTN_DUMP(); return; }
   {
     const float* mb = mbase + (KP == 2 ? qs : 0) * (34 * 64);
     float mm = m;
@@ -1069,6 +1091,7 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
         for (int r = 0; r < 16; ++r) o[dt][r] += mj[(2 + dt * 16 + r) * 64] * aj;
     }
   }
+  ATTN_STAMP(4);
   const float inv = 1.0f / l;
   char* ob = smem + ((NPARK * 8704 + 4095) & ~4095) + qs * 4096;          // behind the parked images (8704 B each)
 #pragma unroll
@@ -1088,6 +1111,8 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
     const int q = q0 + row;
     if (q < p.Nq) *reinterpret_cast<i32x4*>(Og + (size_t)q * p.ldo + piece * 8) = v;
   }
+  ATTN_STAMP(5);
+  ATTN_DUMP();
 }
 
 template <int PRIO = 2>
@@ -1554,6 +1579,9 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
       return;
     }
     if (ks_pick) {
+      // (round 4: a software-pipelined form of this body -- QK^T of tile t issued around the softmax of tile t - 1, K and V^T on
+      // separate rings -- measured 24.9 vs 22.6 us at the 32^2 level and was removed again: with three blocks per CU the other waves
+      // already fill the chain's gaps, and the second live score tile costs registers; profiles/r04_attention_swp_ab.txt)
       hipLaunchKernelGGL(attn_d64_ks_kernel<2>, dim3(((p.Nq + 63) / 64) * p.B * p.H), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero);
       return;
     }

@@ -181,6 +181,11 @@ int sdxl_debug_timeline(void* device_buf) {
 }
 int sdxl_debug_timeline_words(void) { return igemm_timeline_words(); }
 // device buffer [workgroups][8][8] unsigned for the coarse s_memtime stamps of the wide (GEGLU) kernel; null switches it off
+int sdxl_debug_attn_timeline(void* device_buf) {
+  API_BEGIN
+  attention_set_timeline(device_buf);
+  API_END
+}
 int sdxl_debug_wide_timeline(void* device_buf) {
   API_BEGIN
   igemm_set_wide_timeline(device_buf);

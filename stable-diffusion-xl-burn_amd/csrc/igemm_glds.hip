@@ -728,7 +728,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
 // Per k-tile: {frags kk=0 -> 10 MFMA} {frags kk=1 -> wait own pieces of tile kt+1 -> barrier -> 10 MFMA with the pieces of
 // tile kt+NS (slot just freed) issued between them}.  GEGLU epilogue only (staged through LDS in two 32-row passes).
 #ifdef SDXL_MEASURE
-// coarse s_memtime stamps of the wide kernel (tools/wide_timeline.py): [workgroup][wave][8] = entry, ring fill issued, tile 0 landed
+// coarse s_memtime stamps of the wide kernel (tools/wide_timeline.py): [workgroup][wave][16], words 0..7 = entry, ring fill issued, tile 0 landed
 // (first barrier passed), k-loop done, ring dead (barrier), first / second epilogue pass issued, stores drained
 __device__ unsigned* g_wide_tl = nullptr;
 void igemm_set_wide_timeline(void* buf) {
@@ -742,7 +742,8 @@ void igemm_set_wide_timeline(void* buf) {
 template <int NS>
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, const void* zeros) {
 #ifdef SDXL_MEASURE
-  unsigned wtl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned wtl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  wtl[8] = (unsigned)__builtin_amdgcn_s_memrealtime();     // 100 MHz constant clock: shader clock of this launch = d(memtime) / d(realtime)
 #endif
   WIDE_STAMP(0);
   kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();   // every argument line in flight at once (one wait instead of five)
@@ -917,9 +918,10 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   WIDE_STAMP(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WIDE_STAMP(7);
+  wtl[9] = (unsigned)__builtin_amdgcn_s_memrealtime();
   if (g_wide_tl && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) g_wide_tl[((size_t)blockIdx.x * 8 + wave) * 8 + i] = wtl[i];
+    for (int i = 0; i < 10; ++i) g_wide_tl[((size_t)blockIdx.x * 8 + wave) * 16 + i] = wtl[i];
   }
 #endif
 }

@@ -152,6 +152,9 @@ bool launch_attention_d64_hl(const AttnParams& p, hipStream_t s);
 // returns false when the shape / alignment needs the unfused path.  p.scale = d^-1/2.
 bool launch_attention_hd512(const AttnParams& p, hipStream_t s);
 void attention_init();                 // zero page for the DMA-staged f16 kernel (once per process)
+#ifdef SDXL_MEASURE
+void attention_set_timeline(void* device_buf);   // [workgroups][4 waves][8] coarse stamps of the key-split attention body
+#endif
 void attention_set_variant(int v);     // -1: generic kernel only, 0: auto, 1: DMA-staged 16x16x32 kernel, 2: 32x32x16 deferred-max kernel, 6: key-split kernel
 
 // row softmax for the unfused attention path (VAE mid block, d=512, 1 head): P[r][:] = softmax(S[r][:]*scale + mask)

@@ -618,3 +618,4 @@ def test_split_operand_operands_outside_the_f16_range(pkg, ctx, mag):
     ec = rel_err(outc, refc)
     print(f"split-operand conv3x3, |x| ~ {mag:g}: rel err {ec:.3e}")
     assert torch.isfinite(outc).all() and ec < 4e-6
+
