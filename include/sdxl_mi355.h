@@ -266,6 +266,9 @@ int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int 
 /* benchmarking / debugging knobs.  "igemm_variant": -1 generic kernel only, 0 auto, > 0 forced fast-path tile / pipeline
  * (list in csrc/igemm_glds.hip); "attn_variant": -1 generic, 0 auto, 1/2/4/6 forced f16 kernels, 7/8 forced mixed block sizes,
  * 9 = auto without them (csrc/attention.hip);
+ * "igemm_wreg": 0 = the auto selection never picks the weights-in-registers GEMM (csrc/igemm_wreg.hip; A/B, default 1), forced by
+ * "igemm_variant" 60 / 62 (96 / 64 rows per tile); "igemm_epilogue_staged", "hl_weights_exact": A/B knobs of the epilogue form / the
+ * two-MFMA loop of exact-f16 split-operand weights;
  * "igemm_unrolled": 0 = auto selection launches the rolled k-loop kernels (A/B; default 1);
  * "split_cfg": 1 = a batch-2 UNet::forward runs its two entries as two concurrent batch-1 chains (bit-identical results);
  * "split_offset": GEMM launches of the first chain before the second is released; "no_cfg": base model without the
