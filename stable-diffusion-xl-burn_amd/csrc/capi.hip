@@ -186,6 +186,11 @@ int sdxl_debug_attn_timeline(void* device_buf) {
   attention_set_timeline(device_buf);
   API_END
 }
+int sdxl_debug_wreg_timeline(void* device_buf) {
+  API_BEGIN
+  igemm_set_wreg_timeline(device_buf);
+  API_END
+}
 int sdxl_debug_wide_timeline(void* device_buf) {
   API_BEGIN
   igemm_set_wide_timeline(device_buf);

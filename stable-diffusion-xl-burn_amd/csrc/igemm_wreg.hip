@@ -77,9 +77,6 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
 #pragma unroll
   for (int i = 0; i < TM; ++i) { m[i] = mw + i * 32 + fr; mok[i] = m[i] < p.M; }
   if (active) {
-    int bidx[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) bidx[i] = (p.ebias && mok[i]) ? m[i] / p.rpb : 0;
     const bool r16 = p.R && p.r_dt == DT_F16, r32 = p.R && p.r_dt == DT_F32;
     half8 rh[TM][2];
     f32x4 rf[TM][2][2];
@@ -95,14 +92,9 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
           rf[i][t][1] = *(mok[i] ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o + 4) : zv);
         }
       }
-    f32x4 bz[4], ez[TM][4];
+    f32x4 bz[4];       // (no time-embedding bias here: it rides on the 3x3 conv_in of a ResBlock only -- the launcher refuses ebias)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int nb = nw + 8 * q + 4 * fh;
-      bz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nb) : zv);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) ez[i][q] = *(p.ebias ? reinterpret_cast<const f32x4*>(p.ebias + (size_t)bidx[i] * p.ebias_ld + nb) : zv);
-    }
+    for (int q = 0; q < 4; ++q) bz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nw + 8 * q + 4 * fh) : zv);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       f32x4 v[4];
@@ -110,7 +102,7 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[q][r] = acc[i][q * 4 + r];
-        v[q] = v[q] + bz[q] + ez[i][q];
+        v[q] = v[q] + bz[q];
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -197,11 +189,29 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
   }
 }
 
+#ifdef SDXL_MEASURE
+// coarse s_memtime stamps (tools/wreg_timeline.py): [workgroup][wave][8] = entry, prologue issued, tile 0 landed, k-loop done, partial
+// sums exchanged, epilogue issued, stores drained; word 7 = shader cycles per 100 MHz tick x 100 (clock) is derived by the tool from
+// words 6 / 7 = s_memrealtime at entry / exit
+__device__ unsigned* g_wreg_tl = nullptr;
+void igemm_set_wreg_timeline(void* buf) {
+  unsigned* b = reinterpret_cast<unsigned*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wreg_tl), &b, sizeof(b)) != hipSuccess) throw std::runtime_error("igemm_wreg: cannot set the timeline buffer");
+}
+#define WREG_STAMP(i) do { wtl[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WREG_STAMP(i) do { } while (0)
+#endif
 // MODE (measure builds, forced variants 63 ..): 0 production; knock-outs that time one resource alone (results are garbage):
 // 1 no MFMAs, 2 operand pointers frozen (every fetch after the first hits the L1 / L2: same instruction stream, no fabric traffic),
 // 3 no VMEM at all in the k-loop, 4 no k-loop barriers; 5 = production arithmetic with the other XCD ownership (row tiles)
 template <int BM, int L, int MODE = 0>
 __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, const void* zeros) {
+#ifdef SDXL_MEASURE
+  unsigned wtl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  wtl[6] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
+  WREG_STAMP(0);
   kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();
   constexpr int NG = 2;                       // k-groups per workgroup
   constexpr int NSG = L + 1;                  // ring slots / weight register stages per group
@@ -322,6 +332,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     }
   });
   __builtin_amdgcn_sched_barrier(0);
+  WREG_STAMP(1);
   f32x16 acc[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -336,6 +347,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   __builtin_amdgcn_sched_barrier(0);
   static_for<NSG>([&](auto C) { if (s0 == decltype(C)::value && nkg > 0) ldsA(I0{}, C, I0{}); });
   __builtin_amdgcn_sched_barrier(0);
+  WREG_STAMP(2);
 
   // TM MFMAs of kk-step KK from fragment set SET; steady tiles put VMEM operations X0 .. of tile j + L behind MFMAs 0, 1, ...
   auto mma = [&](auto SET, auto S, auto KK, auto SF, auto X0) {
@@ -400,6 +412,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     constexpr int D = L - decltype(X)::value;
     if (D <= nkg) ktile(std::integral_constant<int, L + 1 - D>{}, std::integral_constant<int, D>{});
   });
+  WREG_STAMP(3);
   // odd k-tile count: group 1 has one tile -- and one rendezvous -- less; barrier counts must match across the workgroup
   if constexpr (MODE != 4) { if ((nk & 1) && g == 1) __builtin_amdgcn_s_barrier(); }
   __builtin_amdgcn_s_barrier();                    // both rings are dead: they become the exchange area
@@ -428,8 +441,16 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
         for (int r = 0; r < 4; ++r) acc[i][4 * q + r] += o[r];
       }
   }
+  WREG_STAMP(4);
   float* xch = reinterpret_cast<float*>(smem + 4 * TM * 4096);      // statistics exchange: behind the accumulator exchange area
   wreg_epilogue<TM>(p, acc, m0, n0 + w * 32, lane, w, g == 0, xch, zeros);
+#ifdef SDXL_MEASURE
+  WREG_STAMP(5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wtl[7] = (unsigned)__builtin_amdgcn_s_memrealtime();
+  { const unsigned t6 = (unsigned)__builtin_amdgcn_s_memtime();
+    if (g_wreg_tl && lane == 0) { unsigned* d = g_wreg_tl + ((size_t)blockIdx.x * 8 + wave) * 16; for (int i = 0; i < 8; ++i) d[i] = wtl[i]; d[8] = t6; } }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -461,7 +482,7 @@ bool igemm_wreg_ok(const IgemmParams& p) {
   if ((p.lda & 7) != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
   if ((p.ldc & 7) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0) return false;
   if (p.R && ((p.ldr & 7) != 0 || (reinterpret_cast<uintptr_t>(p.R) & 15) != 0)) return false;
-  if (p.ebias && (p.ebias_ld & 3) != 0) return false;
+  if (p.ebias) return false;
   if (p.stat_out && p.c_dt != DT_F16) return false;
   return true;
 }
@@ -472,33 +493,33 @@ bool launch_igemm_wreg(const IgemmParams& p, int variant, hipStream_t s) {
   if (!igemm_wreg_ok(p)) return false;
   if (variant == 0) {
     if (!g_wreg_enable.load()) return false;
-    // where it pays (profiles/r04_wreg_first_ab.txt): grids of at most one round of 96-row tiles -- the 32^2 level of the UNet
-    // (220 workgroups: 16.0 vs 18.2 us out-projection, 42.4 vs 47.8 us FF-out, cold weights) and everything smaller; at the 64^2
-    // level (430 tiles) the 128x160 / 256x128 pipe kernels' whole-round grids win.  Evaluated on the CFG PAIR's shape (2 entries of
-    // rpb rows) whatever the actual batch: the two structures sum k in different orders, and an entry must come out bit-identical
-    // alone or batched.
+    // where it pays (profiles/r04_wreg_first_ab.txt, r04_wreg_ab_l2.txt): grids of at most TWO 96-row tiles per CU -- with the
+    // shallow prefetch (L = 2: 72 KiB of LDS) two workgroups share a CU, so the 64^2 level's 430 tiles are one resident round
+    // (out-projection 19.5 -> 16.9 us, FF-out 44.5 -> 41.6 us, 1920 -> 640 skip 36.1 -> 33.1 us, cold weights) like the 32^2 level's 220
+    // (18.2 -> 15.0, 47.8 -> 41.2 us).  Evaluated on the CFG PAIR's shape (2 entries of rpb rows) whatever the actual batch: the two
+    // structures sum k in different orders, and an entry must come out bit-identical alone or batched.
     const long rows = 2L * (p.rpb > 0 ? p.rpb : p.M);
-    if (((rows + 95) / 96) * (long)(p.N / 128) > 256) return false;
+    if (((rows + 95) / 96) * (long)(p.N / 128) > 512) return false;
   }
 #ifdef SDXL_MEASURE
+  if (variant == 68) { launch_wreg_t<96, 3>(p, s); return true; }     // prefetch-depth A/B partners of the 96-row kernel (L = 2 in production)
+  if (variant == 69) { launch_wreg_t<96, 4>(p, s); return true; }
+  if (variant == 61) { launch_wreg_t<128, 2>(p, s); return true; }    // 128-row tile (64 accumulators) at the shallow depth
   if (variant >= 63 && variant <= 67) {     // knock-out timing modes of the 96-row kernel (garbage results except 67)
-    if (variant == 63) launch_wreg_t<96, 4, 1>(p, s); else if (variant == 64) launch_wreg_t<96, 4, 2>(p, s);
-    else if (variant == 65) launch_wreg_t<96, 4, 3>(p, s); else if (variant == 66) launch_wreg_t<96, 4, 4>(p, s);
-    else launch_wreg_t<96, 4, 5>(p, s);
+    if (variant == 63) launch_wreg_t<96, 2, 1>(p, s); else if (variant == 64) launch_wreg_t<96, 2, 2>(p, s);
+    else if (variant == 65) launch_wreg_t<96, 2, 3>(p, s); else if (variant == 66) launch_wreg_t<96, 2, 4>(p, s);
+    else launch_wreg_t<96, 2, 5>(p, s);
     return true;
   }
 #endif
   int bm = variant == 60 ? 96 : variant == 62 ? 64 : 0;
-  if (!bm) {
-    double best = 1e300;
-    for (int c : {64, 96}) {
-      const long tiles = (long)((p.M + c - 1) / c) * (p.N / 128);
-      const double cost = (double)((tiles + 255) / 256) * (c + 40);
-      if (cost < best) { best = cost; bm = c; }
-    }
+  if (!bm) {      // 64 rows where that is still a single round of one tile per CU (small M: 512^2 images, single entries), else 96
+    const long t64 = (long)((p.M + 63) / 64) * (p.N / 128);
+    bm = t64 <= 256 && (double)(64 + 40) < (double)(96 + 40) ? 64 : 96;
+    if (t64 > 256) bm = 96;
   }
-  if (bm == 64) launch_wreg_t<64, 4>(p, s);
-  else launch_wreg_t<96, 4>(p, s);
+  if (bm == 64) launch_wreg_t<64, 2>(p, s);
+  else launch_wreg_t<96, 2>(p, s);
   return true;
 }
 

@@ -90,6 +90,7 @@ void igemm_set_epilogue_staged(int v);   // A/B: 1 forces the LDS-staged epilogu
 void igemm_set_unrolled(int v);   // auto selection: pipelined kernels with the k-loop unrolled by the ring depth (default on)
 #ifdef SDXL_MEASURE
 void igemm_set_timeline(void* device_buf);
+void igemm_set_wreg_timeline(void* device_buf);   // igemm_wreg.hip: [workgroups][8 waves][16] coarse stamps
 void igemm_set_wide_timeline(void* device_buf);   // igemm_glds.hip: [workgroups][8 waves][8] coarse stamps of the wide (GEGLU) kernel   // igemm_measure.hip: stamp buffer of the timeline kernel variants
 int igemm_timeline_words();
 #endif

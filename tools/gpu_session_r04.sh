@@ -15,7 +15,10 @@ for p in $PARTS; do
     attntl) SDXL_MEASURE_LIB=1 timeout 300 python tools/attn_timeline.py > $OUT/attn_timeline.txt 2>&1; cat $OUT/attn_timeline.txt;;
     attntests) timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -s -k "attention" --maxfail=8 > $OUT/attntests.log 2>&1; echo "rc=$?" >> $OUT/attntests.log; grep -E "passed|failed|pipelined vs serial|Error" $OUT/attntests.log | tail -14;;
     attnab) for v in 10 6 10 6; do SDXL_DEBUG_SET=attn_variant=$v python -c "import os,sys; sys.path.insert(0, \".\"); import __graft_entry__ as ge; pkg=ge.load_package(); ctx=pkg.Context(0); pkg.debug_set(\"attn_variant\", $v); print(\"attn_variant $v: 32^2 self-attention\", round(min(pkg.bench_attention(ctx,2,20,1024,1024,50) for _ in range(3))*1e3,2), \"us\")"; done 2>&1 | grep -v amdgpu.ids | tee $OUT/attn_ab.txt;;
-    wregab) timeout 600 python tools/wreg_ab.py ${WREG_ITERS:-20} > $OUT/wreg_ab.txt 2>&1; cat $OUT/wreg_ab.txt | tail -14;;
+    wregtl) SDXL_MEASURE_LIB=1 timeout 300 python tools/wreg_timeline.py > $OUT/wreg_timeline.txt 2>&1; cat $OUT/wreg_timeline.txt;;
+    wregdepth) SDXL_MEASURE_LIB=1 timeout 300 python tools/wreg_depth_ab.py > $OUT/wreg_depth.txt 2>&1; cat $OUT/wreg_depth.txt;;
+    libab) bash tools/lib_ab.sh ${LIB_AB} 2>&1 | tee $OUT/lib_ab.txt;;
+    wregab) SDXL_MEASURE_LIB=1 timeout 600 python tools/wreg_ab.py ${WREG_ITERS:-20} > $OUT/wreg_ab.txt 2>&1; cat $OUT/wreg_ab.txt | tail -14;;
     tests) timeout 1800 python -m pytest tests -m gpu -q -s --maxfail=12 > $OUT/tests.log 2>&1; echo "tests rc=$?" >> $OUT/tests.log; grep -E "passed|failed|error" $OUT/tests.log | tail -5;;
     ptests) timeout 1200 python -m pytest tests/test_gpu_baseline_parity.py tests/test_gpu_fullsize.py -m gpu -q -s > $OUT/ptests.log 2>&1; echo "ptests rc=$?" >> $OUT/ptests.log; grep -E "vs oracle|drift|passed|failed|Error" $OUT/ptests.log | tail -30;;
     bench) SDXL_PROFILE_DUMP=$OUT/step_launches.csv timeout 900 python bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1800 $OUT/bench.json;;
