@@ -60,92 +60,100 @@ void launch_repack_wfrag(const void* w, void* wf, int Npad, int Kpad, hipStream_
                      reinterpret_cast<f32x4*>(wf), nblocks, nk);
 }
 
-// direct row-per-lane epilogue of a BM x 32 wave tile (igemm_epilogue_rows with one column tile), plus the row statistics of
-// the stored values for the next folded LayerNorm: a 64-column statistics slot spans the wave PAIR (w, w ^ 1), so the slot's pivot
-// (its first stored value, held by the even wave) and the odd wave's half of the sums cross through LDS.  The arithmetic -- per
-// 8-column piece shifted sums, pieces paired across the lane halves, (p0 + p1) + (p2 + p3) per 32 columns, even + odd -- is the
-// tree of igemm_epilogue_rows / the staged epilogue, so the (mean, M2) bits do not depend on which kernel produced the rows.
-// Called by ALL waves of the workgroup (two barriers when p.stat_out); `active` = this wave holds a finished tile.
+// direct row-per-lane epilogue of a wave's share of a BM x 32 wave tile.  BOTH k-groups finalize: group t of the wave pair that
+// computed columns nw .. nw + 31 (even / odd k-tiles) takes the 16 columns nw + 16 t .. + 15 -- the accumulator groups q = 2t, 2t + 1, whose
+// other-group partial sums it has just added -- one v_permlane32_swap per value pair leaves a lane 8 consecutive columns of its row:
+// one 16-byte residual load and one 16-byte store per 32-row block.  Row statistics for the next folded LayerNorm: a 64-column slot is
+// held by FOUR waves here (columns: wave pair (w & ~1, w | 1); halves of 16: the two groups), so the slot's pivot (its first stored
+// value: even wave, group 0) and three partial sums cross through LDS.  The arithmetic -- per 8-column piece shifted sums, pieces
+// paired across the lane halves, then ((p0+p1) + (p2+p3)) + ((p4+p5) + (p6+p7)) -- is the tree of igemm_epilogue_rows / the staged
+// epilogue, so the (mean, M2) bits do not depend on which kernel produced the rows.  Called by all 8 waves (two barriers when p.stat_out).
+// the epilogue's operands that do not depend on the accumulators -- residual rows, bias -- are requested BEFORE the partial sums
+// cross LDS (~1.7 k cycles of barriers and LDS traffic that would otherwise precede an exposed L2 / Infinity-Cache round trip)
+template <int TM> struct WregEpiOperands { half8 rh[TM]; f32x4 rf[TM][2]; f32x4 bz0, bz1; };
 template <int TM>
-__device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM], int mw, int nw, int lane, int w,
-                                              bool active, float* xch, const void* zeros) {
+__device__ __forceinline__ void wreg_epilogue_request(const IgemmParams& p, int mw, int nw, int lane, int t, const void* zeros, WregEpiOperands<TM>& op) {
   const int fr = lane & 31, fh = lane >> 5;
   const f32x4* zv = reinterpret_cast<const f32x4*>(zeros);
-  half8 hv[TM][2];
+  const int n0 = nw + t * 16 + 8 * fh;
+  const bool r16 = p.R && p.r_dt == DT_F16, r32 = p.R && p.r_dt == DT_F32;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mw + i * 32 + fr;
+    const bool ok = m < p.M;
+    const size_t o = (size_t)(ok ? m : 0) * p.ldr + n0;
+    op.rh[i] = *((r16 && ok) ? reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.R) + o) : reinterpret_cast<const half8*>(zeros));
+    if (r32) {
+      op.rf[i][0] = *(ok ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o) : zv);
+      op.rf[i][1] = *(ok ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o + 4) : zv);
+    }
+  }
+  // (no time-embedding bias here: it rides on the 3x3 conv_in of a ResBlock only -- the launcher refuses ebias)
+  op.bz0 = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nw + 16 * t + 4 * fh) : zv);
+  op.bz1 = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nw + 16 * t + 8 + 4 * fh) : zv);
+}
+template <int TM>
+__device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM], int mw, int nw, int lane, int w, int t,
+                                              float* xch, const WregEpiOperands<TM>& op) {
+  const int fr = lane & 31, fh = lane >> 5;
+  half8 hv[TM];
   int m[TM];
   bool mok[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) { m[i] = mw + i * 32 + fr; mok[i] = m[i] < p.M; }
-  if (active) {
+  const int n0 = nw + t * 16 + 8 * fh;            // this lane's 8 consecutive output columns
+  {
     const bool r16 = p.R && p.r_dt == DT_F16, r32 = p.R && p.r_dt == DT_F32;
-    half8 rh[TM][2];
-    f32x4 rf[TM][2][2];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int n0 = nw + t * 16 + 8 * fh;
-        const size_t o = (size_t)(mok[i] ? m[i] : 0) * p.ldr + n0;
-        rh[i][t] = *((r16 && mok[i]) ? reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(p.R) + o) : reinterpret_cast<const half8*>(zeros));
-        if (r32) {
-          rf[i][t][0] = *(mok[i] ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o) : zv);
-          rf[i][t][1] = *(mok[i] ? reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + o + 4) : zv);
-        }
-      }
-    f32x4 bz[4];       // (no time-embedding bias here: it rides on the 3x3 conv_in of a ResBlock only -- the launcher refuses ebias)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bz[q] = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nw + 8 * q + 4 * fh) : zv);
+    const half8 (&rh)[TM] = op.rh;
+    const f32x4 (&rf)[TM][2] = op.rf;
+    const f32x4 bz0 = op.bz0, bz1 = op.bz1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      f32x4 v[4];
+      f32x4 v0, v1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[q][r] = acc[i][q * 4 + r];
-        v[q] = v[q] + bz[q];
+      for (int r = 0; r < 4; ++r) {               // accumulator groups q = 2t and 2t + 1 (wave-uniform t: a select, not an index)
+        v0[r] = t ? acc[i][8 + r] : acc[i][r];
+        v1[r] = t ? acc[i][12 + r] : acc[i][4 + r];
       }
+      v0 = v0 + bz0; v1 = v1 + bz1;
+      float wv[8];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        float wv[8];
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0[r]), __float_as_uint(v1[r]), false, false);
+        wv[r] = __uint_as_float(sw[0]);
+        wv[4 + r] = __uint_as_float(sw[1]);
+      }
+      if (r16) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * t][r]), __float_as_uint(v[2 * t + 1][r]), false, false);
-          wv[r] = __uint_as_float(sw[0]);
-          wv[4 + r] = __uint_as_float(sw[1]);
-        }
-        if (r16) {
+        for (int e = 0; e < 8; ++e) wv[e] += (float)rh[i][e];
+      } else if (r32) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) wv[e] += (float)rh[i][t][e];
-        } else if (r32) {
+        for (int e = 0; e < 4; ++e) { wv[e] += rf[i][0][e]; wv[4 + e] += rf[i][1][e]; }
+      }
+      if (p.c_dt == DT_F16) {
+        half8 h;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { wv[e] += rf[i][t][0][e]; wv[4 + e] += rf[i][t][1][e]; }
-        }
-        const int n0 = nw + t * 16 + 8 * fh;
-        if (p.c_dt == DT_F16) {
-          half8 h;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) h[e] = (half_t)wv[e];
-          if (mok[i]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.C) + (size_t)m[i] * p.ldc + n0) = h;
-          hv[i][t] = h;
-        } else if (mok[i]) {
-          float* cp = reinterpret_cast<float*>(p.C) + (size_t)m[i] * p.ldc + n0;
-          *reinterpret_cast<f32x4*>(cp) = f32x4{wv[0], wv[1], wv[2], wv[3]};
-          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{wv[4], wv[5], wv[6], wv[7]};
-        }
+        for (int e = 0; e < 8; ++e) h[e] = (half_t)wv[e];
+        if (mok[i]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.C) + (size_t)m[i] * p.ldc + n0) = h;
+        hv[i] = h;
+      } else if (mok[i]) {
+        float* cp = reinterpret_cast<float*>(p.C) + (size_t)m[i] * p.ldc + n0;
+        *reinterpret_cast<f32x4*>(cp) = f32x4{wv[0], wv[1], wv[2], wv[3]};
+        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{wv[4], wv[5], wv[6], wv[7]};
       }
     }
   }
   if (!p.stat_out) return;          // (kernel argument: uniform over the workgroup; the launcher admits stat_out with f16 outputs only)
-  // ---- row statistics of the stored (rounded) values, slot = the 64 columns of the wave pair (w & ~1, w | 1)
+  // ---- row statistics of the stored (rounded) values, slot = the 64 columns of the wave pair (w & ~1, w | 1) x both groups
   const int pair = w >> 1;
-  const bool odd = (w & 1) != 0;
+  const int part = (w & 1) * 2 + t;                      // position of this wave's 16 columns in the slot: pieces 2 part, 2 part + 1
   float* xpiv = xch + pair * (TM * 32);                  // [pair][row]
-  float* xsum = xch + 2 * (TM * 32) + pair * (TM * 64);  // [pair][row][2]
+  float* xsum = xch + 2 * (TM * 32) + pair * (3 * TM * 64);   // [pair][part - 1][row][2]
   float piv[TM];
-  if (active && !odd) {
+  if (part == 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      piv[i] = __shfl((float)hv[i][0][0], fr);           // the slot's first stored value (lanes 0..31 of the even wave hold it)
+      piv[i] = __shfl((float)hv[i][0], fr);              // the slot's first stored value (lanes 0..31 of the first wave hold it)
       if (fh == 0) xpiv[i * 32 + fr] = piv[i];
     }
   }
@@ -153,33 +161,27 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   float A1[TM], A2[TM];
-  if (active) {
-    if (odd) {
+  if (part != 0) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) piv[i] = xpiv[i * 32 + fr];
-    }
+    for (int i = 0; i < TM; ++i) piv[i] = xpiv[i * 32 + fr];
+  }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float s1[2], s2[2];
+  for (int i = 0; i < TM; ++i) {
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        s1[t] = 0.f; s2[t] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = (float)hv[i][t][e] - piv[i]; s1[t] += d; s2[t] = fmaf(d, d, s2[t]); }
-        s1[t] += __shfl_xor(s1[t], 32); s2[t] += __shfl_xor(s2[t], 32);
-      }
-      A1[i] = s1[0] + s1[1]; A2[i] = s2[0] + s2[1];
-      if (odd && fh == 0) { xsum[(i * 32 + fr) * 2] = A1[i]; xsum[(i * 32 + fr) * 2 + 1] = A2[i]; }
-    }
+    for (int e = 0; e < 8; ++e) { const float d = (float)hv[i][e] - piv[i]; s1 += d; s2 = fmaf(d, d, s2); }
+    A1[i] = s1 + __shfl_xor(s1, 32); A2[i] = s2 + __shfl_xor(s2, 32);        // pieces 2 part (lanes 0..31) + 2 part + 1 (lanes 32..63)
+    if (part != 0 && fh == 0) { xsum[((part - 1) * TM * 32 + i * 32 + fr) * 2] = A1[i]; xsum[((part - 1) * TM * 32 + i * 32 + fr) * 2 + 1] = A2[i]; }
   }
   wait_lgkmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (active && !odd && fh == 0) {
+  if (part == 0 && fh == 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const float s1 = A1[i] + xsum[(i * 32 + fr) * 2];
-      const float s2 = A2[i] + xsum[(i * 32 + fr) * 2 + 1];
+      const int r2 = (i * 32 + fr) * 2;
+      const float s1 = (A1[i] + xsum[r2]) + (xsum[TM * 64 + r2] + xsum[2 * TM * 64 + r2]);
+      const float s2 = (A2[i] + xsum[r2 + 1]) + (xsum[TM * 64 + r2 + 1] + xsum[2 * TM * 64 + r2 + 1]);
       if (mok[i]) {
         float* dst = p.stat_out + ((size_t)(nw >> 6) * p.M + m[i]) * 2;
         dst[0] = piv[i] + s1 * (1.0f / 64.0f);
@@ -419,31 +421,39 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- the two groups' partial sums meet in LDS: group 1 parks its accumulators (lane-linear 16-byte pieces), group 0 adds them
-  // (even k-tiles + odd k-tiles: one fixed order) and runs the epilogue
-  f32x4* xr = reinterpret_cast<f32x4*>(smem) + (size_t)w * (TM * 4 * 64) + lane;
-  if (g == 1) {
+  // ---- the two groups' partial sums meet in LDS.  Each group finalizes HALF of every wave tile's columns (group t: accumulator
+  // groups q = 2t, 2t + 1), so it parks the other half for its partner (lane-linear 16-byte pieces) and adds the partner's half
+  // to its own: even k-tiles + odd k-tiles whichever group does the add (fp32 addition commutes bit for bit)
+  WregEpiOperands<TM> eop;
+  wreg_epilogue_request<TM>(p, m0, n0 + w * 32, lane, g, zeros, eop);
+  f32x4* xw = reinterpret_cast<f32x4*>(smem) + (size_t)(g * 4 + w) * (TM * 2 * 64) + lane;          // written by (g, w)
+  const f32x4* xo = reinterpret_cast<const f32x4*>(smem) + (size_t)((1 - g) * 4 + w) * (TM * 2 * 64) + lane;   // partner's
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xr[(i * 4 + q) * 64] = f32x4{acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-  }
+    for (int qq = 0; qq < 2; ++qq) {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = g ? acc[i][4 * qq + r] : acc[i][8 + 4 * qq + r];     // group 1 parks q = 0, 1; group 0 parks q = 2, 3
+      xw[(i * 2 + qq) * 64] = v;
+    }
   wait_lgkmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (g == 0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 o = xr[(i * 4 + q) * 64];
+    for (int qq = 0; qq < 2; ++qq) {
+      const f32x4 o = xo[(i * 2 + qq) * 64];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][4 * q + r] += o[r];
+      for (int r = 0; r < 4; ++r) {
+        if (g) acc[i][8 + 4 * qq + r] = o[r] + acc[i][8 + 4 * qq + r];      // (even-tile partial + odd-tile partial in both groups)
+        else acc[i][4 * qq + r] = acc[i][4 * qq + r] + o[r];
       }
-  }
+    }
   WREG_STAMP(4);
-  float* xch = reinterpret_cast<float*>(smem + 4 * TM * 4096);      // statistics exchange: behind the accumulator exchange area
-  wreg_epilogue<TM>(p, acc, m0, n0 + w * 32, lane, w, g == 0, xch, zeros);
+  float* xch = reinterpret_cast<float*>(smem + 8 * TM * 2048);      // statistics exchange: behind the accumulator exchange area
+  wreg_epilogue<TM>(p, acc, m0, n0 + w * 32, lane, w, g, xch, eop);
 #ifdef SDXL_MEASURE
   WREG_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -460,7 +470,7 @@ void igemm_set_wreg(int v) { g_wreg_enable = v; }
 template <int BM, int L, int MODE = 0>
 static void launch_wreg_t(const IgemmParams& p, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (L + 1) * BM * 128;
-  static_assert(lds >= (size_t)4 * (BM / 32) * 4096 + (size_t)6 * BM * 4, "exchange areas must fit the dead rings");
+  static_assert(lds >= (size_t)8 * (BM / 32) * 2048 + (size_t)(2 * BM + 6 * 2 * BM) * 4, "exchange areas must fit the dead rings");
   static bool attr_set[kIgemmMaxDev] = {};
   const int dev = igemm_current_device();
   if (!attr_set[dev]) {
