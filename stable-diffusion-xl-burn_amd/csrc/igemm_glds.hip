@@ -982,7 +982,9 @@ static void launch_pipe(const IgemmParams& p, hipStream_t s) {
 }
 
 static void launch_wide(const IgemmParams& p, hipStream_t s) {
-  constexpr int NS = 4;
+  // three slots (was four): the k-loop is not latency-bound and the whole ring is requested before the first MFMA -- 108 instead of
+  // 144 KiB per CU; same-box library A/B on the bench line 21.19 / 21.12 -> 21.07 / 21.09 ms per step (profiles/r04_ring_depth_lib_ab.txt)
+  constexpr int NS = 3;
   const int tilesM = (p.M + 255) / 256, tilesN = (p.N + 319) / 320;
   const size_t lds = (size_t)NS * (256 + 320) * 64 + 2048;   // ring + LayerNorm coefficients
   static bool attr_set[kMaxDev] = {};
@@ -1143,7 +1145,7 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     if (v == 35) launch_pipe<256, 128, 3, 4, 8, half_t, true>(psk, s);
     else if (v == 36) launch_pipe<128, 128, 4, 4, 8, half_t, true>(psk, s);
     else if (v == 44) launch_pipe<128, 128, 5, 4, 8, half_t, true>(psk, s);
-    else launch_pipe<96, 128, 5, 3, 6, half_t, true>(psk, s);
+    else launch_pipe<96, 128, 3, 3, 6, half_t, true>(psk, s);     // (three slots, was five: 21.47 -> 21.39 / 21.38 ms per step with three / four, profiles/r04_ring_depth_lib_ab.txt)
     return true;
   }
   if (p.gn_part) {
