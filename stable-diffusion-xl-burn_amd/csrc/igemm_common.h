@@ -376,8 +376,7 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
         for (int q = 0; q < 4; ++q) {
           f32x4 v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][q * 4 + r];
-          v = lna * v + lnc * cz[q] + bz[q];
+          for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(lna, acc[i][j][q * 4 + r], __builtin_fmaf(lnc, cz[q][r], bz[q][r]));   // (written out: igemm_epilogue_swapped rounds alike)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int nrow = j * 32 + 8 * q + 4 * fh + r;
@@ -789,6 +788,61 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, const 
           dst[0] = st_piv[i] + s1 * (1.0f / 64.0f);
           dst[1] = fmaxf(s2 - s1 * s1 * (1.0f / 64.0f), 0.f);
         }
+      }
+    }
+  }
+}
+
+// ---- direct TRANSPOSED epilogue for operand-swapped accumulators (igemm_pipe_kernel TSW: the V^T part of a fused QKV projection).
+// With the activations as the MFMA A operand a lane holds, per 32x32 tile, ONE output column n = nw + 32 j + (lane & 31) and 4 groups of
+// 4 consecutive ROWS m = mw + 32 i + 8 g + 4 (lane >> 5) + r -- consecutive keys of the transposed output Ct[b][n - n_split][key].  The
+// half swap of igemm_epilogue_rows, on rows instead of columns, leaves a lane 8 consecutive keys: one 16-byte store per pair of groups.
+// Bias and the folded-LayerNorm column sum are per lane (one column), the row coefficients (a, c) of the folded LayerNorm come from the
+// workgroup's coefficient table in LDS (LnCoop; `coef` = the wave's first row, null without a folded LayerNorm).  The values are the staged
+// path's: same products in the same k order, same affine expression, one rounding to f16.
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue_swapped(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane,
+                                                       const float* coef, const void* zeros) {
+  (void)zeros;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int b = mw / p.rpb;                          // (whole wave tiles inside one batch entry: rpb % BM == 0)
+  const int key_w = mw - b * p.rpb;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + fr;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float cs = p.ln_stat ? p.ln_cs[n] : 0.f;
+    half_t* crow = reinterpret_cast<half_t*>(p.Ct) + ((size_t)b * p.ct_rows + (n - p.n_split)) * p.ct_ld + key_w;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f32x4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a4 = {1.f, 1.f, 1.f, 1.f}, c4 = {0.f, 0.f, 0.f, 0.f};
+        if (coef && p.ln_stat) {
+          const f32x4 c01 = *reinterpret_cast<const f32x4*>(coef + (i * 32 + 8 * g + 4 * fh) * 2);        // (a, c) of rows r = 0, 1
+          const f32x4 c23 = *reinterpret_cast<const f32x4*>(coef + (i * 32 + 8 * g + 4 * fh) * 2 + 4);    // rows r = 2, 3
+          a4 = f32x4{c01[0], c01[2], c23[0], c23[2]};
+          c4 = f32x4{c01[1], c01[3], c23[1], c23[3]};
+        }
+#pragma unroll
+        // (the staged transposed path's expression, written out in both places: the two epilogues round alike, so a batch entry stays
+        //  bit-identical whichever tile its batch size selects)
+        for (int r = 0; r < 4; ++r) v[g][r] = __builtin_fmaf(a4[r], acc[i][j][4 * g + r], __builtin_fmaf(c4[r], cs, bias));
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float w[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * t][r]), __float_as_uint(v[2 * t + 1][r]), false, false);
+          w[r] = __uint_as_float(sw[0]);
+          w[4 + r] = __uint_as_float(sw[1]);
+        }
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (half_t)w[e];
+        if (n < p.N) *reinterpret_cast<half8*>(crow + i * 32 + 16 * t + 8 * fh) = h;
       }
     }
   }

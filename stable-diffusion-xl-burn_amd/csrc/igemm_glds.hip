@@ -22,6 +22,7 @@
 //                      f16, strict f32 (4 x v_mfma_f32_32x32x2_f32) and the fused cross-attention instantiations
 //   igemm_wide_kernel  256x320 tile, k-tile 32                                           (GEGLU projections)
 #include "igemm_common.h"
+#include <atomic>
 
 namespace sdxl {
 
@@ -193,7 +194,12 @@ __global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams
 //   * S2 ("two k-tiles per rendezvous", rings of >= 4 slots): the vmcnt wait + s_barrier run in every SECOND k-tile only and cover the
 //     next TWO tiles; the DMA lead is one tile shorter (tile kt + NS - 2 goes into the slot of tile kt - 2, which the last barrier
 //     -- in tile kt - 1 or kt - 2 -- has freed).  Half the rendezvous of a launch for one tile less in flight.
-template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false>
+// TSW ("transposed by operand swap", f16 256x128 only): workgroups whose whole tile lies in the transposed part of the output (the V^T
+// columns of a fused QKV projection) run a copy of the k-loop with the MFMA operand roles swapped -- activations as the A operand -- so a
+// lane's accumulators are 4 x 4 consecutive ROWS (keys) of one column: the transposed store is then the direct row-per-lane epilogue
+// (permlane32 half swap, 16-byte stores along the key axis) instead of the LDS-staged transpose (12.6 k cycles per 64x64 wave tile, the
+// longest epilogue of the launch: tools/timeline_probe.py).  Same products, same k order: bit-identical values.
+template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false, bool TSW = false>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
   kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();   // every argument line in flight at once (one wait instead of five)
   typedef typename PipeElem<T>::frag frag_t;
@@ -238,6 +244,13 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   if ((size_t)p.N * p.K > (size_t)p.M * p.Cin) { tn = bid / tilesM; tm = bid - tn * tilesM; }
   else { tm = bid / tilesN; tn = bid - tm * tilesN; }
   const int m0 = tm * BM, n0 = tn * BN;
+  // TSW: the whole tile in the transposed part, whole 8-key pieces inside one batch entry, f16 out -> operand-swapped k-loop + direct transposed store
+  bool tsw_swapped = false;
+  if constexpr (TSW) {
+    const int ok = n0 >= p.n_split && n0 + BN <= p.N && p.c_dt == DT_F16 && p.act == 0 && !p.epi_staged && (p.rpb % BM) == 0 && m0 + BM <= p.M &&
+                   (p.ct_ld & 7) == 0 && (reinterpret_cast<uintptr_t>(p.Ct) & 15) == 0 && (!p.ln_stat || p.ln_slots <= 24);
+    tsw_swapped = __builtin_amdgcn_readfirstlane(ok) != 0;
+  }
   // counted DMA wait: K tiles of this wave's pieces may stay in flight
   auto wait_tiles = [&](auto KK) {
     constexpr int k = decltype(KK)::value;
@@ -420,11 +433,13 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<decltype(J)::value * 4096, frag_t>(ab); });
   };
   // MFMAs of one kk-step from fragment set SET; DMA pieces PH (or none, PH = 3) are issued between them
-  auto mma = [&](auto SET, int buf, auto PH, bool more) {
+  auto mma = [&](auto SET, int buf, auto PH, bool more, auto SWT) {
     constexpr int set = decltype(SET)::value;
     constexpr int ph = decltype(PH)::value;
+    constexpr bool sw = decltype(SWT)::value;      // operand roles swapped (TSW): D^T tiles
     if constexpr (!HL) {
-    acc[0][0] = PipeElem<T>::mma(fB[set][0], fA[set][0], acc[0][0]);
+    if constexpr (sw) acc[0][0] = PipeElem<T>::mma(fA[set][0], fB[set][0], acc[0][0]);
+    else acc[0][0] = PipeElem<T>::mma(fB[set][0], fA[set][0], acc[0][0]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ph < 3) {
       if (more) issue(buf, PH);            // wave-uniform branch around the DMA pieces only, never around MFMAs
@@ -432,7 +447,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     }
     static_for<TM * TN - 1>([&](auto X) {
       constexpr int x = decltype(X)::value + 1, i = x / TN, j = x % TN;
-      acc[i][j] = PipeElem<T>::mma(fB[set][j], fA[set][i], acc[i][j]);
+      if constexpr (sw) acc[i][j] = PipeElem<T>::mma(fA[set][i], fB[set][j], acc[i][j]);
+      else acc[i][j] = PipeElem<T>::mma(fB[set][j], fA[set][i], acc[i][j]);
     });
     __builtin_amdgcn_sched_barrier(0);
     }
@@ -589,15 +605,16 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       mma_hl(I2{}, I3{}, Tt{}, WX{}, fl, I3{}, false);    // w_hi1 x a_lo1 (+ w_lo1 x a_hi1)
       return;
     }
+    using SWT = std::integral_constant<bool, !HL && wx>;     // (non-split kernels: the flag selects the operand-swapped copy, TSW)
     ldf(SO{}, I1{}, I1{}, NB0{});
     wait_lgkmcnt<NF>();
-    mma(I0{}, fl, I0{}, more);
+    mma(I0{}, fl, I0{}, more, SWT{});
     ldf(SO{}, I2{}, I0{}, NB0{});
     wait_lgkmcnt<NF>();
-    mma(I1{}, fl, I1{}, more);
+    mma(I1{}, fl, I1{}, more, SWT{});
     ldf(SO{}, I3{}, I1{}, NB0{});
     wait_lgkmcnt<NF>();
-    mma(I0{}, fl, I2{}, more);
+    mma(I0{}, fl, I2{}, more, SWT{});
     if (more) tile_done();
     if (kt + 1 < nk) {
       if (!S2 || (kt & 1)) {
@@ -617,7 +634,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     } else {
       wait_lgkmcnt<0>();
     }
-    mma(I1{}, fl, I3{}, false);
+    mma(I1{}, fl, I3{}, false, SWT{});
   };
   int kt = 0;
   auto kloop = [&](auto WXT) {
@@ -629,6 +646,11 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     // registers at the loop entry -- they must have LANDED before that (one LDS latency per launch)
     wait_lgkmcnt<0>();
     if (hl_wexact) kloop(std::true_type{}); else kloop(std::false_type{});       // wave-uniform: a device scalar next to the weight scale
+  } else if constexpr (TSW) {
+    // (two copies of the k-loop, as the split-operand kernel's: the choice is made wave-uniform for the compiler, and the first
+    // fragments -- asm reads it believes complete -- must have landed before either copy takes them over)
+    wait_lgkmcnt<0>();
+    if (tsw_swapped) kloop(std::true_type{}); else kloop(std::false_type{});
   } else kloop(std::false_type{});
   __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring: it becomes the staging area
   asm volatile("" ::: "memory");
@@ -697,6 +719,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   // (GEGLU projections keep the staged epilogue: measured per shape in the step, tools/launch_ab.py, the direct form is 1 - 5 us
   // faster on every plain shape and 23 - 50 us SLOWER on the 256x320 GEGLU kernel, whose 160 accumulator registers leave no
   // room for the per-column vectors -- profiles/r03_epilogue_ab.txt)
+  if constexpr (TSW) {
+    if (tsw_swapped) {
+      igemm_epilogue_swapped<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, ln_coop ? ln_coef + (wm * WM) * 2 : nullptr, zeros);
+      return;
+    }
+  }
   if (!p.epi_staged && p.act != 1 && igemm_rows_ok<TM, TN, false>(p, n0 + wn * WN)) {
     igemm_epilogue_rows<TM, TN, false>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros);
     return;
@@ -967,18 +995,18 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_pages[dev]);
 }
 
-template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false>
+template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false, bool TSW = false>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)pipe_lds_total(NS * (BM + BN) * 128, 0);   // ring + LayerNorm coefficients
   static bool attr_set[kMaxDev] = {};
   const int dev = current_device();
-  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2>, lds, attr_set, dev);
+  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2, TSW>, lds, attr_set, dev);
   const int sk = (BN == 128 && p.splitk > 1) ? p.splitk : 1;
   if (sk > 1 && (size_t)tilesM * tilesN * sk * BM * BN * 4 > p.splitk_ws_bytes) throw std::runtime_error("igemm: split-K workspace too small");
   IgemmParams q = p;
   q.splitk = sk;
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2, TSW>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
 }
 
 static void launch_wide(const IgemmParams& p, hipStream_t s) {
@@ -996,6 +1024,8 @@ static void launch_wide(const IgemmParams& p, hipStream_t s) {
 
 // variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
 // 6 = 64x128 ring 2; 7 = 128x128 ring 4; 8 = 64x128 ring 3.  Returns false when the shape needs the generic kernel.
+static std::atomic<int> g_tsw{1};      // A/B knob (sdxl_debug_set "igemm_tsw"): 0 = the V^T part of a fused QKV projection keeps the LDS-staged transposed epilogue
+void igemm_set_tsw(int v) { g_tsw = v; }
 static bool g_igemm_unrolled = true;
 void igemm_set_unrolled(int v) { g_igemm_unrolled = v != 0; }
 
@@ -1175,7 +1205,10 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     // ---- production kernels (what the auto selection launches)
     case 4: launch_glds<128, 128, 2>(psk, s); break;                          // 4 waves, 2-3 co-resident blocks: ragged multi-round grids
     case 6: launch_glds<64, 128, 2>(psk, s); break;
-    case 35: launch_pipe<256, 128, 3, 4, 8>(psk, s); break;   // 8 waves, hand-ordered k-loop unrolled by the ring depth
+    case 35:    // 8 waves, hand-ordered k-loop unrolled by the ring depth; outputs with a transposed part (fused QKV: V^T) take the operand-swap twin
+      if (p.n_split < p.N && g_tsw.load()) launch_pipe<256, 128, 3, 4, 8, half_t, false, false, true>(psk, s);
+      else launch_pipe<256, 128, 3, 4, 8>(psk, s);
+      break;
     case 36: launch_pipe<128, 128, 4, 4, 8>(psk, s); break;
     case 38:                                                                // 256x160 GEGLU tile (8x1 waves)
       if (p.N % 160 != 0) return false;

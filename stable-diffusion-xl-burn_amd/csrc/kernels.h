@@ -82,6 +82,7 @@ void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
 // A-operand fragments, contiguous over k -- what igemm_wreg_kernel streams straight into registers.  Npad % 32 == 0, Kpad % 64 == 0.
 void launch_repack_wfrag(const void* w, void* wf, int Npad, int Kpad, hipStream_t s);
 bool igemm_wreg_ok(const IgemmParams& p);   // shapes the weights-in-registers kernel takes (plain f16 linear / 1x1, N % 128 == 0, Wf set)
+void igemm_set_tsw(int v);       // A/B knob (sdxl_debug_set "igemm_tsw"): 0 = no operand-swapped k-loop for the transposed part of a fused QKV projection
 void igemm_set_wreg(int v);      // A/B knob (sdxl_debug_set "igemm_wreg"): 0 = the auto selection never picks the weights-in-registers kernel
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
 void igemm_set_hl_weights_exact(int v); // A/B: 0 keeps all three MFMAs per product even where the packed weights are exact f16 values

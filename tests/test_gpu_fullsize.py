@@ -35,6 +35,16 @@ def test_fullsize_unet_properties(pkg, ctx, base_inputs):
         one = u.forward(x[i:i + 1].cuda(), t[i:i + 1].cuda(), ctxt[i:i + 1].cuda(), y[i:i + 1].cuda()).cpu()
         assert torch.equal(one[0], outs[0][i]), f"batch entry {i} depends on its batch neighbour"
     # (accuracy at this size is held against the ORACLE in test_gpu_baseline_parity.py::test_unet_forward_1024_matches_oracle)
+    # the V^T part of the fused QKV projections: operand-swapped k-loop + direct transposed store (default) against the LDS-staged
+    # transposed epilogue (knob off) -- same products, same k order, same affine expression: the whole forward must not move a bit
+    del u
+    pkg.debug_set("igemm_tsw", 0)
+    try:
+        u0 = pkg.UNet(ctx, cfg, pkg.DTYPE_F16, seed=0)
+        staged = u0.forward(x.cuda(), t.cuda(), ctxt.cuda(), y.cuda()).cpu()
+    finally:
+        pkg.debug_set("igemm_tsw", 1)
+    assert torch.equal(staged, outs[0]), "operand-swapped V^T epilogue changes the result"
 
 
 def _prompt_ids(seed, n_tok, pad):
