@@ -398,6 +398,26 @@ __device__ __forceinline__ void igemm_epilogue_staged_impl(const IgemmParams& p,
     // requested up front through a pointer select, one wait for the lot instead of a load -> wait -> add -> store chain
     // per piece; anything else (fp32 residual stream, ragged or unaligned pieces) takes the per-piece path below
     constexpr int NIT = (ITEMS + 63) / 64;
+    // lean form for whole, aligned f16 tiles without residual or statistics (every GEGLU projection of the UNet): the general loop
+    // below spends most of its instructions on per-item validity / alignment selects and 64-bit pointer arithmetic -- the two staged
+    // passes of the wide GEGLU kernel are 21 k of its 106 k cycles (profiles/r04_wide_geglu_timeline.txt)
+    if (GEGLU && !p.R && !p.stat_out && !gc && p.c_dt == DT_F16 && mw + ROWS <= p.M && nwo + COLS <= nlim && (p.ldc & 7) == 0 &&
+        (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {
+      half_t* cbase = reinterpret_cast<half_t*>(p.C) + (size_t)mw * p.ldc + nwo;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / LPR, piece = idx - row * LPR;
+        if (ITEMS % 64 != 0 && idx >= ITEMS) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece) ^ (row & SWN)) << 4));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + row * RB + (((2 * piece + 1) ^ (row & SWN)) << 4));
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (half_t)a[e]; h[4 + e] = (half_t)b[e]; }
+        *reinterpret_cast<half8*>(cbase + row * p.ldc + piece * 8) = h;
+      }
+      return;
+    }
     half8 rpre[NIT];
     bool rfast[NIT];
     // GroupNorm statistics of the stored tile (gn_part): a lane keeps the same 8 columns over the NIT row groups, so the column
