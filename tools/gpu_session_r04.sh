@@ -19,6 +19,7 @@ for p in $PARTS; do
     wregdepth) SDXL_MEASURE_LIB=1 timeout 300 python tools/wreg_depth_ab.py > $OUT/wreg_depth.txt 2>&1; cat $OUT/wreg_depth.txt;;
     libab) bash tools/lib_ab.sh ${LIB_AB} 2>&1 | tee $OUT/lib_ab.txt;;
     fstests) timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -s -x > $OUT/fstests.log 2>&1; echo "rc=$?" >> $OUT/fstests.log; grep -E "passed|failed|Error|assert" $OUT/fstests.log | tail -8;;
+    icache) SDXL_MEASURE_LIB=1 timeout 300 python tools/icache_probe.py > $OUT/icache_probe.txt 2>&1; cat $OUT/icache_probe.txt;;
     wregab) SDXL_MEASURE_LIB=1 timeout 600 python tools/wreg_ab.py ${WREG_ITERS:-20} > $OUT/wreg_ab.txt 2>&1; cat $OUT/wreg_ab.txt | tail -14;;
     tests) timeout 1800 python -m pytest tests -m gpu -q -s --maxfail=12 > $OUT/tests.log 2>&1; echo "tests rc=$?" >> $OUT/tests.log; grep -E "passed|failed|error" $OUT/tests.log | tail -5;;
     ptests) timeout 1200 python -m pytest tests/test_gpu_baseline_parity.py tests/test_gpu_fullsize.py -m gpu -q -s > $OUT/ptests.log 2>&1; echo "ptests rc=$?" >> $OUT/ptests.log; grep -E "vs oracle|drift|passed|failed|Error" $OUT/ptests.log | tail -30;;
