@@ -134,6 +134,7 @@ struct WeightBuilder {
   int dt;
   hipStream_t st;
   float* tmp = nullptr; size_t tmp_numel = 0;
+  std::string last_fetched;      // name of the tensor `tmp` holds (fetch() of the same name again is free)
   WeightBuilder(const std::vector<ParamSpec>& sp, WeightSource& s, DeviceArena& a, int dtype, hipStream_t stream);
   ~WeightBuilder();
   static size_t arena_bound(const std::vector<ParamSpec>& specs, int dt);

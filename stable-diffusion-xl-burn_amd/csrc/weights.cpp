@@ -96,7 +96,8 @@ void FlatSourceF16::fetch(const ParamSpec& s, size_t index, float* dst, hipStrea
     uint16_t h = 0;
     SDXL_HIP(hipMemcpyAsync(&h, base + offsets[index], sizeof(h), hipMemcpyDefault, st));
     SDXL_HIP(hipStreamSynchronize(st));
-    const float v = h == 0x00A8u ? 1e-5f : f16_bits_to_float(h);
+    // (likewise 1e-6, the VAE GroupNorm eps python/save.py writes: 0x0011 is its f16 image, 1.013e-6 when widened)
+    const float v = h == 0x00A8u ? 1e-5f : (h == 0x0011u ? 1e-6f : f16_bits_to_float(h));
     SDXL_HIP(hipMemcpyAsync(dst, &v, sizeof(float), hipMemcpyHostToDevice, st));
     SDXL_HIP(hipStreamSynchronize(st));
     return;
@@ -139,8 +140,12 @@ const ParamSpec& WeightBuilder::spec(const std::string& name, size_t* idx) const
   return specs[it->second];
 }
 const float* WeightBuilder::fetch(const std::string& name) {
+  // (the split-operand packing asks for a weight three times in a row -- absmax, exactness flag, packer: the staging buffer still holds
+  //  it, and a host-backed source would otherwise pay three H2D copies of up to 26 MB per layer)
+  if (name == last_fetched) return tmp;
   size_t i; const ParamSpec& s = spec(name, &i);
   src.fetch(s, i, tmp, st);
+  last_fetched = name;
   return tmp;
 }
 // Split-operand packing (DT_HL): hi = f16(w * 2^e), lo = f16(w * 2^e - hi).  With 2^e * max|w| in [2^13, 2^14) both halves of every
