@@ -1184,8 +1184,8 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   }
   // plain linear layers / 1x1 convs whose weights also exist in fragment order: the weights-in-registers kernel (igemm_wreg.hip).
   // The rule is static per layer (never the batch), so its k-summation order (even + odd k-tiles) is what such a layer always gets.
-  if ((variant == 0 || (variant >= 60 && variant <= 69)) && launch_igemm_wreg(psk, variant, s)) return true;
-  if (variant >= 60 && variant <= 69) return false;
+  if ((variant == 0 || (variant >= 60 && variant <= 77)) && launch_igemm_wreg(psk, variant, s)) return true;
+  if (variant >= 60 && variant <= 77) return false;
   if (variant == 0 && igemm_splitk_slices(p) > 1) {
     // long contractions over a small output (FF-out and the 32^2 convs of the CFG pair: M = 2048, N = 1280 is 80 tiles of
     // 256x128 on 256 CUs): three k-slices per tile fill the chip with the tile shape that moves the fewest bytes per flop

@@ -206,7 +206,14 @@ void igemm_set_wreg_timeline(void* buf) {
 #endif
 // MODE (measure builds, forced variants 63 ..): 0 production; knock-outs that time one resource alone (results are garbage):
 // 1 no MFMAs, 2 operand pointers frozen (every fetch after the first hits the L1 / L2: same instruction stream, no fabric traffic),
-// 3 no VMEM at all in the k-loop, 4 no k-loop barriers; 5 = production arithmetic with the other XCD ownership (row tiles)
+// 3 no VMEM at all in the k-loop, 4 no k-loop barriers; 5 = production arithmetic with the other XCD ownership (row tiles);
+// 6 weight stream only (no activation pieces), 7 activation pieces only (no weight loads), 8 activation pieces read as CONTIGUOUS
+// 1-KiB runs (what a k-tile-major activation layout would give) instead of 8 rows x 128 B at the row stride -- waits stay exact in 6 / 7
+// MODE >= 16: a bit set of the same knock-outs (16 no MFMAs, 32 frozen pointers, 64 no VMEM, 128 no barriers, 256 other XCD ownership,
+// 512 no activation pieces, 1024 no weight loads, 2048 contiguous activation pieces, 4096 no LDS fragment reads)
+constexpr int wreg_mode_flags(int m) {
+  return m >= 16 ? m : m == 1 ? 16 : m == 2 ? 32 : m == 3 ? 64 : m == 4 ? 128 : m == 5 ? 256 : m == 6 ? 512 : m == 7 ? 1024 : m == 8 ? 2048 : 0;
+}
 template <int BM, int L, int MODE = 0>
 __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, const void* zeros) {
 #ifdef SDXL_MEASURE
@@ -219,7 +226,12 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   constexpr int NSG = L + 1;                  // ring slots / weight register stages per group
   constexpr int TM = BM / 32;                 // accumulator tiles per wave (wave tile BM x 32)
   constexpr int PP = BM / 32;                 // activation DMA pieces (8 rows x 128 B) per wave and k-tile
-  constexpr int U = PP + 4;                   // VMEM operations per wave and k-tile
+  constexpr int FL = wreg_mode_flags(MODE);
+  constexpr bool NOMFMA = FL & 16, FROZEN = FL & 32, NOVMEM = FL & 64, NOBAR = FL & 128, XCDALT = FL & 256, NOA = FL & 512, NOWL = FL & 1024,
+                 ACONTIG = FL & 2048, NOLDS = FL & 4096;
+  constexpr int NW = NOWL ? 0 : 4;            // weight fragment loads per wave and k-tile
+  constexpr int NA = NOA ? 0 : PP;            // activation pieces the wave issues per k-tile
+  constexpr int U = NA + NW;                  // VMEM operations per wave and k-tile
   constexpr int NOPS = U;
   constexpr int SLOT = BM * 128;              // bytes per ring slot
   constexpr int RING = NSG * SLOT;            // bytes per group
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   // (profiles/r04_wreg_knockout.txt).
   const int tilesN = p.N >> 7;
   int tm = bid / tilesN, tn = bid - tm * tilesN;
-  if constexpr (MODE == 5) { tn = bid / tilesM; tm = bid - tn * tilesM; }
+  if constexpr (XCDALT) { tn = bid / tilesM; tm = bid - tn * tilesM; }
   const int m0 = tm * BM, n0 = tn * 128;
   const int nk = p.Kpad >> 6;
   const int nkg = (nk - g + 1) >> 1;          // k-tiles of this group: g, g + 2, ...
@@ -258,11 +270,11 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   // ---- weight stream: this wave's 32 columns, fragment order, contiguous over k
   const half_t* wp = reinterpret_cast<const half_t*>(p.Wf) + ((size_t)((n0 >> 5) + w) * nk + g) * 2048 + lane * 8;
   half8 Wr[NSG][4];
-  if constexpr (MODE == 3) { static_for<NSG>([&](auto S_) { static_for<4>([&](auto K_) { Wr[decltype(S_)::value][decltype(K_)::value] = half8{1, 1, 1, 1, 1, 1, 1, 1}; }); }); }
+  if constexpr (NOVMEM || NOWL) { static_for<NSG>([&](auto S_) { static_for<4>([&](auto K_) { Wr[decltype(S_)::value][decltype(K_)::value] = half8{1, 1, 1, 1, 1, 1, 1, 1}; }); }); }
   auto loadW = [&](auto S, auto KK) {
     constexpr int s = decltype(S)::value, kk = decltype(KK)::value;
-    if constexpr (MODE != 3) Wr[s][kk] = wreg_gload128<kk * 1024>(wp);
-    if constexpr (kk == 3 && MODE != 2) wp += NG * 2048;
+    if constexpr (!NOVMEM && !NOWL) Wr[s][kk] = wreg_gload128<kk * 1024>(wp);
+    if constexpr (kk == 3 && !FROZEN) wp += NG * 2048;
   };
   // ---- activation pieces: piece q of this wave = tile rows (4 q + w) * 8 .. + 7 of the group's k-tile; lane -> (row, 16-byte slot)
   const half_t* Ag = reinterpret_cast<const half_t*>(p.A);
@@ -277,18 +289,22 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
       const bool ok = m < p.M;
       aptr[q] = ok ? Ag + (size_t)m * p.lda + g * 64 + (((lane & 7) ^ ((row >> 1) & 7)) << 3) : reinterpret_cast<const half_t*>(zeros);
       aadv[q] = ok ? KSTEP : 0;
+      if constexpr (ACONTIG) {       // the same bytes per tile and the same sharing between the column tiles of a row tile, one run per piece
+        aptr[q] = Ag + ((size_t)(tm % (p.M / BM)) * nk + g) * (BM * 64) + (q * 4 + w) * 512 + lane * 8;
+        aadv[q] = NG * BM * 64;
+      }
     }
   };
   auto pieceA = [&](auto S, auto Q) {
     constexpr int s = decltype(S)::value, q = decltype(Q)::value;
-    if constexpr (MODE != 3) __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(ring + s * SLOT + (q * 4 + w) * 1024), 16, 0, 0);
-    if constexpr (MODE != 2) aptr[q] += aadv[q];
+    if constexpr (!NOVMEM && !NOA) __builtin_amdgcn_global_load_lds((gptr_t)aptr[q], (lptr_t)(ring + s * SLOT + (q * 4 + w) * 1024), 16, 0, 0);
+    if constexpr (!FROZEN) aptr[q] += aadv[q];
   };
   // operation x of a k-tile's VMEM sequence: 0..3 weight fragments, 4.. activation pieces
   auto vmem_op = [&](auto S, auto X) {
     constexpr int x = decltype(X)::value;
-    if constexpr (x < 4) loadW(S, X);
-    else pieceA(S, std::integral_constant<int, x - 4>{});
+    if constexpr (x < NW) loadW(S, X);
+    else pieceA(S, std::integral_constant<int, x - NW>{});
   };
 
   const int fr = lane & 31, fh = lane >> 5;
@@ -299,9 +315,10 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     for (int kk = 0; kk < 4; ++kk) fa[kk] = basea ^ (kk << 5);
   }
   half8 fA[2][TM];
+  if constexpr (NOLDS) { static_for<TM>([&](auto I) { fA[0][decltype(I)::value] = fA[1][decltype(I)::value] = half8{1, 1, 1, 1, 1, 1, 1, 1}; }); }
   auto ldsA = [&](auto SET, auto S, auto KK) {
     constexpr int set = decltype(SET)::value, s = decltype(S)::value, kk = decltype(KK)::value;
-    static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<s * SLOT + decltype(I)::value * 4096>(fa[kk]); });
+    if constexpr (!NOLDS) static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<s * SLOT + decltype(I)::value * 4096>(fa[kk]); });
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -356,7 +373,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     constexpr int set = decltype(SET)::value, s = decltype(S)::value, kk = decltype(KK)::value, x0 = decltype(X0)::value;
     static_for<TM>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      if constexpr (MODE != 1) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[s][kk], fA[set][i], acc[i], 0, 0, 0);
+      if constexpr (!NOMFMA) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wr[s][kk], fA[set][i], acc[i], 0, 0, 0);
       else asm volatile("" ::"v"(Wr[s][kk]), "v"(fA[set][i]));      // (keeps the in-flight destination registers allocated up to here)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (x0 >= 0 && x0 + i < NOPS) {
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     using X1 = std::integral_constant<int, steady ? TM : -1>;
     using X2 = std::integral_constant<int, steady ? 2 * TM : -1>;
     ldsA(I1{}, S, I1{});
-    wait_vmcnt<steady ? PP + (L - 1) * U : PP + (D - 1) * U>();        // W(j) has landed
+    wait_vmcnt<steady ? NA + (L - 1) * U : NA + (D - 1) * U>();        // W(j) has landed
     wait_lgkmcnt<TM>();
     mma(I0{}, S, I0{}, SF{}, X0{});
     ldsA(I0{}, S, I2{});
@@ -389,7 +406,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
     if constexpr (steady || D > 1) {
       wait_vmcnt<steady ? (L - 1) * U : (D - 2) * U>();                // own pieces of tile j + 1 have landed
       wait_lgkmcnt<0>();
-      if constexpr (MODE != 4) __builtin_amdgcn_s_barrier();
+      if constexpr (!NOBAR) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       ldsA(I0{}, SN{}, I0{});
@@ -416,7 +433,7 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   });
   WREG_STAMP(3);
   // odd k-tile count: group 1 has one tile -- and one rendezvous -- less; barrier counts must match across the workgroup
-  if constexpr (MODE != 4) { if ((nk & 1) && g == 1) __builtin_amdgcn_s_barrier(); }
+  if constexpr (!NOBAR) { if ((nk & 1) && g == 1) __builtin_amdgcn_s_barrier(); }
   __builtin_amdgcn_s_barrier();                    // both rings are dead: they become the exchange area
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -521,6 +538,14 @@ bool launch_igemm_wreg(const IgemmParams& p, int variant, hipStream_t s) {
     else launch_wreg_t<96, 2, 5>(p, s);
     return true;
   }
+  if (variant == 70) { launch_wreg_t<96, 2, 6>(p, s); return true; }     // per-stream knock-outs: weights only / activations only / contiguous activations
+  if (variant == 71) { launch_wreg_t<96, 2, 7>(p, s); return true; }
+  if (variant == 72) { launch_wreg_t<96, 2, 8>(p, s); return true; }
+  if (variant == 73) { launch_wreg_t<96, 2, 16 | 32>(p, s); return true; }                 // fetch stream + LDS reads, every byte an L2 hit
+  if (variant == 74) { launch_wreg_t<96, 2, 16 | 32 | 4096>(p, s); return true; }          // ... without the LDS reads
+  if (variant == 75) { launch_wreg_t<96, 2, 16 | 32 | 4096 | 128>(p, s); return true; }    // ... and without the rendezvous
+  if (variant == 76) { launch_wreg_t<96, 2, 16 | 4096>(p, s); return true; }               // fetch stream alone, real pointers
+  if (variant == 77) { launch_wreg_t<96, 2, 4096>(p, s); return true; }                    // MFMAs + fetch stream, no LDS reads
 #endif
   int bm = variant == 60 ? 96 : variant == 62 ? 64 : 0;
   if (!bm) {      // 64 rows where that is still a single round of one tile per CU (small M: 512^2 images, single entries), else 96
