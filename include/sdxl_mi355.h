@@ -269,6 +269,8 @@ int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int 
  * "igemm_wreg": 0 = the auto selection never picks the weights-in-registers GEMM (csrc/igemm_wreg.hip; A/B, default 1), forced by
  * "igemm_variant" 60 / 62 (96 / 64 rows per tile); "igemm_epilogue_staged", "hl_weights_exact": A/B knobs of the epilogue form / the
  * two-MFMA loop of exact-f16 split-operand weights;
+ * "igemm_warm": 0 = no weight-warming workgroups (spare workgroups of a weights-in-registers launch read a later GEMM's weights into the
+ * Infinity Cache; results unchanged; A/B, default 1; a UNet picks it up on its next forward);
  * "igemm_unrolled": 0 = auto selection launches the rolled k-loop kernels (A/B; default 1);
  * "split_cfg": 1 = a batch-2 UNet::forward runs its two entries as two concurrent batch-1 chains (bit-identical results);
  * "split_offset": GEMM launches of the first chain before the second is released; "no_cfg": base model without the

@@ -164,6 +164,7 @@ int sdxl_debug_set(const char* key, int value) {
   else if (std::strcmp(key, "hl_weights_exact") == 0) igemm_set_hl_weights_exact(value);
   else if (std::strcmp(key, "igemm_wreg") == 0) igemm_set_wreg(value);
   else if (std::strcmp(key, "igemm_tsw") == 0) igemm_set_tsw(value);
+  else if (std::strcmp(key, "igemm_warm") == 0) igemm_set_warm(value);
 #ifdef SDXL_MEASURE
   else if (std::strcmp(key, "igemm_unrolled") == 0) igemm_set_unrolled(value);
   else if (std::strcmp(key, "xa_vec64") == 0) igemm_set_xa_vec64(value);

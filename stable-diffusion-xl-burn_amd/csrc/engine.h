@@ -177,6 +177,16 @@ struct Profiler {
   void collect(float ms[NCLS], int launches[NCLS], double flops[NCLS]);   // synchronises, then frees the events
 };
 
+// the GEMM launches of one forward in launch order (weights each one reads, whether its kernel can host warming workgroups):
+// recorded on the plan's first eager forward, replayed on every later one -- launch i is handed the weights of a later launch
+// (IgemmParams::warm).  Static shapes: the sequence of a plan never changes.
+struct WarmSeq {
+  struct Item { const void* w; unsigned bytes; bool host; unsigned budget; const void* warm; unsigned warm_bytes; const void* warm2; unsigned warm2_bytes; };
+  std::vector<Item> seq;
+  size_t pos = 0;
+  bool recording = false, ready = false;
+  void finish();       // assigns targets to hosts (weights.cpp)
+};
 struct Exec {
   Profiler* prof = nullptr;
   hipStream_t s = nullptr;
@@ -190,6 +200,7 @@ struct Exec {
   int b0 = 0;                      // first batch entry of this run (split-CFG chains address the K/V caches with it)
   hipEvent_t fork_ev = nullptr;    // split-CFG: recorded on s after the fork_after-th GEMM launch of chain 0 -- the second
   int fork_after = 0, launches = 0; // chain starts there, so the two chains run out of phase (GEMMs of one under the attention of the other)
+  WarmSeq* warm = nullptr;         // weight warming schedule of the plan (null: off)
   Act alloc(size_t rows, int C, int dt) {
     return Act(act->alloc(rows * (size_t)C * dt_size(dt)), C, dt);
   }
@@ -294,6 +305,8 @@ class UNet {
   bool split_cfg_ = false; int split_offset_ = 0;
   bool plan_split_ = false; int graph_off_ = 0;
   bool fuse_xattn_ = true, plan_xattn_ = true;   // cross-attention inside the query projection's epilogue (f16 engines)
+  WarmSeq warm_;                    // weight warming schedule of the current plan (recorded on its first forward)
+  bool graph_warm_ = false;         // the captured graph carries the warming workgroups
   bool gn_from_producer_ = true, plan_gn_ = true;   // GroupNorm statistics from the producing convolution's epilogue where its kernel can (f16); part of the plan key
   hipStream_t s2_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena act2_;

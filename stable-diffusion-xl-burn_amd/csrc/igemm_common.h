@@ -292,6 +292,27 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
 // 160 KiB leave the room (the 5-slot 128x128 ring does not: it keeps the per-lane form)
 __host__ __device__ constexpr int pipe_lds_total(int ring, int extra) { return ring + extra + 2048 <= 163840 ? ring + extra + 2048 : ring + extra; }
 
+// body of a weight-warming workgroup (IgemmParams::warm): NT threads read `bytes` at `base` -- workgroup wi of nw takes every nw-th
+// run of 8 x NT x 16 bytes, 8 loads in flight per lane -- and drop them: what matters is that the lines now sit in the memory-side cache
+typedef int warm_i32x4 __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ void igemm_warm_body(const void* base, unsigned bytes, int wi, int nw) {
+  const char* b = reinterpret_cast<const char*>(base);
+  constexpr unsigned span = NT * 16, step = span * 8;
+  warm_i32x4 acc = {0, 0, 0, 0};
+  for (size_t off = (size_t)wi * step; off < bytes; off += (size_t)nw * step) {
+    warm_i32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t o = off + (size_t)u * span + (size_t)threadIdx.x * 16;
+      v[u] = o + 16 <= bytes ? *reinterpret_cast<const warm_i32x4*>(b + o) : warm_i32x4{0, 0, 0, 0};      // (plain loads: nontemporal ones measured no warming at all)
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= v[u];
+  }
+  asm volatile("" ::"v"(acc));
+}
+
 // block context of the GroupNorm-statistics epilogue (IgemmParams::gn_part): 4 KiB of LDS scratch past the staging regions,
 // the wave's place in the 4 x 2 wave grid and the tile origin
 struct GnCtx { char* scratch; int wave, wm, wn, m0, n0; };

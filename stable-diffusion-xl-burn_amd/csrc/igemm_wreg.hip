@@ -7,9 +7,9 @@
 //   * the WEIGHTS never touch LDS.  They are re-packed once at model build in MFMA A-operand order (launch_repack_wfrag: per
 //     32-column block and 64-deep k-tile four 1-KiB fragments, lane l = weight row l&31, k = 16 kk + 8 (l>>5) .. +7), so a wave
 //     streams its own 32 columns as ONE contiguous run with plain `global_load_dwordx4` (1 KiB per instruction, whole lines), L + 1
-//     k-tiles deep in registers.  A weight fragment is private to its wave: no barrier, no LDS bytes, no ds_read for this operand.
+//     k-tiles deep in registers (3 in production).  A weight fragment is private to its wave: no barrier, no LDS bytes, no ds_read for this operand.
 //   * only the ACTIVATIONS go through LDS (global_load_lds, the pipe kernel's swizzled 128-byte rows): BM x 128 B per k-tile, so
-//     a ring slot is 8 - 16 KiB instead of 28 - 48 and the ring is L + 1 = 4 - 5 tiles deep per k-group.
+//     a ring slot is 8 - 16 KiB instead of 28 - 48 (L + 1 = 3 slots per k-group in production: two workgroups fit a CU).
 //   * wave tile = BM rows x 32 columns (TM = BM / 32 accumulator tiles): TM ds_read_b128 per TM MFMAs, every wave of a group on
 //     its own SIMD with the same work (no 6-waves-on-4-SIMDs imbalance).
 //   * TWO k-groups per workgroup (waves 0-3: even k-tiles, waves 4-7: odd k-tiles of the SAME output tile): two waves per SIMD
@@ -248,7 +248,13 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   const int g = wave >> 2, w = wave & 3;
 
   const int tilesM = (p.M + BM - 1) / BM;
-  const int nwg = gridDim.x;
+  const int nwg = tilesM * (p.N >> 7);
+  // workgroups behind the tile grid (CUs this launch would leave idle) only read the weights of a later GEMM (IgemmParams::warm)
+  if ((int)blockIdx.x >= nwg) {
+    igemm_warm_body<512>(p.warm, p.warm_bytes, (int)blockIdx.x - nwg, (int)gridDim.x - nwg);
+    if (p.warm2) igemm_warm_body<512>(p.warm2, p.warm2_bytes, (int)blockIdx.x - nwg, (int)gridDim.x - nwg);
+    return;
+  }
   int bid = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -484,6 +490,13 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
 static std::atomic<int> g_wreg_enable{1};
 void igemm_set_wreg(int v) { g_wreg_enable = v; }
 
+// warming workgroups of a launch: the CU slots its tile grid leaves empty in its (single) round -- one workgroup per CU up to 256 tiles,
+// two up to 512 -- at most 64 (a warmer pulls ~30 GB/s out of HBM: 36 of them move 13 MB inside an out-projection's 15 us)
+static int wreg_warm_groups(const IgemmParams& p, int ntiles) {
+  if (!p.warm || !p.warm_bytes || ntiles > 512) return 0;
+  const int spare = (ntiles <= 256 ? 256 : 512) - ntiles;
+  return spare < 8 ? 0 : spare > 64 ? 64 : spare;
+}
 template <int BM, int L, int MODE = 0>
 static void launch_wreg_t(const IgemmParams& p, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (L + 1) * BM * 128;
@@ -496,7 +509,8 @@ static void launch_wreg_t(const IgemmParams& p, hipStream_t s) {
     attr_set[dev] = true;
   }
   const int tilesM = (p.M + BM - 1) / BM, tilesN = p.N / 128;
-  hipLaunchKernelGGL((igemm_wreg_kernel<BM, L, MODE>), dim3(tilesM * tilesN), dim3(512), lds, s, p, igemm_zero_page());
+  const int ntiles = tilesM * tilesN;
+  hipLaunchKernelGGL((igemm_wreg_kernel<BM, L, MODE>), dim3(ntiles + wreg_warm_groups(p, ntiles)), dim3(512), lds, s, p, igemm_zero_page());
 }
 
 // shapes this kernel takes: plain f16 linear layers / 1x1 convolutions whose weights were also packed in fragment order
@@ -516,6 +530,14 @@ bool igemm_wreg_ok(const IgemmParams& p) {
 // variant 0: rows per tile from the grid it makes on 256 CUs (the k-summation order does not depend on it); 60 / 62 force 96 / 64
 // rows.  (A 128-row tile -- 64 accumulators + 4 weight stages + 2 x 4 fragments -- spilled fragment registers that were still in
 // flight and was 30 - 75 % slower than the 96-row tile on every shape of the step: removed, profiles/r04_wreg_first_ab.txt.)
+static std::atomic<int> g_warm_enable{1};
+void igemm_set_warm(int v) { g_warm_enable = v; }
+int igemm_warm_enabled() { return g_warm_enable.load(); }
+bool igemm_wreg_selected(const IgemmParams& p) {
+  if (!igemm_wreg_ok(p) || !g_wreg_enable.load()) return false;
+  const long rows = 2L * (p.rpb > 0 ? p.rpb : p.M);
+  return ((rows + 95) / 96) * (long)(p.N / 128) <= 512;
+}
 bool launch_igemm_wreg(const IgemmParams& p, int variant, hipStream_t s) {
   if (!igemm_wreg_ok(p)) return false;
   if (variant == 0) {
@@ -550,8 +572,7 @@ bool launch_igemm_wreg(const IgemmParams& p, int variant, hipStream_t s) {
   int bm = variant == 60 ? 96 : variant == 62 ? 64 : 0;
   if (!bm) {      // 64 rows where that is still a single round of one tile per CU (small M: 512^2 images, single entries), else 96
     const long t64 = (long)((p.M + 63) / 64) * (p.N / 128);
-    bm = t64 <= 256 && (double)(64 + 40) < (double)(96 + 40) ? 64 : 96;
-    if (t64 > 256) bm = 96;
+    bm = t64 <= 256 ? 64 : 96;
   }
   if (bm == 64) launch_wreg_t<64, 2>(p, s);
   else launch_wreg_t<96, 2>(p, s);

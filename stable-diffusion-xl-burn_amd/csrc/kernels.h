@@ -64,6 +64,11 @@ struct IgemmParams {
   const float* a_scale;     // DT_HL compute: device scalar 2^-e of an A operand converted by launch_f32_to_hl_scaled (null = 1); exact
   int hl_wexact_ok; // A/B knob (sdxl_debug_set "hl_weights_exact", default 1): split-operand launches may leave out the w_lo MFMAs when acc_scale[1] says every weight is one f16
   int xa_vec64;     // measure builds (sdxl_debug_set "xa_vec64"): the fused cross-attention epilogue reads its per-column vectors with the original 64-lane
+  // weight warming (round 4): the launch also brings `warm_bytes` of the weights a LATER GEMM of the same stream will read into the
+  // memory-side Infinity Cache -- spare workgroups behind the tile grid (kernels whose grid leaves CUs idle: igemm_wreg_selected) do
+  // nothing but read them.  No effect on any result; null = off.
+  const void* warm; unsigned warm_bytes;
+  const void* warm2; unsigned warm2_bytes;     // a second region (the launch after the next)
                     // VMEM loads instead of the scalar cache -- the hazard experiment of DESIGN 9.2 / 10.4
   int epi_staged;   // A/B knob (sdxl_debug_set "igemm_epilogue_staged"): 1 = LDS-staged epilogue everywhere, 0 = direct row-per-lane where it applies
 };
@@ -83,6 +88,9 @@ void launch_igemm(const IgemmParams& p, int compute_dt, hipStream_t s);
 void launch_repack_wfrag(const void* w, void* wf, int Npad, int Kpad, hipStream_t s);
 bool igemm_wreg_ok(const IgemmParams& p);   // shapes the weights-in-registers kernel takes (plain f16 linear / 1x1, N % 128 == 0, Wf set)
 void igemm_set_tsw(int v);       // A/B knob (sdxl_debug_set "igemm_tsw"): 0 = no operand-swapped k-loop for the transposed part of a fused QKV projection
+bool igemm_wreg_selected(const IgemmParams& p);   // the auto selection (variant 0) would run this launch on the weights-in-registers kernel
+void igemm_set_warm(int v);      // A/B knob (sdxl_debug_set "igemm_warm"): 0 = no weight warming workgroups; read when a UNet plan records its GEMM sequence
+int igemm_warm_enabled();
 void igemm_set_wreg(int v);      // A/B knob (sdxl_debug_set "igemm_wreg"): 0 = the auto selection never picks the weights-in-registers kernel
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
 void igemm_set_hl_weights_exact(int v); // A/B: 0 keeps all three MFMAs per product even where the packed weights are exact f16 values

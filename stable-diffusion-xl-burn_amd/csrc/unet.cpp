@@ -502,6 +502,7 @@ void UNet::ensure_plan(int B, int H, int W) {
                "UNet input height/width must be divisible by 2^(levels-1)");
   if (graph_) { (void)hipGraphExecDestroy(graph_); graph_ = nullptr; }
   plan_runs_ = 0;
+  warm_ = WarmSeq();
   pB_ = B; pH_ = H; pW_ = W;
   const int mc = cfg_.model_channels, emb = 4 * mc;
   auto persist = [&]() {
@@ -567,10 +568,14 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
   SDXL_REQUIRE(ctx_B_ == B && !kv_.empty(), "set_context must be called with the same batch before forward");
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_;
   ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
+  // weight warming (f16 engine, batched chain): the plan's first forward records the GEMM sequence, every later one replays it
+  const bool warming = cdt_ == DT_F16 && !plan_split_ && igemm_warm_enabled();
+  if (warming) { ex.warm = &warm_; if (!warm_.ready) { warm_.seq.clear(); warm_.recording = true; } }
   const size_t m = act_.mark();
   // one batched chain, or (split-CFG) entry 0 on s and entry 1 on the side stream between a fork and a join event
   auto go = [&]() {
-    if (!plan_split_) { run(ex, t_dev, t_stride, 0, B); return; }
+    warm_.pos = 0;
+    if (!plan_split_) { run(ex, t_dev, t_stride, 0, B); if (warm_.recording) warm_.finish(); return; }
     Exec e2; e2.s = s2_; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_;
     e2.splitk_ws = skws_[1]; e2.splitk_ws_bytes = skws_bytes_; e2.splitk_cnt = skcnt_[1];
     act2_.off = 0;
@@ -584,7 +589,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     SDXL_HIP(hipEventRecord(ev_join_, s2_));
     SDXL_HIP(hipStreamWaitEvent(s, ev_join_, 0));
   };
-  if (use_graph_ && graph_ && (graph_t_ != t_dev || graph_ts_ != t_stride || graph_off_ != split_offset_)) {
+  if (use_graph_ && graph_ && (graph_t_ != t_dev || graph_ts_ != t_stride || graph_off_ != split_offset_ || graph_warm_ != warming)) {
     (void)hipGraphExecDestroy(graph_); graph_ = nullptr;
   }
   if (use_graph_ && !graph_ && plan_runs_ >= 1) {
@@ -595,7 +600,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     SDXL_HIP(hipStreamEndCapture(s, &g));
     SDXL_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
     SDXL_HIP(hipGraphDestroy(g));
-    graph_t_ = t_dev; graph_ts_ = t_stride; graph_off_ = split_offset_;
+    graph_t_ = t_dev; graph_ts_ = t_stride; graph_off_ = split_offset_; graph_warm_ = warming;
     act_.reset(m);
   }
   if (use_graph_ && graph_) {

@@ -336,6 +336,27 @@ NormW WeightBuilder::norm(const std::string& name) {
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
+void WarmSeq::finish() {
+  // every launch that reads 0.5 - 8 MiB of weights (14 MiB if it runs on the weights-in-registers kernel: FF-out) gets a host among the
+  // three launches in front of it (the nearest with room; the sequence wraps: the first launches of the next forward are warmed by the
+  // last ones of this); a host carries at most two targets inside its 14 MiB budget.  Measured (profiles/r04_weight_warming_ab.txt):
+  // the N = 1280 projections start ~2 us earlier on warmed weights (their prologue waits for the Infinity Cache instead of HBM); the
+  // fused QKV (9.8 MB) and GEGLU (26 MB) weights gain nothing, and a host that carries 26 MB outlives its own tiles.
+  const size_t n = seq.size();
+  for (Item& it : seq) { it.warm = it.warm2 = nullptr; it.warm_bytes = it.warm2_bytes = 0; }
+  for (size_t j = 0; j < n && n > 4; ++j) {
+    const unsigned bytes = seq[j].bytes;
+    if (bytes < (1u << 19) || bytes > (seq[j].host ? 14u << 20 : 8u << 20)) continue;
+    for (size_t d = 1; d <= 3; ++d) {
+      Item& h = seq[(j + n - d) % n];
+      if (!h.host || h.warm2 || h.w == seq[j].w || h.budget < bytes) continue;
+      if (!h.warm) { h.warm = seq[j].w; h.warm_bytes = bytes; } else { h.warm2 = seq[j].w; h.warm2_bytes = bytes; }
+      h.budget -= bytes;
+      break;
+    }
+  }
+  recording = false; ready = true; pos = 0;
+}
 bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e) {
   if (ex.dry) return false;
   SDXL_REQUIRE(cin == w.cin, "run_conv: channel mismatch");
@@ -368,6 +389,20 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize);
   p.acc_scale = w.acc_scale;
   p.a_scale = (w.dt >= 0 ? w.dt : ex.cdt) == DT_HL ? a.a_scale : nullptr;
+  if (ex.warm && (w.dt >= 0 ? w.dt : ex.cdt) == DT_F16) {
+    // weight warming: the plan's first forward records which weights every launch reads and whether its kernel has idle CUs to host
+    // warming workgroups; later forwards hand launch i the weights of a later launch (WarmSeq::finish)
+    WarmSeq& ws = *ex.warm;
+    if (ws.recording) {
+      const bool host = igemm_wreg_selected(p);
+      // what a host can carry without outliving its own tiles: its >= 36 warmers pull ~30 GB/s each, the shortest host runs 13 us
+      const unsigned budget = host ? 14u << 20 : 0u;
+      ws.seq.push_back(WarmSeq::Item{host ? p.Wf : p.W, (unsigned)((size_t)w.Npad * w.Kpad * 2), host, budget, nullptr, 0u, nullptr, 0u});
+    } else if (ws.ready && ws.pos < ws.seq.size()) {
+      const WarmSeq::Item& it = ws.seq[ws.pos++];
+      if (it.w == (igemm_wreg_selected(p) ? p.Wf : p.W)) { p.warm = it.warm; p.warm_bytes = it.warm_bytes; p.warm2 = it.warm2; p.warm2_bytes = it.warm2_bytes; }     // (the recorded launch: anything else means a different plan)
+    }
+  }
   launch_igemm(p, w.dt >= 0 ? w.dt : ex.cdt, ex.s);
   {   // a refused launch (bad grid / LDS attribute) must not pass silently
     const hipError_t le = hipGetLastError();

@@ -45,6 +45,16 @@ def test_fullsize_unet_properties(pkg, ctx, base_inputs):
     finally:
         pkg.debug_set("igemm_tsw", 1)
     assert torch.equal(staged, outs[0]), "operand-swapped V^T epilogue changes the result"
+    # weight warming (spare workgroups of a launch read a later launch's weights): outs[0] above is the recording forward (no warming),
+    # outs[1] / outs[2] the captured graph WITH the warming workgroups; and with the knob off nothing may move either
+    del u0
+    pkg.debug_set("igemm_warm", 0)
+    try:
+        u1 = pkg.UNet(ctx, cfg, pkg.DTYPE_F16, seed=0)
+        cold = [u1.forward(x.cuda(), t.cuda(), ctxt.cuda(), y.cuda()).cpu() for _ in range(2)]
+    finally:
+        pkg.debug_set("igemm_warm", 1)
+    assert torch.equal(cold[0], outs[0]) and torch.equal(cold[1], outs[0]), "weight warming changes the result"
 
 
 def _prompt_ids(seed, n_tok, pad):
