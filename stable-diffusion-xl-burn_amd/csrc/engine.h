@@ -181,7 +181,7 @@ struct Profiler {
 // recorded on the plan's first eager forward, replayed on every later one -- launch i is handed the weights of a later launch
 // (IgemmParams::warm).  Static shapes: the sequence of a plan never changes.
 struct WarmSeq {
-  struct Item { const void* w; unsigned bytes; bool host; unsigned budget; const void* warm; unsigned warm_bytes; const void* warm2; unsigned warm2_bytes; };
+  struct Item { const void* w; unsigned bytes; bool host; unsigned budget; const void* warm[3]; unsigned warm_bytes[3]; };
   std::vector<Item> seq;
   size_t pos = 0;
   bool recording = false, ready = false;

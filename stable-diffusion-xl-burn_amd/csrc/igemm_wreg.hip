@@ -251,8 +251,9 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   const int nwg = tilesM * (p.N >> 7);
   // workgroups behind the tile grid (CUs this launch would leave idle) only read the weights of a later GEMM (IgemmParams::warm)
   if ((int)blockIdx.x >= nwg) {
-    igemm_warm_body<512>(p.warm, p.warm_bytes, (int)blockIdx.x - nwg, (int)gridDim.x - nwg);
-    if (p.warm2) igemm_warm_body<512>(p.warm2, p.warm2_bytes, (int)blockIdx.x - nwg, (int)gridDim.x - nwg);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (p.warm[r]) igemm_warm_body<512>(p.warm[r], p.warm_bytes[r], (int)blockIdx.x - nwg, (int)gridDim.x - nwg);
     return;
   }
   int bid = blockIdx.x;
@@ -493,7 +494,7 @@ void igemm_set_wreg(int v) { g_wreg_enable = v; }
 // warming workgroups of a launch: the CU slots its tile grid leaves empty in its (single) round -- one workgroup per CU up to 256 tiles,
 // two up to 512 -- at most 64 (a warmer pulls ~30 GB/s out of HBM: 36 of them move 13 MB inside an out-projection's 15 us)
 static int wreg_warm_groups(const IgemmParams& p, int ntiles) {
-  if (!p.warm || !p.warm_bytes || ntiles > 512) return 0;
+  if (!p.warm[0] || !p.warm_bytes[0] || ntiles > 512) return 0;
   const int spare = (ntiles <= 256 ? 256 : 512) - ntiles;
   return spare < 8 ? 0 : spare > 64 ? 64 : spare;
 }

@@ -67,8 +67,7 @@ struct IgemmParams {
   // weight warming (round 4): the launch also brings `warm_bytes` of the weights a LATER GEMM of the same stream will read into the
   // memory-side Infinity Cache -- spare workgroups behind the tile grid (kernels whose grid leaves CUs idle: igemm_wreg_selected) do
   // nothing but read them.  No effect on any result; null = off.
-  const void* warm; unsigned warm_bytes;
-  const void* warm2; unsigned warm2_bytes;     // a second region (the launch after the next)
+  const void* warm[3]; unsigned warm_bytes[3];     // up to three regions (filled from the front)
                     // VMEM loads instead of the scalar cache -- the hazard experiment of DESIGN 9.2 / 10.4
   int epi_staged;   // A/B knob (sdxl_debug_set "igemm_epilogue_staged"): 1 = LDS-staged epilogue everywhere, 0 = direct row-per-lane where it applies
 };

@@ -338,19 +338,20 @@ NormW WeightBuilder::norm(const std::string& name) {
 // ------------------------------------------------------------------------------------------ launch helpers
 void WarmSeq::finish() {
   // every launch that reads 0.5 - 8 MiB of weights (14 MiB if it runs on the weights-in-registers kernel: FF-out) gets a host among the
-  // three launches in front of it (the nearest with room; the sequence wraps: the first launches of the next forward are warmed by the
-  // last ones of this); a host carries at most two targets inside its 14 MiB budget.  Measured (profiles/r04_weight_warming_ab.txt):
+  // four sequence entries in front of it (the nearest with room; the sequence wraps: the first launches of the next forward are warmed by the
+  // last ones of this); a host carries at most three regions inside its 14 MiB budget (the packed context a fused cross-attention projection reads is a region of its own).  Measured (profiles/r04_weight_warming_ab.txt):
   // the N = 1280 projections start ~2 us earlier on warmed weights (their prologue waits for the Infinity Cache instead of HBM); the
   // fused QKV (9.8 MB) and GEGLU (26 MB) weights gain nothing, and a host that carries 26 MB outlives its own tiles.
   const size_t n = seq.size();
-  for (Item& it : seq) { it.warm = it.warm2 = nullptr; it.warm_bytes = it.warm2_bytes = 0; }
+  for (Item& it : seq) for (int r = 0; r < 3; ++r) { it.warm[r] = nullptr; it.warm_bytes[r] = 0; }
   for (size_t j = 0; j < n && n > 4; ++j) {
     const unsigned bytes = seq[j].bytes;
     if (bytes < (1u << 19) || bytes > (seq[j].host ? 14u << 20 : 8u << 20)) continue;
-    for (size_t d = 1; d <= 3; ++d) {
+    for (size_t d = 1; d <= 4; ++d) {
       Item& h = seq[(j + n - d) % n];
-      if (!h.host || h.warm2 || h.w == seq[j].w || h.budget < bytes) continue;
-      if (!h.warm) { h.warm = seq[j].w; h.warm_bytes = bytes; } else { h.warm2 = seq[j].w; h.warm2_bytes = bytes; }
+      if (!h.host || h.warm[2] || h.w == seq[j].w || h.budget < bytes) continue;
+      const int r = !h.warm[0] ? 0 : !h.warm[1] ? 1 : 2;
+      h.warm[r] = seq[j].w; h.warm_bytes[r] = bytes;
       h.budget -= bytes;
       break;
     }
@@ -393,14 +394,32 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
     // weight warming: the plan's first forward records which weights every launch reads and whether its kernel has idle CUs to host
     // warming workgroups; later forwards hand launch i the weights of a later launch (WarmSeq::finish)
     WarmSeq& ws = *ex.warm;
+    // the region the launch reads cold: its weights and the per-column vectors next to them in the arena (allocation order: packed
+    // weights, bias, [column sums, eps of a folded LayerNorm], [fragment-order image])
+    const bool host = igemm_wreg_selected(p);
+    const size_t wbytes = (size_t)w.Npad * w.Kpad * 2;
+    const char* lo; const char* hi;
+    if (host) {
+      const char* f = reinterpret_cast<const char*>(p.Wf), *b = reinterpret_cast<const char*>(w.b);
+      lo = (b && b < f && f - b <= (64 << 10)) ? b : f;
+      hi = f + wbytes;
+    } else {
+      lo = reinterpret_cast<const char*>(p.W); hi = lo + wbytes;
+      auto ext = [&](const void* q, size_t sz) { const char* c = reinterpret_cast<const char*>(q); if (q && c >= hi && c - hi <= (64 << 10)) hi = c + sz; };
+      ext(w.b, (size_t)w.Npad * 4); ext(w.cs, (size_t)w.Npad * 4); ext(w.ln_eps, 4);
+    }
     if (ws.recording) {
-      const bool host = igemm_wreg_selected(p);
+      // (a fused cross-attention projection also reads the packed context of its batch entries: a target of its own in front of it)
+      if (p.xa_k) ws.seq.push_back(WarmSeq::Item{p.xa_k, (unsigned)xattn_pack_bytes(p.M / p.rpb, p.N), false, 0u, {nullptr, nullptr, nullptr}, {0u, 0u, 0u}});
       // what a host can carry without outliving its own tiles: its >= 36 warmers pull ~30 GB/s each, the shortest host runs 13 us
       const unsigned budget = host ? 14u << 20 : 0u;
-      ws.seq.push_back(WarmSeq::Item{host ? p.Wf : p.W, (unsigned)((size_t)w.Npad * w.Kpad * 2), host, budget, nullptr, 0u, nullptr, 0u});
-    } else if (ws.ready && ws.pos < ws.seq.size()) {
-      const WarmSeq::Item& it = ws.seq[ws.pos++];
-      if (it.w == (igemm_wreg_selected(p) ? p.Wf : p.W)) { p.warm = it.warm; p.warm_bytes = it.warm_bytes; p.warm2 = it.warm2; p.warm2_bytes = it.warm2_bytes; }     // (the recorded launch: anything else means a different plan)
+      ws.seq.push_back(WarmSeq::Item{lo, (unsigned)(hi - lo), host, budget, {nullptr, nullptr, nullptr}, {0u, 0u, 0u}});
+    } else if (ws.ready) {
+      if (p.xa_k) ++ws.pos;
+      if (ws.pos < ws.seq.size()) {
+        const WarmSeq::Item& it = ws.seq[ws.pos++];
+        if (it.w == lo) for (int r = 0; r < 3; ++r) { p.warm[r] = it.warm[r]; p.warm_bytes[r] = it.warm_bytes[r]; }     // (the recorded launch: anything else means a different plan)
+      }
     }
   }
   launch_igemm(p, w.dt >= 0 ? w.dt : ex.cdt, ex.s);
