@@ -880,16 +880,18 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   LnC lnc;
   lnc.load(p, m0, tid);
   __builtin_amdgcn_sched_barrier(0);
-  // ---- prologue: the whole ring in flight, wait for tile 0 only
+  // ---- prologue: NS - 1 tiles in flight, wait for tile 0 only.  The last ring slot is filled from inside k-tile 0 (its first kk-step
+  // carries the pieces of tile NS - 1): the first MFMA does not wait behind the issue of a whole ring (every wave's VMEM issue queues
+  // behind the CU's fetch rate: entry -> "ring fill issued" was 7.5 - 9 k cycles with three tiles, profiles/r04_wide_geglu_timeline.txt)
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
+  for (int s = 0; s < NS - 1; ++s)
     if (s < nk) static_for<PER>([&](auto Q) { issue(s, Q); });
   WIDE_STAMP(1);
   float lnA[TM], lnC[TM];
   const bool ln_coop = p.ln_slots <= 24;
   lnc.finish(p, m0, ln_coef);
   if (!ln_coop) ln_prologue<TM>(p, m0 + wm * WM, fr, lnA, lnC);
-  if (NS <= nk) wait_tiles(std::integral_constant<int, NS - 1>{}); else wait_vmcnt<0>();
+  if (NS - 1 <= nk) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
   wait_lgkmcnt<0>();                             // the coefficients' ds_write has landed (raw s_barrier waits for nothing)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
     const unsigned so = cur * STAGE;
     ldfrag(so, 0);
     wait_lgkmcnt<0>();
-    mma(cur, false);
+    if (kt == 0) mma(NS - 1, NS - 1 < nk); else mma(cur, false);      // (k-tile 0 completes the ring: slot NS - 1 has never been read)
     ldfrag(so, 1);
     wait_lgkmcnt<0>();                          // own reads of tile kt complete
     const bool more = kt + NS < nk;
