@@ -441,17 +441,20 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   WREG_STAMP(3);
   // odd k-tile count: group 1 has one tile -- and one rendezvous -- less; barrier counts must match across the workgroup
   if constexpr (!NOBAR) { if ((nk & 1) && g == 1) __builtin_amdgcn_s_barrier(); }
-  __builtin_amdgcn_s_barrier();                    // both rings are dead: they become the exchange area
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  // No rendezvous here: the LAST tile of a group always sits in slot L, and every wave has passed the last k-loop rendezvous (all reads of
+  // the other slots complete in front of it), so slots 0 .. L - 1 of BOTH rings are dead while slower waves still read their slot L --
+  // the exchange area lives in those slots.
 
   // ---- the two groups' partial sums meet in LDS.  Each group finalizes HALF of every wave tile's columns (group t: accumulator
   // groups q = 2t, 2t + 1), so it parks the other half for its partner (lane-linear 16-byte pieces) and adds the partner's half
   // to its own: even k-tiles + odd k-tiles whichever group does the add (fp32 addition commutes bit for bit)
   WregEpiOperands<TM> eop;
   wreg_epilogue_request<TM>(p, m0, n0 + w * 32, lane, g, zeros, eop);
-  f32x4* xw = reinterpret_cast<f32x4*>(smem) + (size_t)(g * 4 + w) * (TM * 2 * 64) + lane;          // written by (g, w)
-  const f32x4* xo = reinterpret_cast<const f32x4*>(smem) + (size_t)((1 - g) * 4 + w) * (TM * 2 * 64) + lane;   // partner's
+  static_assert(4 * TM * 2 * 64 * 16 <= L * SLOT, "a group's four exchange pieces must fit its dead slots 0 .. L - 1");
+  f32x4* xw = reinterpret_cast<f32x4*>(smem + g * RING) + (size_t)w * (TM * 2 * 64) + lane;                    // written by (g, w): own group's slots 0 ..
+  const f32x4* xo = reinterpret_cast<const f32x4*>(smem + (1 - g) * RING) + (size_t)w * (TM * 2 * 64) + lane;  // partner's
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -476,7 +479,8 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
       }
     }
   WREG_STAMP(4);
-  float* xch = reinterpret_cast<float*>(smem + 8 * TM * 2048);      // statistics exchange: behind the accumulator exchange area
+  static_assert((2 * BM + 6 * 2 * BM) * 4 <= SLOT, "statistics exchange must fit one slot");
+  float* xch = reinterpret_cast<float*>(smem + L * SLOT);           // statistics exchange: slot L of ring 0 (dead behind the exchange rendezvous)
   wreg_epilogue<TM>(p, acc, m0, n0 + w * 32, lane, w, g, xch, eop);
 #ifdef SDXL_MEASURE
   WREG_STAMP(5);
