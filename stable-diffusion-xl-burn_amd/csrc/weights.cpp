@@ -337,7 +337,7 @@ NormW WeightBuilder::norm(const std::string& name) {
 
 // ------------------------------------------------------------------------------------------ launch helpers
 void WarmSeq::finish() {
-  // every launch that reads 0.5 - 8 MiB of weights (14 MiB if it runs on the weights-in-registers kernel: FF-out) gets a host among the
+  // every launch that reads 0.25 - 8 MiB of weights (14 MiB if it runs on the weights-in-registers kernel: FF-out) gets a host among the
   // four sequence entries in front of it (the nearest with room; the sequence wraps: the first launches of the next forward are warmed by the
   // last ones of this); a host carries at most three regions inside its 14 MiB budget (the packed context a fused cross-attention projection reads is a region of its own).  Measured (profiles/r04_weight_warming_ab.txt):
   // the N = 1280 projections start ~2 us earlier on warmed weights (their prologue waits for the Infinity Cache instead of HBM); the
@@ -346,7 +346,7 @@ void WarmSeq::finish() {
   for (Item& it : seq) for (int r = 0; r < 3; ++r) { it.warm[r] = nullptr; it.warm_bytes[r] = 0; }
   for (size_t j = 0; j < n && n > 4; ++j) {
     const unsigned bytes = seq[j].bytes;
-    if (bytes < (1u << 19) || bytes > (seq[j].host ? 14u << 20 : 8u << 20)) continue;
+    if (bytes < (1u << 18) || bytes > (seq[j].host ? 14u << 20 : 8u << 20)) continue;
     for (size_t d = 1; d <= 4; ++d) {
       Item& h = seq[(j + n - d) % n];
       if (!h.host || h.warm[2] || h.w == seq[j].w || h.budget < bytes) continue;
@@ -357,6 +357,17 @@ void WarmSeq::finish() {
     }
   }
   recording = false; ready = true; pos = 0;
+  if (std::getenv("SDXL_WARM_DUMP")) {     // schedule of the plan, one line per sequence entry: bytes, host?, regions it carries; '*' = nobody warms this entry
+    std::vector<char> covered(n, 0);
+    for (size_t i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) if (seq[i].warm[r]) for (size_t j = 0; j < n; ++j) if (seq[j].w == seq[i].warm[r]) covered[j] = 1;
+    size_t tb = 0, cb = 0;
+    for (size_t i = 0; i < n; ++i) {
+      tb += seq[i].bytes; if (covered[i]) cb += seq[i].bytes;
+      std::fprintf(stderr, "[warm] %3zu %9u B %s carries %u + %u + %u B %s\n", i, seq[i].bytes, seq[i].host ? "host" : "    ", seq[i].warm_bytes[0], seq[i].warm_bytes[1],
+                   seq[i].warm_bytes[2], covered[i] ? "" : "*");
+    }
+    std::fprintf(stderr, "[warm] %zu entries, %.1f MB read per forward, %.1f MB of it warmed\n", n, tb / 1048576.0, cb / 1048576.0);
+  }
 }
 bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e) {
   if (ex.dry) return false;
