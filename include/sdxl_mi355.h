@@ -276,6 +276,9 @@ int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int 
  * "split_offset": GEMM launches of the first chain before the second is released; "no_cfg": base model without the
  * unconditional branch (measurement only -- NOT the reference's semantics) */
 int sdxl_debug_set(const char* key, int value);
+/* host logic of the weight-warming schedule on a synthetic launch sequence (no device needed; tests): bytes[j] / host[j] = what entry j reads and
+ * whether its kernel can carry warming workgroups; warmed_by[j] receives the index of the entry that warms j, -1 if nobody does */
+int sdxl_debug_warm_schedule(int n, const unsigned* bytes, const unsigned char* host, int* warmed_by);
 
 /* ---- single-op entry points used by the parity tests (same kernels the models run) */
 /* GroupNorm::forward (groupnorm/mod.rs:52-73) on NCHW fp32 [B,C,H,W]; silu!=0 fuses SILU::forward (silu.rs:14-16) */

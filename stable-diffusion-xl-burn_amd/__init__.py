@@ -78,7 +78,7 @@ ABI_SYMBOLS = [
     "sdxl_vae_create", "sdxl_vae_create_synthetic", "sdxl_vae_destroy", "sdxl_vae_decode_latent",
     "sdxl_latent_to_image", "sdxl_vae_encode_image", "sdxl_image_to_latent",
     "sdxl_unet_weight_arena", "sdxl_vae_weight_arena", "sdxl_diffuser_create_empty", "sdxl_vae_create_empty",
-    "sdxl_unet_profile", "sdxl_bench_igemm", "sdxl_bench_attention", "sdxl_debug_set",
+    "sdxl_unet_profile", "sdxl_bench_igemm", "sdxl_bench_attention", "sdxl_debug_set", "sdxl_debug_warm_schedule",
     "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear", "sdxl_layer_norm_linear", "sdxl_ln_query_cross_attention", "sdxl_conv2d_group_norm",
     "sdxl_clip_config_clip_l", "sdxl_clip_config_open_clip_bigg", "sdxl_clip_param_count", "sdxl_clip_param_spec",
     "sdxl_clip_create", "sdxl_clip_create_synthetic", "sdxl_clip_destroy", "sdxl_clip_forward_hidden",

@@ -173,6 +173,20 @@ int sdxl_debug_set(const char* key, int value) {
   else throw Error(std::string("unknown debug key ") + key);
   API_END
 }
+// host logic of the weight-warming schedule (WarmSeq::finish) on a synthetic launch sequence -- no device needed.  bytes[j] / host[j]: what entry j
+// reads and whether its kernel can carry warming workgroups; warmed_by[j] receives the index of the entry that warms j (-1: nobody)
+int sdxl_debug_warm_schedule(int n, const unsigned* bytes, const unsigned char* host, int* warmed_by) {
+  API_BEGIN
+  WarmSeq ws;
+  for (int j = 0; j < n; ++j)
+    ws.seq.push_back(WarmSeq::Item{reinterpret_cast<const void*>((uintptr_t)(j + 1) << 12), bytes[j], host[j] != 0, host[j] ? 14u << 20 : 0u, {nullptr, nullptr, nullptr}, {0u, 0u, 0u}});
+  ws.finish();
+  for (int j = 0; j < n; ++j) warmed_by[j] = -1;
+  for (int i = 0; i < n; ++i)
+    for (int r = 0; r < 3; ++r)
+      if (ws.seq[i].warm[r]) warmed_by[(int)(reinterpret_cast<uintptr_t>(ws.seq[i].warm[r]) >> 12) - 1] = i;
+  API_END
+}
 #ifdef SDXL_MEASURE
 // measure builds only: device buffer [workgroups][waves][sdxl_debug_timeline_words()] unsigned that the s_memtime-stamped kernel
 // variants (igemm_measure.hip, variants 135 / 136 / 145) dump their per-wave phase stamps into; null switches it off

@@ -150,6 +150,46 @@ def built(pkg):
     return pkg
 
 
+def test_weight_warming_schedule_host_logic(built):
+    """WarmSeq::finish (csrc/weights.cpp) on a synthetic UNet-like launch sequence: which entry warms which.  Pure host code behind a test hook
+    of the C-ABI library (no device): a transformer block is QKV (pipe kernel, 9.9 MB) / out-projection (weights-in-registers kernel = host, 3.3 MB) /
+    packed cross-attention context (0.98 MB, read by the next entry) / fused cross-attention projection (pipe, 3.3 MB) / out-projection (host) /
+    GEGLU (pipe, 26 MB) / FF-out (host, 13.1 MB)."""
+    l = ctypes.CDLL(built.LIB_PATH)
+    MB = 1 << 20
+    block = [(9.9, 0), (3.3, 1), (0.98, 0), (3.3, 0), (3.3, 1), (26.3, 0), (13.1, 1)]
+    seq = [(29.5, 0), (29.5, 0), (3.3, 1)] + block * 3 + [(3.3, 1), (0.05, 0)]          # convs, proj_in, blocks, proj_out, a tiny conv
+    n = len(seq)
+    nbytes = (ctypes.c_uint * n)(*[int(b * MB) for b, _ in seq])
+    host = (ctypes.c_ubyte * n)(*[h for _, h in seq])
+    by = (ctypes.c_int * n)()
+    assert l.sdxl_debug_warm_schedule(n, nbytes, host, by) == 0
+    by = list(by)
+    carried = {}
+    for j, h in enumerate(by):
+        if h < 0:
+            continue
+        assert seq[h][1] == 1, "only launches with idle CUs host warming workgroups"
+        assert h != j and 1 <= (j - h) % n <= 4, "a host sits at most four entries in front of its target"
+        carried.setdefault(h, []).append(j)
+    for h, js in carried.items():
+        assert len(js) <= 3 and sum(seq[j][0] for j in js) <= 14.0, "three regions, 14 MiB per host"
+    for j, (b, h) in enumerate(seq):
+        if b > (14.0 if h else 8.0) or b < 0.25:
+            assert by[j] < 0, f"entry {j} ({b} MB) must not be a target"
+    for k in range(3):                                    # every block: out-projections, context, cross-attention projection and FF-out are warmed
+        o = 3 + 7 * k
+        assert by[o + 0] < 0 and by[o + 5] < 0            # QKV and GEGLU: too large by rule
+        assert by[o + 2] == o + 1 and by[o + 3] == o + 1  # context + cross-attention projection: by the attention out-projection in front of them
+        assert by[o + 4] == o + 1                         # the second out-projection too (the projection in between is no host)
+        assert by[o + 6] == o + 4                         # FF-out by the cross-attention out-projection
+        assert by[o + 1] >= 0                             # the first out-projection: by FF-out of the block in front (proj_in for block 0)
+    assert by[3 + 1] == 2 and by[3 + 7 + 1] == 3 + 6
+    # degenerate inputs
+    one = (ctypes.c_int * 1)()
+    assert l.sdxl_debug_warm_schedule(1, (ctypes.c_uint * 1)(4 * MB), (ctypes.c_ubyte * 1)(1), one) == 0 and one[0] == -1
+
+
 def test_library_exports_every_declared_symbol(built):
     hdr = open(os.path.join(ROOT, "include", "sdxl_mi355.h")).read()
     declared = set(re.findall(r"\b(sdxl_[a-z0-9_]+)\s*\(", hdr))
