@@ -906,7 +906,9 @@ void attention_set_timeline(void* buf) {
 #define ATTN_STAMP(i) do { } while (0)
 #define ATTN_DUMP() do { } while (0)
 #endif
-template <int KP, int PRIO = 2>
+// KO (measure builds, attn_variant 11 ..): knock-outs that time one resource of the k-loop alone (results are garbage): bit 0 no DMA inside the
+// loop, 1 no softmax arithmetic (scores converted as they are), 2 no per-tile barrier, 3 no MFMAs, 4 no LDS fragment reads
+template <int KP, int PRIO = 2, int KO = 0>
 __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void* zeros, char* smem, int b, int hd, int qb) {
   static_assert(KP == 2 || KP == 4, "key parts per query sub-tile");
 #ifdef SDXL_MEASURE
@@ -985,10 +987,10 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
   for (int t = 0; t < nt; ++t) {
     if (t + NS - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(KO & 4)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (t == 0) ATTN_STAMP(2);
-    if (t + NS - 1 < nt) stage(t + NS - 1, cur == 0 ? NS - 1 : cur - 1);
+    if constexpr (!(KO & 1)) { if (t + NS - 1 < nt) stage(t + NS - 1, cur == 0 ? NS - 1 : cur - 1); }
     const char* kb = smem + cur * 2 * TILE;
     const char* vb = kb + TILE;
     cur = cur == NS - 1 ? 0 : cur + 1;
@@ -999,15 +1001,17 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
     f32x16 sv;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const half8 kf = *reinterpret_cast<const half8*>(kb + (koff ^ (ks << 5)));
-      sv = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? minit : sv, 0, 0, 0);
+      half8 kf;
+      if constexpr (KO & 16) kf = qf[ks]; else kf = *reinterpret_cast<const half8*>(kb + (koff ^ (ks << 5)));
+      if constexpr (KO & 8) { if (ks == 0) sv = minit; asm volatile("" ::"v"(kf), "v"(qf[ks])); }
+      else sv = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? minit : sv, 0, 0, 0);
     }
     if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(2);
     float lm[2] = {sv[0], sv[8]};                 // (two independent chains, see variant 2)
 #pragma unroll
     for (int r = 1; r < 8; ++r) { lm[0] = fmaxf(lm[0], sv[r]); lm[1] = fmaxf(lm[1], sv[8 + r]); }
-    const float lmax = fmaxf(lm[0], lm[1]);
-    if (first || __any(lmax > THR)) {
+    const float lmax = (KO & 2) ? 0.f : fmaxf(lm[0], lm[1]);
+    if (!(KO & 2) && (first || __any(lmax > THR))) {
       const float pm = fmaxf(lmax, __shfl_xor(lmax, 32));
       const float delta = first ? pm : fmaxf(pm, 0.f);
       const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
@@ -1030,8 +1034,8 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
       float ls = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(sv[8 * hf + e]);
-        ls += pe;
+        const float pe = (KO & 2) ? sv[8 * hf + e] : __builtin_amdgcn_exp2f(sv[8 * hf + e]);
+        if constexpr (!(KO & 2)) ls += pe;
         hh[e] = (half_t)pe;
       }
       l += ls;
@@ -1044,10 +1048,15 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const int b1 = (base + 4 * h) * 2, b2 = b1 + 16;
-        const i32x2 v1 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b1 >> 4)) ^ vsw[dt]) << 4) + (b1 & 15));
-        const i32x2 v2 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b2 >> 4)) ^ vsw[dt]) << 4) + (b2 & 15));
+        i32x2 v1, v2;
+        if constexpr (KO & 16) { v1 = i32x2{b1, b2}; v2 = i32x2{b2, b1}; }
+        else {
+          v1 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b1 >> 4)) ^ vsw[dt]) << 4) + (b1 & 15));
+          v2 = *reinterpret_cast<const i32x2*>(vb + voff[dt] + ((((b2 >> 4)) ^ vsw[dt]) << 4) + (b2 & 15));
+        }
         const i32x4 vf = i32x4{v1[0], v1[1], v2[0], v2[1]};
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, vf), pf[hf], o[dt], 0, 0, 0);
+        if constexpr (KO & 8) asm volatile("" ::"v"(vf), "v"(pf[hf]));
+        else o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, vf), pf[hf], o[dt], 0, 0, 0);
       }
     }
   }
@@ -1115,14 +1124,14 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
   ATTN_DUMP();
 }
 
-template <int PRIO = 2>
+template <int PRIO = 2, int KO = 0>
 __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p, const void* zeros) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][K tile | V^T tile]
   const int nqb = (p.Nq + 63) / 64;
   const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
   const int bh = bid / nqb, qb = bid - bh * nqb;
   const int b = bh / p.H;
-  attn_d64_ks_body<2, PRIO>(p, zeros, smem, b, bh - b * p.H, qb);
+  attn_d64_ks_body<2, PRIO, KO>(p, zeros, smem, b, bh - b * p.H, qb);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1551,7 +1560,7 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
   const bool aligned = ((p.ldq | p.ldk | p.vt_ld | p.ldo) & 7) == 0 &&
                        ((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) |
                          reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) == 0;
-  if (p.dt == DT_F16 && (g_attn_variant == 0 || (g_attn_variant >= 2 && g_attn_variant <= 9)) && g_attn_zero && aligned && !p.mask) {
+  if (p.dt == DT_F16 && (g_attn_variant == 0 || (g_attn_variant >= 2 && g_attn_variant <= 17)) && g_attn_zero && aligned && !p.mask) {
     // 3-slot ring = 48 KiB per block -> three blocks per CU: the 640 blocks of the 64^2 level run as ONE round (a 4-slot
     // ring admits two per CU, a second half-empty round: 147 us vs 126 us measured); variant 3 keeps the 4-slot ring for A/B
     const dim3 g1(grid.x * grid.y);
@@ -1588,6 +1597,20 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
 #ifdef SDXL_MEASURE
     if (g_attn_variant == 4) {
       hipLaunchKernelGGL(attn_d64_v3_kernel, g1, dim3(256), 6 * 64 * 128, s, p, g_attn_zero);
+      return;
+    }
+    if (g_attn_variant >= 11 && g_attn_variant <= 17 && ks_ok) {     // knock-out timings of the key-split body (tools/attn_knockout.py)
+      const dim3 gk(((p.Nq + 63) / 64) * p.B * p.H);
+      constexpr int lds = 3 * 2 * 64 * 128;
+      switch (g_attn_variant) {
+        case 11: hipLaunchKernelGGL((attn_d64_ks_kernel<2, 1>), gk, dim3(256), lds, s, p, g_attn_zero); break;
+        case 12: hipLaunchKernelGGL((attn_d64_ks_kernel<2, 2>), gk, dim3(256), lds, s, p, g_attn_zero); break;
+        case 13: hipLaunchKernelGGL((attn_d64_ks_kernel<2, 4>), gk, dim3(256), lds, s, p, g_attn_zero); break;
+        case 14: hipLaunchKernelGGL((attn_d64_ks_kernel<2, 8>), gk, dim3(256), lds, s, p, g_attn_zero); break;
+        case 15: hipLaunchKernelGGL((attn_d64_ks_kernel<2, 16>), gk, dim3(256), lds, s, p, g_attn_zero); break;
+        case 16: hipLaunchKernelGGL((attn_d64_ks_kernel<2, 1 | 4>), gk, dim3(256), lds, s, p, g_attn_zero); break;
+        default: hipLaunchKernelGGL((attn_d64_ks_kernel<2, 2 | 8>), gk, dim3(256), lds, s, p, g_attn_zero); break;
+      }
       return;
     }
     if (g_attn_variant == 3 && p.Nk > 128) {

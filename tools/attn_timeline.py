@@ -23,8 +23,9 @@ for (B, H, N) in [(2, 20, 1024)]:
     d = np.diff(main[:, :, :6], axis=2) & 0xFFFFFFFF
     life = (main[:, :, 5] - main[:, :, 0]) & 0xFFFFFFFF
     real = (main[:, :, 7] - main[:, :, 6]) & 0xFFFFFFFF
-    ramp = (t[:, :, 0] - t[:, :, 0].min()) & 0xFFFFFFFF
+    ramp = ((t[:, :, 6] - t[:, :, 6].min()) & 0xFFFFFFFF) * 0.01      # s_memrealtime: one 100 MHz counter for the whole chip -> us
+    end = ((t[:, :, 7] - t[:, :, 6].min()) & 0xFFFFFFFF) * 0.01
     print(f"self-attention B{B} H{H} N{N}: {nwg} workgroups, unstamped {us0:.1f} us, stamped {us:.1f} us; lifetime of the merging waves mean {life.mean():.0f} max {life.max():.0f} cycles, "
-          f"shader clock {(life / np.maximum(real, 1)).mean() * 100:.0f} MHz; entry of a wave after the first: p50 {np.median(ramp):.0f} p90 {np.percentile(ramp, 90):.0f} max {ramp.max():.0f} cycles")
+          f"shader clock {(life / np.maximum(real, 1)).mean() * 100:.0f} MHz; entry of a wave after the first one (us): p50 {np.median(ramp):.2f} p90 {np.percentile(ramp, 90):.2f} max {ramp.max():.2f}; exit: p50 {np.median(end):.2f} p90 {np.percentile(end, 90):.2f} max {end.max():.2f}")
     for i, n in enumerate(["entry->Q loaded, first tiles issued", "->tile 0 landed (first barrier)", "k-loop (16 tiles)", "merge of the key parts", "output transpose + stores"]):
         print(f"    {n:38s} mean {d[:, :, i].mean():8.0f}  p90 {np.percentile(d[:, :, i], 90):8.0f}  max {d[:, :, i].max():8.0f} cycles")

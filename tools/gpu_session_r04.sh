@@ -12,6 +12,7 @@ for p in $PARTS; do
     hazard) SDXL_MEASURE_LIB=1 timeout 900 python tools/hazard_xa_probe.py ${HAZ_N:-500} > $OUT/hazard_xa.txt 2>&1; cat $OUT/hazard_xa.txt | tail -10;;
     newtests) timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -m gpu -q -s -k "outside_the_f16_range or token_count or wreg or vae or split_operand" --maxfail=8 > $OUT/newtests.log 2>&1; echo "rc=$?" >> $OUT/newtests.log; grep -E "passed|failed|rel err|Error" $OUT/newtests.log | tail -25;;
     widetl) SDXL_MEASURE_LIB=1 timeout 300 python tools/wide_timeline.py > $OUT/wide_timeline.txt 2>&1; cat $OUT/wide_timeline.txt;;
+    attnko) SDXL_MEASURE_LIB=1 timeout 600 python tools/attn_knockout.py > $OUT/attn_knockout.txt 2>&1; cat $OUT/attn_knockout.txt;;
     attntl) SDXL_MEASURE_LIB=1 timeout 300 python tools/attn_timeline.py > $OUT/attn_timeline.txt 2>&1; cat $OUT/attn_timeline.txt;;
     attntests) timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -s -k "attention" --maxfail=8 > $OUT/attntests.log 2>&1; echo "rc=$?" >> $OUT/attntests.log; grep -E "passed|failed|pipelined vs serial|Error" $OUT/attntests.log | tail -14;;
     attnab) for v in 10 6 10 6; do SDXL_DEBUG_SET=attn_variant=$v python -c "import os,sys; sys.path.insert(0, \".\"); import __graft_entry__ as ge; pkg=ge.load_package(); ctx=pkg.Context(0); pkg.debug_set(\"attn_variant\", $v); print(\"attn_variant $v: 32^2 self-attention\", round(min(pkg.bench_attention(ctx,2,20,1024,1024,50) for _ in range(3))*1e3,2), \"us\")"; done 2>&1 | grep -v amdgpu.ids | tee $OUT/attn_ab.txt;;
