@@ -908,9 +908,14 @@ void attention_set_timeline(void* buf) {
 #endif
 // KO (measure builds, attn_variant 11 ..): knock-outs that time one resource of the k-loop alone (results are garbage): bit 0 no DMA inside the
 // loop, 1 no softmax arithmetic (scores converted as they are), 2 no per-tile barrier, 3 no MFMAs, 4 no LDS fragment reads
-template <int KP, int PRIO = 2, int KO = 0>
-__device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void* zeros, char* smem, int b, int hd, int qb) {
+// XH (level 2 of attn_d64_mix_kernel): the block takes key HALF kx of its 64 queries -- tiles [kx nt / 2, (kx + 1) nt / 2) -- and its partner block
+// the other half.  Each merging wave parks its (m, l, O) image in the workspace slot of (pair, half, query sub-tile), releases at agent scope and draws a
+// ticket; the wave that draws the second one acquires, merges   O = O_0 2^(m_0 - m) + O_1 2^(m_1 - m)   in the fixed order half 0, half 1 -- so the
+// result does not depend on which block arrived last -- and stores the output rows.  Nobody waits for anybody: no co-residency is assumed.
+template <int KP, int PRIO = 2, int KO = 0, bool XH = false>
+__device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void* zeros, char* smem, int b, int hd, int qb, int kx = 0, int pair = 0) {
   static_assert(KP == 2 || KP == 4, "key parts per query sub-tile");
+  static_assert(!XH || KP == 2, "cross-workgroup key halves: 64-query blocks");
 #ifdef SDXL_MEASURE
   unsigned atl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   atl[6] = (unsigned)__builtin_amdgcn_s_memrealtime();
@@ -978,10 +983,11 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
   f32x16 minit;                                 // -m, the C operand of every score tile's first MFMA (see variant 2)
 #pragma unroll
   for (int r = 0; r < 16; ++r) minit[r] = 0.f;
-  const int nt = p.Nk / KV;
+  const int nt = XH ? (p.Nk / KV) >> 1 : p.Nk / KV;      // tiles of this block
+  const int tb = XH ? kx * nt : 0;                       // its first tile
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
-    if (s0 < nt) stage(s0, s0);
+    if (s0 < nt) stage(tb + s0, s0);
   ATTN_STAMP(1);
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
@@ -990,7 +996,7 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
     if constexpr (!(KO & 4)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (t == 0) ATTN_STAMP(2);
-    if constexpr (!(KO & 1)) { if (t + NS - 1 < nt) stage(t + NS - 1, cur == 0 ? NS - 1 : cur - 1); }
+    if constexpr (!(KO & 1)) { if (t + NS - 1 < nt) stage(tb + t + NS - 1, cur == 0 ? NS - 1 : cur - 1); }
     const char* kb = smem + cur * 2 * TILE;
     const char* vb = kb + TILE;
     cur = cur == NS - 1 ? 0 : cur + 1;
@@ -1084,6 +1090,7 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
 #pragma unroll
     for (int j = 0; j < NMERGE; ++j) mm = fmaxf(mm, mb[j * (34 * 64)]);
     const float a0 = __builtin_amdgcn_exp2f(m - mm);
+    m = mm;
     l *= a0;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -1101,6 +1108,50 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
     }
   }
   ATTN_STAMP(4);
+  if constexpr (XH) {
+    // ---- the other key half lives on another workgroup (possibly another XCD).  Wave-level handshake, guideline 16 of the programming guide: plain
+    // stores -> vmcnt(0) -> agent release -> relaxed agent ticket; the second arriver re-arms the ticket, acquires once and reads the partner's image
+    // (first form: plain stores + agent release fence = an L2 write-back per wave: 33.6 vs 21.2 us per launch.  Now the image goes out as
+    //  write-through 16-byte stores and comes back through L1-bypassing loads: no fence on either side -- the lines were never in the reader's L2:
+    //  a launch starts with the caches acquired, and an image is read once)
+    f32x4* img = reinterpret_cast<f32x4*>(p.xws) + ((size_t)(pair * 2 + kx) * 2 + qs) * (9 * 64) + lane;
+    {
+      const f32x4 ml = f32x4{m, l, 0.f, 0.f};
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(img), "v"(ml) : "memory");
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 v = f32x4{o[dt][4 * g4], o[dt][4 * g4 + 1], o[dt][4 * g4 + 2], o[dt][4 * g4 + 3]};
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(img + (1 + dt * 4 + g4) * 64), "v"(v) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(p.xcnt + pair * 2 + qs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk = __builtin_amdgcn_readfirstlane(tk);
+    if (tk == 0) { ATTN_DUMP(); return; }                    // first of the pair: the partner finishes the rows
+    if (lane == 0) __hip_atomic_store(p.xcnt + pair * 2 + qs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+    const f32x4* oimg = reinterpret_cast<const f32x4*>(p.xws) + ((size_t)(pair * 2 + (1 - kx)) * 2 + qs) * (9 * 64) + lane;
+    f32x4 pi[9];
+#pragma unroll
+    for (int q9 = 0; q9 < 9; ++q9) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pi[q9]) : "v"(oimg + q9 * 64) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pi[0]), "+v"(pi[1]), "+v"(pi[2]), "+v"(pi[3]), "+v"(pi[4]), "+v"(pi[5]), "+v"(pi[6]), "+v"(pi[7]), "+v"(pi[8])::"memory");
+    const float mo = pi[0][0], lo = pi[0][1];
+    const float m0 = kx == 0 ? m : mo, m1 = kx == 0 ? mo : m;           // operands by HALF index, whoever holds them
+    const float mm = fmaxf(m0, m1);
+    const float e0 = __builtin_amdgcn_exp2f(m0 - mm), e1 = __builtin_amdgcn_exp2f(m1 - mm);
+    const float l0 = kx == 0 ? l : lo, l1 = kx == 0 ? lo : l;
+    l = fmaf(l1, e1, l0 * e0);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float po = pi[1 + dt * 4 + (r >> 2)][r & 3];
+        const float o0 = kx == 0 ? o[dt][r] : po, o1 = kx == 0 ? po : o[dt][r];
+        o[dt][r] = fmaf(o1, e1, o0 * e0);
+      }
+  }
   const float inv = 1.0f / l;
   char* ob = smem + ((NPARK * 8704 + 4095) & ~4095) + qs * 4096;          // behind the parked images (8704 B each)
 #pragma unroll
@@ -1149,8 +1200,9 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
 template <int LEVEL, int PRIO = 2>
 __global__ __launch_bounds__(256, 2) void attn_d64_mix_kernel(const AttnParams p, const void* zeros, int big_heads) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][K tile | V^T tile]
-  constexpr int QL = LEVEL == 0 ? 128 : 64, QS = QL / 2;
-  const int nql = (p.Nq + QL - 1) / QL, nqs = (p.Nq + QS - 1) / QS;
+  constexpr int QL = LEVEL == 0 ? 128 : 64, QS = LEVEL == 2 ? 64 : QL / 2;
+  // (level 2: a "small" block is one key HALF of a 64-query block -- two of them per query block, consecutive ids)
+  const int nql = (p.Nq + QL - 1) / QL, nqs = LEVEL == 2 ? 2 * ((p.Nq + 63) / 64) : (p.Nq + QS - 1) / QS;
   const int NL = p.B * big_heads * nql, NSM = p.B * (p.H - big_heads) * nqs;       // large / small blocks of the launch
   int bid = blockIdx.x;
   bool large;
@@ -1171,7 +1223,8 @@ __global__ __launch_bounds__(256, 2) void attn_d64_mix_kernel(const AttnParams p
     const int per = (p.H - big_heads) * nqs;
     const int b = bid / per, r = bid - b * per, hs = r / nqs, qb = r - hs * nqs;
     if constexpr (LEVEL == 0) attn_d64_ks_body<2, PRIO>(p, zeros, smem, b, big_heads + hs, qb);
-    else attn_d64_ks_body<4, PRIO>(p, zeros, smem, b, big_heads + hs, qb);
+    else if constexpr (LEVEL == 1) attn_d64_ks_body<4, PRIO>(p, zeros, smem, b, big_heads + hs, qb);
+    else attn_d64_ks_body<2, PRIO, 0, true>(p, zeros, smem, b, big_heads + hs, qb >> 1, qb & 1, (b * (p.H - big_heads) + hs) * (nqs >> 1) + (qb >> 1));
   }
 }
 
@@ -1552,6 +1605,15 @@ void attention_init() {
   g_attn_zeros[d] = z;
 }
 
+// cross-workgroup key halves (attn_d64_mix_kernel level 2): 1/5 of the heads run as two half-key blocks per 64 queries, so that the CFG
+// pair at the 32^2 level is 512 whole + 256 half blocks = two whole and one half block on every CU (2.5 units of work each) instead of
+// three blocks on one half of the CUs and two on the other
+static std::atomic<int> g_attn_xsplit{1};
+void attention_set_xsplit(int v) { g_attn_xsplit = v; }
+static int xsplit_heads(int H) { return H - std::max(1, H * 4 / 5); }
+size_t attention_xsplit_counters(int B, int H, int Nq) { return (size_t)B * xsplit_heads(H) * ((Nq + 63) / 64) * 2; }
+size_t attention_xsplit_ws_bytes(int B, int H, int Nq) { return attention_xsplit_counters(B, H, Nq) * 2 * (9 * 64 * 4 * sizeof(float)); }
+
 void launch_attention_d64(const AttnParams& p, hipStream_t s) {
   const int dev = attn_device();
   const void* g_attn_zero = g_attn_zeros[dev];
@@ -1579,12 +1641,16 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
     if (ks_ok && g_attn_variant == 7) mix = 0;
     else if (ks_ok && g_attn_variant == 8) mix = 1;
     else if (ks_ok && g_attn_variant == 0 && !ks_pick && p.H % 5 == 0) mix = 0;
+    // level 2 where the key-split kernel would run: whole 128-key pairs of tiles, a workspace from the caller, heads divisible 4 : 1
+    else if (ks_pick && g_attn_variant == 0 && p.xws && p.xcnt && g_attn_xsplit.load() && p.H % 5 == 0 && p.H >= 5 && (p.Nk % 128) == 0 && (p.Nq % 64) == 0) mix = 2;
     if (mix >= 0) {
       const int big_heads = p.H >= 2 ? std::max(1, p.H * 4 / 5) : 0;
       const int ql = mix == 0 ? 128 : 64;
-      const int nl = p.B * big_heads * ((p.Nq + ql - 1) / ql), nsm = p.B * (p.H - big_heads) * ((p.Nq + ql / 2 - 1) / (ql / 2));
+      const int nl = p.B * big_heads * ((p.Nq + ql - 1) / ql);
+      const int nsm = mix == 2 ? p.B * (p.H - big_heads) * 2 * ((p.Nq + 63) / 64) : p.B * (p.H - big_heads) * ((p.Nq + ql / 2 - 1) / (ql / 2));
       if (mix == 0) hipLaunchKernelGGL(attn_d64_mix_kernel<0>, dim3(nl + nsm), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero, big_heads);
-      else hipLaunchKernelGGL(attn_d64_mix_kernel<1>, dim3(nl + nsm), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero, big_heads);
+      else if (mix == 1) hipLaunchKernelGGL(attn_d64_mix_kernel<1>, dim3(nl + nsm), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero, big_heads);
+      else hipLaunchKernelGGL(attn_d64_mix_kernel<2>, dim3(nl + nsm), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero, big_heads);
       return;
     }
     if (ks_pick) {

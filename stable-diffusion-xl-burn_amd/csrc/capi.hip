@@ -165,6 +165,7 @@ int sdxl_debug_set(const char* key, int value) {
   else if (std::strcmp(key, "igemm_wreg") == 0) igemm_set_wreg(value);
   else if (std::strcmp(key, "igemm_tsw") == 0) igemm_set_tsw(value);
   else if (std::strcmp(key, "igemm_warm") == 0) igemm_set_warm(value);
+  else if (std::strcmp(key, "attn_xsplit") == 0) attention_set_xsplit(value);
 #ifdef SDXL_MEASURE
   else if (std::strcmp(key, "igemm_unrolled") == 0) igemm_set_unrolled(value);
   else if (std::strcmp(key, "xa_vec64") == 0) igemm_set_xa_vec64(value);
@@ -314,6 +315,10 @@ int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int 
   AttnParams p{};
   p.Q = q; p.ldq = C; p.K = k; p.ldk = C; p.Vt = vt; p.vt_ld = npad; p.O = o; p.ldo = C;
   p.dt = DT_F16; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+  // workspace + tickets of the cross-workgroup key split (what the UNet hands its self-attention calls)
+  p.xws = (float*)tmp.get(attention_xsplit_ws_bytes(B, H, Nq) + 256);
+  p.xcnt = (unsigned*)tmp.get(attention_xsplit_counters(B, H, Nq) * sizeof(unsigned) + 256);
+  launch_fill_zero(p.xcnt, attention_xsplit_counters(B, H, Nq) * sizeof(unsigned), s);
   for (int i = 0; i < 3; ++i) launch_attention_d64(p, s);
   hipEvent_t a, b;
   SDXL_HIP(hipEventCreate(&a)); SDXL_HIP(hipEventCreate(&b));
@@ -515,6 +520,11 @@ int sdxl_qkv_attention(sdxl_ctx* ctx, void* stream, const float* q, const float*
     AttnParams p{};
     p.Q = qd; p.ldq = n_state; p.K = kd; p.ldk = n_state; p.Vt = vt; p.vt_ld = npad; p.O = od; p.ldo = n_state;
     p.dt = cdt; p.B = B; p.H = n_head; p.Nq = Nq; p.Nk = Nk; p.scale = (float)(1.0 / std::sqrt((double)d)); p.mask = mask; p.ldmask = Nk;
+    if (d == 64 && cdt == DT_F16 && !mask) {   // workspace + tickets of the cross-workgroup key split (what the UNet hands its self-attention calls)
+      p.xws = (float*)tmp.get(attention_xsplit_ws_bytes(B, n_head, Nq) + 256);
+      p.xcnt = (unsigned*)tmp.get(attention_xsplit_counters(B, n_head, Nq) * sizeof(unsigned) + 256);
+      launch_fill_zero(p.xcnt, attention_xsplit_counters(B, n_head, Nq) * sizeof(unsigned), s);
+    }
     if (d == 64) launch_attention_d64(p, s);
     else SDXL_REQUIRE(launch_attention_hd512(p, s), "wide-head attention kernel refused an aligned f16 shape");
     launch_copy_rows(od, cdt, n_state, out, DT_F32, n_state, B * Nq, n_state, s);

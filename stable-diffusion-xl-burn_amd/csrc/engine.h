@@ -201,6 +201,7 @@ struct Exec {
   hipEvent_t fork_ev = nullptr;    // split-CFG: recorded on s after the fork_after-th GEMM launch of chain 0 -- the second
   int fork_after = 0, launches = 0; // chain starts there, so the two chains run out of phase (GEMMs of one under the attention of the other)
   WarmSeq* warm = nullptr;         // weight warming schedule of the plan (null: off)
+  float* attn_xws = nullptr; unsigned* attn_xcnt = nullptr;   // workspace / tickets of the cross-workgroup key split (AttnParams::xws)
   Act alloc(size_t rows, int C, int dt) {
     return Act(act->alloc(rows * (size_t)C * dt_size(dt)), C, dt);
   }
@@ -306,7 +307,9 @@ class UNet {
   bool plan_split_ = false; int graph_off_ = 0;
   bool fuse_xattn_ = true, plan_xattn_ = true;   // cross-attention inside the query projection's epilogue (f16 engines)
   WarmSeq warm_;                    // weight warming schedule of the current plan (recorded on its first forward)
+  float* attn_xws_[2] = {nullptr, nullptr}; unsigned* attn_xcnt_[2] = {nullptr, nullptr};   // cross-workgroup key split: per chain (split-CFG runs two)
   bool graph_warm_ = false;         // the captured graph carries the warming workgroups
+  size_t attn_xcnt_bytes_ = 0;
   bool gn_from_producer_ = true, plan_gn_ = true;   // GroupNorm statistics from the producing convolution's epilogue where its kernel can (f16); part of the plan key
   hipStream_t s2_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena act2_;

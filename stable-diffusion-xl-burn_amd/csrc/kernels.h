@@ -150,7 +150,13 @@ struct AttnParams {
   const float* mask; int ldmask;   // optional additive [Nq][Nk] fp32 (0 / -inf), null in UNet/VAE
   int q_dt = 0;                // split-operand kernel only: DT_F32 (0) or DT_HL -- Q rows in HL16 (ldq in logical elements)
   int o_dt = 0;                // split-operand kernel only: DT_F32 (0) or DT_HL -- O written as HL16 rows (ldo in logical elements), the next GEMM's operand
+  // key halves on DIFFERENT workgroups (attn_d64_mix_kernel level 2, round 4): workspace of attention_xsplit_ws_bytes(B, H, Nq) bytes and
+  // attention_xsplit_counters(B, H, Nq) zero-initialised tickets (they re-arm themselves); null = that form is never picked
+  float* xws = nullptr; unsigned* xcnt = nullptr;
 };
+size_t attention_xsplit_ws_bytes(int B, int H, int Nq);
+size_t attention_xsplit_counters(int B, int H, int Nq);
+void attention_set_xsplit(int v);      // A/B knob (sdxl_debug_set "attn_xsplit"): 0 = never pick the cross-workgroup key split
 void launch_attention_d64(const AttnParams& p, hipStream_t s);
 // split-operand (fp32-class) head-dim-64 attention: Q / O fp32 (ldq / ldo in floats), K [B][Nk] rows and Vt [B][H*64][vt_ld] rows in
 // HL16 (ldk / vt_ld in LOGICAL elements: a row is 2 * ld halfs), no mask; vt_ld a multiple of 64 keys, zero beyond Nk.  Returns false

@@ -89,6 +89,7 @@ void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, 
   p.Q = q.p; p.ldq = q.ld; p.K = k.p; p.ldk = k.ld; p.Vt = vt; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
   // (the split-operand mode runs the attention on fp32 tensors: q / k / V^T / o all carry q's dtype)
   p.dt = q.dt; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+  if (Nq == Nk) { p.xws = ex.attn_xws; p.xcnt = ex.attn_xcnt; }      // self-attention: room for the cross-workgroup key split (sized for it in ensure_plan)
   if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0);
   launch_attention_d64(p, ex.s);
   {
@@ -514,6 +515,21 @@ void UNet::ensure_plan(int B, int H, int W) {
     ebias_ = (float*)act_.alloc((size_t)B * emb_total_ * sizeof(float));
     gn_partial_ = (float*)act_.alloc(groupnorm_workspace_floats(B, 32) * sizeof(float));
     tconv_ = (float*)act_.alloc(8 * sizeof(float));
+    if (cdt_ == DT_F16) {   // cross-workgroup key split of the self-attention: workspace + tickets per chain, sized for the largest level
+      size_t wsb = 0, cnt = 0;
+      { int h = H, w = W;
+        for (size_t lv = 0; lv < cfg_.channel_mults.size(); ++lv) {
+          const int heads = cfg_.model_channels * cfg_.channel_mults[lv] / cfg_.n_head_channels;
+          wsb = std::max(wsb, attention_xsplit_ws_bytes(B, heads, h * w)); cnt = std::max(cnt, attention_xsplit_counters(B, heads, h * w));
+          h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
+        } }
+      attn_xcnt_bytes_ = cnt * sizeof(unsigned);
+      attn_xws_[1] = nullptr; attn_xcnt_[1] = nullptr;
+      for (int c = 0; c < (split ? 2 : 1); ++c) {
+        attn_xws_[c] = (float*)act_.alloc(wsb + 256);
+        attn_xcnt_[c] = (unsigned*)act_.alloc(attn_xcnt_bytes_ + 256);
+      }
+    }
     if (cdt_ == DT_F16) {   // split-K slabs + counters: chain 0 (and the second split-CFG chain)
       skws_bytes_ = igemm_splitk_ws_bytes(B, 1024, 1280);
       skws_[1] = nullptr; skcnt_[1] = nullptr;
@@ -559,6 +575,7 @@ void UNet::ensure_plan(int B, int H, int W) {
   act_.off = 0; act_.peak = 0;
   persist();
   for (int c = 0; c < 2; ++c) if (skcnt_[c]) SDXL_HIP(hipMemset(skcnt_[c], 0, kSplitkCounters * sizeof(unsigned)));   // armed once
+  for (int c = 0; c < (split ? 2 : 1); ++c) if (attn_xcnt_[c] && cdt_ == DT_F16) SDXL_HIP(hipMemset(attn_xcnt_[c], 0, attn_xcnt_bytes_));
 }
 
 void* UNet::unet_in(int B, int H, int W) { ensure_plan(B, H, W); return in_; }
@@ -568,6 +585,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
   SDXL_REQUIRE(ctx_B_ == B && !kv_.empty(), "set_context must be called with the same batch before forward");
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_;
   ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
+  if (cdt_ == DT_F16) { ex.attn_xws = attn_xws_[0]; ex.attn_xcnt = attn_xcnt_[0]; }
   // weight warming (f16 engine, batched chain): the plan's first forward records the GEMM sequence, every later one replays it
   const bool warming = cdt_ == DT_F16 && !plan_split_ && igemm_warm_enabled();
   if (warming) { ex.warm = &warm_; if (!warm_.ready) { warm_.seq.clear(); warm_.recording = true; } }
@@ -578,6 +596,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     if (!plan_split_) { run(ex, t_dev, t_stride, 0, B); if (warm_.recording) warm_.finish(); return; }
     Exec e2; e2.s = s2_; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_;
     e2.splitk_ws = skws_[1]; e2.splitk_ws_bytes = skws_bytes_; e2.splitk_cnt = skcnt_[1];
+    if (cdt_ == DT_F16) { e2.attn_xws = attn_xws_[1]; e2.attn_xcnt = attn_xcnt_[1]; }
     act2_.off = 0;
     ex.fork_ev = ev_fork_; ex.fork_after = split_offset_; ex.launches = 0;
     if (ex.fork_after <= 0) SDXL_HIP(hipEventRecord(ev_fork_, s));
@@ -622,6 +641,7 @@ void UNet::profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[P
   Profiler prof;
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.prof = &prof;
   ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
+  if (cdt_ == DT_F16) { ex.attn_xws = attn_xws_[0]; ex.attn_xcnt = attn_xcnt_[0]; }
   const size_t m = act_.mark();
   run(ex, tconv_, 1, 0, B);   // always the batched chain: per-launch events need one stream
   act_.reset(m);

@@ -412,11 +412,42 @@ def test_qkv_attention_mixed_block_sizes_are_their_bodies(pkg, ctx, variant, hea
     assert torch.equal(run(variant, slice(1, 2)), out[1:2])
     big = 64 * (heads * 4 // 5)
     if variant == 0 and N < 3328:
-        assert torch.equal(out, run(6))
+        # automatic choice where the key-split kernel runs: the first 4/5 of the heads in whole-key blocks (= the key-split body), the rest as
+        # two half-key blocks per 64 queries merged across workgroups (test_qkv_attention_key_halves_across_workgroups); knob off = key split alone
+        assert torch.equal(out[..., :big], run(6)[..., :big])
+        pkg.debug_set("attn_xsplit", 0)
+        try:
+            assert torch.equal(run(0), run(6))
+        finally:
+            pkg.debug_set("attn_xsplit", 1)
     else:
         assert torch.equal(out[..., :big], run(6 if variant == 8 else 2)[..., :big])
         if variant != 8:
             assert torch.equal(out[..., big:], run(6)[..., big:])
+
+
+@pytest.mark.parametrize("B,heads,N", [(2, 20, 1024), (1, 20, 1024), (3, 10, 384), (1, 5, 128), (2, 5, 2048)])
+def test_qkv_attention_key_halves_across_workgroups(pkg, ctx, B, heads, N):
+    # attn_d64_mix_kernel level 2 (the automatic choice where the key-split kernel would run): the last 1/5 of the heads run as TWO blocks per
+    # 64 queries, one per key half, and the second of the two to arrive merges the halves in the fixed order (half 0, half 1): the result must
+    # not depend on the arrival order (repeated launches bit-identical), on the batch neighbours, and must match the oracle like the other heads
+    C = 64 * heads
+    q, k, v = seeded(B, N, C, seed=41), seeded(B, N, C, seed=42), seeded(B, N, C, seed=43)
+    ref = OM.qkv_attention(q, k, v, None, heads)
+    outs = [pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, heads, 1) for _ in range(6)]
+    big = 64 * max(1, heads * 4 // 5)
+    assert rel_err(outs[0], ref) < 6e-3 and rel_err(outs[0][..., big:], ref[..., big:]) < 6e-3
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "the merge depends on which half arrived last"
+    one = pkg.qkv_attention(ctx, q[B - 1:].cuda(), k[B - 1:].cuda(), v[B - 1:].cuda(), None, heads, 1)
+    assert torch.equal(one, outs[0][B - 1:]), "a batch entry depends on its neighbours"
+    pkg.debug_set("attn_xsplit", 0)
+    try:
+        off = pkg.qkv_attention(ctx, q.cuda(), k.cuda(), v.cuda(), None, heads, 1)
+    finally:
+        pkg.debug_set("attn_xsplit", 1)
+    assert torch.equal(off[..., :big], outs[0][..., :big])            # the whole-key heads are the same blocks either way
+    assert rel_err(off[..., big:], outs[0][..., big:]) < 2e-3         # the split heads differ by rounding only (two-level online softmax)
 
 
 def test_attn_decoder_mask(pkg, ctx):
