@@ -445,6 +445,53 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
 // PRIO = 2: the softmax / PV phase of a wave runs at raised issue priority (s_setprio), the score MFMAs at base priority -- with three
 // waves per SIMD in different phases the exp-heavy phase is the one that must not wait (measured, profiles/r03_attention_block_balance.txt:
 // 113.4 -> 111.1 us at 64^2, key split 22.0 -> 21.6 us at 32^2, mixed blocks 101.2 -> 99.8 us; raising the MFMA phase instead: no change)
+// wave-level hand-over of an un-normalised (m, l, O) image between the two key halves of a query block that live on DIFFERENT workgroups (XH bodies
+// below): nine write-through 16-byte pieces per lane, a ticket per slot; returns false in the wave that arrived first (its partner finishes the
+// rows), true -- with (m, l, O) merged in the fixed order half 0, half 1 -- in the wave that arrived second.  No fence on either side: the image
+// lines were never in the reader's L2 (a launch starts with the caches acquired, an image is read once), and nobody waits for anybody.
+// (First form: plain stores + agent-scope release = an L2 write-back per wave: 33.6 against 21.2 us per launch of the 32^2 self-attention.)
+__device__ __forceinline__ bool attn_xhalf_merge(const AttnParams& p, int slot, int kx, int lane, float& m, float& l, f32x16 (&o)[2]) {
+  f32x4* img = reinterpret_cast<f32x4*>(p.xws) + ((size_t)slot * 2 + kx) * (9 * 64) + lane;
+  {
+    const f32x4 ml = f32x4{m, l, 0.f, 0.f};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(img), "v"(ml) : "memory");
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 v = f32x4{o[dt][4 * g4], o[dt][4 * g4 + 1], o[dt][4 * g4 + 2], o[dt][4 * g4 + 3]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(img + (1 + dt * 4 + g4) * 64), "v"(v) : "memory");
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned tk = 0;
+  if (lane == 0) tk = __hip_atomic_fetch_add(p.xcnt + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tk = __builtin_amdgcn_readfirstlane(tk);
+  if (tk == 0) return false;
+  if (lane == 0) __hip_atomic_store(p.xcnt + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+  const f32x4* oimg = reinterpret_cast<const f32x4*>(p.xws) + ((size_t)slot * 2 + (1 - kx)) * (9 * 64) + lane;
+  f32x4 pi[9];
+#pragma unroll
+  for (int q9 = 0; q9 < 9; ++q9) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pi[q9]) : "v"(oimg + q9 * 64) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pi[0]), "+v"(pi[1]), "+v"(pi[2]), "+v"(pi[3]), "+v"(pi[4]), "+v"(pi[5]), "+v"(pi[6]), "+v"(pi[7]), "+v"(pi[8])::"memory");
+  const float mo = pi[0][0], lo = pi[0][1];
+  const float m0 = kx == 0 ? m : mo, m1 = kx == 0 ? mo : m;           // operands by HALF index, whoever holds them
+  const float mm = fmaxf(m0, m1);
+  const float e0 = __builtin_amdgcn_exp2f(m0 - mm), e1 = __builtin_amdgcn_exp2f(m1 - mm);
+  const float l0 = kx == 0 ? l : lo, l1 = kx == 0 ? lo : l;
+  l = fmaf(l1, e1, l0 * e0);
+  m = mm;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float po = pi[1 + dt * 4 + (r >> 2)][r & 3];
+      const float o0 = kx == 0 ? o[dt][r] : po, o1 = kx == 0 ? po : o[dt][r];
+      o[dt][r] = fmaf(o1, e1, o0 * e0);
+    }
+  return true;
+}
+
 template <int NS, int PRIO = 2>
 __device__ __forceinline__ void attn_d64_v2_body(const AttnParams& p, const void* zeros, char* smem, int b, int hd, int qb) {
   constexpr int KV = 64, TILE = 64 * 128;
@@ -1109,48 +1156,7 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
   }
   ATTN_STAMP(4);
   if constexpr (XH) {
-    // ---- the other key half lives on another workgroup (possibly another XCD).  Wave-level handshake, guideline 16 of the programming guide: plain
-    // stores -> vmcnt(0) -> agent release -> relaxed agent ticket; the second arriver re-arms the ticket, acquires once and reads the partner's image
-    // (first form: plain stores + agent release fence = an L2 write-back per wave: 33.6 vs 21.2 us per launch.  Now the image goes out as
-    //  write-through 16-byte stores and comes back through L1-bypassing loads: no fence on either side -- the lines were never in the reader's L2:
-    //  a launch starts with the caches acquired, and an image is read once)
-    f32x4* img = reinterpret_cast<f32x4*>(p.xws) + ((size_t)(pair * 2 + kx) * 2 + qs) * (9 * 64) + lane;
-    {
-      const f32x4 ml = f32x4{m, l, 0.f, 0.f};
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(img), "v"(ml) : "memory");
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 v = f32x4{o[dt][4 * g4], o[dt][4 * g4 + 1], o[dt][4 * g4 + 2], o[dt][4 * g4 + 3]};
-          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(img + (1 + dt * 4 + g4) * 64), "v"(v) : "memory");
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned tk = 0;
-    if (lane == 0) tk = __hip_atomic_fetch_add(p.xcnt + pair * 2 + qs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tk = __builtin_amdgcn_readfirstlane(tk);
-    if (tk == 0) { ATTN_DUMP(); return; }                    // first of the pair: the partner finishes the rows
-    if (lane == 0) __hip_atomic_store(p.xcnt + pair * 2 + qs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-    const f32x4* oimg = reinterpret_cast<const f32x4*>(p.xws) + ((size_t)(pair * 2 + (1 - kx)) * 2 + qs) * (9 * 64) + lane;
-    f32x4 pi[9];
-#pragma unroll
-    for (int q9 = 0; q9 < 9; ++q9) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pi[q9]) : "v"(oimg + q9 * 64) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pi[0]), "+v"(pi[1]), "+v"(pi[2]), "+v"(pi[3]), "+v"(pi[4]), "+v"(pi[5]), "+v"(pi[6]), "+v"(pi[7]), "+v"(pi[8])::"memory");
-    const float mo = pi[0][0], lo = pi[0][1];
-    const float m0 = kx == 0 ? m : mo, m1 = kx == 0 ? mo : m;           // operands by HALF index, whoever holds them
-    const float mm = fmaxf(m0, m1);
-    const float e0 = __builtin_amdgcn_exp2f(m0 - mm), e1 = __builtin_amdgcn_exp2f(m1 - mm);
-    const float l0 = kx == 0 ? l : lo, l1 = kx == 0 ? lo : l;
-    l = fmaf(l1, e1, l0 * e0);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float po = pi[1 + dt * 4 + (r >> 2)][r & 3];
-        const float o0 = kx == 0 ? o[dt][r] : po, o1 = kx == 0 ? po : o[dt][r];
-        o[dt][r] = fmaf(o1, e1, o0 * e0);
-      }
+    if (!attn_xhalf_merge(p, pair * 2 + qs, kx, lane, m, l, o)) { ATTN_DUMP(); return; }
   }
   const float inv = 1.0f / l;
   char* ob = smem + ((NPARK * 8704 + 4095) & ~4095) + qs * 4096;          // behind the parked images (8704 B each)
@@ -1200,9 +1206,11 @@ __global__ __launch_bounds__(256, 2) void attn_d64_ks_kernel(const AttnParams p,
 template <int LEVEL, int PRIO = 2>
 __global__ __launch_bounds__(256, 2) void attn_d64_mix_kernel(const AttnParams p, const void* zeros, int big_heads) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][K tile | V^T tile]
-  constexpr int QL = LEVEL == 0 ? 128 : 64, QS = LEVEL == 2 ? 64 : QL / 2;
-  // (level 2: a "small" block is one key HALF of a 64-query block -- two of them per query block, consecutive ids)
-  const int nql = (p.Nq + QL - 1) / QL, nqs = LEVEL == 2 ? 2 * ((p.Nq + 63) / 64) : (p.Nq + QS - 1) / QS;
+  constexpr int QL = LEVEL == 0 ? 128 : 64, QS = LEVEL == 2 ? QL : QL / 2;
+  // (level 2: a "small" block is one key HALF of a large block's 64 queries -- two of them per query block, consecutive ids.  The same for the
+  //  128-query blocks of the 64^2 level -- large = variant 2, small = its key halves -- measured 110.0 - 110.9 against 108.8 - 109.2 us for level 0 and
+  //  was not kept: profiles/r04_attention_key_halves_ab.txt)
+  const int nql = (p.Nq + QL - 1) / QL, nqs = LEVEL == 2 ? 2 * nql : (p.Nq + QS - 1) / QS;
   const int NL = p.B * big_heads * nql, NSM = p.B * (p.H - big_heads) * nqs;       // large / small blocks of the launch
   int bid = blockIdx.x;
   bool large;
@@ -1647,7 +1655,7 @@ void launch_attention_d64(const AttnParams& p, hipStream_t s) {
       const int big_heads = p.H >= 2 ? std::max(1, p.H * 4 / 5) : 0;
       const int ql = mix == 0 ? 128 : 64;
       const int nl = p.B * big_heads * ((p.Nq + ql - 1) / ql);
-      const int nsm = mix == 2 ? p.B * (p.H - big_heads) * 2 * ((p.Nq + 63) / 64) : p.B * (p.H - big_heads) * ((p.Nq + ql / 2 - 1) / (ql / 2));
+      const int nsm = mix == 2 ? p.B * (p.H - big_heads) * 2 * ((p.Nq + ql - 1) / ql) : p.B * (p.H - big_heads) * ((p.Nq + ql / 2 - 1) / (ql / 2));
       if (mix == 0) hipLaunchKernelGGL(attn_d64_mix_kernel<0>, dim3(nl + nsm), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero, big_heads);
       else if (mix == 1) hipLaunchKernelGGL(attn_d64_mix_kernel<1>, dim3(nl + nsm), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero, big_heads);
       else hipLaunchKernelGGL(attn_d64_mix_kernel<2>, dim3(nl + nsm), dim3(256), 3 * 2 * 64 * 128, s, p, g_attn_zero, big_heads);
