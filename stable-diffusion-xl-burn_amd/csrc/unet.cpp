@@ -520,7 +520,9 @@ void UNet::ensure_plan(int B, int H, int W) {
       { int h = H, w = W;
         for (size_t lv = 0; lv < cfg_.channel_mults.size(); ++lv) {
           const int heads = cfg_.model_channels * cfg_.channel_mults[lv] / cfg_.n_head_channels;
-          wsb = std::max(wsb, attention_xsplit_ws_bytes(B, heads, h * w)); cnt = std::max(cnt, attention_xsplit_counters(B, heads, h * w));
+          if (lv < cfg_.transformer_depths.size() && cfg_.transformer_depths[lv] > 0) {      // (levels without a SpatialTransformer run no attention)
+            wsb = std::max(wsb, attention_xsplit_ws_bytes(B, heads, h * w)); cnt = std::max(cnt, attention_xsplit_counters(B, heads, h * w));
+          }
           h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
         } }
       attn_xcnt_bytes_ = cnt * sizeof(unsigned);
