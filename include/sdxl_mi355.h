@@ -273,6 +273,7 @@ int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int 
  * Infinity Cache; results unchanged; A/B, default 1; a UNet picks it up on its next forward);
  * "attn_xsplit": 0 = the self-attention of the 32^2 level never runs 1/5 of its heads as two half-key blocks per 64 queries merged across
  * workgroups (csrc/attention.hip, attn_d64_mix_kernel level 2; A/B, default 1);
+ * "splitk_wt": 0 = split-K slabs published by plain stores + an agent-scope release instead of write-through stores (A/B, default 1);
  * "igemm_unrolled": 0 = auto selection launches the rolled k-loop kernels (A/B; default 1);
  * "split_cfg": 1 = a batch-2 UNet::forward runs its two entries as two concurrent batch-1 chains (bit-identical results);
  * "split_offset": GEMM launches of the first chain before the second is released; "no_cfg": base model without the

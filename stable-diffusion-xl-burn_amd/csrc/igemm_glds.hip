@@ -667,14 +667,20 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
       static_for<TM * TN>([&](auto X) {
         constexpr int x = decltype(X)::value, i = x / TN, j = x % TN;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          slab[(size_t)((wave * NV + x * 4 + q) * 64 + lane)] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        for (int q = 0; q < 4; ++q) {
+          // (round 4: write-through stores instead of plain stores + an agent-scope release -- the release writes the XCD's L2 back once per
+          //  workgroup, 240 times per launch; the write-through pieces leave as they are issued and vmcnt(0) covers them: g_splitk_wt = 0 restores the fence)
+          const f32x4 v = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          f32x4* dst = slab + (size_t)((wave * NV + x * 4 + q) * 64 + lane);
+          if (p.splitk_wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+          else *dst = v;
+        }
       });
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       volatile int* flag = reinterpret_cast<volatile int*>(smem + NS * STAGE - 16);   // inside the one LDS array, beyond the staging regions
       if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (!p.splitk_wt) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = t == (unsigned)(SK - 1);
@@ -1026,6 +1032,8 @@ static void launch_wide(const IgemmParams& p, hipStream_t s) {
 
 // variant: 0 auto; 1 = 128x128 ring 3; 2 = 128x64 ring 4; 3 = 64x128 ring 4; 4 = 128x128 ring 2; 5 = 128x64 ring 2;
 // 6 = 64x128 ring 2; 7 = 128x128 ring 4; 8 = 64x128 ring 3.  Returns false when the shape needs the generic kernel.
+static std::atomic<int> g_splitk_wt{1};   // A/B knob (sdxl_debug_set "splitk_wt"): 0 = split-K slabs by plain stores + agent-scope release (the round-2 form)
+void igemm_set_splitk_wt(int v) { g_splitk_wt = v; }
 static std::atomic<int> g_tsw{1};      // A/B knob (sdxl_debug_set "igemm_tsw"): 0 = the V^T part of a fused QKV projection keeps the LDS-staged transposed epilogue
 void igemm_set_tsw(int v) { g_tsw = v; }
 static bool g_igemm_unrolled = true;
@@ -1163,6 +1171,7 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   const bool was_auto = variant == 0;
   IgemmParams psk = p;
   psk.splitk = 1;
+  psk.splitk_wt = g_splitk_wt.load();
   if (p.xa_k) {
     // fused cross-attention: wave tiles of 64 columns only (256x128 / 128x128), chosen by the same cost model
     if (p.act != 0 || p.n_split < p.N || p.stat_out || p.R || p.ebias ||

@@ -68,6 +68,7 @@ struct IgemmParams {
   // memory-side Infinity Cache -- spare workgroups behind the tile grid (kernels whose grid leaves CUs idle: igemm_wreg_selected) do
   // nothing but read them.  No effect on any result; null = off.
   const void* warm[3]; unsigned warm_bytes[3];     // up to three regions (filled from the front)
+  int splitk_wt;    // split-K slabs published by write-through stores instead of plain stores + release fence (set by the launcher from the A/B knob "splitk_wt", default 1)
                     // VMEM loads instead of the scalar cache -- the hazard experiment of DESIGN 9.2 / 10.4
   int epi_staged;   // A/B knob (sdxl_debug_set "igemm_epilogue_staged"): 1 = LDS-staged epilogue everywhere, 0 = direct row-per-lane where it applies
 };
@@ -90,6 +91,7 @@ void igemm_set_tsw(int v);       // A/B knob (sdxl_debug_set "igemm_tsw"): 0 = n
 bool igemm_wreg_selected(const IgemmParams& p);   // the auto selection (variant 0) would run this launch on the weights-in-registers kernel
 void igemm_set_warm(int v);      // A/B knob (sdxl_debug_set "igemm_warm"): 0 = no weight warming workgroups; read when a UNet plan records its GEMM sequence
 int igemm_warm_enabled();
+void igemm_set_splitk_wt(int v);
 void igemm_set_wreg(int v);      // A/B knob (sdxl_debug_set "igemm_wreg"): 0 = the auto selection never picks the weights-in-registers kernel
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
 void igemm_set_hl_weights_exact(int v); // A/B: 0 keeps all three MFMAs per product even where the packed weights are exact f16 values
