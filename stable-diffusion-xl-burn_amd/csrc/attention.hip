@@ -454,13 +454,13 @@ __device__ __forceinline__ bool attn_xhalf_merge(const AttnParams& p, int slot, 
   f32x4* img = reinterpret_cast<f32x4*>(p.xws) + ((size_t)slot * 2 + kx) * (9 * 64) + lane;
   {
     const f32x4 ml = f32x4{m, l, 0.f, 0.f};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(img), "v"(ml) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(img), "v"(ml) : "memory");
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const f32x4 v = f32x4{o[dt][4 * g4], o[dt][4 * g4 + 1], o[dt][4 * g4 + 2], o[dt][4 * g4 + 3]};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(img + (1 + dt * 4 + g4) * 64), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(img + (1 + dt * 4 + g4) * 64), "v"(v) : "memory");
       }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

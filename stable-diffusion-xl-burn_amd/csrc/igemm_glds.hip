@@ -672,7 +672,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
           //  workgroup, 240 times per launch; the write-through pieces leave as they are issued and vmcnt(0) covers them: g_splitk_wt = 0 restores the fence)
           const f32x4 v = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
           f32x4* dst = slab + (size_t)((wave * NV + x * 4 + q) * 64 + lane);
-          if (p.splitk_wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+          if (p.splitk_wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
           else *dst = v;
         }
       });

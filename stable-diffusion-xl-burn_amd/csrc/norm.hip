@@ -31,7 +31,10 @@ template <> __device__ __forceinline__ void store8<half_t>(half_t* p, const floa
   half8 h;
 #pragma unroll
   for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
-  *reinterpret_cast<half8*>(p) = h;
+  // write-through (round 4): the rows go out to the memory side while the block is still streaming instead of staying dirty in this XCD's L2 until the
+  // end-of-kernel write-back -- 7 of 8 consumers sit on other XCDs anyway (step 21.13 / 21.09 -> 21.08 / 21.02 ms, profiles/r04_write_through_outputs_ab.txt).
+  // The s_nop is the VMEM-store data hazard (> 64 bits of store data, then a VALU write of those registers): the compiler cannot see into the asm.
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(h) : "memory");
 }
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
   f32x4 a, b;
