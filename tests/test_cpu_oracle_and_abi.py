@@ -150,6 +150,20 @@ def built(pkg):
     return pkg
 
 
+def test_inline_asm_stores_carry_the_store_data_hazard_nop():
+    """An inline-asm VMEM store of more than 64 bits hides the store-data hazard from the compiler (a VALU write of the data registers right behind it
+    needs a wait state): every such statement in csrc/ must end with its own s_nop (the first write-through GroupNorm build produced NaNs)."""
+    src_dir = os.path.join(ROOT, "stable-diffusion-xl-burn_amd", "csrc")
+    found = 0
+    for name in sorted(os.listdir(src_dir)):
+        if not name.endswith((".hip", ".h", ".cpp")):
+            continue
+        for m in re.finditer(r'asm volatile\("([^"]*global_store_dwordx[34][^"]*)"', open(os.path.join(src_dir, name)).read()):
+            found += 1
+            assert "s_nop" in m.group(1), f"{name}: asm store without a hazard nop: {m.group(1)}"
+    assert found >= 3
+
+
 def test_weight_warming_schedule_host_logic(built):
     """WarmSeq::finish (csrc/weights.cpp) on a synthetic UNet-like launch sequence: which entry warms which.  Pure host code behind a test hook
     of the C-ABI library (no device): a transformer block is QKV (pipe kernel, 9.9 MB) / out-projection (weights-in-registers kernel = host, 3.3 MB) /
