@@ -680,7 +680,7 @@ __device__ __forceinline__ void attn_d64_v2_body(const AttnParams& p, const void
     const int row = it * 8 + (lane >> 3), piece = lane & 7;
     const i32x4 v = *reinterpret_cast<const i32x4*>(ob + row * 128 + ((piece ^ (row & 7)) << 4));
     const int q = q0 + row;
-    if (q < p.Nq) *reinterpret_cast<i32x4*>(Og + (size_t)q * p.ldo + piece * 8) = v;
+    if (q < p.Nq) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(Og + (size_t)q * p.ldo + piece * 8), "v"(v) : "memory");
   }
 }
 
@@ -1175,7 +1175,7 @@ __device__ __forceinline__ void attn_d64_ks_body(const AttnParams& p, const void
     const int row = it * 8 + (lane >> 3), piece = lane & 7;
     const i32x4 v = *reinterpret_cast<const i32x4*>(ob + row * 128 + ((piece ^ (row & 7)) << 4));
     const int q = q0 + row;
-    if (q < p.Nq) *reinterpret_cast<i32x4*>(Og + (size_t)q * p.ldo + piece * 8) = v;
+    if (q < p.Nq) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(Og + (size_t)q * p.ldo + piece * 8), "v"(v) : "memory");
   }
   ATTN_STAMP(5);
   ATTN_DUMP();
@@ -1431,7 +1431,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64_v3_kernel(const AttnParams p,
     const int row = it * 8 + (lane >> 3), piece = lane & 7;
     const i32x4 v = *reinterpret_cast<const i32x4*>(ob + row * 128 + ((piece ^ (row & 7)) << 4));
     const int q = q0 + row;
-    if (q < p.Nq) *reinterpret_cast<i32x4*>(Og + (size_t)q * p.ldo + piece * 8) = v;
+    if (q < p.Nq) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(Og + (size_t)q * p.ldo + piece * 8), "v"(v) : "memory");
   }
 }
 
