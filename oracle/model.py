@@ -19,6 +19,63 @@ Tensor = torch.Tensor
 EPS = 1e-5  # GroupNormConfig / LayerNormConfig default (groupnorm/mod.rs:13-14, layernorm/mod.rs:12-13)
 
 
+# ----------------------------------------------------------------------------- arithmetic emulation (round 5)
+class Numerics:
+    """Which arithmetic the restatement runs in.  The default (mode None) is plain fp32 -- every hook below is the identity and the
+    results are bit for bit what they were before the hooks existed.  Two emulations, both computed in fp32 with explicit roundings:
+
+    ``f16ref``   the REFERENCE's own GPU arithmetic: ``LibTorch<f16>`` (src/bin/sample/main.rs:122) holds every tensor -- the f16
+                 parameters of the record (``HalfPrecisionSettings``, :37) and the output of EVERY burn op -- in f16; libtorch's half
+                 kernels accumulate matmul / conv / reductions in fp32 and round the result once.  So: parameters rounded to f16, and
+                 the output of every op of the restated graph rounded to f16, at the granularity the reference issues them (its
+                 hand-written layernorm is seven ops, groupnorm/mod.rs:75-82; SiLU two, silu.rs:14-16; nn::Linear matmul + bias add;
+                 the LibTorch attention override ONE fused scaled_dot_product_attention, backend.rs:31-80).
+    ``operands`` the ENGINE's f16 mode seen from the oracle: only the two operands of the GEMMs of the listed classes are rounded to
+                 f16 (fp32 accumulation, fp32 everything else) -- classes: qkv, attn (q, k, v and the probabilities), out (attention
+                 out-projections), xattn (cross-attention projections + its attention), geglu, ff, and conv = conv_res (the two 3x3 convs of every
+                 ResBlock) + conv_skip (1x1 skip connections) + conv_io (the UNet's first and last conv) + conv_updown + conv_proj (proj_in / proj_out).
+    """
+
+    def __init__(self):
+        self.mode = None
+        self.classes = frozenset()
+        self._wcache = {}
+
+    def set(self, mode=None, classes=()):
+        assert mode in (None, "f16ref", "operands")
+        self.mode, self.classes = mode, frozenset(classes)
+        self._wcache = {}
+
+    @staticmethod
+    def _h(x: Tensor) -> Tensor:
+        return x.half().float()
+
+    def r(self, x: Tensor) -> Tensor:
+        """output of one reference op"""
+        return self._h(x) if self.mode == "f16ref" else x
+
+    def on(self, cls: str) -> bool:
+        """operands emulation: is GEMM class cls demoted?  ("conv" names all its sub-classes conv_res / conv_skip / conv_io / conv_updown / conv_proj)"""
+        return self.mode == "operands" and (cls in self.classes or cls.split("_")[0] in self.classes)
+
+    def w(self, W, name: str, cls: str) -> Tensor:
+        """a parameter tensor as the arithmetic holds it (cached: the 31-step trajectory asks 62 times)"""
+        t = W[name]
+        if self.mode == "f16ref" or self.on(cls):
+            c = self._wcache.get(name)
+            if c is None:
+                c = self._wcache[name] = self._h(t)
+            return c
+        return t
+
+    def a(self, x: Tensor, cls: str) -> Tensor:
+        """activation operand of a GEMM of class cls"""
+        return self._h(x) if self.on(cls) else x
+
+
+NUM = Numerics()
+
+
 def to_torch(weights: Dict[str, "np.ndarray"]) -> Dict[str, Tensor]:  # noqa: F821
     return {k: torch.from_numpy(v) for k, v in weights.items()}
 
@@ -27,14 +84,18 @@ def to_torch(weights: Dict[str, "np.ndarray"]) -> Dict[str, Tensor]:  # noqa: F8
 
 def silu(x: Tensor) -> Tensor:
     """src/model/silu.rs:14-16: x * sigmoid(x)."""
-    return x * torch.sigmoid(x)
+    return NUM.r(x * NUM.r(torch.sigmoid(x)))
 
 
 def layernorm_fn(x: Tensor, eps: float) -> Tensor:
     """src/model/groupnorm/mod.rs:75-82 == layernorm/mod.rs:42-49:
     u = x - mean(x, last); u / sqrt(mean(u*u, last) + eps)   (biased variance, eps inside the sqrt)."""
-    u = x - x.mean(dim=-1, keepdim=True)
-    return u / torch.sqrt((u * u).mean(dim=-1, keepdim=True) + eps)
+    if NUM.mode != "f16ref":
+        u = x - x.mean(dim=-1, keepdim=True)
+        return u / torch.sqrt((u * u).mean(dim=-1, keepdim=True) + eps)
+    r = NUM.r     # seven ops, each output an f16 tensor: mean_dim, sub, mul, mean_dim, add_scalar, sqrt, div
+    u = r(x - r(x.mean(dim=-1, keepdim=True)))
+    return r(u / r(torch.sqrt(r(r(r(u * u).mean(dim=-1, keepdim=True)) + eps))))
 
 
 def group_norm(x: Tensor, gamma: Tensor, beta: Tensor, n_group: int = 32, eps: float = EPS) -> Tensor:
@@ -44,12 +105,12 @@ def group_norm(x: Tensor, gamma: Tensor, beta: Tensor, n_group: int = 32, eps: f
     aff = [1] * x.dim()
     aff[1] = shape[1]
     y = layernorm_fn(x.reshape(b, n_group, -1), eps).reshape(shape)
-    return y * gamma.reshape(aff) + beta.reshape(aff)
+    return NUM.r(NUM.r(y * gamma.reshape(aff)) + beta.reshape(aff))
 
 
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = EPS) -> Tensor:
     """LayerNorm::forward src/model/layernorm/mod.rs:34-40."""
-    return layernorm_fn(x, eps) * gamma + beta
+    return NUM.r(NUM.r(layernorm_fn(x, eps) * gamma) + beta)
 
 
 def _eps(W, p: str) -> float:
@@ -60,26 +121,30 @@ def _eps(W, p: str) -> float:
 
 
 def gn(x: Tensor, W, p: str, n_group: int = 32) -> Tensor:
-    return group_norm(x, W[p + ".gamma"], W[p + ".beta"], n_group, _eps(W, p))
+    return group_norm(x, NUM.w(W, p + ".gamma", "-"), NUM.w(W, p + ".beta", "-"), n_group, _eps(W, p))
 
 
 def ln(x: Tensor, W, p: str) -> Tensor:
-    return layer_norm(x, W[p + ".gamma"], W[p + ".beta"], _eps(W, p))
+    return layer_norm(x, NUM.w(W, p + ".gamma", "-"), NUM.w(W, p + ".beta", "-"), _eps(W, p))
 
 
-def linear(x: Tensor, W: Dict[str, Tensor], name: str) -> Tensor:
-    """burn nn::Linear: y = x @ W[d_in,d_out] (+ b)."""
-    y = x @ W[name + ".weight"]
-    b = W.get(name + ".bias")
-    return y if b is None else y + b
+def linear(x: Tensor, W: Dict[str, Tensor], name: str, cls: str = "-") -> Tensor:
+    """burn nn::Linear: y = x @ W[d_in,d_out] (+ b).  cls: GEMM class for the operand-rounding emulation (Numerics)."""
+    y = NUM.r(NUM.a(x, cls) @ NUM.w(W, name + ".weight", cls))
+    if (name + ".bias") not in W:
+        return y
+    return NUM.r(y + NUM.w(W, name + ".bias", "-"))
 
 
-def conv2d(x: Tensor, W: Dict[str, Tensor], name: str, stride: int = 1, padding: int = 0) -> Tensor:
-    return F.conv2d(x, W[name + ".weight"], W[name + ".bias"], stride=stride, padding=padding)
+def conv2d(x: Tensor, W: Dict[str, Tensor], name: str, stride: int = 1, padding: int = 0, cls: str = "conv_res") -> Tensor:
+    return NUM.r(F.conv2d(NUM.a(x, cls), NUM.w(W, name + ".weight", cls), NUM.w(W, name + ".bias", "-"), stride=stride, padding=padding))
 
 
-def qkv_attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], n_head: int) -> Tensor:
-    """Generic path src/backend.rs:88-128: q,k each scaled by d^-0.25, softmax over keys, [B,N,H*d] in/out."""
+def qkv_attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], n_head: int, cls: str = "attn") -> Tensor:
+    """Generic path src/backend.rs:88-128: q,k each scaled by d^-0.25, softmax over keys, [B,N,H*d] in/out.
+    (f16ref: the LibTorch override, backend.rs:31-80, is ONE fused scaled_dot_product_attention -- fp32 inside, output rounded once;
+    operands emulation: q, k, v and the probabilities rounded to f16, as the engine's flash kernel holds them.)"""
+    q, k, v = NUM.a(q, cls), NUM.a(k, cls), NUM.a(v, cls)
     n_batch, n_qctx, n_state = q.shape
     n_ctx = k.shape[1]
     scale = (n_state / n_head) ** -0.25
@@ -91,7 +156,11 @@ def qkv_attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], n_hea
     if mask is not None:
         qk = qk + mask[:n_qctx, :n_ctx]
     w = torch.softmax(qk, dim=3)
-    return (w @ vh).transpose(1, 2).flatten(2, 3)
+    if NUM.on(cls):
+        # the engine keeps P = exp2(s - m) <= 1 unnormalised in f16 and divides the fp32 sums at the end
+        mx = w.amax(dim=3, keepdim=True)
+        return (NUM.a(w / mx, cls) @ vh * mx).transpose(1, 2).flatten(2, 3)
+    return NUM.r((w @ vh).transpose(1, 2).flatten(2, 3))
 
 
 def attn_decoder_mask(seq_length: int) -> Tensor:
@@ -111,9 +180,9 @@ def upsample_nearest2x(x: Tensor) -> Tensor:
 def timestep_embedding(timesteps: Tensor, dim: int, max_period: int = 10000) -> Tensor:
     """src/model/unet/mod.rs:21-39 (cos first, then sin)."""
     half = dim // 2
-    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * (-math.log(max_period) / half))
-    args = timesteps.float()[:, None] * freqs[None]
-    return torch.cat([args.cos(), args.sin()], dim=1)
+    freqs = NUM.r(torch.exp(NUM.r(torch.arange(half, dtype=torch.float32) * (-math.log(max_period) / half))))
+    args = NUM.r(NUM.r(timesteps.float())[:, None] * freqs[None])
+    return torch.cat([NUM.r(args.cos()), NUM.r(args.sin())], dim=1)
 
 
 def conditioning_embedding(pooled: Tensor, dim: int, size: Tensor, crop: Tensor, ar: Tensor) -> Tensor:
@@ -128,35 +197,36 @@ def res_block(x: Tensor, emb: Tensor, W, p: str) -> Tensor:
     """ResBlock::forward src/model/unet/mod.rs:1082-1106."""
     h = conv2d(silu(gn(x, W, p + ".norm_in")), W, p + ".conv_in", padding=1)
     e = linear(silu(emb), W, p + ".lin_embed")
-    h = h + e[:, :, None, None]
+    h = NUM.r(h + e[:, :, None, None])
     h = conv2d(silu(gn(h, W, p + ".norm_out")), W, p + ".conv_out", padding=1)
     if (p + ".skip_connection.weight") in W:
-        return conv2d(x, W, p + ".skip_connection") + h
-    return x + h
+        return NUM.r(conv2d(x, W, p + ".skip_connection", cls="conv_skip") + h)
+    return NUM.r(x + h)
 
 
 def multi_head_attention(x: Tensor, context: Optional[Tensor], W, p: str, n_head: int) -> Tensor:
     """MultiHeadAttention::forward src/model/unet/mod.rs:1005-1023."""
     xa = x if context is None else context
-    q = linear(x, W, p + ".query")
-    k = linear(xa, W, p + ".key")
-    v = linear(xa, W, p + ".value")
-    return linear(qkv_attention(q, k, v, None, n_head), W, p + ".out")
+    cq, ca = ("qkv", "attn") if context is None else ("xattn", "xattn")
+    q = linear(x, W, p + ".query", cq)
+    k = linear(xa, W, p + ".key", cq)
+    v = linear(xa, W, p + ".value", cq)
+    return linear(qkv_attention(q, k, v, None, n_head, ca), W, p + ".out", "out")
 
 
 def geglu(x: Tensor, W, p: str) -> Tensor:
     """GEGLU::forward src/model/unet/mod.rs:942-956 (burn nn::Gelu = exact erf GELU)."""
-    pr = linear(x, W, p + ".proj")
+    pr = linear(x, W, p + ".proj", "geglu")
     n = pr.shape[-1] // 2
-    return pr[..., :n] * F.gelu(pr[..., n:])
+    return NUM.r(pr[..., :n] * NUM.r(F.gelu(pr[..., n:])))
 
 
 def transformer_block(x: Tensor, context: Tensor, W, p: str, n_head: int) -> Tensor:
     """TransformerBlock::forward src/model/unet/mod.rs:885-891."""
-    x = x + multi_head_attention(ln(x, W, p + ".norm1"), None, W, p + ".attn1", n_head)
-    x = x + multi_head_attention(ln(x, W, p + ".norm2"), context, W, p + ".attn2", n_head)
+    x = NUM.r(x + multi_head_attention(ln(x, W, p + ".norm1"), None, W, p + ".attn1", n_head))
+    x = NUM.r(x + multi_head_attention(ln(x, W, p + ".norm2"), context, W, p + ".attn2", n_head))
     h = ln(x, W, p + ".norm3")
-    return x + linear(geglu(h, W, p + ".mlp.geglu"), W, p + ".mlp.lin")   # MLP::forward :915-918
+    return NUM.r(x + linear(geglu(h, W, p + ".mlp.geglu"), W, p + ".mlp.lin", "ff"))   # MLP::forward :915-918
 
 
 def spatial_transformer(x: Tensor, context: Tensor, W, p: str, n_head: int, depth: int) -> Tensor:
@@ -164,36 +234,37 @@ def spatial_transformer(x: Tensor, context: Tensor, W, p: str, n_head: int, dept
     b, c, h, w = x.shape
     x_in = x
     t = gn(x, W, p + ".norm").reshape(b, c, h * w).transpose(1, 2)
-    t = linear(t, W, p + ".proj_in")
+    t = linear(t, W, p + ".proj_in", "conv_proj")
     for j in range(depth):
         t = transformer_block(t, context, W, f"{p}.blocks.{j}", n_head)
-    t = linear(t, W, p + ".proj_out").transpose(1, 2).reshape(b, c, h, w)
-    return x_in + t
+    t = linear(t, W, p + ".proj_out", "conv_proj").transpose(1, 2).reshape(b, c, h, w)
+    return NUM.r(x_in + t)
 
 
 def _unet_block(x, emb, ctx, W, p, b):
     k = b["kind"]
     if k == "Conv":
-        return conv2d(x, W, p, padding=1)
+        return conv2d(x, W, p, padding=1, cls="conv_io")
     if k == "Down":                                  # DownsampleConfig::init unet/mod.rs:765-772
-        return conv2d(x, W, p, stride=2, padding=1)
+        return conv2d(x, W, p, stride=2, padding=1, cls="conv_updown")
     if k == "Res":
         return res_block(x, emb, W, p)
     x = res_block(x, emb, W, p + ".res")
     if k in ("ResT", "ResTU"):                       # :571-577, :657-664
         x = spatial_transformer(x, ctx, W, p + ".transformer", b["n_head"], b["depth"])
     if k in ("ResTU", "ResU"):                       # Upsample::forward :742-752
-        x = conv2d(upsample_nearest2x(x), W, p + ".upsample.conv", padding=1)
+        x = conv2d(upsample_nearest2x(x), W, p + ".upsample.conv", padding=1, cls="conv_updown")
     return x
 
 
 def unet_forward(cfg: UNetConfig, W, x: Tensor, timesteps: Tensor, context: Tensor, label: Tensor) -> Tensor:
     """UNet::forward src/model/unet/mod.rs:450-492.  x [B,4,H,W], timesteps [B] int, context [B,77,ctx], label [B,adm]."""
     inp, mid, out = unet_block_plan(cfg)
+    x, context, label = NUM.r(x), NUM.r(context), NUM.r(label)   # f16ref: Conditioning::convert hands the f16 backend f16 tensors (stablediffusion/mod.rs:559-580)
     t_emb = timestep_embedding(timesteps, cfg.model_channels, 10000)
     t_emb = linear(silu(linear(t_emb, W, "lin1_time_embed")), W, "lin2_time_embed")
     l_emb = linear(silu(linear(label, W, "lin1_label_embed")), W, "lin2_label_embed")
-    emb = t_emb + l_emb
+    emb = NUM.r(t_emb + l_emb)
     saved = []
     for i, b in enumerate(inp):
         x = _unet_block(x, emb, context, W, f"input_blocks.{i}", b)
@@ -205,7 +276,7 @@ def unet_forward(cfg: UNetConfig, W, x: Tensor, timesteps: Tensor, context: Tens
         x = torch.cat([x, saved.pop()], dim=1)                                      # :484
         x = _unet_block(x, emb, context, W, f"output_blocks.{i}", b)
     x = silu(gn(x, W, "norm_out"))
-    return conv2d(x, W, "conv_out", padding=1)
+    return conv2d(x, W, "conv_out", padding=1, cls="conv_io")
 
 
 # ----------------------------------------------------------------------------- VAE

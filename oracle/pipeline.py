@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .config import UNetConfig, VAEConfig
-from .model import decode_latent_vae, encode_image_vae, unet_forward
+from .model import NUM, decode_latent_vae, encode_image_vae, unet_forward
 
 Tensor = torch.Tensor
 
@@ -64,7 +64,7 @@ class Diffuser:
         if self.is_refiner:
             return c
         u = unet_forward(self.cfg, self.W, latent, ts, uctx[None].repeat(n, 1, 1), uy[None].repeat(n, 1))
-        return u + (c - u) * cfg_scale
+        return NUM.r(u + NUM.r(NUM.r(c - u) * cfg_scale))      # (f16ref: three ops on f16 tensors, :538-540)
 
     def diffuse_latent(self, latent, cond, step_start, n_steps, cfg_scale, trace: Optional[list] = None):
         """:390-432 (sigma = 0, so the per-step gen_noise()*sigma term vanishes)."""
@@ -74,8 +74,9 @@ class Diffuser:
             a_prev = self.get_alpha(t - step_size) if t >= step_size else 1.0
             sqrt_noise = (1.0 - a_t) ** 0.5
             eps = self.forward_diffuser(latent, t, cond, cfg_scale)
-            predx0 = (latent - eps * sqrt_noise) / (a_t ** 0.5)
-            latent = predx0 * (a_prev ** 0.5) + eps * ((1.0 - a_prev) ** 0.5)
+            r = NUM.r      # identity in fp32; f16ref: the Diffuser's backend is LibTorch<f16> too (sample/main.rs:122), every op output an f16 tensor
+            predx0 = r(r(latent - r(eps * sqrt_noise)) / (a_t ** 0.5))
+            latent = r(r(predx0 * (a_prev ** 0.5)) + r(eps * ((1.0 - a_prev) ** 0.5)))
             if trace is not None:
                 trace.append(latent.clone())
         return latent

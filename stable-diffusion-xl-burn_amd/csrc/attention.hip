@@ -757,6 +757,13 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
       }
     }
   }
+  const bool demote = __builtin_amdgcn_readfirstlane(p.demote) != 0;
+  if (demote) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ql[ks][e] = (half_t)0.f;
+  }
   // DMA geometry: a 1-KiB piece = 4 rows x 16 chunks (lane -> row lane>>4, slot lane&15); wave w stages rows [16w, 16w+16) of K
   // and of V^T, four pieces each.  LDS slot c of row r holds source chunk c ^ (r & 7): rows 256 bytes apart spread over the banks.
   const int prow = lane >> 4, pslot = lane & 15;
@@ -862,6 +869,12 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
         }
         l += ls;
       }
+    if (demote) {                       // (wave-uniform; precision-frontier instrument only)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pl[s4][e] = (half_t)0.f;
+    }
     // ---- O^T += V^T P^T: k-step s4 = the 16 keys of HL16 group s4 in the order {4h..4h+3, 8+4h..8+4h+3}
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)

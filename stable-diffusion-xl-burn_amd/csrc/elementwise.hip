@@ -338,6 +338,23 @@ void launch_f32_to_hl(const void* src, int lds_, void* dst, int ldd, size_t rows
   hipLaunchKernelGGL(f32_to_hl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
                      reinterpret_cast<half_t*>(dst), ldd, rows, C / 8);
 }
+// precision-frontier instrument (round 5, UNet "hl_demote" classes): the lo halves of an HL16 tensor set to zero -- the (hi, lo) GEMM that
+// reads it then multiplies exactly the f16 rounding of every element, i.e. the f16 engine's operand arithmetic on the split engine's kernels
+__global__ void hl_zero_lo_kernel(half_t* dst, int ldd, size_t rows, int C16) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C16) return;
+  const size_t r = i / C16;
+  half_t* dp = dst + r * 2 * (size_t)ldd + (size_t)(i - r * C16) * 32 + 16;
+  const half8 z = half8{0, 0, 0, 0, 0, 0, 0, 0};
+  *reinterpret_cast<half8*>(dp) = z;
+  *reinterpret_cast<half8*>(dp + 8) = z;
+}
+void launch_hl_zero_lo(void* dst, int ldd, size_t rows, int C, hipStream_t s) {
+  if ((C & 15) != 0 || (ldd & 15) != 0) throw std::runtime_error("hl_zero_lo: C % 16 == 0 rows with aligned strides only");
+  const size_t total = rows * (size_t)(C / 16);
+  if (!total) return;
+  hipLaunchKernelGGL(hl_zero_lo_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<half_t*>(dst), ldd, rows, C / 16);
+}
 __global__ void round_f16_kernel(float* p, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = (float)(half_t)p[i];

@@ -137,7 +137,10 @@ struct WeightBuilder {
   std::string last_fetched;      // name of the tensor `tmp` holds (fetch() of the same name again is free)
   WeightBuilder(const std::vector<ParamSpec>& sp, WeightSource& s, DeviceArena& a, int dtype, hipStream_t stream);
   ~WeightBuilder();
-  static size_t arena_bound(const std::vector<ParamSpec>& specs, int dt);
+  // wfrag: the model keeps fragment-order images of its plain f16 linear / 1x1 weights (attach_wfrag) -- only the UNet's layers can be
+  // routed to the weights-in-registers kernel, so the CLIP towers and the VAE leave it off (half the arena / broadcast bytes for those layers)
+  bool wfrag = true;
+  static size_t arena_bound(const std::vector<ParamSpec>& specs, int dt, bool wfrag = true);
   const ParamSpec& spec(const std::string& name, size_t* idx = nullptr) const;
   bool has(const std::string& name) const { return index.count(name) != 0; }
   const float* fetch(const std::string& name);            // canonical fp32 tensor in tmp
@@ -170,9 +173,9 @@ struct Act {
 // per-kernel-class hipEvent profiler (eager runs only): live measurement of the dominant kernel for bench.py's roofline
 struct Profiler {
   enum { IGEMM = 0, ATTENTION = 1, GROUPNORM = 2, LAYERNORM = 3, OTHER = 4, NCLS = 5 };
-  struct Rec { hipEvent_t a, b; int cls; double flops; int m, n, k, ks; };
+  struct Rec { hipEvent_t a, b; int cls; double flops; int m, n, k, ks, tag; };
   std::vector<Rec> recs;
-  void begin(int cls, double flops, hipStream_t s, int m = 0, int n = 0, int k = 0, int ks = 0);
+  void begin(int cls, double flops, hipStream_t s, int m = 0, int n = 0, int k = 0, int ks = 0, int tag = 0);   // tag: DemoteClass bit of the launch (UNet; 0 = untagged)
   void end(hipStream_t s);
   void collect(float ms[NCLS], int launches[NCLS], double flops[NCLS]);   // synchronises, then frees the events
 };
@@ -202,10 +205,24 @@ struct Exec {
   int fork_after = 0, launches = 0; // chain starts there, so the two chains run out of phase (GEMMs of one under the attention of the other)
   WarmSeq* warm = nullptr;         // weight warming schedule of the plan (null: off)
   float* attn_xws = nullptr; unsigned* attn_xcnt = nullptr;   // workspace / tickets of the cross-workgroup key split (AttnParams::xws)
+  int demote = 0;                  // split-operand UNet, precision-frontier instrument: GEMM classes (DemoteClass bits) whose operands lose their lo halves
   Act alloc(size_t rows, int C, int dt) {
     return Act(act->alloc(rows * (size_t)C * dt_size(dt)), C, dt);
   }
 };
+
+// Precision-frontier instrument (round 5; sdxl_debug_set "hl_demote" = bit set).  A split-operand (DT_HL) UNet runs the GEMMs of the listed
+// classes on operands whose lo halves are zero -- activations by a zeroing pass behind their producer, weights through the "every weight is
+// one f16" flag of the packed matrix (IgemmParams::acc_scale[1]: the kernel leaves the w_lo MFMAs out), the attention through
+// AttnParams::demote -- i.e. with exactly the f16 engine's operand rounding (f16 x f16 products, fp32 accumulation) while every other class
+// keeps fp32-class operands.  Measures each class's share of the f16 mode's error on the config-2 trajectory (tools/precision_frontier.py).
+// Classes: self-attention QKV projection, the self-attention itself (q, k, v, p), attention out-projections, cross-attention (query / key / value
+// projections + the 77-key attention), GEGLU projection, FF-out, and five kinds of convolution: the two 3x3 convs of every ResBlock, the 1x1 skip
+// connections, the UNet's last conv (its first has 4 input channels and is plain fp32 in this engine), the down / up-sampling convs, proj_in / proj_out.
+enum DemoteClass { DM_QKV = 1, DM_ATTN = 2, DM_OUT = 4, DM_XATTN = 8, DM_GEGLU = 16, DM_FF = 32, DM_CONV_RES = 64, DM_CONV_SKIP = 128,
+                   DM_CONV_IO = 256, DM_CONV_UPDOWN = 512, DM_CONV_PROJ = 1024 };
+void unet_set_hl_demote(int mask);
+int unet_hl_demote();
 
 // thin launch helpers shared by unet.cpp / vae.cpp (skip the launch on dry runs)
 struct ConvGeom { int B, Hin, Win, Hout, Wout, ksize, stride, pad, up; };
@@ -223,6 +240,7 @@ struct Epi {
   // room for the GroupNorm statistics of the output ([M/256][N] float pairs); run_conv reports whether the kernel it picked
   // filled it (igemm_gn_part_ok), the caller then tags the output Act
   float* gn_part = nullptr;
+  int cls = 0;       // DemoteClass bit of this GEMM (UNet call sites): label of the launch in the per-launch profile dump, nothing else
 };
 bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());   // true: e.gn_part was filled
 bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());
@@ -310,6 +328,10 @@ class UNet {
   float* attn_xws_[2] = {nullptr, nullptr}; unsigned* attn_xcnt_[2] = {nullptr, nullptr};   // cross-workgroup key split: per chain (split-CFG runs two)
   bool graph_warm_ = false;         // the captured graph carries the warming workgroups
   size_t attn_xcnt_bytes_ = 0;
+  int demote_mask_ = 0, graph_demote_ = 0;                 // hl_demote classes in force since the last set_context / captured in the graph
+  std::vector<std::pair<float*, float>> demote_flags_;      // (device address of a packed matrix's exact-f16 flag, its packed value) per class bit, filled lazily
+  std::vector<int> demote_flag_cls_;
+  void apply_demote_weights(hipStream_t s);
   bool gn_from_producer_ = true, plan_gn_ = true;   // GroupNorm statistics from the producing convolution's epilogue where its kernel can (f16); part of the plan key
   hipStream_t s2_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   DeviceArena act2_;

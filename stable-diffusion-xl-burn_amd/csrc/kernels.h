@@ -155,6 +155,8 @@ struct AttnParams {
   // key halves on DIFFERENT workgroups (attn_d64_mix_kernel level 2, round 4): workspace of attention_xsplit_ws_bytes(B, H, Nq) bytes and
   // attention_xsplit_counters(B, H, Nq) zero-initialised tickets (they re-arm themselves); null = that form is never picked
   float* xws = nullptr; unsigned* xcnt = nullptr;
+  int demote = 0;              // split-operand kernel only (precision-frontier instrument): lo halves of Q and P dropped -- with K / V^T lo halves zeroed
+                               // by the caller the kernel computes the f16 flash kernel's products (f16 q, k, v, p; fp32 accumulation)
 };
 size_t attention_xsplit_ws_bytes(int B, int H, int Nq);
 size_t attention_xsplit_counters(int B, int H, int Nq);
@@ -214,6 +216,7 @@ void launch_f32_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows,
 // the same for a tensor whose range the model does not bound (residual stream, VAE hidden state): converted times the power of two
 // that brings max|x| into [2^13, 2^14); scale_io (2 device floats) receives {max|x|, 2^-e} -- pass scale_io + 1 as IgemmParams::a_scale
 void launch_f32_to_hl_scaled(const void* src, int lds, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s);
+void launch_hl_zero_lo(void* dst, int ldd, size_t rows, int C, hipStream_t s);   // HL16 rows: lo halves := 0 (precision-frontier instrument, UNet hl_demote)
 void launch_round_f16(float* p, size_t n, hipStream_t s);   // p[i] = float(half(p[i])): parameters as a HalfPrecisionSettings record holds them
 void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s);
 // CLIP text encoder (clip/mod.rs:99-105,139-147): x[b][t][:] = tok[ids[b][t]][:] + pos[t][:] (tables in dtype w_dt);

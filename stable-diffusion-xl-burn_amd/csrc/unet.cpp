@@ -15,6 +15,7 @@
 //     Infinity Cache) -> stable addresses -> the whole forward is captured once into a hipGraph and replayed.
 #include "engine.h"
 
+#include <atomic>
 #include <cmath>
 
 namespace sdxl {
@@ -83,14 +84,14 @@ void gemv(Exec& ex, const Lin& w, const float* x, int ldx, float* y, int ldy, in
   if (ex.prof) ex.prof->end(ex.s);
 }
 void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, const Act& o, int B, int H, int Nq,
-               int Nk) {
+               int Nk, int tag = 0) {
   if (ex.dry) return;
   AttnParams p{};
   p.Q = q.p; p.ldq = q.ld; p.K = k.p; p.ldk = k.ld; p.Vt = vt; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
   // (the split-operand mode runs the attention on fp32 tensors: q / k / V^T / o all carry q's dtype)
   p.dt = q.dt; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
   if (Nq == Nk) { p.xws = ex.attn_xws; p.xcnt = ex.attn_xcnt; }      // self-attention: room for the cross-workgroup key split (sized for it in ensure_plan)
-  if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0);
+  if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0, tag ? tag : (Nq == Nk ? DM_ATTN : DM_XATTN));
   launch_attention_d64(p, ex.s);
   {
     const hipError_t le = hipGetLastError();
@@ -98,15 +99,27 @@ void attention(Exec& ex, const Act& q, const Act& k, const void* vt, int vt_ld, 
   }
   if (ex.prof) ex.prof->end(ex.s);
 }
+Epi tag_epi(int cls) { Epi e; e.cls = cls; return e; }      // plain epilogue carrying only the launch's class label
+// hl_demote: lo halves of an HL16 operand := 0 when its consumer's class is demoted (no-op otherwise / for other dtypes)
+void demote_lo(Exec& ex, int cls, const Act& a, size_t rows, int C) {
+  if (ex.dry || !(ex.demote & cls) || a.dt != DT_HL) return;
+  launch_hl_zero_lo(a.p, a.ld, rows, C, ex.s);
+}
+Act hl_op(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int cls) {      // hl_operand + the demotion of the copy when the consumer's class asks
+  Act o = hl_operand(ex, w, x, rows, C);
+  if (o.p != x.p) demote_lo(ex, cls, o, rows, C);
+  return o;
+}
 // split-operand mode: q / o fp32, K [B][Nk][ldk] and V^T [B][H*64][vt_ld] in HL16 (attn_d64_hl_kernel)
-void attention_hl(Exec& ex, const Act& q, const void* kh, int ldk, const void* vth, int vt_ld, const Act& o, int B, int H, int Nq, int Nk) {
+void attention_hl(Exec& ex, const Act& q, const void* kh, int ldk, const void* vth, int vt_ld, const Act& o, int B, int H, int Nq, int Nk, int demote_cls = 0) {
   if (ex.dry) return;
   AttnParams p{};
+  p.demote = (ex.demote & demote_cls) ? 1 : 0;
   p.Q = q.p; p.ldq = q.ld; p.K = kh; p.ldk = ldk; p.Vt = vth; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
   p.dt = DT_HL; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
   p.o_dt = o.dt == DT_HL ? DT_HL : DT_F32;
   p.q_dt = q.dt == DT_HL ? DT_HL : DT_F32;
-  if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0);
+  if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0, demote_cls);
   if (!launch_attention_d64_hl(p, ex.s)) throw Error("split-operand attention: unsupported shape / alignment (Nq=" + std::to_string(Nq) + " Nk=" + std::to_string(Nk) + ")");
   {
     const hipError_t le = hipGetLastError();
@@ -115,6 +128,42 @@ void attention_hl(Exec& ex, const Act& q, const void* kh, int ldk, const void* v
   if (ex.prof) ex.prof->end(ex.s);
 }
 }  // namespace
+
+static std::atomic<int> g_hl_demote{0};
+void unet_set_hl_demote(int mask) { g_hl_demote = mask; }
+int unet_hl_demote() { return g_hl_demote.load(); }
+
+// the exact-f16 flag (acc_scale[1]) of every packed matrix of a demoted class reads 1 -- the kernel then leaves its w_lo MFMAs out --
+// and its packed value otherwise; the packed values are read back once
+void UNet::apply_demote_weights(hipStream_t s) {
+  if (cdt_ != DT_HL) return;
+  if (demote_flags_.empty()) {
+    auto add = [&](const Lin& l, int cls) {
+      if (!l.acc_scale) return;
+      float v = 0.f;
+      SDXL_HIP(hipMemcpy(&v, l.acc_scale + 1, sizeof(float), hipMemcpyDeviceToHost));
+      demote_flags_.push_back({const_cast<float*>(l.acc_scale) + 1, v}); demote_flag_cls_.push_back(cls);
+    };
+    auto add_res = [&](const ResBlockW& r) { add(r.conv_in, DM_CONV_RES); add(r.conv_out, DM_CONV_RES); if (r.has_skip) add(r.skip, DM_CONV_SKIP); };
+    auto add_st = [&](const STW& st) {
+      add(st.proj_in, DM_CONV_PROJ); add(st.proj_out, DM_CONV_PROJ);
+      for (const TBlockW& b : st.blocks) {
+        add(b.qkv, DM_QKV); add(b.out1, DM_OUT); add(b.q2, DM_XATTN); add(b.kv2, DM_XATTN); add(b.out2, DM_OUT); add(b.geglu, DM_GEGLU); add(b.ff, DM_FF);
+      }
+    };
+    auto add_block = [&](const BlockW& b) { add(b.conv, b.d.kind == BK_CONV ? DM_CONV_IO : DM_CONV_UPDOWN); add_res(b.res); add_st(b.st); };
+    for (const BlockW& b : inp_) add_block(b);
+    add_block(mid_res1_); add_res(mid_res2_.res);
+    for (const BlockW& b : out_) add_block(b);
+    add(conv_out_, DM_CONV_IO);
+  }
+  std::vector<float> vals(demote_flags_.size());
+  for (size_t i = 0; i < demote_flags_.size(); ++i) {
+    vals[i] = (demote_mask_ & demote_flag_cls_[i]) ? 1.0f : demote_flags_[i].second;
+    SDXL_HIP(hipMemcpyAsync(demote_flags_[i].first, &vals[i], sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  SDXL_HIP(hipStreamSynchronize(s));     // (vals is host memory of this frame)
+}
 
 UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st)
     : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt) {
@@ -181,9 +230,17 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
   const bool pack_xa = cdt_ == DT_F16 && n_ctx <= 96;   // operand-order copies for the fused cross-attention epilogue
   const int kvdt = attn_dt();                           // dtype of the K / V^T caches (fp32 in the split-operand mode)
   const int emb = 4 * cfg_.model_channels;
+  {   // precision-frontier instrument: the demoted classes take effect from here (weights now, activations in every forward after)
+    const int dm = cdt_ == DT_HL ? unet_hl_demote() : 0;
+    if (dm != demote_mask_ || (dm && demote_flags_.empty())) { demote_mask_ = dm; apply_demote_weights(s); }
+  }
   if (B != ctx_B_ || n_ctx != n_ctx_) {
     // (re)allocate the caches; captured graphs hold these addresses
     if (graph_) { (void)hipGraphExecDestroy(graph_); graph_ = nullptr; plan_runs_ = 0; }
+    // the recorded warming schedule holds raw pointers into ctx_arena_ (the packed context of the fused cross-attention
+    // projections is a warm target): a re-laid-out / reallocated arena invalidates them -> record again on the next eager forward
+    warm_ = WarmSeq();
+    plan_runs_ = 0;
     size_t bytes = 1 << 16;
     for (const STW* st : st_list_)
       bytes += st->blocks.size() * (round_up((size_t)B * n_ctx * st->C * dt_size(kvdt), 256) +
@@ -214,11 +271,13 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
     label_emb_ = (float*)ctx_arena_.alloc((size_t)B * emb * sizeof(float));
     ctx_B_ = B; n_ctx_ = n_ctx; vt_ld_ctx_ = vt_ld;
   }
-  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &ctx_arena_;
+  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &ctx_arena_; ex.demote = demote_mask_;
   const size_t m0 = ctx_arena_.mark();
   Act ctx((void*)context, cfg_.context_dim, DT_F32);
-  if (cdt_ == DT_HL && !st_list_.empty() && !st_list_[0]->blocks.empty())      // one HL16 copy of the context for all 70 projections
+  if (cdt_ == DT_HL && !st_list_.empty() && !st_list_[0]->blocks.empty()) {    // one HL16 copy of the context for all 70 projections
     ctx = hl_operand(ex, st_list_[0]->blocks[0].kv2, ctx, (size_t)B * n_ctx, cfg_.context_dim);
+    demote_lo(ex, DM_XATTN, ctx, (size_t)B * n_ctx, cfg_.context_dim);
+  }
   for (size_t si = 0; si < st_list_.size(); ++si) {
     const STW* st = st_list_[si];
     for (size_t j = 0; j < st->blocks.size(); ++j) {
@@ -227,14 +286,16 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
         void* k32 = ctx_arena_.alloc((size_t)B * n_ctx * st->C * 4);
         void* vt32 = ctx_arena_.alloc((size_t)B * st->C * vt_ld * 4);
         launch_fill_zero(vt32, (size_t)B * st->C * vt_ld * 4, s);                     // V^T key padding must be zero
-        Epi e; e.n_split = st->C; e.Ct = vt32; e.ct_rows = st->C; e.ct_ld = vt_ld; e.rpb = n_ctx;
+        Epi e; e.n_split = st->C; e.Ct = vt32; e.ct_rows = st->C; e.ct_ld = vt_ld; e.rpb = n_ctx; e.cls = DM_XATTN;
         run_linear(ex, st->blocks[j].kv2, ctx, B * n_ctx, Act(k32, st->C, DT_F32), e);
         launch_f32_to_hl(k32, st->C, kv_[si][j].k, st->C, (size_t)B * n_ctx, st->C, s);
         launch_f32_to_hl(vt32, vt_ld, kv_[si][j].vt, vt_ld, (size_t)B * st->C, vt_ld, s);
+        demote_lo(ex, DM_XATTN, Act(kv_[si][j].k, st->C, DT_HL), (size_t)B * n_ctx, st->C);
+        demote_lo(ex, DM_XATTN, Act(kv_[si][j].vt, vt_ld, DT_HL), (size_t)B * st->C, vt_ld);
         ctx_arena_.reset(ms);
         continue;
       }
-      Epi e; e.n_split = st->C; e.Ct = kv_[si][j].vt; e.ct_rows = st->C; e.ct_ld = vt_ld; e.rpb = n_ctx;
+      Epi e; e.n_split = st->C; e.Ct = kv_[si][j].vt; e.ct_rows = st->C; e.ct_ld = vt_ld; e.rpb = n_ctx; e.cls = DM_XATTN;
       run_linear(ex, st->blocks[j].kv2, ctx, B * n_ctx, Act(kv_[si][j].k, st->C, kvdt), e);
       if (kv_[si][j].xa) launch_xattn_pack(kv_[si][j].k, kv_[si][j].vt, kv_[si][j].xa, B, st->C, n_ctx, vt_ld, s);
     }
@@ -260,14 +321,16 @@ const float* UNet::res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, 
   const bool tiles256 = gn_from_producer_ && HW % 256 == 0;
   Act gn1 = ex.alloc(M, w.cin, ex.cdt);
   run_groupnorm(ex, w.norm_in, x, B, HW, gn1, true);
+  demote_lo(ex, DM_CONV_RES, gn1, M, w.cin);
   Act h = ex.alloc(M, w.cout, ex.cdt == DT_HL ? ex.sdt : ex.cdt);     // (read by a GroupNorm only: fp32 in the split-operand mode)
-  Epi e1; e1.ebias = ex.ebias + w.emb_off; e1.ebias_ld = emb_total_;
+  Epi e1; e1.ebias = ex.ebias + w.emb_off; e1.ebias_ld = emb_total_; e1.cls = DM_CONV_RES;
   if (tiles256) e1.gn_part = (float*)ex.act->alloc(M / 256 * (size_t)w.cout * 2 * sizeof(float));
   if (run_conv(ex, w.conv_in, gn1, w.cin, g3, h, e1)) { h.gn_part = e1.gn_part; h.gn_rt = HW / 256; }
   Act gn2 = ex.alloc(M, w.cout, ex.cdt);
   run_groupnorm(ex, w.norm_out, h, B, HW, gn2, true);
-  Epi e2;
-  if (w.has_skip) { run_conv(ex, w.skip, hl_operand(ex, w.skip, x, M, w.cin), w.cin, g1, out); e2.R = out; }
+  demote_lo(ex, DM_CONV_RES, gn2, M, w.cout);
+  Epi e2; e2.cls = DM_CONV_RES;
+  if (w.has_skip) { Epi es; es.cls = DM_CONV_SKIP; run_conv(ex, w.skip, hl_op(ex, w.skip, x, M, w.cin, DM_CONV_SKIP), w.cin, g1, out, es); e2.R = out; }
   else e2.R = x;
   if (tiles256) e2.gn_part = out_gn_part;
   const bool produced = run_conv(ex, w.conv_out, gn2, w.cout, g3, out, e2);
@@ -289,6 +352,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   auto kv_vt = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].vt; return (const void*)(v ? v + (size_t)ex.b0 * C * vt_ld_ctx_ * dt_size(adt) : v); };
   Act gn = ex.alloc(M, C, ex.cdt);
   run_groupnorm(ex, w.norm, x, B, HW, gn, false);
+  demote_lo(ex, DM_CONV_PROJ, gn, M, C);
   Act t = ex.alloc(M, C, ex.sdt);
   // cross-attention fused into the query projection (f16 operands, <= 96 context tokens; igemm_xattn_ok)
   const bool xattn = plan_xattn_ && igemm_xattn_ok(fuse_ln_ ? ex.sdt : ex.cdt, ex.cdt, (int)M, C, C, HW, n_ctx_);
@@ -296,7 +360,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   float* stbuf[2] = {nullptr, nullptr};
   if (fuse_ln_) for (int i = 0; i < 2; ++i) stbuf[i] = (float*)ex.act->alloc(M * (size_t)(C / 64) * 2 * sizeof(float));
   int stp = 0;
-  { Epi ep; ep.stat_out = w.blocks.empty() ? nullptr : stbuf[stp]; ep.rpb = HW; run_linear(ex, w.proj_in, gn, (int)M, t, ep); }   // (rpb: kernel selection looks at ONE entry's rows)
+  { Epi ep; ep.stat_out = w.blocks.empty() ? nullptr : stbuf[stp]; ep.rpb = HW; ep.cls = DM_CONV_PROJ; run_linear(ex, w.proj_in, gn, (int)M, t, ep); }   // (rpb: kernel selection looks at ONE entry's rows)
   Act ln = ex.alloc(M, C, ex.cdt);
   // (split-operand mode: the projections write q | k and V^T as HL16 -- 4 bytes per element like fp32 -- what attention_hl reads)
   // (HL16 pieces are 8 keys wide: token counts that are not multiples of 8 -- tiny test nets -- go through fp32 + a conversion)
@@ -319,13 +383,13 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     SDXL_REQUIRE(w.blocks.empty() || w.blocks[0].qkv.cs, "transformer weights were not LayerNorm-folded");
     for (size_t j = 0; j < w.blocks.size(); ++j) {
       const TBlockW& b = w.blocks[j];
-      Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.ln_stat = stbuf[stp];
+      Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.ln_stat = stbuf[stp]; eq.cls = DM_QKV;
       run_linear(ex, b.qkv, t, (int)M, qk, eq);
       attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
       stp ^= 1;
-      Epi e1; e1.R = t; e1.stat_out = stbuf[stp]; e1.rpb = HW;
+      Epi e1; e1.R = t; e1.stat_out = stbuf[stp]; e1.rpb = HW; e1.cls = DM_OUT;
       run_linear(ex, b.out1, ao, (int)M, t, e1);
-      Epi e2q; e2q.ln_stat = stbuf[stp]; e2q.rpb = HW;
+      Epi e2q; e2q.ln_stat = stbuf[stp]; e2q.rpb = HW; e2q.cls = DM_XATTN;
       if (xattn) {   // the projection's waves run the 77-key attention on their own q tiles: no q round trip, no launch
         e2q.xa_k = kv_xa(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
         run_linear(ex, b.q2, t, (int)M, ao, e2q);
@@ -334,21 +398,26 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
         attention(ex, q, Act(kv_k(si, j), C, ex.cdt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
       }
       stp ^= 1;
-      Epi e2; e2.R = t; e2.stat_out = stbuf[stp]; e2.rpb = HW;
+      Epi e2; e2.R = t; e2.stat_out = stbuf[stp]; e2.rpb = HW; e2.cls = DM_OUT;
       run_linear(ex, b.out2, ao, (int)M, t, e2);
-      Epi eg; eg.act = 1; eg.ln_stat = stbuf[stp]; eg.rpb = HW;
+      Epi eg; eg.act = 1; eg.ln_stat = stbuf[stp]; eg.rpb = HW; eg.cls = DM_GEGLU;
       run_linear(ex, b.geglu, t, (int)M, gg, eg);
       stp ^= 1;
-      Epi ef; ef.R = t; ef.stat_out = j + 1 < w.blocks.size() ? stbuf[stp] : nullptr; ef.rpb = HW;
+      Epi ef; ef.R = t; ef.stat_out = j + 1 < w.blocks.size() ? stbuf[stp] : nullptr; ef.rpb = HW; ef.cls = DM_FF;
       run_linear(ex, b.ff, gg, (int)M, t, ef);
     }
   } else
   for (size_t j = 0; j < w.blocks.size(); ++j) {
     const TBlockW& b = w.blocks[j];
     run_layernorm(ex, b.n1, t, (int)M, ln);
-    Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW;
+    demote_lo(ex, DM_QKV, ln, M, C);
+    Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.cls = DM_QKV;
     run_linear(ex, b.qkv, ln, (int)M, qk, eq);
-    if (hl_attn && hl_direct) attention_hl(ex, qk, qk.cols(C).p, qk.ld, vt, npad, ao, B, w.heads, HW, HW);   // q | k and V^T are HL16; writes the out-projection's operand
+    if (hl_attn && hl_direct) {     // q | k and V^T are HL16; the attention writes the out-projection's operand
+      demote_lo(ex, DM_ATTN, qk, M, 2 * C);
+      demote_lo(ex, DM_ATTN, Act(vt, npad, DT_HL), (size_t)B * C, npad);
+      attention_hl(ex, qk, qk.cols(C).p, qk.ld, vt, npad, ao, B, w.heads, HW, HW, DM_ATTN);
+    }
     else if (hl_attn) {
       if (!ex.dry) {
         launch_f32_to_hl(qk.cols(C).p, qk.ld, kh, C, M, C, ex.s);
@@ -357,26 +426,33 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       attention_hl(ex, qk, kh, C, vth, npad, ao, B, w.heads, HW, HW);
     }
     else attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
-    Epi er; er.R = t; er.rpb = HW;
+    Epi er; er.R = t; er.rpb = HW; er.cls = DM_OUT;
+    demote_lo(ex, DM_OUT, ao, M, C);
     run_linear(ex, b.out1, ao, (int)M, t, er);
     run_layernorm(ex, b.n2, t, (int)M, ln);
+    demote_lo(ex, DM_XATTN, ln, M, C);
     if (xattn) {
-      Epi e2q; e2q.rpb = HW;
+      Epi e2q; e2q.rpb = HW; e2q.cls = DM_XATTN;
       e2q.xa_k = kv_xa(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
       run_linear(ex, b.q2, ln, (int)M, ao, e2q);
     } else {
-      run_linear(ex, b.q2, ln, (int)M, q);
-      if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);   // caches are HL16 (set_context)
+      { Epi e2q; e2q.cls = DM_XATTN; run_linear(ex, b.q2, ln, (int)M, q, e2q); }
+      demote_lo(ex, DM_XATTN, q, M, C);
+      if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_, DM_XATTN);   // caches are HL16 (set_context)
       else attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
     }
+    demote_lo(ex, DM_OUT, ao, M, C);
     run_linear(ex, b.out2, ao, (int)M, t, er);
     run_layernorm(ex, b.n3, t, (int)M, ln);
-    Epi eg; eg.act = 1;
+    demote_lo(ex, DM_GEGLU, ln, M, C);
+    Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
     run_linear(ex, b.geglu, ln, (int)M, gg, eg);
+    demote_lo(ex, DM_FF, gg, M, 4 * C);
+    er.cls = DM_FF;
     run_linear(ex, b.ff, gg, (int)M, t, er);
   }
-  Epi eo; eo.R = x; eo.rpb = HW;
-  run_linear(ex, w.proj_out, hl_operand(ex, w.proj_out, t, M, C), (int)M, x, eo);
+  Epi eo; eo.R = x; eo.rpb = HW; eo.cls = DM_CONV_PROJ;
+  run_linear(ex, w.proj_out, hl_op(ex, w.proj_out, t, M, C, DM_CONV_PROJ), (int)M, x, eo);
   ex.act->reset(mk);
 }
 
@@ -429,10 +505,10 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
     const int j = n_in - 1 - i;
     const Act dest = cat[j].cols(cx[j]);
     switch (b.d.kind) {
-      case BK_CONV: run_conv(ex, b.conv, hl_operand(ex, b.conv, cur, (size_t)B * h * w, cur_c), cur_c, ConvGeom{B, h, w, h, w, 3, 1, 1, 0}, dest); break;
+      case BK_CONV: run_conv(ex, b.conv, hl_op(ex, b.conv, cur, (size_t)B * h * w, cur_c, DM_CONV_IO), cur_c, ConvGeom{B, h, w, h, w, 3, 1, 1, 0}, dest, tag_epi(DM_CONV_IO)); break;
       case BK_DOWN: {
         const int h2 = (h - 1) / 2 + 1, w2 = (w - 1) / 2 + 1;
-        run_conv(ex, b.conv, hl_operand(ex, b.conv, cur, (size_t)B * h * w, cur_c), cur_c, ConvGeom{B, h, w, h2, w2, 3, 2, 1, 0}, dest);
+        run_conv(ex, b.conv, hl_op(ex, b.conv, cur, (size_t)B * h * w, cur_c, DM_CONV_UPDOWN), cur_c, ConvGeom{B, h, w, h2, w2, 3, 2, 1, 0}, dest, tag_epi(DM_CONV_UPDOWN));
         h = h2; w = w2;
         break;
       }
@@ -478,7 +554,7 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
       res_block(ex, b.res, cat[j], B, h, w, dest);
     }
     if (up) {   // Upsample::forward :742-752 -- nearest 2x fused into the conv gather
-      run_conv(ex, b.conv, hl_operand(ex, b.conv, dest, (size_t)B * h * w, b.d.c_out), b.d.c_out, ConvGeom{B, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next);
+      run_conv(ex, b.conv, hl_op(ex, b.conv, dest, (size_t)B * h * w, b.d.c_out, DM_CONV_UPDOWN), b.d.c_out, ConvGeom{B, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next, tag_epi(DM_CONV_UPDOWN));
       h *= 2; w *= 2;
     }
     ex.act->reset(mk);
@@ -489,7 +565,8 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
     const size_t mk = ex.act->mark();
     Act gn = ex.alloc((size_t)B * H * W, mc, ex.cdt);
     run_groupnorm(ex, norm_out_, last, B, H * W, gn, true);
-    run_conv(ex, conv_out_, gn, mc, ConvGeom{B, H, W, H, W, 3, 1, 1, 0}, Act(eps, cfg_.out_channels, DT_F32));
+    demote_lo(ex, DM_CONV_IO, gn, (size_t)B * H * W, mc);
+    run_conv(ex, conv_out_, gn, mc, ConvGeom{B, H, W, H, W, 3, 1, 1, 0}, Act(eps, cfg_.out_channels, DT_F32), tag_epi(DM_CONV_IO));
     ex.act->reset(mk);
   }
 }
@@ -585,7 +662,7 @@ void* UNet::unet_in(int B, int H, int W) { ensure_plan(B, H, W); return in_; }
 void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStream_t s) {
   ensure_plan(B, H, W);
   SDXL_REQUIRE(ctx_B_ == B && !kv_.empty(), "set_context must be called with the same batch before forward");
-  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_;
+  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.demote = demote_mask_;
   ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
   if (cdt_ == DT_F16) { ex.attn_xws = attn_xws_[0]; ex.attn_xcnt = attn_xcnt_[0]; }
   // weight warming (f16 engine, batched chain): the plan's first forward records the GEMM sequence, every later one replays it
@@ -596,7 +673,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
   auto go = [&]() {
     warm_.pos = 0;
     if (!plan_split_) { run(ex, t_dev, t_stride, 0, B); if (warm_.recording) warm_.finish(); return; }
-    Exec e2; e2.s = s2_; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_;
+    Exec e2; e2.s = s2_; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_; e2.demote = demote_mask_;
     e2.splitk_ws = skws_[1]; e2.splitk_ws_bytes = skws_bytes_; e2.splitk_cnt = skcnt_[1];
     if (cdt_ == DT_F16) { e2.attn_xws = attn_xws_[1]; e2.attn_xcnt = attn_xcnt_[1]; }
     act2_.off = 0;
@@ -610,7 +687,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     SDXL_HIP(hipEventRecord(ev_join_, s2_));
     SDXL_HIP(hipStreamWaitEvent(s, ev_join_, 0));
   };
-  if (use_graph_ && graph_ && (graph_t_ != t_dev || graph_ts_ != t_stride || graph_off_ != split_offset_ || graph_warm_ != warming)) {
+  if (use_graph_ && graph_ && (graph_t_ != t_dev || graph_ts_ != t_stride || graph_off_ != split_offset_ || graph_warm_ != warming || graph_demote_ != demote_mask_)) {
     (void)hipGraphExecDestroy(graph_); graph_ = nullptr;
   }
   if (use_graph_ && !graph_ && plan_runs_ >= 1) {
@@ -621,7 +698,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     SDXL_HIP(hipStreamEndCapture(s, &g));
     SDXL_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
     SDXL_HIP(hipGraphDestroy(g));
-    graph_t_ = t_dev; graph_ts_ = t_stride; graph_off_ = split_offset_; graph_warm_ = warming;
+    graph_t_ = t_dev; graph_ts_ = t_stride; graph_off_ = split_offset_; graph_warm_ = warming; graph_demote_ = demote_mask_;
     act_.reset(m);
   }
   if (use_graph_ && graph_) {
@@ -641,7 +718,7 @@ void UNet::profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[P
   SDXL_HIP(hipMemcpyAsync(tconv_, t500, sizeof(t500), hipMemcpyHostToDevice, s));
   SDXL_HIP(hipStreamSynchronize(s));
   Profiler prof;
-  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.prof = &prof;
+  Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.prof = &prof; ex.demote = demote_mask_;
   ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
   if (cdt_ == DT_F16) { ex.attn_xws = attn_xws_[0]; ex.attn_xcnt = attn_xcnt_[0]; }
   const size_t m = act_.mark();

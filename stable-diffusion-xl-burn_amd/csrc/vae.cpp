@@ -31,11 +31,13 @@ Vae::Vae(const VaeCfg& cfg, int compute_dt, WeightSource* dec_src, WeightSource*
     : cfg_(cfg), cdt_(compute_dt) {
   const std::vector<ParamSpec> dspecs = vae_decoder_param_specs(cfg_), especs = vae_encoder_param_specs(cfg_);
   size_t bound = 0;
-  if (dec_src) bound += WeightBuilder::arena_bound(dspecs, cdt_);
-  if (enc_src) bound += WeightBuilder::arena_bound(especs, cdt_);
+  // (no fragment-order weight images: the VAE's 1x1 convs run on >= 4096 rows per entry, never on the weights-in-registers kernel)
+  if (dec_src) bound += WeightBuilder::arena_bound(dspecs, cdt_, false);
+  if (enc_src) bound += WeightBuilder::arena_bound(especs, cdt_, false);
   warena_.reserve(bound + 4096);
   if (dec_src) {
     WeightBuilder wb(dspecs, *dec_src, warena_, cdt_, st);
+    wb.wfrag = false;
     post_quant_ = wb.conv("post_quant_conv");
     d_conv_in_ = wb.conv("decoder.conv_in");
     d_mid_ = load_mid(wb, "decoder.mid", cfg_.dec.front().first);
@@ -56,6 +58,7 @@ Vae::Vae(const VaeCfg& cfg, int compute_dt, WeightSource* dec_src, WeightSource*
   }
   if (enc_src) {
     WeightBuilder wb(especs, *enc_src, warena_, cdt_, st);
+    wb.wfrag = false;
     e_conv_in_ = wb.conv("encoder.conv_in");
     for (size_t i = 0; i < cfg_.enc.size(); ++i) {
       const std::string p = "encoder.blocks." + std::to_string(i);

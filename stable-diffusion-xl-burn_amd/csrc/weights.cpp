@@ -30,8 +30,8 @@ void* DeviceArena::alloc(size_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------ profiler
-void Profiler::begin(int cls, double flops, hipStream_t s, int m, int n, int k, int ks) {
-  Rec r; r.cls = cls; r.flops = flops; r.m = m; r.n = n; r.k = k; r.ks = ks;
+void Profiler::begin(int cls, double flops, hipStream_t s, int m, int n, int k, int ks, int tag) {
+  Rec r; r.cls = cls; r.flops = flops; r.m = m; r.n = n; r.k = k; r.ks = ks; r.tag = tag;
   SDXL_HIP(hipEventCreate(&r.a)); SDXL_HIP(hipEventCreate(&r.b));
   SDXL_HIP(hipEventRecord(r.a, s));
   recs.push_back(r);
@@ -41,13 +41,13 @@ void Profiler::collect(float ms[NCLS], int launches[NCLS], double flops[NCLS]) {
   for (int i = 0; i < NCLS; ++i) { ms[i] = 0.f; launches[i] = 0; flops[i] = 0.0; }
   const char* dump = std::getenv("SDXL_PROFILE_DUMP");   // optional per-launch CSV (class, M, N, K, ksize, ms)
   FILE* f = dump ? std::fopen(dump, "w") : nullptr;
-  if (f) std::fprintf(f, "class,M,N,K,ksize,ms\n");
+  if (f) std::fprintf(f, "class,M,N,K,ksize,ms,tag\n");
   for (Rec& r : recs) {
     SDXL_HIP(hipEventSynchronize(r.b));
     float t = 0.f;
     SDXL_HIP(hipEventElapsedTime(&t, r.a, r.b));
     ms[r.cls] += t; launches[r.cls] += 1; flops[r.cls] += r.flops;
-    if (f) std::fprintf(f, "%d,%d,%d,%d,%d,%.4f\n", r.cls, r.m, r.n, r.k, r.ks, t);
+    if (f) std::fprintf(f, "%d,%d,%d,%d,%d,%.4f,%d\n", r.cls, r.m, r.n, r.k, r.ks, t, r.tag);
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   recs.clear();
@@ -118,7 +118,7 @@ WeightBuilder::WeightBuilder(const std::vector<ParamSpec>& sp, WeightSource& s, 
 }
 WeightBuilder::~WeightBuilder() { if (tmp) (void)hipFree(tmp); if (tmp2) (void)hipFree(tmp2); }
 
-size_t WeightBuilder::arena_bound(const std::vector<ParamSpec>& specs, int dt) {
+size_t WeightBuilder::arena_bound(const std::vector<ParamSpec>& specs, int dt, bool wfrag) {
   size_t total = 1 << 20;
   for (const ParamSpec& p : specs) {
     if (p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * round_up(p.shape[0], 64) * dt_size(dt) + 768;   // (+ the DT_HL scale scalar)
@@ -128,8 +128,8 @@ size_t WeightBuilder::arena_bound(const std::vector<ParamSpec>& specs, int dt) {
     if (p.kind == PK_LINEAR_W || p.kind == PK_CONV_W) total += round_up(p.kind == PK_LINEAR_W ? p.shape[1] : p.shape[0], 128) * 4 + 256;
     if (p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * 4 + 256;   // column sums of LayerNorm-folded projections
     // fragment-order image of the f16 linear / 1x1 weights (attach_wfrag)
-    if (dt == DT_F16 && p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * round_up(p.shape[0], 64) * 2 + 256;
-    if (dt == DT_F16 && p.kind == PK_CONV_W && p.shape[2] == 1) total += round_up(p.shape[0], 128) * round_up((size_t)p.shape[1], 64) * 2 + 256;
+    if (wfrag && dt == DT_F16 && p.kind == PK_LINEAR_W) total += round_up(p.shape[1], 128) * round_up(p.shape[0], 64) * 2 + 256;
+    if (wfrag && dt == DT_F16 && p.kind == PK_CONV_W && p.shape[2] == 1) total += round_up(p.shape[0], 128) * round_up((size_t)p.shape[1], 64) * 2 + 256;
   }
   return total;
 }
@@ -179,6 +179,7 @@ float WeightBuilder::hl_scale(Lin& l, const std::vector<std::string>& weight_nam
 // replica receives it with the weight broadcast); allocated on empty replicas too (identical arena layout).
 void WeightBuilder::attach_wfrag(Lin& l, bool fill) {
   const int wdt = l.dt >= 0 ? l.dt : dt;
+  if (!wfrag) return;
   if (wdt != DT_F16 || l.ksize != 1 || l.N % 128 != 0 || l.K != l.Kpad || l.Kpad % 64 != 0 || l.Kpad < 128 || l.cs || l.acc_scale) return;
   void* wf = arena.alloc((size_t)l.Npad * l.Kpad * 2);
   l.wf = wf;
@@ -398,7 +399,7 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   SDXL_REQUIRE(!e.ln_stat || w.cs, "ln_stat given but the weight is not LayerNorm-folded");
   SDXL_REQUIRE(!w.cs || e.ln_stat, "LayerNorm-folded weight used without row statistics");
   SDXL_REQUIRE(!((w.dt >= 0 ? w.dt : ex.cdt) == DT_F32 && a.dt != DT_F32), "f32 compute needs f32 activations");
-  if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize);
+  if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize, e.cls);
   p.acc_scale = w.acc_scale;
   p.a_scale = (w.dt >= 0 ? w.dt : ex.cdt) == DT_HL ? a.a_scale : nullptr;
   if (ex.warm && (w.dt >= 0 ? w.dt : ex.cdt) == DT_F16) {

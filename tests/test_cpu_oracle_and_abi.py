@@ -150,6 +150,43 @@ def built(pkg):
     return pkg
 
 
+def test_oracle_arithmetic_emulations():
+    """oracle.model.NUM (round 5): mode None leaves the fp32 restatement untouched; "f16ref" (the reference's LibTorch<f16> arithmetic, every op
+    output an f16 tensor) and "operands" (the engine's f16 mode as the oracle models it: only GEMM operands rounded) on the tiny net.  Checked:
+    f16ref outputs ARE f16 values, the hand-written layernorm rounds at each of its seven ops, a single class is never worse than all classes,
+    and the class of the reference's own GPU arithmetic is several times wider than the f16-operand model (what the smoke / GPU bounds rest on)."""
+    cfg = OC.tiny_config()
+    W = OM.to_torch(OC.synth_weights(OC.unet_param_specs(cfg), seed=0))
+    g = torch.Generator().manual_seed(5)
+    x, t = torch.randn(1, 4, 8, 8, generator=g) * 3, torch.tensor([500])
+    c, y = torch.randn(1, 7, cfg.context_dim, generator=g), torch.randn(1, cfg.adm_in_channels, generator=g)
+    assert OM.NUM.mode is None
+    ref = OM.unet_forward(cfg, W, x, t, c, y)
+    try:
+        OM.NUM.set("f16ref")
+        u = torch.randn(3, 5, 40, generator=g) * 50 + 7
+        ln16 = OM.layernorm_fn(u, 1e-5)
+        assert torch.equal(ln16, ln16.half().float())
+        h = lambda v: v.half().float()      # noqa: E731
+        uu = h(u - h(u.mean(-1, keepdim=True)))
+        assert torch.equal(ln16, h(uu / h(torch.sqrt(h(h(h(uu * uu).mean(-1, keepdim=True)) + 1e-5)))))
+        o16 = OM.unet_forward(cfg, W, x, t, c, y)
+        assert torch.equal(o16, o16.half().float()) and torch.isfinite(o16).all()
+        e16 = float((o16 - ref).abs().max())
+        errs = {}
+        for cl in ("qkv", "attn", "out", "xattn", "geglu", "ff", "conv", "conv_res", "conv_skip", "conv_io", "conv_updown", "conv_proj"):
+            OM.NUM.set("operands", (cl,))
+            errs[cl] = float((OM.unet_forward(cfg, W, x, t, c, y) - ref).abs().max())
+        OM.NUM.set("operands", ("qkv", "attn", "out", "xattn", "geglu", "ff", "conv"))
+        eall = float((OM.unet_forward(cfg, W, x, t, c, y) - ref).abs().max())
+    finally:
+        OM.NUM.set(None)
+    assert torch.equal(OM.unet_forward(cfg, W, x, t, c, y), ref), "NUM.set(None) must restore the fp32 restatement bit for bit"
+    assert all(0 < e <= 1.5 * eall for e in errs.values()), (errs, eall)
+    assert max(errs[k] for k in ("conv_res", "conv_skip", "conv_io", "conv_updown", "conv_proj")) <= 1.2 * errs["conv"]
+    assert e16 > 2.0 * eall, (e16, eall)      # one rounding per op output costs several times what operand rounding of the GEMMs costs
+
+
 def test_inline_asm_stores_carry_the_store_data_hazard_nop():
     """An inline-asm VMEM store of more than 64 bits hides the store-data hazard from the compiler (a VALU write of the data registers right behind it
     needs a wait state): every such statement in csrc/ must end with its own s_nop (the first write-through GroupNorm build produced NaNs)."""
