@@ -58,12 +58,17 @@ VaeCfg to_vcfg(const sdxl_vae_config* c) {
                    "The number of channels must be divisible by the number of groups (and by 8)");   // groupnorm/mod.rs:19-24
   return v;
 }
+void no_mix(int dtype) {     // the mixed mode is a property of the UNet driver (which classes run in f16): UNet / Diffuser handles only
+  if (dtype == SDXL_DTYPE_F32_SPLIT_MIX) throw Error("SDXL_DTYPE_F32_SPLIT_MIX is a UNet / Diffuser mode (use SDXL_DTYPE_F32_SPLIT here)");
+}
+int mix_of(int dtype) { return dtype == SDXL_DTYPE_F32_SPLIT_MIX ? (MIX_ATTN_F16 | MIX_GEGLU_F16) : 0; }
 void dtypes(int dtype, int& cdt, int& sdt) {
   switch (dtype) {
     case SDXL_DTYPE_F32: cdt = DT_F32; sdt = DT_F32; break;
     case SDXL_DTYPE_F16: cdt = DT_F16; sdt = DT_F16; break;
     case SDXL_DTYPE_F16_F32RES: cdt = DT_F16; sdt = DT_F32; break;
     case SDXL_DTYPE_F32_SPLIT: cdt = DT_HL; sdt = DT_F32; break;   // UNet / Diffuser / VAE only (no_split() guards the rest)
+    case SDXL_DTYPE_F32_SPLIT_MIX: cdt = DT_HL; sdt = DT_F32; break;   // UNet / Diffuser only (mix_of() carries the f16 classes)
     default: throw Error("unknown dtype");
   }
 }
@@ -73,7 +78,7 @@ void no_split(int cdt, const char* what) {
 void vae_dtype(int dtype, int& cdt) {     // the VAE additionally takes the split-operand fp32-class mode
   int sdt;
   if (dtype == SDXL_DTYPE_F32_SPLIT) { cdt = DT_HL; return; }
-  dtypes(dtype, cdt, sdt);
+  no_mix(dtype); dtypes(dtype, cdt, sdt);
 }
 int spec_out(const std::vector<ParamSpec>& specs, int index, const char** name, int* ndim, int64_t shape[4], int* kind,
              float* sc, float* mean) {
@@ -398,7 +403,7 @@ static int unet_create_impl(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int dtyp
   int cdt, sdt; dtypes(dtype, cdt, sdt);
   sdxl_unet* h = new sdxl_unet();
   h->ctx = ctx;
-  try { h->u = new UNet(to_cfg(cfg), cdt, sdt, src, ctx->stream); } catch (...) { delete h; throw; }
+  try { h->u = new UNet(to_cfg(cfg), cdt, sdt, src, ctx->stream, mix_of(dtype)); } catch (...) { delete h; throw; }
   *out = h;
   return SDXL_OK;
 }
@@ -477,7 +482,7 @@ int sdxl_qkv_attention(sdxl_ctx* ctx, void* stream, const float* q, const float*
   SDXL_REQUIRE(n_head > 0 && n_state % n_head == 0, "State size must be a multiple of head size");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt, sdt; no_mix(dtype); dtypes(dtype, cdt, sdt);
   const int d = n_state / n_head;
   if (cdt == DT_HL) {
     // split-operand mode: Q / O stay fp32, K and V^T go through the HL16 format of the split GEMMs (attn_d64_hl_kernel)
@@ -589,7 +594,7 @@ int sdxl_clip_param_spec(const sdxl_clip_config* cfg, int index, const char** na
 static int clip_create_impl(sdxl_ctx* ctx, const sdxl_clip_config* cfg, int dtype, WeightSource& src, sdxl_clip** out) {
   SDXL_REQUIRE(ctx && out, "bad argument");
   use(ctx);
-  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "the CLIP text encoders");
+  int cdt, sdt; no_mix(dtype); dtypes(dtype, cdt, sdt); no_split(cdt, "the CLIP text encoders");
   sdxl_clip* h = new sdxl_clip();
   h->ctx = ctx;
   try { h->c = new ClipText(to_ccfg(cfg), cdt, sdt, src, ctx->stream); } catch (...) { delete h; throw; }
@@ -662,7 +667,7 @@ static int diffuser_create_impl(sdxl_ctx* ctx, const sdxl_unet_config* cfg, int 
   int cdt, sdt; dtypes(dtype, cdt, sdt);
   sdxl_diffuser* h = new sdxl_diffuser();
   h->ctx = ctx;
-  try { h->d = new Diffuser(to_cfg(cfg), cdt, sdt, src, alphas, n_train, ctx->stream); } catch (...) { delete h; throw; }
+  try { h->d = new Diffuser(to_cfg(cfg), cdt, sdt, src, alphas, n_train, ctx->stream, mix_of(dtype)); } catch (...) { delete h; throw; }
   h->view.ctx = ctx; h->view.u = &h->d->unet(); h->view.owned = false;
   *out = h;
   return SDXL_OK;
@@ -704,7 +709,7 @@ int sdxl_vae_create_empty(sdxl_ctx* ctx, const sdxl_vae_config* cfg, int dtype, 
   API_BEGIN
   SDXL_REQUIRE(ctx && out, "bad argument");
   use(ctx);
-  int cdt, sdt; dtypes(dtype, cdt, sdt);
+  int cdt, sdt; no_mix(dtype); dtypes(dtype, cdt, sdt);
   NullSource src;
   sdxl_vae* h = new sdxl_vae();
   h->ctx = ctx;
@@ -901,7 +906,7 @@ int sdxl_group_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* ga
   SDXL_REQUIRE(C % 8 == 0 && n_group <= 256, "unsupported GroupNorm shape");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_group_norm");
+  int cdt, sdt; no_mix(dtype); dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_group_norm");
   Tmp tmp;
   void* xi = tmp.get((size_t)B * HW * C * dt_size(sdt));
   void* yo = tmp.get((size_t)B * HW * C * dt_size(cdt));
@@ -922,7 +927,7 @@ int sdxl_layer_norm(sdxl_ctx* ctx, void* stream, const float* x, const float* ga
   SDXL_REQUIRE(C % 8 == 0, "unsupported LayerNorm width");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_layer_norm");
+  int cdt, sdt; no_mix(dtype); dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_layer_norm");
   Tmp tmp;
   void* xi = tmp.get((size_t)rows * C * dt_size(sdt));
   void* yo = tmp.get((size_t)rows * C * dt_size(cdt));
@@ -942,7 +947,7 @@ int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   hipStream_t s = pick(ctx, stream);
   int cdt, sdt;
   if (dtype == SDXL_DTYPE_F32_SPLIT) { cdt = DT_HL; sdt = DT_HL; }   // split-operand GEMM as an operator (the VAE's precision): HL16 operands
-  else dtypes(dtype, cdt, sdt);
+  else { no_mix(dtype); dtypes(dtype, cdt, sdt); }
   SDXL_REQUIRE(cdt != DT_HL || Cin % 32 == 0, "SDXL_DTYPE_F32_SPLIT convolutions need Cin % 32 == 0");
   const int Hs = upsample ? 2 * H : H, Ws = upsample ? 2 * W : W;
   const int Ho = (Hs + 2 * pad - ksize) / stride + 1, Wo = (Ws + 2 * pad - ksize) / stride + 1;
@@ -999,7 +1004,7 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   hipStream_t s = pick(ctx, stream);
   int cdt, sdt;
   if (dtype == SDXL_DTYPE_F32_SPLIT) { cdt = DT_HL; sdt = DT_HL; }   // split-operand GEMM as an operator: HL16 operands (incl. the GEGLU epilogue)
-  else dtypes(dtype, cdt, sdt);
+  else { no_mix(dtype); dtypes(dtype, cdt, sdt); }
   SDXL_REQUIRE(cdt != DT_HL || K % 32 == 0, "SDXL_DTYPE_F32_SPLIT linear layers need K % 32 == 0");
   const int kt = cdt == DT_F16 ? 64 : 32;
   Lin l; l.N = N; l.K = K; l.cin = K; l.ksize = 1; l.Kpad = (int)round_up(K, kt); l.Npad = (int)round_up(N, 128);
@@ -1049,7 +1054,7 @@ int sdxl_layer_norm_linear(sdxl_ctx* ctx, void* stream, const float* x, const fl
   SDXL_REQUIRE(K % 64 == 0, "LayerNorm width must be a multiple of 64");
   use(ctx);
   hipStream_t s = pick(ctx, stream);
-  int cdt, sdt; dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_layer_norm_linear");
+  int cdt, sdt; no_mix(dtype); dtypes(dtype, cdt, sdt); no_split(cdt, "sdxl_layer_norm_linear");
   // the model's own builder does the packing / folding: a five-entry parameter list over a device-side flat buffer
   std::vector<ParamSpec> specs(5);
   specs[0].name = "lin.weight"; specs[0].shape = {K, N}; specs[0].kind = PK_LINEAR_W;

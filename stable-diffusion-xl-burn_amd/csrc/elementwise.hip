@@ -338,6 +338,25 @@ void launch_f32_to_hl(const void* src, int lds_, void* dst, int ldd, size_t rows
   hipLaunchKernelGGL(f32_to_hl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
                      reinterpret_cast<half_t*>(dst), ldd, rows, C / 8);
 }
+// f16 rows -> HL16 rows with zero lo halves (an f16 value IS its own hi half): the hand-over from an f16 kernel (the mixed mode's flash
+// attention) to a split-operand GEMM.  C % 16 == 0, lds % 8 == 0, ldd % 16 == 0.
+__global__ void f16_to_hl_kernel(const half_t* src, int lds_, half_t* dst, int ldd, size_t rows, int C8) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C8) return;
+  const size_t r = i / C8;
+  const int c = (int)(i - r * C8) * 8;
+  const half8 hi = *reinterpret_cast<const half8*>(src + r * lds_ + c);
+  half_t* dp = dst + r * 2 * (size_t)ldd + ((c >> 4) << 5) + (c & 15);
+  *reinterpret_cast<half8*>(dp) = hi;
+  *reinterpret_cast<half8*>(dp + 16) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+}
+void launch_f16_to_hl(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, hipStream_t s) {
+  if ((C & 15) != 0 || (lds_ & 7) != 0 || (ldd & 15) != 0) throw std::runtime_error("f16_to_hl: C % 16 == 0 rows with aligned strides only");
+  const size_t total = rows * (size_t)(C / 8);
+  if (!total) return;
+  hipLaunchKernelGGL(f16_to_hl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const half_t*>(src), lds_,
+                     reinterpret_cast<half_t*>(dst), ldd, rows, C / 8);
+}
 // precision-frontier instrument (round 5, UNet "hl_demote" classes): the lo halves of an HL16 tensor set to zero -- the (hi, lo) GEMM that
 // reads it then multiplies exactly the f16 rounding of every element, i.e. the f16 engine's operand arithmetic on the split engine's kernels
 __global__ void hl_zero_lo_kernel(half_t* dst, int ldd, size_t rows, int C16) {

@@ -219,6 +219,8 @@ struct Exec {
 // Classes: self-attention QKV projection, the self-attention itself (q, k, v, p), attention out-projections, cross-attention (query / key / value
 // projections + the 77-key attention), GEGLU projection, FF-out, and five kinds of convolution: the two 3x3 convs of every ResBlock, the 1x1 skip
 // connections, the UNet's last conv (its first has 4 input channels and is plain fp32 in this engine), the down / up-sampling convs, proj_in / proj_out.
+// SDXL_DTYPE_F32_SPLIT_MIX: what the measured frontier (profiles/r05_precision_frontier.json) lets a latents-within-bound engine run in f16
+enum MixClass { MIX_ATTN_F16 = 1, MIX_GEGLU_F16 = 2 };
 enum DemoteClass { DM_QKV = 1, DM_ATTN = 2, DM_OUT = 4, DM_XATTN = 8, DM_GEGLU = 16, DM_FF = 32, DM_CONV_RES = 64, DM_CONV_SKIP = 128,
                    DM_CONV_IO = 256, DM_CONV_UPDOWN = 512, DM_CONV_PROJ = 1024 };
 void unet_set_hl_demote(int mask);
@@ -256,7 +258,8 @@ struct BlockW { BlockDesc d; ResBlockW res; STW st; Lin conv; };
 
 class UNet {
  public:
-  UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st);
+  // mix (split-operand compute only): MIX_* classes that run on plain f16 operands instead (SDXL_DTYPE_F32_SPLIT_MIX)
+  UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st, int mix = 0);
   ~UNet();
   const UNetCfg& cfg() const { return cfg_; }
   // conditioning that is constant over a trajectory: context [B][n_ctx][ctx_dim] fp32 (device), label [B][adm] fp32.
@@ -297,6 +300,7 @@ class UNet {
 
   UNetCfg cfg_;
   int cdt_, sdt_;
+  int mix_ = 0;                          // MixClass bits (split-operand engine): classes on plain f16 operands
   DeviceArena warena_;
   std::vector<BlockW> inp_, out_;
   BlockW mid_res1_, mid_res2_;   // middle_block: res1 -> transformer (in mid_res1_.st) -> res2
@@ -444,7 +448,7 @@ extern bool g_debug_no_cfg;   // sdxl_debug_set("no_cfg"): base model without th
 class Diffuser {
  public:
   Diffuser(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, const float* alphas_host, int n_train,
-           hipStream_t st);
+           hipStream_t st, int mix = 0);
   ~Diffuser();
   UNet& unet() { return *unet_; }
   // Diffuser::sample_latent (stablediffusion/mod.rs:317-332); noise0 plays gen_noise(); out: NCHW fp32 [n,4,h/8,w/8]

@@ -25,9 +25,9 @@ std::vector<int> Diffuser::step_schedule(int n_steps, int step_start, int n_trai
 }
 
 Diffuser::Diffuser(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, const float* alphas_host,
-                   int n_train, hipStream_t st)
+                   int n_train, hipStream_t st, int mix)
     : n_train_(n_train), is_refiner_(cfg.is_refiner) {
-  unet_.reset(new UNet(cfg, compute_dt, stream_dt, src, st));
+  unet_.reset(new UNet(cfg, compute_dt, stream_dt, src, st, mix));
   alphas_.resize(n_train);
   for (int i = 0; i < n_train; ++i) alphas_[i] = (double)alphas_host[i];   // get_alpha :485-492 (elem -> f64)
   SDXL_HIP(hipMalloc((void**)&step_idx_, sizeof(int)));

@@ -36,7 +36,7 @@ ResBlockW load_res(WeightBuilder& wb, const std::string& p, int cin, int cout, s
   emb_off += cout;
   return r;
 }
-STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln) {
+STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln, bool geglu_f16 = false) {
   STW s;
   s.C = C; s.heads = heads;
   s.norm = wb.norm(p + ".norm");
@@ -65,7 +65,8 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     t.kv2 = wb.fused_linear({q + ".attn2.key", q + ".attn2.value"});
     t.out2 = wb.linear(q + ".attn2.out");
     t.n3 = wb.norm(q + ".norm3");
-    t.geglu = wb.linear(q + ".mlp.geglu.proj", true);
+    // (mixed mode: the GEGLU projection of a split-operand model packed as plain f16 -- it runs on the f16 wide-tile kernel)
+    t.geglu = wb.linear(q + ".mlp.geglu.proj", true, geglu_f16 ? (int)DT_F16 : -1);
     t.ff = wb.linear(q + ".mlp.lin");
     s.blocks.push_back(t);
   }
@@ -165,8 +166,8 @@ void UNet::apply_demote_weights(hipStream_t s) {
   SDXL_HIP(hipStreamSynchronize(s));     // (vals is host memory of this frame)
 }
 
-UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st)
-    : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt) {
+UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st, int mix)
+    : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt), mix_(compute_dt == DT_HL ? mix : 0) {
   SDXL_REQUIRE(cfg.n_head_channels == 64, "this engine's fused attention kernel is specialised for 64 channels per head");
   SDXL_REQUIRE(!((compute_dt == DT_F32 || compute_dt == DT_HL) && stream_dt != DT_F32), "f32 / split-operand compute implies an f32 residual stream");
   SDXL_REQUIRE(cfg.model_channels % 32 == 0, "GroupNorm(32) needs model_channels % 32 == 0");
@@ -200,7 +201,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
       case BK_RES: b.res = load_res(wb, p, d.c_in, d.c_out, emb_names, emb_off); break;
       default:
         b.res = load_res(wb, p + ".res", d.c_in, d.c_out, emb_names, emb_off);
-        if (d.kind == BK_REST || d.kind == BK_RESTU) b.st = load_st(wb, p + ".transformer", d.c_out, d.n_head, d.depth, fuse_ln_);
+        if (d.kind == BK_REST || d.kind == BK_RESTU) b.st = load_st(wb, p + ".transformer", d.c_out, d.n_head, d.depth, fuse_ln_, (mix_ & MIX_GEGLU_F16) != 0);
         if (d.kind == BK_RESTU || d.kind == BK_RESU) b.conv = wb.conv(p + ".upsample.conv");
     }
     return b;
@@ -208,7 +209,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
   for (size_t i = 0; i < inp.size(); ++i) inp_.push_back(load_block("input_blocks." + std::to_string(i), inp[i]));
   mid_res1_.d = mid;
   mid_res1_.res = load_res(wb, "middle_block.res1", mid.c_in, mid.c_out, emb_names, emb_off);
-  mid_res1_.st = load_st(wb, "middle_block.transformer", mid.c_out, mid.n_head, mid.depth, fuse_ln_);
+  mid_res1_.st = load_st(wb, "middle_block.transformer", mid.c_out, mid.n_head, mid.depth, fuse_ln_, (mix_ & MIX_GEGLU_F16) != 0);
   mid_res2_.d = mid;
   mid_res2_.res = load_res(wb, "middle_block.res2", mid.c_in, mid.c_out, emb_names, emb_off);
   for (size_t i = 0; i < out.size(); ++i) out_.push_back(load_block("output_blocks." + std::to_string(i), out[i]));
@@ -375,6 +376,20 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   if (npad != HW && !ex.dry) launch_fill_zero(vt, (size_t)B * C * npad * dt_size(adt), ex.s);
   // split-operand mode: the attention kernel takes K and V^T in HL16 (same bytes as fp32); q and the output stay fp32
   const bool hl_attn = ex.cdt == DT_HL;
+  // mixed mode (SDXL_DTYPE_F32_SPLIT_MIX; classes chosen on the measured precision frontier, profiles/r05_precision_frontier.json):
+  //   * self-attention on the f16 flash kernels: the (split-operand) QKV projection writes q | k and V^T as f16, the attention output is
+  //     handed to the out-projection as HL16 with zero lo halves (an f16 value is its own hi half);
+  //   * GEGLU projection on f16 operands (f16 LayerNorm output x f16-packed weights, the f16 wide-tile kernel) -- its output leaves the
+  //     epilogue as HL16 (fp32-class), so FF-out's operand is not rounded a second time.
+  const bool mix_attn = hl_attn && (mix_ & MIX_ATTN_F16) && C % 16 == 0;
+  const bool mix_geglu = hl_attn && (mix_ & MIX_GEGLU_F16) && !w.blocks.empty() && w.blocks[0].geglu.dt == DT_F16 && M % 8 == 0;
+  Act qk16, ao16, ln16; void* vt16 = nullptr;
+  if (mix_attn) {
+    qk16 = ex.alloc(M, 2 * C, DT_F16); ao16 = ex.alloc(M, C, DT_F16);
+    vt16 = ex.act->alloc((size_t)B * C * npad * 2);
+    if (npad != HW && !ex.dry) launch_fill_zero(vt16, (size_t)B * C * npad * 2, ex.s);
+  }
+  if (mix_geglu) ln16 = ex.alloc(M, C, DT_F16);
   void* kh = hl_attn && !hl_direct ? ex.act->alloc(M * (size_t)C * 4) : nullptr;
   void* vth = hl_attn && !hl_direct ? ex.act->alloc((size_t)B * C * npad * 4) : nullptr;
   if (fuse_ln_) {
@@ -411,9 +426,13 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     const TBlockW& b = w.blocks[j];
     run_layernorm(ex, b.n1, t, (int)M, ln);
     demote_lo(ex, DM_QKV, ln, M, C);
-    Epi eq; eq.n_split = 2 * C; eq.Ct = vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.cls = DM_QKV;
-    run_linear(ex, b.qkv, ln, (int)M, qk, eq);
-    if (hl_attn && hl_direct) {     // q | k and V^T are HL16; the attention writes the out-projection's operand
+    Epi eq; eq.n_split = 2 * C; eq.Ct = mix_attn ? vt16 : vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.cls = DM_QKV;
+    run_linear(ex, b.qkv, ln, (int)M, mix_attn ? qk16 : qk, eq);
+    if (mix_attn) {
+      attention(ex, qk16, qk16.cols(C), vt16, npad, ao16, B, w.heads, HW, HW);
+      if (!ex.dry) launch_f16_to_hl(ao16.p, ao16.ld, ao.p, ao.ld, M, C, ex.s);
+    }
+    else if (hl_attn && hl_direct) {     // q | k and V^T are HL16; the attention writes the out-projection's operand
       demote_lo(ex, DM_ATTN, qk, M, 2 * C);
       demote_lo(ex, DM_ATTN, Act(vt, npad, DT_HL), (size_t)B * C, npad);
       attention_hl(ex, qk, qk.cols(C).p, qk.ld, vt, npad, ao, B, w.heads, HW, HW, DM_ATTN);
@@ -443,10 +462,10 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     }
     demote_lo(ex, DM_OUT, ao, M, C);
     run_linear(ex, b.out2, ao, (int)M, t, er);
-    run_layernorm(ex, b.n3, t, (int)M, ln);
+    run_layernorm(ex, b.n3, t, (int)M, mix_geglu ? ln16 : ln);
     demote_lo(ex, DM_GEGLU, ln, M, C);
     Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
-    run_linear(ex, b.geglu, ln, (int)M, gg, eg);
+    run_linear(ex, b.geglu, mix_geglu ? ln16 : ln, (int)M, gg, eg);
     demote_lo(ex, DM_FF, gg, M, 4 * C);
     er.cls = DM_FF;
     run_linear(ex, b.ff, gg, (int)M, t, er);
@@ -592,7 +611,7 @@ void UNet::ensure_plan(int B, int H, int W) {
     ebias_ = (float*)act_.alloc((size_t)B * emb_total_ * sizeof(float));
     gn_partial_ = (float*)act_.alloc(groupnorm_workspace_floats(B, 32) * sizeof(float));
     tconv_ = (float*)act_.alloc(8 * sizeof(float));
-    if (cdt_ == DT_F16) {   // cross-workgroup key split of the self-attention: workspace + tickets per chain, sized for the largest level
+    if (cdt_ == DT_F16 || (mix_ & MIX_ATTN_F16)) {   // cross-workgroup key split of the (f16) self-attention: workspace + tickets per chain, sized for the largest level
       size_t wsb = 0, cnt = 0;
       { int h = H, w = W;
         for (size_t lv = 0; lv < cfg_.channel_mults.size(); ++lv) {
@@ -654,7 +673,7 @@ void UNet::ensure_plan(int B, int H, int W) {
   act_.off = 0; act_.peak = 0;
   persist();
   for (int c = 0; c < 2; ++c) if (skcnt_[c]) SDXL_HIP(hipMemset(skcnt_[c], 0, kSplitkCounters * sizeof(unsigned)));   // armed once
-  for (int c = 0; c < (split ? 2 : 1); ++c) if (attn_xcnt_[c] && cdt_ == DT_F16) SDXL_HIP(hipMemset(attn_xcnt_[c], 0, attn_xcnt_bytes_));
+  for (int c = 0; c < (split ? 2 : 1); ++c) if (attn_xcnt_[c] && (cdt_ == DT_F16 || (mix_ & MIX_ATTN_F16))) SDXL_HIP(hipMemset(attn_xcnt_[c], 0, attn_xcnt_bytes_));
 }
 
 void* UNet::unet_in(int B, int H, int W) { ensure_plan(B, H, W); return in_; }
@@ -664,7 +683,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
   SDXL_REQUIRE(ctx_B_ == B && !kv_.empty(), "set_context must be called with the same batch before forward");
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.demote = demote_mask_;
   ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
-  if (cdt_ == DT_F16) { ex.attn_xws = attn_xws_[0]; ex.attn_xcnt = attn_xcnt_[0]; }
+  if (cdt_ == DT_F16 || (mix_ & MIX_ATTN_F16)) { ex.attn_xws = attn_xws_[0]; ex.attn_xcnt = attn_xcnt_[0]; }
   // weight warming (f16 engine, batched chain): the plan's first forward records the GEMM sequence, every later one replays it
   const bool warming = cdt_ == DT_F16 && !plan_split_ && igemm_warm_enabled();
   if (warming) { ex.warm = &warm_; if (!warm_.ready) { warm_.seq.clear(); warm_.recording = true; } }
@@ -675,7 +694,7 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
     if (!plan_split_) { run(ex, t_dev, t_stride, 0, B); if (warm_.recording) warm_.finish(); return; }
     Exec e2; e2.s = s2_; e2.cdt = cdt_; e2.sdt = sdt_; e2.act = &act2_; e2.demote = demote_mask_;
     e2.splitk_ws = skws_[1]; e2.splitk_ws_bytes = skws_bytes_; e2.splitk_cnt = skcnt_[1];
-    if (cdt_ == DT_F16) { e2.attn_xws = attn_xws_[1]; e2.attn_xcnt = attn_xcnt_[1]; }
+    if (cdt_ == DT_F16 || (mix_ & MIX_ATTN_F16)) { e2.attn_xws = attn_xws_[1]; e2.attn_xcnt = attn_xcnt_[1]; }
     act2_.off = 0;
     ex.fork_ev = ev_fork_; ex.fork_after = split_offset_; ex.launches = 0;
     if (ex.fork_after <= 0) SDXL_HIP(hipEventRecord(ev_fork_, s));
@@ -720,7 +739,7 @@ void UNet::profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[P
   Profiler prof;
   Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.prof = &prof; ex.demote = demote_mask_;
   ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
-  if (cdt_ == DT_F16) { ex.attn_xws = attn_xws_[0]; ex.attn_xcnt = attn_xcnt_[0]; }
+  if (cdt_ == DT_F16 || (mix_ & MIX_ATTN_F16)) { ex.attn_xws = attn_xws_[0]; ex.attn_xcnt = attn_xcnt_[0]; }
   const size_t m = act_.mark();
   run(ex, tconv_, 1, 0, B);   // always the batched chain: per-launch events need one stream
   act_.reset(m);

@@ -23,7 +23,8 @@ pytestmark = pytest.mark.gpu
 # 2.3e-3 on 32^2 inputs; F16_F32RES 1.2e-3), so a 2x regression fails
 # dtype 3 = SDXL_DTYPE_F32_SPLIT: fp32 residual stream, GEMM operands as (hi, lo) f16 pairs (3 MFMAs per product), fp32 attention --
 # held to the strict mode's bounds
-FWD_TOL = {0: 1e-5, 1: 4.5e-3, 2: 2.5e-3, 3: 1e-5}      # measured 2.3e-6 / 1.4e-3 (16^2), 2.26e-3 (32^2) / 1.2e-3 / 1.8e-6
+# dtype 4 = SDXL_DTYPE_F32_SPLIT_MIX (round 5): dtype 3 with the self-attention and the GEGLU projection on f16 operands -- between 2 and 3
+FWD_TOL = {0: 1e-5, 1: 4.5e-3, 2: 2.5e-3, 3: 1e-5, 4: 1.5e-3}      # measured 2.3e-6 / 1.4e-3 (16^2), 2.26e-3 (32^2) / 1.2e-3 / 1.8e-6
 EPS_TOL = {0: 4e-5, 1: 5.8e-3, 2: 5.5e-3, 3: 4e-5}    # the low-variance per-norm-eps probe (measured 1.2e-5 / 2.9e-3 / 2.7e-3)
 LAT_ABS_F32 = 1e-3           # north_star: latents within 1e-3 of the fp32 CPU reference (strict-parity mode)
 LAT_REL_F16 = 6.0e-3         # fp16-operand modes: max-abs error relative to max|latent|; measured 3.0e-3 (4 CFG-7.5 steps) and 3.8e-3
@@ -54,7 +55,7 @@ def _pkg_cond(pkg, c, res, refiner=False):
                             resolution=res)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("which", ["tiny", "tiny_refiner"])
 def test_unet_forward(pkg, ctx, dtype, which):
     ocfg = OC.tiny_config() if which == "tiny" else OC.tiny_refiner_config()
