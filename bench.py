@@ -422,7 +422,7 @@ def main():
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--n-steps", type=int, default=None, help="--n-diffusion-steps of the reference CLI (30 -> 31 iterations)")
     ap.add_argument("--cfg", type=float, default=None)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res", "f32_split"],
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res", "f32_split", "f32_split_mix"],
                     help="UNet arithmetic: f16 (the reference's GPU precision, src/bin/sample/main.rs:122), f16_f32res, f32 (exact-fp32 MFMA: the strict-parity "
                          "mode) or f32_split (fp32-class: fp32 stream, (hi, lo) f16 operands with three MFMAs per product in the GEMMs and in the attention)")
     ap.add_argument("--vae-dtype", default="f32_split", choices=["f16", "f32", "f32_split"],
@@ -477,7 +477,8 @@ def main():
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    dts = {"f16": pkg.DTYPE_F16, "f32": pkg.DTYPE_F32, "f16_f32res": pkg.DTYPE_F16_F32RES, "f32_split": pkg.DTYPE_F32_SPLIT}
+    dts = {"f16": pkg.DTYPE_F16, "f32": pkg.DTYPE_F32, "f16_f32res": pkg.DTYPE_F16_F32RES, "f32_split": pkg.DTYPE_F32_SPLIT,
+           "f32_split_mix": pkg.DTYPE_F32_SPLIT_MIX}
     dt, vdt = dts[args.dtype], dts[args.vae_dtype]
 
     ctx = pkg.Context(local_rank)
@@ -658,7 +659,7 @@ def main():
     adj_ms = {k: max(raw_ms[k] - n_launch[k] * ev_over_ms, 0.0) for k in raw_ms}
     ig_ms, ig_n, ig_fl = adj_ms["igemm"], prof["igemm"][1], prof["igemm"][2]
     # f32: exact-fp32 MFMA peak; f32_split: three f16 MFMAs per product -> a third of the f16 matrix peak in algorithmic FLOPs
-    peak = PEAK_F32_TFLOPS if args.dtype == "f32" else (PEAK_F16_TFLOPS / 3.0 if args.dtype == "f32_split" else PEAK_F16_TFLOPS)
+    peak = PEAK_F32_TFLOPS if args.dtype == "f32" else (PEAK_F16_TFLOPS / 3.0 if args.dtype in ("f32_split", "f32_split_mix") else PEAK_F16_TFLOPS)
     achieved = ig_fl / 1e12 / (ig_ms / 1e3) if ig_ms > 0 else 0.0
     # HBM-side traffic of the same launches: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_step.py,
     # summarised by tools/pmc_traffic.py (gfx950 correction applied there); null when no committed summary exists
@@ -719,7 +720,7 @@ def main():
             "metric": "images/sec SDXL-base 1024x1024 30-step CFG7.5 (whole job); UNet step ms p50",
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"f32": "f32", "f32_split": "f32 (split f16 operands)"}.get(args.dtype, "f16"), "data": "synthetic",
+            "vs_baseline": None, "dtype": {"f32": "f32", "f32_split": "f32 (split f16 operands)", "f32_split_mix": "f32 (split f16 operands; self-attention and GEGLU projection on plain f16)"}.get(args.dtype, "f16"), "data": "synthetic",
             "config": {"workload": wl, "baseline_config_index": args.config - 1,
                        "precision": args.dtype, "vae_dtype": args.vae_dtype,
                        "weights": "synthetic seeded (random-init SDXL-base architecture)",

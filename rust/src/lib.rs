@@ -132,6 +132,11 @@ pub enum Precision {
     /// fp16 storage and MFMA operands, fp32 accumulation (what `LibTorch<f16>` is in `src/bin/sample/main.rs:122`)
     F16 = ffi::SDXL_DTYPE_F16 as isize,
     F16F32Res = ffi::SDXL_DTYPE_F16_F32RES as isize,
+    /// fp32-class results on the f16 matrix pipe: (hi, lo) f16 operand pairs, three MFMAs per product (UNet / Diffuser / VAE)
+    F32Split = ffi::SDXL_DTYPE_F32_SPLIT as isize,
+    /// `F32Split` with the self-attention and the GEGLU projection on plain f16 operands (UNet / Diffuser only): the fastest mode whose
+    /// config-2 latents stay inside the parity tests' scaled 1e-3 bound
+    F32SplitMix = ffi::SDXL_DTYPE_F32_SPLIT_MIX as isize,
 }
 
 /// one per GPU (the reference hard-codes `LibTorchDevice::Cuda(0)`, `src/bin/sample/main.rs:131`)

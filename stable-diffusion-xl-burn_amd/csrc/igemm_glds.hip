@@ -1268,6 +1268,8 @@ bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s) {
   return true;
 }
 
+static std::atomic<int> g_hl_tile96{1};
+void igemm_set_hl_tile96(int v) { g_hl_tile96 = v; }
 // Split-operand mode (DT_HL; igemm_common.h): HL16 operands on the same direct-to-LDS pipeline, 3 f16 MFMAs per 16-deep product.
 // Returns false for shapes the generic kernel must take (none in the VAE: its Cin % 32 != 0 layers are packed fp32).
 bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
@@ -1292,6 +1294,14 @@ bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
   const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
   IgemmParams q = p;
   q.splitk = 1;
+  // round 5: the 96-row tile of the f16 engine for the shapes where it fills more of the chip's single round -- the M = 2048 x N = 1280 linears of the
+  // 32^2 level (out-projections, cross-attention query projection, FF-out: 220 workgroups instead of 160).  Same k order in every tile shape, so the
+  // choice never changes a result bit (A/B knob: sdxl_debug_set "hl_tile96").
+  const long t96 = (long)((p.M + 95) / 96) * ((p.N + 127) / 128);
+  if (g_hl_tile96.load() && p.ksize == 1 && p.n_split >= p.N && t128 < 256 && t96 <= 256 && t96 > t128 && eff256 < (double)t96 / 256.0) {
+    launch_pipe<96, 128, 5, 3, 6, hl16_t>(q, s);
+    return true;
+  }
   if (eff256 >= eff128) launch_pipe<256, 128, 3, 4, 8, hl16_t>(q, s);
   else launch_pipe<128, 128, 4, 4, 8, hl16_t>(q, s);
   return true;
