@@ -280,6 +280,10 @@ int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int 
  * "attn_xsplit": 0 = the self-attention of the 32^2 level never runs 1/5 of its heads as two half-key blocks per 64 queries merged across
  * workgroups (csrc/attention.hip, attn_d64_mix_kernel level 2; A/B, default 1);
  * "splitk_wt": 0 = split-K slabs published by plain stores + an agent-scope release instead of write-through stores (A/B, default 1);
+ * "hl_tile96": 0 = the split-operand GEMMs never take the 96x128 tile (A/B, default 1; results unchanged);
+ * "hl_demote": bit set of GEMM classes (csrc/engine.h DemoteClass) that a SDXL_DTYPE_F32_SPLIT UNet runs on operands with zero lo halves --
+ *   the f16 engine's operand rounding class by class on the split engine's kernels: the precision-frontier instrument
+ *   (tools/precision_frontier.py, profiles/r05_precision_frontier.json); takes effect at the next set_context / trajectory; default 0;
  * "igemm_unrolled": 0 = auto selection launches the rolled k-loop kernels (A/B; default 1);
  * "split_cfg": 1 = a batch-2 UNet::forward runs its two entries as two concurrent batch-1 chains (bit-identical results);
  * "split_offset": GEMM launches of the first chain before the second is released; "no_cfg": base model without the

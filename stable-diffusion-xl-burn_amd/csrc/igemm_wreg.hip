@@ -270,6 +270,16 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
   const int tilesN = p.N >> 7;
   int tm = bid / tilesN, tn = bid - tm * tilesN;
   if constexpr (XCDALT) { tn = bid / tilesM; tm = bid - tn * tilesM; }
+  // round 5 A/B (knob wreg_xcd2d): 2-D ownership.  With whole row-tile runs an XCD streams EVERY weight column tile under its ~tilesM / 8 row tiles
+  // (M = 2048 x N = 1280: 3 x 96 rows + 1280 columns of operands per XCD, 26 % of its fetches compulsory misses -- the 73 % L2 hit rate of DESIGN 10.2);
+  // four patches of (tilesM / 2 row tiles) x (tilesN / 2 column tiles), two XCDs per patch in row-major order inside it, make that ~6 x 96 rows + 640 columns.
+  if (p.wreg_xcd2d && !(tilesM & 1) && !(tilesN & 1) && tilesN >= 8) {
+    const int ch = tilesN >> 1, prow = tilesM >> 1, ptiles = prow * ch;
+    const int patch = bid / ptiles, idx = bid - patch * ptiles;
+    const int r = idx / ch;
+    tm = (patch >> 1) * prow + r;
+    tn = (patch & 1) * ch + (idx - r * ch);
+  }
   const int m0 = tm * BM, n0 = tn * 128;
   const int nk = p.Kpad >> 6;
   const int nkg = (nk - g + 1) >> 1;          // k-tiles of this group: g, g + 2, ...
@@ -494,6 +504,8 @@ __global__ __launch_bounds__(512) void igemm_wreg_kernel(const IgemmParams p, co
 // ---------------------------------------------------------------------------------------------------------
 static std::atomic<int> g_wreg_enable{1};
 void igemm_set_wreg(int v) { g_wreg_enable = v; }
+static std::atomic<int> g_wreg_xcd2d{0};
+void igemm_set_wreg_xcd2d(int v) { g_wreg_xcd2d = v; }
 
 // warming workgroups of a launch: the CU slots its tile grid leaves empty in its (single) round -- one workgroup per CU up to 256 tiles,
 // two up to 512 -- at most 64 (a warmer pulls ~30 GB/s out of HBM: 36 of them move 13 MB inside an out-projection's 15 us)
@@ -515,7 +527,9 @@ static void launch_wreg_t(const IgemmParams& p, hipStream_t s) {
   }
   const int tilesM = (p.M + BM - 1) / BM, tilesN = p.N / 128;
   const int ntiles = tilesM * tilesN;
-  hipLaunchKernelGGL((igemm_wreg_kernel<BM, L, MODE>), dim3(ntiles + wreg_warm_groups(p, ntiles)), dim3(512), lds, s, p, igemm_zero_page());
+  IgemmParams q = p;
+  q.wreg_xcd2d = g_wreg_xcd2d.load();
+  hipLaunchKernelGGL((igemm_wreg_kernel<BM, L, MODE>), dim3(ntiles + wreg_warm_groups(p, ntiles)), dim3(512), lds, s, q, igemm_zero_page());
 }
 
 // shapes this kernel takes: plain f16 linear layers / 1x1 convolutions whose weights were also packed in fragment order

@@ -70,6 +70,8 @@ struct IgemmParams {
   const void* warm[3]; unsigned warm_bytes[3];     // up to three regions (filled from the front)
   int splitk_wt;    // split-K slabs published by write-through stores instead of plain stores + release fence (set by the launcher from the A/B knob "splitk_wt", default 1)
                     // VMEM loads instead of the scalar cache -- the hazard experiment of DESIGN 9.2 / 10.4
+  int wreg_xcd2d;   // A/B knob (sdxl_debug_set "wreg_xcd2d"): weights-in-registers kernel, XCDs own 2-D patches of tiles (half the column tiles x ~ a quarter of
+                    // the row tiles each) instead of whole row-tile runs -- fewer unique operand bytes per XCD's L2; set by the launcher
   int epi_staged;   // A/B knob (sdxl_debug_set "igemm_epilogue_staged"): 1 = LDS-staged epilogue everywhere, 0 = direct row-per-lane where it applies
 };
 bool igemm_gn_part_ok(const IgemmParams& p);
@@ -93,6 +95,7 @@ void igemm_set_warm(int v);      // A/B knob (sdxl_debug_set "igemm_warm"): 0 = 
 int igemm_warm_enabled();
 void igemm_set_splitk_wt(int v);
 void igemm_set_hl_tile96(int v); // A/B knob (sdxl_debug_set "hl_tile96"): 0 = the split-operand GEMMs never take the 96-row tile
+void igemm_set_wreg_xcd2d(int v);
 void igemm_set_wreg(int v);      // A/B knob (sdxl_debug_set "igemm_wreg"): 0 = the auto selection never picks the weights-in-registers kernel
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
 void igemm_set_hl_weights_exact(int v); // A/B: 0 keeps all three MFMAs per product even where the packed weights are exact f16 values
