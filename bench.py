@@ -214,8 +214,10 @@ def cpu_oracle_config1():
     threads = min(cores, 32)
     torch.set_num_threads(threads)
     t0 = time.time()
-    cfg, W = MG.base_weights()
-    v, Wv = MG.vae_weights()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # (the fixture generator narrates on stdout; the bench prints ONE JSON line there)
+        cfg, W = MG.base_weights()
+        v, Wv = MG.vae_weights()
     t_w = time.time() - t0
     i = MG.config1_inputs(cfg)
     cond = OP.Conditioning(i["uctx"], None, i["ctx"], None, i["uy"], None, i["y"], None, (512, 512))
@@ -245,7 +247,7 @@ def load_parity():
     STATIC part of the line's parity object -- what live_parity() below does not re-measure in this run"""
     out = {}
     try:
-        name = next(n for n in ("r04_parity_baseline.json", "r03_parity_baseline.json", "r02_parity_baseline.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r05_parity_baseline.json", "r04_parity_baseline.json", "r03_parity_baseline.json", "r02_parity_baseline.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as fh:
             r = json.load(fh)
         c1 = r.get("config1_f32_vs_oracle", {}).get("final")
@@ -253,9 +255,12 @@ def load_parity():
             out["config1_f32_vs_oracle_latent_max_abs"] = c1["max_abs"]
             out["config1_f32_vs_oracle_latent_rel"] = c1["rel"]
         u = r.get("unet_forward_1024_vs_oracle", {})
-        for k in ("f32", "f16", "f16_f32res"):
+        for k in ("f32", "f32_split", "f32_split_mix", "f16", "f16_f32res"):
             if k in u:
                 out[f"unet_forward_1024_{k}_vs_oracle_rel"] = u[k]["rel"]
+        if "reference_f16_class" in u:      # the oracle in the reference's own GPU arithmetic (LibTorch<f16>: every op output an f16 tensor) vs the fp32 oracle
+            out["unet_forward_1024_reference_f16_class_rel"] = u["reference_f16_class"]["rel"]
+            out["unet_forward_1024_oracle_f16_operand_model_rel"] = u.get("oracle_f16_operand_model_rel")
         t = r.get("config2_trajectory", {})
         if "f32_vs_oracle" in t:
             out["config2_f32_vs_oracle_final_max_abs"] = t["f32_vs_oracle"]["final"]["max_abs"]
@@ -279,7 +284,8 @@ def load_parity():
         for k, v in r.get("encode_1024_vs_oracle", {}).items():
             out[f"encode_1024_{k}_vs_oracle_rel"] = v["rel"]
         out["source"] = f"profiles/{name} (tests/test_gpu_baseline_parity.py on MI355X; committed, NOT measured in this run)"
-        out["latent_tolerance"] = "north_star 1e-3 is met by SDXL_DTYPE_F32 only; fp16-operand modes report measured drift"
+        out["latent_tolerance"] = ("north_star's 1e-3 on latents (unscaled) is met by SDXL_DTYPE_F32 and SDXL_DTYPE_F32_SPLIT; SDXL_DTYPE_F32_SPLIT_MIX is inside the tests' scaled bound "
+                                   "at config 2 only; the f16 mode reports its measured drift, 4.9x inside the reference's own f16 numerical class")
     except Exception:
         return None
     return out
@@ -664,7 +670,7 @@ def main():
     # HBM-side traffic of the same launches: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_step.py,
     # summarised by tools/pmc_traffic.py (gfx950 correction applied there); null when no committed summary exists
     traffic, traffic_src = None, None
-    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and args.dtype == "f16" and res == 1024:
             try:

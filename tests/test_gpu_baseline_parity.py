@@ -21,10 +21,10 @@ What is compared, and to which bar:
     trajectories grow well past real SDXL latents (|x| <~ 4), so the absolute bound is scaled with the trajectory:
     1e-3 * max(1, max|latent_ref| / 4); both the raw absolute and the relative error are recorded.
   * SDXL_DTYPE_F16 / SDXL_DTYPE_F16_F32RES (the speed modes) against the now oracle-anchored F32 engine on the SAME 31-step
-    1024x1024 CFG-7.5 trajectory: per-step max-abs / relative / rms error -> gpurun_out/r04_drift_*.json (committed under
+    1024x1024 CFG-7.5 trajectory: per-step max-abs / relative / rms error -> gpurun_out/r05_drift_*.json (committed under
     profiles/).  fp16 operands cannot meet 1e-3 absolute (one rounding is 4.9e-4 relative, CFG 7.5 multiplies the error of
     eps by up to 7.5 per step); the bound asserted here is the measured class with headroom, stated in DESIGN.md section 5.
-Everything goes through the C ABI (ctypes); measured numbers are written to gpurun_out/r04_parity_baseline.json.
+Everything goes through the C ABI (ctypes); measured numbers are written to gpurun_out/r05_parity_baseline.json.
 """
 import json
 import os
@@ -78,7 +78,7 @@ def _write_report():
     yield
     try:
         os.makedirs(OUT_DIR, exist_ok=True)
-        path = os.path.join(OUT_DIR, "r04_parity_baseline.json")
+        path = os.path.join(OUT_DIR, "r05_parity_baseline.json")
         merged = {}
         if os.path.exists(path):          # a partial run (-k ...) updates its own entries only
             try:
@@ -343,9 +343,9 @@ def test_config2_trajectory_parity_and_drift(pkg, ctx):
               f"(max-abs {per[-1]['max_abs']:.3e}, rms-rel {per[-1]['rms_rel']:.2e}); {secs[name]:.2f} s")
         try:
             os.makedirs(OUT_DIR, exist_ok=True)
-            with open(os.path.join(OUT_DIR, f"r04_drift_{name}.json"), "w") as fh:
+            with open(os.path.join(OUT_DIR, f"r05_drift_{name}.json"), "w") as fh:
                 json.dump(dict(config="SDXL-base 1024x1024, n_steps=30 (31 iterations), CFG 7.5, synthetic weights seed 0",
-                               reference="SDXL_DTYPE_F32 engine trajectory (oracle-anchored: f32_vs_oracle in r04_parity_baseline.json)",
+                               reference="SDXL_DTYPE_F32 engine trajectory (oracle-anchored: f32_vs_oracle in r05_parity_baseline.json)",
                                mode=name, per_step=per, ref_absmax=rep["ref_absmax"]), fh, indent=1)
         except OSError:
             pass
