@@ -175,6 +175,7 @@ int sdxl_debug_set(const char* key, int value) {
   else if (std::strcmp(key, "hl_demote") == 0) unet_set_hl_demote(value);
   else if (std::strcmp(key, "hl_tile96") == 0) igemm_set_hl_tile96(value);
   else if (std::strcmp(key, "wreg_xcd2d") == 0) igemm_set_wreg_xcd2d(value);
+  else if (std::strcmp(key, "wide_db") == 0) igemm_set_wide_db(value);
 #ifdef SDXL_MEASURE
   else if (std::strcmp(key, "igemm_unrolled") == 0) igemm_set_unrolled(value);
   else if (std::strcmp(key, "xa_vec64") == 0) igemm_set_xa_vec64(value);

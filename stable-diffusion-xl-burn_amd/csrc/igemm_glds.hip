@@ -773,7 +773,10 @@ void igemm_set_wide_timeline(void* buf) {
 #else
 #define WIDE_STAMP(i) do { } while (0)
 #endif
-template <int NS>
+// DB (round 5): fragments of the NEXT kk-step are requested before the MFMAs of the current one (two register sets, counted lgkmcnt, the pipe
+// kernels' scheme): the rolled form above waits for its seven ds_read_b128 in front of every 10-MFMA burst with nothing of its own to issue
+// meanwhile -- 1.85 - 1.97 k cycles per 32-deep k-tile for 1.28 k cycles of matrix-pipe work (profiles/r04_wide_geglu_timeline.txt).
+template <int NS, bool DB = false>
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, const void* zeros) {
 #ifdef SDXL_MEASURE
   unsigned wtl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -857,19 +860,23 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
     basea = lds0 + ra * ROWB + ((fh ^ ((ra >> 2) & 3)) << 4);
     baseb = lds0 + BM * ROWB + rbw * ROWB + ((fh ^ ((rbw >> 2) & 3)) << 4);
   }
-  half8 fA[TM], fB[TN];
-  auto ldfrag = [&](unsigned so, int kk) {       // chunk(kk) = (kk*2 + fh) ^ sw = (fh ^ sw) ^ (kk << 1) -> byte offset ^ (kk << 5)
+  constexpr int NSET = DB ? 2 : 1;
+  half8 fA[NSET][TM], fB[NSET][TN];
+  auto ldfrag = [&](auto SET, unsigned so, int kk) {       // chunk(kk) = (kk*2 + fh) ^ sw = (fh ^ sw) ^ (kk << 1) -> byte offset ^ (kk << 5)
+    constexpr int set = decltype(SET)::value;
     const unsigned aa = (basea ^ (kk << 5)) + so, ab = (baseb ^ (kk << 5)) + so;
-    static_for<TM>([&](auto I) { fA[decltype(I)::value] = lds_read128<decltype(I)::value * 32 * ROWB>(aa); });
-    static_for<TN>([&](auto J) { fB[decltype(J)::value] = lds_read128<decltype(J)::value * 32 * ROWB>(ab); });
+    static_for<TM>([&](auto I) { fA[set][decltype(I)::value] = lds_read128<decltype(I)::value * 32 * ROWB>(aa); });
+    static_for<TN>([&](auto J) { fB[set][decltype(J)::value] = lds_read128<decltype(J)::value * 32 * ROWB>(ab); });
   };
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, NSET - 1>;
   // ten MFMAs of one kk-step; with DMA: the PER pieces of the next tile go behind MFMAs 0, 2, 4, 6, 8
-  auto mma = [&](int buf, bool dma) {
+  auto mma = [&](auto SET, int buf, bool dma) {
+    constexpr int set = decltype(SET)::value;
     __builtin_amdgcn_s_setprio(1);
     static_for<TM * TN>([&](auto X) {
       constexpr int x = decltype(X)::value, i = x / TN, j = x % TN;
-      if constexpr (i == 0) acc0[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[j], fA[0], acc0[0][j], 0, 0, 0);
-      else acc1[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[j], fA[1], acc1[0][j], 0, 0, 0);
+      if constexpr (i == 0) acc0[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][j], fA[set][0], acc0[0][j], 0, 0, 0);
+      else acc1[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fB[set][j], fA[set][1], acc1[0][j], 0, 0, 0);
       if constexpr ((x & 1) == 0 && x / 2 < PER) {
         __builtin_amdgcn_sched_barrier(0);
         if (dma) issue(buf, std::integral_constant<int, x / 2>{});
@@ -916,12 +923,39 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[0][j][r] = 0.f; acc1[0][j][r] = 0.f; }
   int cur = 0;
+  if constexpr (DB) {
+    // set 0 = kk-step 0, set 1 = kk-step 1 of the current tile.  Per tile: {request set 1 | wait set 0 | 10 MFMAs} {own pieces of tile kt + 1,
+    // lgkmcnt(0) = every read of tile kt complete, barrier | request set 0 of tile kt + 1 | 10 MFMAs + the pieces of tile kt + NS}
+    ldfrag(S0{}, 0, 0);
+    wait_lgkmcnt<0>();       // (the compiler believes an asm read complete when the statement ends: nothing in flight across the loop entry)
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned so = cur * STAGE;
+      const int nxt = cur + 1 == NS ? 0 : cur + 1;
+      ldfrag(S1{}, so, 1);
+      wait_lgkmcnt<NF>();                         // set 0 has landed (the seven reads just issued may still be in flight)
+      if (kt == 0) mma(S0{}, NS - 1, NS - 1 < nk); else mma(S0{}, cur, false);
+      const bool more = kt + NS < nk;
+      if (kt + 1 < nk) {
+        if (kt + NS - 1 < nk) wait_tiles(std::integral_constant<int, NS - 2>{}); else wait_vmcnt<0>();
+        wait_lgkmcnt<0>();                        // set 1 has landed: all of this wave's reads of tile kt are complete
+        __builtin_amdgcn_s_barrier();             // tile kt+1 visible; slot of tile kt free for tile kt+NS
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ldfrag(S0{}, nxt * STAGE, 0);             // in flight under the MFMAs of kk-step 1
+      } else {
+        wait_lgkmcnt<0>();
+      }
+      mma(S1{}, cur, more);
+      cur = nxt;
+    }
+    wait_lgkmcnt<0>();
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned so = cur * STAGE;
-    ldfrag(so, 0);
+    ldfrag(S0{}, so, 0);
     wait_lgkmcnt<0>();
-    if (kt == 0) mma(NS - 1, NS - 1 < nk); else mma(cur, false);      // (k-tile 0 completes the ring: slot NS - 1 has never been read)
-    ldfrag(so, 1);
+    if (kt == 0) mma(S0{}, NS - 1, NS - 1 < nk); else mma(S0{}, cur, false);      // (k-tile 0 completes the ring: slot NS - 1 has never been read)
+    ldfrag(S0{}, so, 1);
     wait_lgkmcnt<0>();                          // own reads of tile kt complete
     const bool more = kt + NS < nk;
     if (kt + 1 < nk) {
@@ -930,7 +964,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
-    mma(cur, more);
+    mma(S0{}, cur, more);
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
   WIDE_STAMP(3);
@@ -1017,16 +1051,28 @@ static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2, TSW>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
 }
 
+static std::atomic<int> g_wide_db{0};     // measure builds, knob (sdxl_debug_set "wide_db"): 1 = the wide GEGLU kernel with register-double-buffered fragments
+void igemm_set_wide_db(int v) { g_wide_db = v; }
 static void launch_wide(const IgemmParams& p, hipStream_t s) {
   // three slots (was four): the k-loop is not latency-bound and the whole ring is requested before the first MFMA -- 108 instead of
   // 144 KiB per CU; same-box library A/B on the bench line 21.19 / 21.12 -> 21.07 / 21.09 ms per step (profiles/r04_ring_depth_lib_ab.txt)
   constexpr int NS = 3;
   const int tilesM = (p.M + 255) / 256, tilesN = (p.N + 319) / 320;
   const size_t lds = (size_t)NS * (256 + 320) * 64 + 2048;   // ring + LayerNorm coefficients
-  static bool attr_set[kMaxDev] = {};
+  static bool attr_set[2][kMaxDev] = {};
   const int dev = current_device();
-  set_lds_attr(&igemm_wide_kernel<NS>, lds, attr_set, dev);
-  hipLaunchKernelGGL((igemm_wide_kernel<NS>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_pages[dev]);
+#ifdef SDXL_MEASURE
+  // register-double-buffered fragment reads (DB): measured on the bench line A/B/A/B, 21.213 / 21.179 (DB) vs 21.209 / 21.190 ms per step -- no
+  // difference (profiles/r05_wide_double_buffer_ab.txt): the k-tile is LDS-bandwidth + matrix-pipe co-bound (112 KiB of fragment reads + 36 KiB of
+  // DMA writes = 1156 LDS cycles against 1280 MFMA cycles), not latency-bound.  Measure builds only.
+  if (g_wide_db.load()) {
+    set_lds_attr(&igemm_wide_kernel<NS, true>, lds, attr_set[1], dev);
+    hipLaunchKernelGGL((igemm_wide_kernel<NS, true>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_pages[dev]);
+    return;
+  }
+#endif
+  set_lds_attr(&igemm_wide_kernel<NS, false>, lds, attr_set[0], dev);
+  hipLaunchKernelGGL((igemm_wide_kernel<NS, false>), dim3(tilesM * tilesN), dim3(512), lds, s, p, g_zero_pages[dev]);
 }
 
 

@@ -96,6 +96,7 @@ int igemm_warm_enabled();
 void igemm_set_splitk_wt(int v);
 void igemm_set_hl_tile96(int v); // A/B knob (sdxl_debug_set "hl_tile96"): 0 = the split-operand GEMMs never take the 96-row tile
 void igemm_set_wreg_xcd2d(int v);
+void igemm_set_wide_db(int v);   // A/B knob (sdxl_debug_set "wide_db"): 0 = wide GEGLU kernel with the rolled fragment reads
 void igemm_set_wreg(int v);      // A/B knob (sdxl_debug_set "igemm_wreg"): 0 = the auto selection never picks the weights-in-registers kernel
 void igemm_set_variant(int v);   // debug / benchmarking knob: -1 generic kernel only, 0 auto, 1..3 forced fast-path tile
 void igemm_set_hl_weights_exact(int v); // A/B: 0 keeps all three MFMAs per product even where the packed weights are exact f16 values
