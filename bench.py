@@ -265,6 +265,12 @@ def load_parity():
         if "f32_vs_oracle" in t:
             out["config2_f32_vs_oracle_final_max_abs"] = t["f32_vs_oracle"]["final"]["max_abs"]
             out["config2_f32_vs_oracle_final_rel"] = t["f32_vs_oracle"]["final"]["rel"]
+        if "reference_f16_class" in t:    # the oracle's own 31-step trajectory in the reference's f16 arithmetic (LibTorch<f16>) vs its fp32 trajectory
+            out["config2_reference_f16_class_final_max_abs"] = t["reference_f16_class"]["final"]["max_abs"]
+            out["config2_reference_f16_class_final_rel"] = t["reference_f16_class"]["final"]["rel"]
+        for k in ("f32_split_mix", "f16", "f16_f32res"):
+            if k + "_vs_oracle" in t:
+                out[f"config2_{k}_vs_oracle_final_max_abs"] = t[k + "_vs_oracle"]["final"]["max_abs"]
         for k in ("f16", "f16_f32res"):
             if k + "_vs_f32" in t:
                 out[f"config2_{k}_vs_f32_final_rel"] = t[k + "_vs_f32"][-1]["rel"]

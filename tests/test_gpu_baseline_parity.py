@@ -336,6 +336,22 @@ def test_config2_trajectory_parity_and_drift(pkg, ctx):
             assert vo["final"]["rel"] < F16_TRAJ_REL[name], (name, vo["final"])
             for s_ in steps:
                 assert vo[str(s_)]["rel"] < F16_TRAJ_REL[name], (name, s_, vo[str(s_)])
+        # round 5: the same trajectory in the REFERENCE's own GPU arithmetic (oracle NUM "f16ref": LibTorch<f16>, every op output an f16 tensor;
+        # fixture fullsize_config2_f16ref.npz, 2721 s of oracle time): 1.03 absolute from the fp32 oracle at the end.  The engine's f16 modes must
+        # stay inside HALF of that class at every recorded step -- a bound that does not move with the engine.
+        g16p = os.path.join(GOLD, "fullsize_config2_f16ref.npz")
+        if os.path.exists(g16p):
+            g16 = np.load(g16p)
+            env_steps = {int(s_): errs(torch.from_numpy(g16["traj"][j]), ref_traj[j]) for j, s_ in enumerate(g16["steps"])}
+            env_final = errs(torch.from_numpy(g16["latent"]), torch.from_numpy(g["latent"]))
+            rep["reference_f16_class"] = {"final": env_final, **{str(k): v for k, v in env_steps.items()}}
+            print(f"config 2: reference f16 class (oracle f16ref vs fp32 oracle) final max-abs {env_final['max_abs']:.3e} rel {env_final['rel']:.3e}; "
+                  f"engine f16 is {env_final['max_abs'] / rep['f16_vs_oracle']['final']['max_abs']:.1f}x inside it")
+            for name in ("f16", "f16_f32res"):
+                assert rep[name + "_vs_oracle"]["final"]["max_abs"] <= 0.5 * env_final["max_abs"], (name, rep[name + "_vs_oracle"]["final"], env_final)
+                for s_ in steps:
+                    if s_ in env_steps:
+                        assert rep[name + "_vs_oracle"][str(s_)]["max_abs"] <= 0.5 * env_steps[s_]["max_abs"], (name, s_)
     for name in ("f16", "f16_f32res"):
         per = [errs(trajs[name][k], trajs["f32"][k]) for k in range(n_it)]
         rep[name + "_vs_f32"] = per
