@@ -712,6 +712,12 @@ void UNet::forward(int B, int H, int W, const float* t_dev, int t_stride, hipStr
   if (use_graph_ && !graph_ && plan_runs_ >= 1) {
     // capture the whole forward (~1.3k launches) once; replay costs one launch per forward
     hipGraph_t g = nullptr;
+    // the cross-workgroup tickets (attention key halves, split-K) re-arm themselves at the end of every launch; a forward that was torn down
+    // half way (device error, cancelled capture) would leave them armed wrongly for good -- re-zero them whenever a graph is (re)captured
+    for (int c = 0; c < 2; ++c) {
+      if (attn_xcnt_[c] && attn_xcnt_bytes_) SDXL_HIP(hipMemsetAsync(attn_xcnt_[c], 0, attn_xcnt_bytes_, s));
+      if (skcnt_[c]) SDXL_HIP(hipMemsetAsync(skcnt_[c], 0, kSplitkCounters * sizeof(unsigned), s));
+    }
     SDXL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     try { go(); } catch (...) { (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); act_.reset(m); throw; }
     SDXL_HIP(hipStreamEndCapture(s, &g));
