@@ -371,8 +371,8 @@ def test_config2_trajectory_parity_and_drift(pkg, ctx):
 
 def test_config2_second_prompt(pkg, ctx):
     """BASELINE configs[1] on a SECOND prompt / noise (seeds 231..235; fixture oracle/make_golden_r5.py config2b): one trajectory is not a distribution.
-    The fp32-class engines are held to the bound on every recorded step as on the first prompt; the mixed mode -- 1.13x under the bound there -- and the
-    f16 mode are recorded, the mixed mode held to 2x the bound."""
+    The fp32-class engines are held to the bound on every recorded step as on the first prompt -- and so is the mixed mode (measured 0.60 ... 0.77 of the
+    bound per step, 0.75 at the end: 0.0179 of 0.0238; first prompt: 0.88); the f16 mode is recorded against its relative bar."""
     gp = os.path.join(GOLD, "fullsize_config2b.npz")
     if not os.path.exists(gp):
         pytest.skip("tests/golden/fullsize_config2b.npz not generated (python -m oracle.make_golden_r5 config2b, ~25 min)")
@@ -399,7 +399,7 @@ def test_config2_second_prompt(pkg, ctx):
     REPORT["config2_second_prompt"] = rep
     for j, s_ in enumerate(steps):
         assert rep["f32_split"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split"][str(s_)])
-        assert rep["f32_split_mix"][str(s_)]["max_abs"] <= 2.0 * lat_bound(ref_traj[j]), (s_, rep["f32_split_mix"][str(s_)])
+        assert rep["f32_split_mix"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split_mix"][str(s_)])
     assert rep["f16"]["final"]["rel"] < F16_TRAJ_REL["f16"], rep["f16"]["final"]
 
 
