@@ -36,6 +36,8 @@ for p in $PARTS; do
     cfg1) timeout 900 python bench.py --config 1 --steps 3 --warmup 1 > $OUT/bench_cfg1.json 2> $OUT/bench_cfg1.err; tail -c 1200 $OUT/bench_cfg1.json;;
     cfg4) timeout 900 python bench.py --config 4 --steps 2 --warmup 1 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; tail -c 1200 $OUT/bench_cfg4.json;;
     cfg5) timeout 900 python bench.py --config 5 --steps 1 --warmup 1 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; tail -c 1200 $OUT/bench_cfg5.json;;
+    ppc) for n in 2 4; do timeout 900 python bench.py --prompts-per-call $n --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_ppc$n.json 2> $OUT/bench_ppc$n.err; python -c "import json; d=json.load(open('$OUT/bench_ppc$n.json')); print('prompts per call $n:', d['value'], d['unet_step_ms_p50'], d['roofline']['frac'])"; done;;
+    rocprofmix) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rpm -o r -- python $GRAFT_REPO_ROOT/bench.py --dtype f32_split_mix --steps 1 --warmup 1 --no-cpu-baseline --no-live-parity > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_mix.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof_mix.err); find /tmp/rpm -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats_mix.csv \; ; head -16 $OUT/kernel_stats_mix.csv | cut -c1-160;;
     custom) bash -c "${CUSTOM_CMD}" > $OUT/custom.log 2>&1; tail -60 $OUT/custom.log;;
   esac
 done
