@@ -291,7 +291,13 @@ __global__ void absmax_rows_kernel(const float* src, int lds_, size_t rows, int 
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns (NaN / inf sort on top)
+  // one atomic per WORKGROUP (round 5): with one per wave the 2048 x 4 atomics on a single address serialised in the L2 -- 97 us per call on
+  // average, 2.5 ms of a split-operand UNet step (profiles/r05_kernel_stats_mixed_mode.csv) -- for a pass that moves 5 - 40 MB
+  __shared__ float wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(out, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));      // non-negative floats order like their bit patterns (NaN / inf sort on top)
 }
 __device__ __forceinline__ float hl_stream_scale(float absmax) {
   if (!(absmax > 0.f) || !(absmax < INFINITY)) return 1.f;            // all-zero or non-finite tensors: nothing to rescue
@@ -326,7 +332,7 @@ void launch_f32_to_hl_scaled(const void* src, int lds_, void* dst, int ldd, size
   if ((C & 15) != 0 || (lds_ & 3) != 0 || (ldd & 15) != 0) throw std::runtime_error("f32_to_hl: C % 16 == 0 rows with aligned strides only");
   (void)hipMemsetAsync(scale_io, 0, 2 * sizeof(float), s);
   const size_t t4 = rows * (size_t)(C / 4);
-  hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)std::min<size_t>(2048, (t4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
+  hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)std::min<size_t>(512, (t4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
                      rows, C / 4, reinterpret_cast<unsigned*>(scale_io));
   const size_t total = rows * (size_t)(C / 8);
   hipLaunchKernelGGL(f32_to_hl_scaled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,

@@ -1344,10 +1344,13 @@ bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
   // 32^2 level (out-projections, cross-attention query projection, FF-out: 220 workgroups instead of 160).  Same k order in every tile shape, so the
   // choice never changes a result bit (A/B knob: sdxl_debug_set "hl_tile96").
   const long t96 = (long)((p.M + 95) / 96) * ((p.N + 127) / 128);
-  if (g_hl_tile96.load() && p.ksize == 1 && p.n_split >= p.N && t128 < 256 && t96 <= 256 && t96 > t128 && eff256 < (double)t96 / 256.0) {
+  const int t96mode = g_hl_tile96.load();      // 1: linear layers / 1x1 only (default), 2: 3x3 convolutions too (measured -0.15 % on the mixed mode's step: not selected)
+  if (t96mode && (p.ksize == 1 || t96mode >= 2) && p.n_split >= p.N && t128 < 256 && t96 <= 256 && t96 > t128 && eff256 < (double)t96 / 256.0) {
     launch_pipe<96, 128, 5, 3, 6, hl16_t>(q, s);
     return true;
   }
+  // (a 256x160 HL tile for the N = 320 convolutions of the 128^2 level -- no 17 % of column padding -- spills DMA pointers inside its k-loop: scratch
+  //  loads in the VM queue break the hand-counted vmcnt waits.  Not instantiated.)
   if (eff256 >= eff128) launch_pipe<256, 128, 3, 4, 8, hl16_t>(q, s);
   else launch_pipe<128, 128, 4, 4, 8, hl16_t>(q, s);
   return true;
