@@ -1314,7 +1314,7 @@ bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s) {
   return true;
 }
 
-static std::atomic<int> g_hl_tile96{1};
+static std::atomic<int> g_hl_tile96{5};      // bit 0: 96x128 for linears, bit 1: ... for 3x3 convs too (not selected), bit 2: 4-wave 128x160 for N % 160 == 0 layers
 void igemm_set_hl_tile96(int v) { g_hl_tile96 = v; }
 // Split-operand mode (DT_HL; igemm_common.h): HL16 operands on the same direct-to-LDS pipeline, 3 f16 MFMAs per 16-deep product.
 // Returns false for shapes the generic kernel must take (none in the VAE: its Cin % 32 != 0 layers are packed fp32).
@@ -1345,12 +1345,19 @@ bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
   // choice never changes a result bit (A/B knob: sdxl_debug_set "hl_tile96").
   const long t96 = (long)((p.M + 95) / 96) * ((p.N + 127) / 128);
   const int t96mode = g_hl_tile96.load();      // 1: linear layers / 1x1 only (default), 2: 3x3 convolutions too (measured -0.15 % on the mixed mode's step: not selected)
-  if (t96mode && (p.ksize == 1 || t96mode >= 2) && p.n_split >= p.N && t128 < 256 && t96 <= 256 && t96 > t128 && eff256 < (double)t96 / 256.0) {
+  if ((t96mode & 1) && (p.ksize == 1 || (t96mode & 2)) && p.n_split >= p.N && t128 < 256 && t96 <= 256 && t96 > t128 && eff256 < (double)t96 / 256.0) {
     launch_pipe<96, 128, 5, 3, 6, hl16_t>(q, s);
     return true;
   }
   // (a 256x160 HL tile for the N = 320 convolutions of the 128^2 level -- no 17 % of column padding -- spills DMA pointers inside its k-loop: scratch
   //  loads in the VM queue break the hand-counted vmcnt waits.  Not instantiated.)
+  // the 4-wave 128x160 tile (one wave per SIMD, up to 512 registers each) for layers whose width is a multiple of 160 but not of 128 -- the N = 320
+  // convolutions of the 128^2 level: two exact column tiles instead of three 128-wide ones with 17 % of padding.  Mixed-mode step 44.58 / 44.36 ->
+  // 44.11 / 44.02 ms, A/B/A/B, results bit-identical (profiles/r05_hl_tile160_ab.txt; knob hl_tile96 bit 2)
+  if ((t96mode & 4) && p.N % 160 == 0 && p.N % 128 != 0 && p.n_split >= p.N && !p.stat_out && p.act == 0) {
+    launch_pipe<128, 160, 3, 4, 4, hl16_t>(q, s);
+    return true;
+  }
   if (eff256 >= eff128) launch_pipe<256, 128, 3, 4, 8, hl16_t>(q, s);
   else launch_pipe<128, 128, 4, 4, 8, hl16_t>(q, s);
   return true;
