@@ -1314,7 +1314,7 @@ bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s) {
   return true;
 }
 
-static std::atomic<int> g_hl_tile96{5};      // bit 0: 96x128 for linears, bit 1: ... for 3x3 convs too (not selected), bit 2: 4-wave 128x160 for N % 160 == 0 layers
+static std::atomic<int> g_hl_tile96{13};     // bit 0: 96x128 for linears, bit 1: ... for 3x3 convs too (not selected), bit 2: 4-wave 128x160 for N % 160 == 0, N % 128 != 0 layers, bit 3: ... wherever the cost model prefers it
 void igemm_set_hl_tile96(int v) { g_hl_tile96 = v; }
 // Split-operand mode (DT_HL; igemm_common.h): HL16 operands on the same direct-to-LDS pipeline, 3 f16 MFMAs per 16-deep product.
 // Returns false for shapes the generic kernel must take (none in the VAE: its Cin % 32 != 0 layers are packed fp32).
@@ -1357,6 +1357,15 @@ bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
   if ((t96mode & 4) && p.N % 160 == 0 && p.N % 128 != 0 && p.n_split >= p.N && !p.stat_out && p.act == 0) {
     launch_pipe<128, 160, 3, 4, 4, hl16_t>(q, s);
     return true;
+  }
+  // ... and where it fills the chip's rounds better than the 128-wide tiles (cost model of the f16 selection, tile_cost): the M = 8192 x N = 640 shapes of
+  // the 64^2 level are exactly 256 tiles of 128x160 where 256x128 makes 160 and 128x128 320.  Mixed-mode step 41.14 / 41.32 -> 40.46 / 40.49 ms, A/B/A/B, bit-identical
+  // (profiles/r05_hl_tile160_ab.txt; knob hl_tile96 bit 3)
+  if ((t96mode & 8) && p.N % 160 == 0 && p.n_split >= p.N && !p.stat_out && p.act == 0) {
+    const int nk = p.Kpad / 32;
+    const double c160 = tile_cost(p.M, p.N, nk, 128, 160, 1.15);
+    const double cbest = std::min(tile_cost(p.M, p.N, nk, 256, 128, 1.0), tile_cost(p.M, p.N, nk, 128, 128, 1.0));
+    if (c160 < cbest) { launch_pipe<128, 160, 3, 4, 4, hl16_t>(q, s); return true; }
   }
   if (eff256 >= eff128) launch_pipe<256, 128, 3, 4, 8, hl16_t>(q, s);
   else launch_pipe<128, 128, 4, 4, 8, hl16_t>(q, s);
