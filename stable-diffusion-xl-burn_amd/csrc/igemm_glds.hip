@@ -1314,7 +1314,7 @@ bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s) {
   return true;
 }
 
-static std::atomic<int> g_hl_tile96{13};     // bit 0: 96x128 for linears, bit 1: ... for 3x3 convs too (not selected), bit 2: 4-wave 128x160 for N % 160 == 0, N % 128 != 0 layers, bit 3: ... wherever the cost model prefers it
+static std::atomic<int> g_hl_tile96{29};     // bit 0: 96x128 for linears, bit 1: ... for 3x3 convs too (not selected), bit 2: 4-wave 128x160 for N % 160 == 0, N % 128 != 0 layers, bit 3: ... wherever the cost model prefers it, bit 4: in-launch split-K for the K >= 10240 convolutions
 void igemm_set_hl_tile96(int v) { g_hl_tile96 = v; }
 // Split-operand mode (DT_HL; igemm_common.h): HL16 operands on the same direct-to-LDS pipeline, 3 f16 MFMAs per 16-deep product.
 // Returns false for shapes the generic kernel must take (none in the VAE: its Cin % 32 != 0 layers are packed fp32).
@@ -1351,6 +1351,16 @@ bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
   }
   // (a 256x160 HL tile for the N = 320 convolutions of the 128^2 level -- no 17 % of column padding -- spills DMA pointers inside its k-loop: scratch
   //  loads in the VM queue break the hand-counted vmcnt waits.  Not instantiated.)
+  // long contractions over a small output (the K >= 10240 convolutions of the 32^2 level: 80 tiles of 256x128): three k-slices per tile combined inside the
+  // launch, as in the f16 engine (igemm_splitk_slices: depends on one batch entry's shape only; slabs summed in slice order: bit-reproducible) -- 240
+  // workgroups instead of the 160 of 128x128 tiles.  Mixed-mode step 41.18 / 41.22 -> 40.60 / 40.56 ms, A/B/A/B; F32_SPLIT forward 2.16e-6 (was 2.12e-6),
+  // config-2 final latent 2.4e-4 (2.1e-4) from the oracle (profiles/r05_hl_tile160_ab.txt; knob hl_tile96 bit 4)
+  if ((t96mode & 16) && igemm_splitk_slices(p) > 1) {
+    q.splitk = igemm_splitk_slices(p);
+    q.splitk_wt = g_splitk_wt.load();
+    launch_pipe<256, 128, 3, 4, 8, hl16_t>(q, s);
+    return true;
+  }
   // the 4-wave 128x160 tile (one wave per SIMD, up to 512 registers each) for layers whose width is a multiple of 160 but not of 128 -- the N = 320
   // convolutions of the 128^2 level: two exact column tiles instead of three 128-wide ones with 17 % of padding.  Mixed-mode step 44.58 / 44.36 ->
   // 44.11 / 44.02 ms, A/B/A/B, results bit-identical (profiles/r05_hl_tile160_ab.txt; knob hl_tile96 bit 2)

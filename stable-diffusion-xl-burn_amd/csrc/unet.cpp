@@ -628,7 +628,7 @@ void UNet::ensure_plan(int B, int H, int W) {
         attn_xcnt_[c] = (unsigned*)act_.alloc(attn_xcnt_bytes_ + 256);
       }
     }
-    if (cdt_ == DT_F16) {   // split-K slabs + counters: chain 0 (and the second split-CFG chain)
+    if (cdt_ == DT_F16 || cdt_ == DT_HL) {   // split-K slabs + counters: chain 0 (and the second split-CFG chain)
       skws_bytes_ = igemm_splitk_ws_bytes(B, 1024, 1280);
       skws_[1] = nullptr; skcnt_[1] = nullptr;
       for (int c = 0; c < (split ? 2 : 1); ++c) {   // the second set only exists for the second split-CFG chain
