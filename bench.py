@@ -698,6 +698,10 @@ def main():
                 "event_overhead_us_per_launch": round(1e3 * ev_over_ms, 3),
                 "class_method": "eager pass with hipEvents around every launch, minus the per-launch event overhead "
                                 "((eager class sum - graph-replayed step p50) / launches) so that the classes sum to unet_step_ms_p50",
+                # the whole CFG step against the peak (2 UNet forwards = SURVEY 8d's 13.52 TFLOP at 1024^2 over the graph-replayed step p50): attention, norms
+                # and every launch boundary included -- next to the GEMM-class fraction above
+                "whole_step_tflops": None if not p50_all else round(2 * npc * fwd_tf / (p50_all / 1e3), 1),
+                "whole_step_frac_of_peak": None if not p50_all else round(2 * npc * fwd_tf / (p50_all / 1e3) / peak, 4),
                 "whole_job_tflops": round(tflop_image * value, 1),
                 "whole_job_frac_of_peak": round(tflop_image * value / (peak * max(world, 1)), 4),
                 "flop_accounting": "tflop_per_image is the REFERENCE's count (SURVEY 8d); the engine hoists the cross-attention K/V "

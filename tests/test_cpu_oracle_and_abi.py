@@ -187,6 +187,30 @@ def test_oracle_arithmetic_emulations():
     assert e16 > 2.0 * eall, (e16, eall)      # one rounding per op output costs several times what operand rounding of the GEMMs costs
 
 
+def test_asm_lint_publication_rule(tmp_path):
+    """tools/asm_lint.py rule 5 (round 5): write-through publication stores must be covered by vmcnt(0) before the ticket, and a publishing function
+    needs an sc1-load / buffer_inv reader path -- checked on hand-made assembly: the shipped form passes, two broken forms are reported."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("asm_lint", os.path.join(ROOT, "tools", "asm_lint.py"))
+    al = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(al)
+    good = """kern_good:
+\tglobal_store_dwordx4 v[0:1], v[2:5], off sc0 sc1
+\ts_nop 1
+\ts_waitcnt vmcnt(0)
+\tglobal_atomic_add_u32 v6, v[0:1], v7, off sc0
+\tglobal_load_dwordx4 v[8:11], v[0:1], off sc1
+\ts_endpgm
+"""
+    bad_wait = good.replace("\ts_waitcnt vmcnt(0)\n", "").replace("kern_good", "kern_no_wait")
+    bad_reader = good.replace("off sc1\n\ts_endpgm", "off\n\ts_endpgm").replace("kern_good", "kern_plain_reader")
+    for name, text, n in (("good", good, 0), ("bad_wait", bad_wait, 1), ("bad_reader", bad_reader, 1)):
+        f = tmp_path / (name + ".s")
+        f.write_text(text)
+        found = al.lint_publication(str(f))
+        assert len(found) == n, (name, found)
+
+
 def test_inline_asm_stores_carry_the_store_data_hazard_nop():
     """An inline-asm VMEM store of more than 64 bits hides the store-data hazard from the compiler (a VALU write of the data registers right behind it
     needs a wait state): every such statement in csrc/ must end with its own s_nop (the first write-through GroupNorm build produced NaNs)."""
@@ -598,7 +622,7 @@ def test_production_gemm_assembly_has_no_async_read_hazard(tmp_path):
     r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "--cuda-device-only", "-S", src, "-o", out,
                         "-Wno-unused-function"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    findings = asm_lint.lint(out)
+    findings = asm_lint.lint(out) + asm_lint.lint_publication(out)
     assert not findings, "\n".join(findings[:10])
     # the lint must see the kernels it is meant to check
     text = open(out).read()
@@ -608,7 +632,7 @@ def test_production_gemm_assembly_has_no_async_read_hazard(tmp_path):
     r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "--cuda-device-only", "-S", src2, "-o", out2,
                         "-Wno-unused-function"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    findings = asm_lint.lint(out2)
+    findings = asm_lint.lint(out2) + asm_lint.lint_publication(out2)
     assert not findings, "\n".join(findings[:10])
     assert "attn_d64_mix_kernel" in open(out2).read()
 

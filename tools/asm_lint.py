@@ -25,6 +25,9 @@ returns are in order).  Unlike the LGKM queue this one survives labels -- the we
 label reached by fall-through the state is kept, behind an unconditional branch it is the state of the first forward branch to that
 label, and every backward branch replays its loop body once with the state it arrives with (the steady state of the k-loop).
 
+Fifth rule (round 5): the write-through publication protocol (lint_publication): every `sc0 sc1` store is covered by `vmcnt(0)` before the next
+atomic RMW (the ticket), and a publishing function has an `sc1`-load / `buffer_inv` reader path.
+
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -x hip --cuda-device-only -S csrc/igemm_glds.hip -o /tmp/glds.s
     python tools/asm_lint.py /tmp/glds.s            -> exit status 1 if anything is reported
 """
@@ -223,10 +226,55 @@ def lint_vm(path):
     return findings
 
 
+def lint_publication(path):
+    """Fifth rule (round 5): the fence-free cross-workgroup publication of round 4 (attention key halves, split-K slabs).  A workgroup publishes with
+    inline-asm WRITE-THROUGH stores (`global_store_* ... sc0 sc1`), waits for them (`s_waitcnt vmcnt(0)`), then draws its ticket (an atomic RMW); the
+    reader takes the partner's image with L1-bypassing loads (`global_load_* ... sc1`) or behind an acquire fence.  Checked per function, in program order:
+      * between the last write-through store and the next atomic RMW there is an `s_waitcnt vmcnt(0)` -- a ticket drawn over stores still in flight
+        publishes bytes that have not left;
+      * a function that publishes this way and also holds a ticket reader path contains at least one `sc1` load or a `buffer_inv` / acquire
+        (`buffer_inv sc1`, or the compiler's acquire sequence) behind an atomic -- a plain load there could be served by a stale L1 line."""
+    findings, kernel = [], None
+    pending, saw_wt, saw_atomic_after_wt, saw_reader = None, False, False, False
+
+    def close():
+        if kernel and saw_wt and saw_atomic_after_wt and not saw_reader:
+            findings.append(f"{kernel}: publishes with write-through stores and draws a ticket, but no `sc1` load / `buffer_inv` reader path was found")
+
+    for ln, raw in enumerate(open(path), 1):
+        line = raw.strip()
+        if not line or line.startswith(";") or line.startswith("."):
+            continue
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m:
+            close()
+            kernel, pending, saw_wt, saw_atomic_after_wt, saw_reader = m.group(1), None, False, False, False
+            continue
+        code = line.split(";")[0].strip()
+        if not code:
+            continue
+        mn = code.split(None, 1)[0]
+        if mn.startswith(("global_store", "flat_store")) and " sc0" in code and " sc1" in code:
+            pending, saw_wt = (ln, code), True
+        elif mn == "s_waitcnt" and re.search(r"vmcnt\(0\)", code):
+            pending = None
+        elif mn.startswith(("global_atomic", "flat_atomic", "buffer_atomic")):
+            if pending is not None:
+                findings.append(f"{kernel}: line {ln}: `{code}` (ticket) issues with the write-through store `{pending[1]}` (line {pending[0]}) not covered "
+                                f"by an `s_waitcnt vmcnt(0)`")
+                pending = None
+            if saw_wt:
+                saw_atomic_after_wt = True
+        elif saw_atomic_after_wt and ((mn.startswith(("global_load", "flat_load")) and " sc1" in code) or mn.startswith("buffer_inv")):
+            saw_reader = True
+    close()
+    return findings
+
+
 if __name__ == "__main__":
     bad = []
     for p in sys.argv[1:]:
-        f = lint(p) + lint_vm(p)
+        f = lint(p) + lint_vm(p) + lint_publication(p)
         print(f"{p}: {len(f)} finding(s)")
         for x in f[:40]:
             print("  " + x)
