@@ -369,6 +369,31 @@ def test_config2_trajectory_parity_and_drift(pkg, ctx):
     REPORT["config2_trajectory"] = rep
 
 
+def test_split_operand_tile_selection_does_not_change_results(pkg, ctx):
+    """round 5: the split-operand GEMMs take the f16 engine's extra tiles (sdxl_debug_set "hl_tile96": 96x128 linears, 4-wave 128x160, in-launch
+    split-K for the long 3x3 convolutions).  Every tile sums k in the same order, so the tile bits (1 | 4 | 8) must not change one output bit;
+    split-K (bit 16) re-associates 13 long contractions and stays inside the strict forward bar."""
+    g = np.load(os.path.join(GOLD, "fullsize_unet1024.npz"))
+    cfg = pkg.sdxl_base_config()
+    x, t = seeded(1, 4, 128, 128, seed=111), torch.tensor([500], dtype=torch.int32)
+    c, y = seeded(1, 77, cfg.context_dim, seed=112), seeded(1, cfg.adm_in_channels, seed=113)
+    ref = torch.from_numpy(g["out"])
+    outs = {}
+    try:
+        for knob in (0, 13, 29):
+            pkg.debug_set("hl_tile96", knob)
+            u = pkg.UNet(ctx, cfg, pkg.DTYPE_F32_SPLIT, seed=0)
+            outs[knob] = u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu()
+            del u
+    finally:
+        pkg.debug_set("hl_tile96", 29)
+    assert torch.equal(outs[0], outs[13]), "a tile shape changed the k-summation order of a split-operand GEMM"
+    e0, e29 = errs(outs[0], ref), errs(outs[29], ref)
+    print(f"F32_SPLIT forward 1024^2 vs oracle: two-tile selection {e0['rel']:.3e}, with in-launch split-K {e29['rel']:.3e}")
+    assert e0["rel"] < F32_FWD_REL and e29["rel"] < F32_FWD_REL
+    REPORT["split_operand_tile_selection"] = {"tiles_256x128_128x128_only": e0, "default": e29}
+
+
 def test_config2_second_prompt(pkg, ctx):
     """BASELINE configs[1] on a SECOND prompt / noise (seeds 231..235; fixture oracle/make_golden_r5.py config2b): one trajectory is not a distribution.
     The fp32-class engines are held to the bound on every recorded step as on the first prompt -- and so is the mixed mode (measured 0.60 ... 0.77 of the
