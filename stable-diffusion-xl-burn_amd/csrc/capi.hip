@@ -173,6 +173,7 @@ int sdxl_debug_set(const char* key, int value) {
   else if (std::strcmp(key, "attn_xsplit") == 0) attention_set_xsplit(value);
   else if (std::strcmp(key, "splitk_wt") == 0) igemm_set_splitk_wt(value);
   else if (std::strcmp(key, "hl_demote") == 0) unet_set_hl_demote(value);
+  else if (std::strcmp(key, "mix_classes") == 0) unet_set_mix_classes(value);
   else if (std::strcmp(key, "hl_tile96") == 0) igemm_set_hl_tile96(value);
   else if (std::strcmp(key, "wreg_xcd2d") == 0) igemm_set_wreg_xcd2d(value);
   else if (std::strcmp(key, "wide_db") == 0) igemm_set_wide_db(value);

@@ -344,6 +344,34 @@ void launch_f32_to_hl(const void* src, int lds_, void* dst, int ldd, size_t rows
   hipLaunchKernelGGL(f32_to_hl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
                      reinterpret_cast<half_t*>(dst), ldd, rows, C / 8);
 }
+// debugging aid (SDXL_NAN_CHECK=1, eager forwards): counts the non-finite elements of a [rows][C] view (HL16 views: both halves of every element)
+__global__ void count_nonfinite_kernel(const void* src, int dt, int lds_, size_t rows, int C, unsigned* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const size_t r = i / C;
+  const int c = (int)(i - r * C);
+  bool bad;
+  if (dt == DT_HL) {
+    const half_t* p = reinterpret_cast<const half_t*>(src) + r * 2 * (size_t)lds_ + ((c >> 4) << 5) + (c & 15);
+    const float hi = (float)p[0], lo = (float)p[16];
+    bad = !(fabsf(hi) < INFINITY) || !(fabsf(lo) < INFINITY);
+  } else {
+    const float v = ld_f(src, r * lds_ + c, dt);
+    bad = !(fabsf(v) < INFINITY);
+  }
+  if (bad) atomicAdd(out, 1u);
+}
+unsigned count_nonfinite(const void* src, int dt, int lds_, size_t rows, int C, hipStream_t s) {
+  static unsigned* dev = nullptr;
+  if (!dev && hipMalloc((void**)&dev, sizeof(unsigned)) != hipSuccess) return 0;
+  (void)hipMemsetAsync(dev, 0, sizeof(unsigned), s);
+  const size_t total = rows * (size_t)C;
+  if (total) hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dt, lds_, rows, C, dev);
+  unsigned h = 0;
+  (void)hipMemcpyAsync(&h, dev, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  return h;
+}
 // f16 rows -> HL16 rows with zero lo halves (an f16 value IS its own hi half): the hand-over from an f16 kernel (the mixed mode's flash
 // attention) to a split-operand GEMM.  C % 16 == 0, lds % 8 == 0, ldd % 16 == 0.
 __global__ void f16_to_hl_kernel(const half_t* src, int lds_, half_t* dst, int ldd, size_t rows, int C8) {

@@ -223,6 +223,7 @@ struct Exec {
 enum MixClass { MIX_ATTN_F16 = 1, MIX_GEGLU_F16 = 2 };
 enum DemoteClass { DM_QKV = 1, DM_ATTN = 2, DM_OUT = 4, DM_XATTN = 8, DM_GEGLU = 16, DM_FF = 32, DM_CONV_RES = 64, DM_CONV_SKIP = 128,
                    DM_CONV_IO = 256, DM_CONV_UPDOWN = 512, DM_CONV_PROJ = 1024 };
+void unet_set_mix_classes(int v);
 void unet_set_hl_demote(int mask);
 int unet_hl_demote();
 

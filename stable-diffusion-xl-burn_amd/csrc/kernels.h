@@ -221,6 +221,7 @@ void launch_f32_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows,
 // the same for a tensor whose range the model does not bound (residual stream, VAE hidden state): converted times the power of two
 // that brings max|x| into [2^13, 2^14); scale_io (2 device floats) receives {max|x|, 2^-e} -- pass scale_io + 1 as IgemmParams::a_scale
 void launch_f32_to_hl_scaled(const void* src, int lds, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s);
+unsigned count_nonfinite(const void* src, int dt, int lds, size_t rows, int C, hipStream_t s);   // debugging aid (SDXL_NAN_CHECK): synchronises
 void launch_f16_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows, int C, hipStream_t s);   // f16 rows -> HL16 rows (lo = 0)
 void launch_hl_zero_lo(void* dst, int ldd, size_t rows, int C, hipStream_t s);   // HL16 rows: lo halves := 0 (precision-frontier instrument, UNet hl_demote)
 void launch_round_f16(float* p, size_t n, hipStream_t s);   // p[i] = float(half(p[i])): parameters as a HalfPrecisionSettings record holds them

@@ -130,6 +130,8 @@ void attention_hl(Exec& ex, const Act& q, const void* kh, int ldk, const void* v
 }
 }  // namespace
 
+static std::atomic<int> g_mix_classes{-1};     // A/B / debugging knob (sdxl_debug_set "mix_classes"): overrides the MixClass bits of SDXL_DTYPE_F32_SPLIT_MIX models built afterwards (-1 = the mode's own)
+void unet_set_mix_classes(int v) { g_mix_classes = v; }
 static std::atomic<int> g_hl_demote{0};
 void unet_set_hl_demote(int mask) { g_hl_demote = mask; }
 int unet_hl_demote() { return g_hl_demote.load(); }
@@ -167,7 +169,7 @@ void UNet::apply_demote_weights(hipStream_t s) {
 }
 
 UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st, int mix)
-    : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt), mix_(compute_dt == DT_HL ? mix : 0) {
+    : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt), mix_(compute_dt == DT_HL ? (mix && g_mix_classes.load() >= 0 ? g_mix_classes.load() : mix) : 0) {
   SDXL_REQUIRE(cfg.n_head_channels == 64, "this engine's fused attention kernel is specialised for 64 channels per head");
   SDXL_REQUIRE(!((compute_dt == DT_F32 || compute_dt == DT_HL) && stream_dt != DT_F32), "f32 / split-operand compute implies an f32 residual stream");
   SDXL_REQUIRE(cfg.model_channels % 32 == 0, "GroupNorm(32) needs model_channels % 32 == 0");
@@ -382,7 +384,8 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   //   * GEGLU projection on f16 operands (f16 LayerNorm output x f16-packed weights, the f16 wide-tile kernel) -- its output leaves the
   //     epilogue as HL16 (fp32-class), so FF-out's operand is not rounded a second time.
   const bool mix_attn = hl_attn && (mix_ & MIX_ATTN_F16) && C % 16 == 0;
-  const bool mix_geglu = hl_attn && (mix_ & MIX_GEGLU_F16) && !w.blocks.empty() && w.blocks[0].geglu.dt == DT_F16 && M % 8 == 0;
+  // (the GEGLU weights of a mixed-mode model are PACKED f16 at build: the f16 path is the only one they can take, whatever the token count)
+  const bool mix_geglu = hl_attn && !w.blocks.empty() && w.blocks[0].geglu.dt == DT_F16;
   Act qk16, ao16, ln16; void* vt16 = nullptr;
   if (mix_attn) {
     qk16 = ex.alloc(M, 2 * C, DT_F16); ao16 = ex.alloc(M, C, DT_F16);
@@ -390,6 +393,12 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     if (npad != HW && !ex.dry) launch_fill_zero(vt16, (size_t)B * C * npad * 2, ex.s);
   }
   if (mix_geglu) ln16 = ex.alloc(M, C, DT_F16);
+  // the f16 GEGLU kernels store an HL16 output through the LDS-staged epilogue of the wide / pipelined tiles -- the kernels every SDXL shape runs on
+  // (M = 2048 ... 32768).  Small token counts (tiny test nets: M < 256) run on other tiles; they take the form the F16_F32RES engine
+  // runs at every size -- f16 output -- and widen it.
+  const bool gg_direct = M >= 256;
+  Act gg16;
+  if (mix_geglu && !gg_direct) gg16 = ex.alloc(M, 4 * C, DT_F16);
   void* kh = hl_attn && !hl_direct ? ex.act->alloc(M * (size_t)C * 4) : nullptr;
   void* vth = hl_attn && !hl_direct ? ex.act->alloc((size_t)B * C * npad * 4) : nullptr;
   if (fuse_ln_) {
@@ -465,6 +474,10 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_layernorm(ex, b.n3, t, (int)M, mix_geglu ? ln16 : ln);
     demote_lo(ex, DM_GEGLU, ln, M, C);
     Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
+    if (mix_geglu && !gg_direct) {
+      run_linear(ex, b.geglu, ln16, (int)M, gg16, eg);
+      if (!ex.dry) launch_f16_to_hl(gg16.p, gg16.ld, gg.p, gg.ld, M, 4 * C, ex.s);
+    } else
     run_linear(ex, b.geglu, mix_geglu ? ln16 : ln, (int)M, gg, eg);
     demote_lo(ex, DM_FF, gg, M, 4 * C);
     er.cls = DM_FF;

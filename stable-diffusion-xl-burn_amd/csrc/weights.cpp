@@ -443,6 +443,19 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
                   " compute=" + std::to_string(w.dt >= 0 ? w.dt : ex.cdt) + " act=" + std::to_string(p.act) + " n_split=" + std::to_string(p.n_split));
   }
   if (ex.prof) ex.prof->end(ex.s);
+  {   // SDXL_NAN_CHECK=1 (eager forwards only: it synchronises): report the first GEMM whose output holds a non-finite value, and its input's state
+    static const bool nan_check = std::getenv("SDXL_NAN_CHECK") != nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (nan_check && hipStreamIsCapturing(ex.s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+      const int nout = p.act == 1 ? p.N / 2 : (p.n_split < p.N ? p.n_split : p.N);
+      const unsigned bo = nout > 0 ? count_nonfinite(out.p, out.dt, out.ld, (size_t)p.M, nout, ex.s) : 0;
+      if (bo) {
+        const unsigned bi = p.ksize == 1 && p.stride == 1 && !p.up ? count_nonfinite(a.p, a.dt, a.ld, (size_t)p.M, cin, ex.s) : 0;
+        std::fprintf(stderr, "[nan] GEMM tag %d M %d N %d K %d ks %d act %d a_dt %d c_dt %d compute %d: %u non-finite outputs, %u non-finite inputs\n", e.cls, p.M, p.N,
+                     p.K, p.ksize, p.act, p.a_dt, p.c_dt, w.dt >= 0 ? w.dt : ex.cdt, bo, bi);
+      }
+    }
+  }
   if (ex.fork_ev && ++ex.launches == ex.fork_after) SDXL_HIP(hipEventRecord(ex.fork_ev, ex.s));
   return p.gn_part != nullptr;
 }

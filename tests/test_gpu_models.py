@@ -177,7 +177,7 @@ def test_fused_cross_attention_matches_two_kernel_path(pkg, ctx):
     assert e_f < FWD_TOL[1] and e_p < FWD_TOL[1] and e_fp < 4e-3
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4])
 def test_unet_forward_batch_independence(pkg, ctx, dtype):
     # the engine batches the CFG pair; per-sample results must not depend on what else is in the batch
     ocfg = OC.tiny_config()
@@ -190,7 +190,7 @@ def test_unet_forward_batch_independence(pkg, ctx, dtype):
         assert torch.equal(one[0], both[i])
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("n,n_steps,cfg_scale", [(1, 4, 7.5), (2, 8, 1.0)])
 def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
     ocfg = OC.tiny_config()
@@ -209,7 +209,7 @@ def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
     assert torch.equal(out, out2), "trajectory is not deterministic"
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 3, 4])
 def test_refine_latent(pkg, ctx, dtype):
     ocfg = OC.tiny_refiner_config()
     res = (64, 64)
@@ -223,7 +223,7 @@ def test_refine_latent(pkg, ctx, dtype):
     assert e < lat_tol(dtype, ref)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 3, 4])
 def test_sample_latent_with_inpainting(pkg, ctx, dtype):
     ocfg = OC.tiny_config()
     res = (64, 64)
