@@ -45,13 +45,18 @@ enum {
                              * accumulation) -- the reference decodes in f32, src/bin/sample/main.rs:121,271-278 -- at a third of the
                              * f16 matrix rate instead of the 1/16 of the exact-fp32 MFMA.  Measured: 2.3e-4 on the 31-step latent
                              * of config 2 against the CPU oracle (SDXL_DTYPE_F32: 3.9e-4) at 2.7x the speed of SDXL_DTYPE_F32      */
-  SDXL_DTYPE_F32_SPLIT_MIX = 4 /* UNet / Diffuser only (round 5): SDXL_DTYPE_F32_SPLIT with the two GEMM classes that the measured precision frontier
+  SDXL_DTYPE_F32_SPLIT_MIX = 4, /* UNet / Diffuser only (round 5): SDXL_DTYPE_F32_SPLIT with the two GEMM classes that the measured precision frontier
                              * (profiles/r05_precision_frontier.json) shows it can afford run on plain f16 operands -- the self-attention (f16 flash
                              * kernel on f16 q / k / v) and the GEGLU projection (f16 LayerNorm output x f16 weights, output kept fp32-class) --
                              * everything else (QKV / out / cross-attention projections, FF-out, every convolution, the residual stream) stays
                              * fp32-class.  Config-2 final latent inside the scaled 1e-3 bound of the parity tests at ~1.3x the speed of
                              * SDXL_DTYPE_F32_SPLIT; not below the UNSCALED 1e-3 (SDXL_DTYPE_F32_SPLIT is), and 1.3-1.4x over the scaled bound on
                              * the 4-step inpainting fixture: a precision point between F32_SPLIT and F16, not a second strict mode              */
+  SDXL_DTYPE_F32_SPLIT_MIX_F16W = 5 /* SDXL_DTYPE_F32_SPLIT_MIX for models whose PARAMETERS ARE f16 VALUES (what the reference's records hold, HalfPrecisionSettings:
+                             * src/bin/sample/main.rs:37): with exact f16 weights a class on f16 operands only rounds activations, and the measured frontier
+                             * affords three more -- the QKV projection, the self-attention's out-projection and FF-out.  Config-2 final latent 0.0169 (scaled
+                             * bound 0.0212) at a UNet step of 29.3 - 30.5 ms = 1.0 img/s on f16-representable weights; on fp32 weights it is OUTSIDE the bound
+                             * (0.029): use SDXL_DTYPE_F32_SPLIT_MIX there                                                                                       */
 };
 
 /* UNetConfig (src/model/unet/mod.rs:59-69) + DiffuserConfig.is_refiner (src/model/stablediffusion/mod.rs:269-278) */
@@ -283,7 +288,8 @@ int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int 
  * "splitk_wt": 0 = split-K slabs published by plain stores + an agent-scope release instead of write-through stores (A/B, default 1);
  * "hl_tile96": bit set of the extra tiles of the split-operand GEMMs (A/B; results unchanged): 1 = 96x128 for the M = 2048 x N = 1280 linears, 2 = ... for
  *   3x3 convolutions too, 4 = 4-wave 128x160 for widths that are multiples of 160 but not of 128, 8 = 128x160 wherever the cost model prefers it, 16 = in-launch split-K (3 slices) for the K >= 10240 convolutions of the 32^2 level (default 29);
- * "mix_classes": overrides the f16 classes of SDXL_DTYPE_F32_SPLIT_MIX models built afterwards (1 = self-attention, 2 = GEGLU projection, -1 = the mode's own);
+ * "mix_classes": overrides the f16 classes of SDXL_DTYPE_F32_SPLIT_MIX* models built afterwards (1 = self-attention, 2 = GEGLU projection, 4 = QKV projection,
+ *   8 = FF-out, 16 = self-attention out-projection, -1 = the mode's own);
  *   A/B and bisecting (environment SDXL_NAN_CHECK=1 makes eager forwards report the first GEMM with a non-finite output on stderr);
  * "hl_demote": bit set of GEMM classes (csrc/engine.h DemoteClass) that a SDXL_DTYPE_F32_SPLIT UNet runs on operands with zero lo halves --
  *   the f16 engine's operand rounding class by class on the split engine's kernels: the precision-frontier instrument

@@ -59,16 +59,19 @@ VaeCfg to_vcfg(const sdxl_vae_config* c) {
   return v;
 }
 void no_mix(int dtype) {     // the mixed mode is a property of the UNet driver (which classes run in f16): UNet / Diffuser handles only
-  if (dtype == SDXL_DTYPE_F32_SPLIT_MIX) throw Error("SDXL_DTYPE_F32_SPLIT_MIX is a UNet / Diffuser mode (use SDXL_DTYPE_F32_SPLIT here)");
+  if (dtype == SDXL_DTYPE_F32_SPLIT_MIX || dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W) throw Error("SDXL_DTYPE_F32_SPLIT_MIX* are UNet / Diffuser modes (use SDXL_DTYPE_F32_SPLIT here)");
 }
-int mix_of(int dtype) { return dtype == SDXL_DTYPE_F32_SPLIT_MIX ? (MIX_ATTN_F16 | MIX_GEGLU_F16) : 0; }
+int mix_of(int dtype) {
+  return dtype == SDXL_DTYPE_F32_SPLIT_MIX ? (MIX_ATTN_F16 | MIX_GEGLU_F16)
+       : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16) : 0;
+}
 void dtypes(int dtype, int& cdt, int& sdt) {
   switch (dtype) {
     case SDXL_DTYPE_F32: cdt = DT_F32; sdt = DT_F32; break;
     case SDXL_DTYPE_F16: cdt = DT_F16; sdt = DT_F16; break;
     case SDXL_DTYPE_F16_F32RES: cdt = DT_F16; sdt = DT_F32; break;
     case SDXL_DTYPE_F32_SPLIT: cdt = DT_HL; sdt = DT_F32; break;   // UNet / Diffuser / VAE only (no_split() guards the rest)
-    case SDXL_DTYPE_F32_SPLIT_MIX: cdt = DT_HL; sdt = DT_F32; break;   // UNet / Diffuser only (mix_of() carries the f16 classes)
+    case SDXL_DTYPE_F32_SPLIT_MIX: case SDXL_DTYPE_F32_SPLIT_MIX_F16W: cdt = DT_HL; sdt = DT_F32; break;   // UNet / Diffuser only (mix_of() carries the f16 classes)
     default: throw Error("unknown dtype");
   }
 }

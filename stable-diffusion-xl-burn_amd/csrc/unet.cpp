@@ -36,7 +36,8 @@ ResBlockW load_res(WeightBuilder& wb, const std::string& p, int cin, int cout, s
   emb_off += cout;
   return r;
 }
-STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln, bool geglu_f16 = false) {
+STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln, int mix = 0) {
+  const bool geglu_f16 = (mix & MIX_GEGLU_F16) != 0, qkv_f16 = (mix & MIX_QKV_F16) != 0, ff_f16 = (mix & MIX_FF_F16) != 0, out1_f16 = (mix & MIX_OUT1_F16) != 0;
   STW s;
   s.C = C; s.heads = heads;
   s.norm = wb.norm(p + ".norm");
@@ -58,8 +59,8 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
       continue;
     }
     t.n1 = wb.norm(q + ".norm1");
-    t.qkv = wb.fused_linear({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"});
-    t.out1 = wb.linear(q + ".attn1.out");
+    t.qkv = wb.fused_linear({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, qkv_f16 ? (int)DT_F16 : -1);
+    t.out1 = wb.linear(q + ".attn1.out", false, out1_f16 ? (int)DT_F16 : -1);
     t.n2 = wb.norm(q + ".norm2");
     t.q2 = wb.linear(q + ".attn2.query");
     t.kv2 = wb.fused_linear({q + ".attn2.key", q + ".attn2.value"});
@@ -67,7 +68,7 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     t.n3 = wb.norm(q + ".norm3");
     // (mixed mode: the GEGLU projection of a split-operand model packed as plain f16 -- it runs on the f16 wide-tile kernel)
     t.geglu = wb.linear(q + ".mlp.geglu.proj", true, geglu_f16 ? (int)DT_F16 : -1);
-    t.ff = wb.linear(q + ".mlp.lin");
+    t.ff = wb.linear(q + ".mlp.lin", false, ff_f16 ? (int)DT_F16 : -1);
     s.blocks.push_back(t);
   }
   s.proj_out = wb.linear(p + ".proj_out");
@@ -203,7 +204,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
       case BK_RES: b.res = load_res(wb, p, d.c_in, d.c_out, emb_names, emb_off); break;
       default:
         b.res = load_res(wb, p + ".res", d.c_in, d.c_out, emb_names, emb_off);
-        if (d.kind == BK_REST || d.kind == BK_RESTU) b.st = load_st(wb, p + ".transformer", d.c_out, d.n_head, d.depth, fuse_ln_, (mix_ & MIX_GEGLU_F16) != 0);
+        if (d.kind == BK_REST || d.kind == BK_RESTU) b.st = load_st(wb, p + ".transformer", d.c_out, d.n_head, d.depth, fuse_ln_, mix_);
         if (d.kind == BK_RESTU || d.kind == BK_RESU) b.conv = wb.conv(p + ".upsample.conv");
     }
     return b;
@@ -211,7 +212,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
   for (size_t i = 0; i < inp.size(); ++i) inp_.push_back(load_block("input_blocks." + std::to_string(i), inp[i]));
   mid_res1_.d = mid;
   mid_res1_.res = load_res(wb, "middle_block.res1", mid.c_in, mid.c_out, emb_names, emb_off);
-  mid_res1_.st = load_st(wb, "middle_block.transformer", mid.c_out, mid.n_head, mid.depth, fuse_ln_, (mix_ & MIX_GEGLU_F16) != 0);
+  mid_res1_.st = load_st(wb, "middle_block.transformer", mid.c_out, mid.n_head, mid.depth, fuse_ln_, mix_);
   mid_res2_.d = mid;
   mid_res2_.res = load_res(wb, "middle_block.res2", mid.c_in, mid.c_out, emb_names, emb_off);
   for (size_t i = 0; i < out.size(); ++i) out_.push_back(load_block("output_blocks." + std::to_string(i), out[i]));
@@ -383,7 +384,12 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   //     handed to the out-projection as HL16 with zero lo halves (an f16 value is its own hi half);
   //   * GEGLU projection on f16 operands (f16 LayerNorm output x f16-packed weights, the f16 wide-tile kernel) -- its output leaves the
   //     epilogue as HL16 (fp32-class), so FF-out's operand is not rounded a second time.
-  const bool mix_attn = hl_attn && (mix_ & MIX_ATTN_F16) && C % 16 == 0;
+  const bool mix_qkv = hl_attn && !w.blocks.empty() && w.blocks[0].qkv.dt == DT_F16;     // (f16-packed at build: the only path those weights can take)
+  const bool mix_ff = hl_attn && !w.blocks.empty() && w.blocks[0].ff.dt == DT_F16;
+  const bool mix_out1 = hl_attn && !w.blocks.empty() && w.blocks[0].out1.dt == DT_F16;
+  const bool mix_attn = hl_attn && ((mix_ & MIX_ATTN_F16) || mix_qkv) && C % 16 == 0;
+  SDXL_REQUIRE(!mix_qkv || mix_attn, "mixed mode: an f16 QKV projection feeds the f16 self-attention");
+  SDXL_REQUIRE(!mix_out1 || mix_attn, "mixed mode: an f16 out-projection reads the f16 self-attention's output");
   // (the GEGLU weights of a mixed-mode model are PACKED f16 at build: the f16 path is the only one they can take, whatever the token count)
   const bool mix_geglu = hl_attn && !w.blocks.empty() && w.blocks[0].geglu.dt == DT_F16;
   Act qk16, ao16, ln16; void* vt16 = nullptr;
@@ -392,13 +398,13 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     vt16 = ex.act->alloc((size_t)B * C * npad * 2);
     if (npad != HW && !ex.dry) launch_fill_zero(vt16, (size_t)B * C * npad * 2, ex.s);
   }
-  if (mix_geglu) ln16 = ex.alloc(M, C, DT_F16);
+  if (mix_geglu || mix_qkv) ln16 = ex.alloc(M, C, DT_F16);
   // the f16 GEGLU kernels store an HL16 output through the LDS-staged epilogue of the wide / pipelined tiles -- the kernels every SDXL shape runs on
   // (M = 2048 ... 32768).  Small token counts (tiny test nets: M < 256) run on other tiles; they take the form the F16_F32RES engine
   // runs at every size -- f16 output -- and widen it.
   const bool gg_direct = M >= 256;
   Act gg16;
-  if (mix_geglu && !gg_direct) gg16 = ex.alloc(M, 4 * C, DT_F16);
+  if ((mix_geglu && !gg_direct) || mix_ff) gg16 = ex.alloc(M, 4 * C, DT_F16);      // (an f16 FF-out reads the GEGLU output as f16, whichever kernel wrote it)
   void* kh = hl_attn && !hl_direct ? ex.act->alloc(M * (size_t)C * 4) : nullptr;
   void* vth = hl_attn && !hl_direct ? ex.act->alloc((size_t)B * C * npad * 4) : nullptr;
   if (fuse_ln_) {
@@ -433,13 +439,13 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   } else
   for (size_t j = 0; j < w.blocks.size(); ++j) {
     const TBlockW& b = w.blocks[j];
-    run_layernorm(ex, b.n1, t, (int)M, ln);
+    run_layernorm(ex, b.n1, t, (int)M, mix_qkv ? ln16 : ln);
     demote_lo(ex, DM_QKV, ln, M, C);
     Epi eq; eq.n_split = 2 * C; eq.Ct = mix_attn ? vt16 : vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.cls = DM_QKV;
-    run_linear(ex, b.qkv, ln, (int)M, mix_attn ? qk16 : qk, eq);
+    run_linear(ex, b.qkv, mix_qkv ? ln16 : ln, (int)M, mix_attn ? qk16 : qk, eq);
     if (mix_attn) {
       attention(ex, qk16, qk16.cols(C), vt16, npad, ao16, B, w.heads, HW, HW);
-      if (!ex.dry) launch_f16_to_hl(ao16.p, ao16.ld, ao.p, ao.ld, M, C, ex.s);
+      if (!ex.dry && !mix_out1) launch_f16_to_hl(ao16.p, ao16.ld, ao.p, ao.ld, M, C, ex.s);
     }
     else if (hl_attn && hl_direct) {     // q | k and V^T are HL16; the attention writes the out-projection's operand
       demote_lo(ex, DM_ATTN, qk, M, 2 * C);
@@ -456,7 +462,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     else attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
     Epi er; er.R = t; er.rpb = HW; er.cls = DM_OUT;
     demote_lo(ex, DM_OUT, ao, M, C);
-    run_linear(ex, b.out1, ao, (int)M, t, er);
+    run_linear(ex, b.out1, mix_out1 ? ao16 : ao, (int)M, t, er);
     run_layernorm(ex, b.n2, t, (int)M, ln);
     demote_lo(ex, DM_XATTN, ln, M, C);
     if (xattn) {
@@ -474,14 +480,16 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_layernorm(ex, b.n3, t, (int)M, mix_geglu ? ln16 : ln);
     demote_lo(ex, DM_GEGLU, ln, M, C);
     Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
-    if (mix_geglu && !gg_direct) {
+    if (mix_ff) {
+      run_linear(ex, b.geglu, mix_geglu ? ln16 : ln, (int)M, gg16, eg);         // f16 output for the f16 FF-out (f16 or split-operand GEGLU compute)
+    } else if (mix_geglu && !gg_direct) {
       run_linear(ex, b.geglu, ln16, (int)M, gg16, eg);
       if (!ex.dry) launch_f16_to_hl(gg16.p, gg16.ld, gg.p, gg.ld, M, 4 * C, ex.s);
     } else
     run_linear(ex, b.geglu, mix_geglu ? ln16 : ln, (int)M, gg, eg);
     demote_lo(ex, DM_FF, gg, M, 4 * C);
     er.cls = DM_FF;
-    run_linear(ex, b.ff, gg, (int)M, t, er);
+    run_linear(ex, b.ff, mix_ff ? gg16 : gg, (int)M, t, er);
   }
   Epi eo; eo.R = x; eo.rpb = HW; eo.cls = DM_CONV_PROJ;
   run_linear(ex, w.proj_out, hl_op(ex, w.proj_out, t, M, C, DM_CONV_PROJ), (int)M, x, eo);

@@ -443,7 +443,8 @@ def test_config2_trajectory_f16_representable_weights(pkg, ctx):
     steps = [int(s_) for s_ in g["steps"]]
     ref_traj, ref = torch.from_numpy(g["traj"]), torch.from_numpy(g["latent"])
     rep = {}
-    for name, dt in (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_mix", pkg.DTYPE_F32_SPLIT_MIX), ("f16", pkg.DTYPE_F16)):
+    for name, dt in (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_mix", pkg.DTYPE_F32_SPLIT_MIX), ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W),
+                     ("f16", pkg.DTYPE_F16)):
         d = pkg.Diffuser(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS)
         trace = torch.zeros(31, 1, 4, 128, 128, device="cuda")
         d.set_trace(trace)
@@ -463,7 +464,10 @@ def test_config2_trajectory_f16_representable_weights(pkg, ctx):
     for j, s_ in enumerate(steps):
         assert rep["f32_split"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split"][str(s_)])
         assert rep["f32_split_mix"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split_mix"][str(s_)])
+        # SDXL_DTYPE_F32_SPLIT_MIX_F16W (QKV projection and FF-out on f16 as well: the mode FOR these weights): same bar on every recorded step
+        assert rep["f32_split_mix_f16w"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split_mix_f16w"][str(s_)])
     assert rep["f32_split_mix"]["final"]["max_abs"] <= lat_bound(ref)
+    assert rep["f32_split_mix_f16w"]["final"]["max_abs"] <= lat_bound(ref)
     assert rep["f16"]["final"]["rel"] < F16_TRAJ_REL["f16"], rep["f16"]["final"]
 
 
