@@ -417,7 +417,7 @@ def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str):
             a5, r5 = _rel(lat5, refw)
             out["config2_f16weights_f32_split_mix_f16w_vs_oracle_final_max_abs"], out["config2_f16weights_f32_split_mix_f16w_vs_oracle_final_rel"] = a5, r5
             strict["f32_split_mix_f16w_mode_f16_weights"] = {
-                "precision": "SDXL_DTYPE_F32_SPLIT_MIX_F16W UNet (split engine; self-attention and its out-projection, GEGLU, QKV projection and FF-out on plain f16 operands: the classes the measured "
+                "precision": "SDXL_DTYPE_F32_SPLIT_MIX_F16W UNet (split engine; self-attention, both attentions' out-projections, GEGLU, QKV projection and FF-out on plain f16 operands: the classes the measured "
                              "frontier affords when the parameters are exact f16 values) on f16-representable weights + the timed VAE; oracle = the same weights",
                 "images_per_sec": round(1.0 / dt5, 4), "unet_step_ms": round(statistics.median(steps5), 2) if steps5 else None, "images_timed": 1,
                 "config2_final_latent_max_abs_vs_oracle": a5, "meets_1e-3": bool(a5 <= 1e-3), "lat_bound_scaled": lbw, "inside_lat_bound_scaled": bool(a5 <= lbw),

@@ -54,8 +54,8 @@ enum {
                              * the 4-step inpainting fixture: a precision point between F32_SPLIT and F16, not a second strict mode              */
   SDXL_DTYPE_F32_SPLIT_MIX_F16W = 5 /* SDXL_DTYPE_F32_SPLIT_MIX for models whose PARAMETERS ARE f16 VALUES (what the reference's records hold, HalfPrecisionSettings:
                              * src/bin/sample/main.rs:37): with exact f16 weights a class on f16 operands only rounds activations, and the measured frontier
-                             * affords three more -- the QKV projection, the self-attention's out-projection and FF-out.  Config-2 final latent 0.0169 (scaled
-                             * bound 0.0212) at a UNet step of 29.3 - 30.5 ms = 1.0 img/s on f16-representable weights; on fp32 weights it is OUTSIDE the bound
+                             * affords four more -- the QKV projection, both attentions' out-projections and FF-out.  Config-2 final latent 0.0170 (scaled
+                             * bound 0.0212) at a UNet step of 29.7 - 30.6 ms = 1.0 img/s on f16-representable weights; on fp32 weights it is OUTSIDE the bound
                              * (0.029): use SDXL_DTYPE_F32_SPLIT_MIX there                                                                                       */
 };
 

@@ -37,7 +37,8 @@ ResBlockW load_res(WeightBuilder& wb, const std::string& p, int cin, int cout, s
   return r;
 }
 STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln, int mix = 0) {
-  const bool geglu_f16 = (mix & MIX_GEGLU_F16) != 0, qkv_f16 = (mix & MIX_QKV_F16) != 0, ff_f16 = (mix & MIX_FF_F16) != 0, out1_f16 = (mix & MIX_OUT1_F16) != 0;
+  const bool geglu_f16 = (mix & MIX_GEGLU_F16) != 0, qkv_f16 = (mix & MIX_QKV_F16) != 0, ff_f16 = (mix & MIX_FF_F16) != 0, out1_f16 = (mix & MIX_OUT1_F16) != 0,
+             out2_f16 = (mix & MIX_OUT2_F16) != 0;
   STW s;
   s.C = C; s.heads = heads;
   s.norm = wb.norm(p + ".norm");
@@ -64,7 +65,7 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     t.n2 = wb.norm(q + ".norm2");
     t.q2 = wb.linear(q + ".attn2.query");
     t.kv2 = wb.fused_linear({q + ".attn2.key", q + ".attn2.value"});
-    t.out2 = wb.linear(q + ".attn2.out");
+    t.out2 = wb.linear(q + ".attn2.out", false, out2_f16 ? (int)DT_F16 : -1);
     t.n3 = wb.norm(q + ".norm3");
     // (mixed mode: the GEGLU projection of a split-operand model packed as plain f16 -- it runs on the f16 wide-tile kernel)
     t.geglu = wb.linear(q + ".mlp.geglu.proj", true, geglu_f16 ? (int)DT_F16 : -1);
@@ -387,6 +388,9 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   const bool mix_qkv = hl_attn && !w.blocks.empty() && w.blocks[0].qkv.dt == DT_F16;     // (f16-packed at build: the only path those weights can take)
   const bool mix_ff = hl_attn && !w.blocks.empty() && w.blocks[0].ff.dt == DT_F16;
   const bool mix_out1 = hl_attn && !w.blocks.empty() && w.blocks[0].out1.dt == DT_F16;
+  const bool mix_out2 = hl_attn && !w.blocks.empty() && w.blocks[0].out2.dt == DT_F16;
+  Act ao32, ao2_16;
+  if (mix_out2) { ao32 = ex.alloc(M, C, DT_F32); ao2_16 = ex.alloc(M, C, DT_F16); }
   const bool mix_attn = hl_attn && ((mix_ & MIX_ATTN_F16) || mix_qkv) && C % 16 == 0;
   SDXL_REQUIRE(!mix_qkv || mix_attn, "mixed mode: an f16 QKV projection feeds the f16 self-attention");
   SDXL_REQUIRE(!mix_out1 || mix_attn, "mixed mode: an f16 out-projection reads the f16 self-attention's output");
@@ -472,11 +476,12 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     } else {
       { Epi e2q; e2q.cls = DM_XATTN; run_linear(ex, b.q2, ln, (int)M, q, e2q); }
       demote_lo(ex, DM_XATTN, q, M, C);
-      if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_, DM_XATTN);   // caches are HL16 (set_context)
+      if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao32 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);   // caches are HL16 (set_context)
       else attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
     }
     demote_lo(ex, DM_OUT, ao, M, C);
-    run_linear(ex, b.out2, ao, (int)M, t, er);
+    if (mix_out2 && !ex.dry) launch_copy_rows(ao32.p, DT_F32, ao32.ld, ao2_16.p, DT_F16, ao2_16.ld, (int)M, C, ex.s);
+    run_linear(ex, b.out2, mix_out2 ? ao2_16 : ao, (int)M, t, er);
     run_layernorm(ex, b.n3, t, (int)M, mix_geglu ? ln16 : ln);
     demote_lo(ex, DM_GEGLU, ln, M, C);
     Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
