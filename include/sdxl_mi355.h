@@ -289,7 +289,8 @@ int sdxl_bench_attention(sdxl_ctx* ctx, void* stream, int B, int H, int Nq, int 
  * "hl_tile96": bit set of the extra tiles of the split-operand GEMMs (A/B; results unchanged): 1 = 96x128 for the M = 2048 x N = 1280 linears, 2 = ... for
  *   3x3 convolutions too, 4 = 4-wave 128x160 for widths that are multiples of 160 but not of 128, 8 = 128x160 wherever the cost model prefers it, 16 = in-launch split-K (3 slices) for the K >= 10240 convolutions of the 32^2 level (default 29);
  * "mix_classes": overrides the f16 classes of SDXL_DTYPE_F32_SPLIT_MIX* models built afterwards (1 = self-attention, 2 = GEGLU projection, 4 = QKV projection,
- *   8 = FF-out, 16 = self-attention out-projection, -1 = the mode's own);
+ *   8 = FF-out, 16 = self-attention out-projection, 32 = cross-attention out-projection, 64 = with 32: the cross-attention and its query projection as the f16
+ *   engine's fused launch on an f16 copy of the context K / V -- measured 27.7 against 29.9 ms per step at 0.0195 of the 0.0212 bound, in no mode; -1 = the mode's own);
  *   A/B and bisecting (environment SDXL_NAN_CHECK=1 makes eager forwards report the first GEMM with a non-finite output on stderr);
  * "hl_demote": bit set of GEMM classes (csrc/engine.h DemoteClass) that a SDXL_DTYPE_F32_SPLIT UNet runs on operands with zero lo halves --
  *   the f16 engine's operand rounding class by class on the split engine's kernels: the precision-frontier instrument

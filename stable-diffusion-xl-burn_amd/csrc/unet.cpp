@@ -38,7 +38,7 @@ ResBlockW load_res(WeightBuilder& wb, const std::string& p, int cin, int cout, s
 }
 STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln, int mix = 0) {
   const bool geglu_f16 = (mix & MIX_GEGLU_F16) != 0, qkv_f16 = (mix & MIX_QKV_F16) != 0, ff_f16 = (mix & MIX_FF_F16) != 0, out1_f16 = (mix & MIX_OUT1_F16) != 0,
-             out2_f16 = (mix & MIX_OUT2_F16) != 0;
+             out2_f16 = (mix & MIX_OUT2_F16) != 0, q2_f16 = out2_f16 && (mix & MIX_XATTN_F16) != 0;
   STW s;
   s.C = C; s.heads = heads;
   s.norm = wb.norm(p + ".norm");
@@ -63,7 +63,7 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     t.qkv = wb.fused_linear({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, qkv_f16 ? (int)DT_F16 : -1);
     t.out1 = wb.linear(q + ".attn1.out", false, out1_f16 ? (int)DT_F16 : -1);
     t.n2 = wb.norm(q + ".norm2");
-    t.q2 = wb.linear(q + ".attn2.query");
+    t.q2 = wb.linear(q + ".attn2.query", false, q2_f16 ? (int)DT_F16 : -1);
     t.kv2 = wb.fused_linear({q + ".attn2.key", q + ".attn2.value"});
     t.out2 = wb.linear(q + ".attn2.out", false, out2_f16 ? (int)DT_F16 : -1);
     t.n3 = wb.norm(q + ".norm3");
@@ -232,7 +232,8 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
 void UNet::set_context(const float* context, int n_ctx, const float* label, int B, hipStream_t s) {
   SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
   const int vt_ld = (int)round_up(n_ctx, 64);
-  const bool pack_xa = cdt_ == DT_F16 && n_ctx <= 96;   // operand-order copies for the fused cross-attention epilogue
+  // operand-order copies for the fused cross-attention epilogue (f16 engines; the split-operand engine when that class runs on f16: MIX_XATTN_F16)
+  const bool pack_xa = (cdt_ == DT_F16 || (cdt_ == DT_HL && (mix_ & MIX_XATTN_F16) && (mix_ & MIX_OUT2_F16))) && n_ctx <= 96;
   const int kvdt = attn_dt();                           // dtype of the K / V^T caches (fp32 in the split-operand mode)
   const int emb = 4 * cfg_.model_channels;
   {   // precision-frontier instrument: the demoted classes take effect from here (weights now, activations in every forward after)
@@ -256,7 +257,7 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
     if (cdt_ == DT_HL) {   // fp32 scratch of one block's K / V^T projection: the caches themselves are HL16 (what the attention kernel reads)
       size_t mx = 0;
       for (const STW* st : st_list_) mx = std::max(mx, round_up((size_t)B * n_ctx * st->C * 4, 256) + round_up((size_t)B * st->C * vt_ld * 4, 256));
-      bytes += mx + 512;
+      bytes += (pack_xa ? mx + mx / 2 + 512 : mx) + 512;     // (+ f16 copies of both when the fused f16 cross-attention reads them packed)
     }
     ctx_arena_.reserve(bytes);
     ctx_arena_.off = 0;
@@ -297,6 +298,13 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
         launch_f32_to_hl(vt32, vt_ld, kv_[si][j].vt, vt_ld, (size_t)B * st->C, vt_ld, s);
         demote_lo(ex, DM_XATTN, Act(kv_[si][j].k, st->C, DT_HL), (size_t)B * n_ctx, st->C);
         demote_lo(ex, DM_XATTN, Act(kv_[si][j].vt, vt_ld, DT_HL), (size_t)B * st->C, vt_ld);
+        if (kv_[si][j].xa) {     // MIX_XATTN_F16: the fp32-class projection rounded once to f16, in the operand order the fused launch reads
+          void* k16 = ctx_arena_.alloc((size_t)B * n_ctx * st->C * 2);
+          void* vt16 = ctx_arena_.alloc((size_t)B * st->C * vt_ld * 2);
+          launch_copy_rows(k32, DT_F32, st->C, k16, DT_F16, st->C, B * n_ctx, st->C, s);
+          launch_copy_rows(vt32, DT_F32, vt_ld, vt16, DT_F16, vt_ld, B * st->C, vt_ld, s);
+          launch_xattn_pack(k16, vt16, kv_[si][j].xa, B, st->C, n_ctx, vt_ld, s);
+        }
         ctx_arena_.reset(ms);
         continue;
       }
@@ -402,7 +410,11 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     vt16 = ex.act->alloc((size_t)B * C * npad * 2);
     if (npad != HW && !ex.dry) launch_fill_zero(vt16, (size_t)B * C * npad * 2, ex.s);
   }
-  if (mix_geglu || mix_qkv) ln16 = ex.alloc(M, C, DT_F16);
+  // cross-attention of the mixed mode on f16 (MIX_XATTN_F16): the f16 engine's fused launch -- query projection and the 77-key attention in one kernel on
+  // the f16 LayerNorm output and the packed f16 context; shapes that launch does not take (tiny nets) widen the f16 query for the split-operand attention
+  const bool mix_q2 = hl_attn && mix_out2 && !w.blocks.empty() && w.blocks[0].q2.dt == DT_F16;
+  const bool mix_xa = mix_q2 && plan_xattn_ && !kv_.empty() && kv_[si][0].xa && igemm_xattn_ok(DT_F16, DT_F16, (int)M, C, C, HW, n_ctx_);
+  if (mix_geglu || mix_qkv || mix_q2) ln16 = ex.alloc(M, C, DT_F16);
   // the f16 GEGLU kernels store an HL16 output through the LDS-staged epilogue of the wide / pipelined tiles -- the kernels every SDXL shape runs on
   // (M = 2048 ... 32768).  Small token counts (tiny test nets: M < 256) run on other tiles; they take the form the F16_F32RES engine
   // runs at every size -- f16 output -- and widen it.
@@ -467,9 +479,20 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     Epi er; er.R = t; er.rpb = HW; er.cls = DM_OUT;
     demote_lo(ex, DM_OUT, ao, M, C);
     run_linear(ex, b.out1, mix_out1 ? ao16 : ao, (int)M, t, er);
-    run_layernorm(ex, b.n2, t, (int)M, ln);
+    run_layernorm(ex, b.n2, t, (int)M, mix_q2 ? ln16 : ln);
     demote_lo(ex, DM_XATTN, ln, M, C);
-    if (xattn) {
+    if (mix_xa) {
+      Epi e2q; e2q.rpb = HW; e2q.cls = DM_XATTN;
+      e2q.xa_k = kv_xa(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
+      run_linear(ex, b.q2, ln16, (int)M, ao2_16, e2q);
+    } else if (mix_q2) {
+      { Epi e2q; e2q.cls = DM_XATTN; run_linear(ex, b.q2, ln16, (int)M, ao2_16, e2q); }
+      if (!ex.dry) {
+        if (q.dt == DT_HL) launch_f16_to_hl(ao2_16.p, ao2_16.ld, q.p, q.ld, M, C, ex.s);
+        else launch_copy_rows(ao2_16.p, DT_F16, ao2_16.ld, q.p, q.dt, q.ld, (int)M, C, ex.s);
+      }
+      attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_, DM_XATTN);
+    } else if (xattn) {
       Epi e2q; e2q.rpb = HW; e2q.cls = DM_XATTN;
       e2q.xa_k = kv_xa(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
       run_linear(ex, b.q2, ln, (int)M, ao, e2q);
@@ -480,7 +503,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       else attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
     }
     demote_lo(ex, DM_OUT, ao, M, C);
-    if (mix_out2 && !ex.dry) launch_copy_rows(ao32.p, DT_F32, ao32.ld, ao2_16.p, DT_F16, ao2_16.ld, (int)M, C, ex.s);
+    if (mix_out2 && !mix_xa && !ex.dry) launch_copy_rows(ao32.p, DT_F32, ao32.ld, ao2_16.p, DT_F16, ao2_16.ld, (int)M, C, ex.s);
     run_linear(ex, b.out2, mix_out2 ? ao2_16 : ao, (int)M, t, er);
     run_layernorm(ex, b.n3, t, (int)M, mix_geglu ? ln16 : ln);
     demote_lo(ex, DM_GEGLU, ln, M, C);

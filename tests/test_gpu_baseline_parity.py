@@ -443,9 +443,16 @@ def test_config2_trajectory_f16_representable_weights(pkg, ctx):
     steps = [int(s_) for s_ in g["steps"]]
     ref_traj, ref = torch.from_numpy(g["traj"]), torch.from_numpy(g["latent"])
     rep = {}
+    # "knob127": the F16W mode's six classes + the cross-attention itself on the f16 engine's fused launch (sdxl_debug_set "mix_classes" bit 64) -- 7 % faster,
+    # 92 % of the bound at the last step: measured and recorded, NOT part of the mode
     for name, dt in (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_mix", pkg.DTYPE_F32_SPLIT_MIX), ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W),
-                     ("f16", pkg.DTYPE_F16)):
-        d = pkg.Diffuser(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS)
+                     ("knob127", pkg.DTYPE_F32_SPLIT_MIX), ("f16", pkg.DTYPE_F16)):
+        if name == "knob127":
+            pkg.debug_set("mix_classes", 127)
+        try:
+            d = pkg.Diffuser(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS)
+        finally:
+            pkg.debug_set("mix_classes", -1)
         trace = torch.zeros(31, 1, 4, 128, 128, device="cuda")
         d.set_trace(trace)
         t0 = time.time()
@@ -468,6 +475,7 @@ def test_config2_trajectory_f16_representable_weights(pkg, ctx):
         assert rep["f32_split_mix_f16w"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split_mix_f16w"][str(s_)])
     assert rep["f32_split_mix"]["final"]["max_abs"] <= lat_bound(ref)
     assert rep["f32_split_mix_f16w"]["final"]["max_abs"] <= lat_bound(ref)
+    assert rep["f32_split_mix_f16w"]["final"]["max_abs"] < rep["knob127"]["final"]["max_abs"] <= lat_bound(ref), rep["knob127"]["final"]     # (measured 0.0195 of 0.0212)
     assert rep["f16"]["final"]["rel"] < F16_TRAJ_REL["f16"], rep["f16"]["final"]
 
 

@@ -14,7 +14,7 @@ def cond(): return pkg.Conditioning(context_full=i["ctx"].cuda(), channel_contex
                                     unconditional_channel_context=i["uy"].cuda(), resolution=(1024, 1024))
 refs = {"fp32 weights": (0, torch.from_numpy(np.load(os.path.join(ROOT, "tests/golden/fullsize_config2.npz"))["latent"])),
         "f16-representable weights": (pkg.SEED_F16_WEIGHTS, torch.from_numpy(np.load(os.path.join(ROOT, "tests/golden/fullsize_config2_f16w.npz"))["latent"]))}
-names = {1: "attn", 2: "geglu", 4: "qkv", 8: "ff", 16: "out1", 32: "out2"}
+names = {1: "attn", 2: "geglu", 4: "qkv", 8: "ff", 16: "out1", 32: "out2", 64: "xattn"}
 print("classes on f16 | weights | final latent max-abs (bound) | UNet step p50 ms | img/s at 31 steps + 39 ms decode + 8 ms")
 for mask in [int(a) for a in sys.argv[1:]] or (3, 7, 11, 15, 31):
     pkg.debug_set("mix_classes", mask)
