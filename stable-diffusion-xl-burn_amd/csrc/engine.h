@@ -220,9 +220,17 @@ struct Exec {
 // projections + the 77-key attention), GEGLU projection, FF-out, and five kinds of convolution: the two 3x3 convs of every ResBlock, the 1x1 skip
 // connections, the UNet's last conv (its first has 4 input channels and is plain fp32 in this engine), the down / up-sampling convs, proj_in / proj_out.
 // SDXL_DTYPE_F32_SPLIT_MIX: what the measured frontier (profiles/r05_precision_frontier.json) lets a latents-within-bound engine run in f16
-// (MIX_QKV_F16 / MIX_FF_F16: optional further classes, sdxl_debug_set "mix_classes" only -- outside the bound on the synthetic fp32 weights, measured on
-//  f16-representable ones; QKV on f16 implies the f16 self-attention)
-enum MixClass { MIX_ATTN_F16 = 1, MIX_GEGLU_F16 = 2, MIX_QKV_F16 = 4, MIX_FF_F16 = 8, MIX_OUT1_F16 = 16, MIX_OUT2_F16 = 32, MIX_XATTN_F16 = 64 };   // XATTN: the cross-attention with its query projection, the f16 engine's fused launch (needs OUT2)    // OUT2: the cross-attention's out-projection (its fp32 attention output narrowed to f16)   // OUT1: the self-attention's out-projection (reads the f16 attention output as it is)
+// (classes 4 ... 32: SDXL_DTYPE_F32_SPLIT_MIX_F16W, or sdxl_debug_set "mix_classes" -- outside the bound on the synthetic fp32 weights, inside it on
+//  f16-representable ones)
+enum MixClass {
+  MIX_ATTN_F16 = 1,     // self-attention on the f16 flash kernels
+  MIX_GEGLU_F16 = 2,    // GEGLU projection (f16 LayerNorm output x f16 weights)
+  MIX_QKV_F16 = 4,      // QKV projection (implies the f16 self-attention)
+  MIX_FF_F16 = 8,       // FF-out (reads the GEGLU kernel's f16 output)
+  MIX_OUT1_F16 = 16,    // self-attention out-projection (reads the f16 attention output as it is)
+  MIX_OUT2_F16 = 32,    // cross-attention out-projection (the fp32 attention output narrowed once by a row copy)
+  MIX_XATTN_F16 = 64    // with OUT2: cross-attention + its query projection as the f16 engine's fused launch -- a knob, in no mode
+};
 enum DemoteClass { DM_QKV = 1, DM_ATTN = 2, DM_OUT = 4, DM_XATTN = 8, DM_GEGLU = 16, DM_FF = 32, DM_CONV_RES = 64, DM_CONV_SKIP = 128,
                    DM_CONV_IO = 256, DM_CONV_UPDOWN = 512, DM_CONV_PROJ = 1024 };
 void unet_set_mix_classes(int v);
