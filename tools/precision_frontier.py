@@ -56,8 +56,8 @@ def label_rows(rows):
     return labels
 
 
-def class_profile(pkg, ctx, cfg, dt, cond, noise):
-    d = pkg.Diffuser(ctx, cfg, dt, seed=0)
+def class_profile(pkg, ctx, cfg, dt, cond, noise, seed=0):
+    d = pkg.Diffuser(ctx, cfg, dt, seed=seed)
     d.sample_latent(cond, 7.5, 2, noise)
     with tempfile.NamedTemporaryFile(suffix=".csv", delete=False) as f:
         path = f.name
