@@ -28,6 +28,9 @@ label, and every backward branch replays its loop body once with the state it ar
 Fifth rule (round 5): the write-through publication protocol (lint_publication): every `sc0 sc1` store is covered by `vmcnt(0)` before the next
 atomic RMW (the ticket), and a publishing function has an `sc1`-load / `buffer_inv` reader path.
 
+Sixth rule (round 5): no `scratch_*` (spill) traffic between the first and the last MFMA of a kernel that carries inline asm (lint_scratch): a spill is a
+VMEM operation and would shift the hand-counted `vmcnt` waits.
+
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -x hip --cuda-device-only -S csrc/igemm_glds.hip -o /tmp/glds.s
     python tools/asm_lint.py /tmp/glds.s            -> exit status 1 if anything is reported
 """
@@ -271,10 +274,49 @@ def lint_publication(path):
     return findings
 
 
+
+def lint_scratch(path):
+    """Sixth rule (round 5): no scratch traffic inside the matrix loop of a kernel with hand-counted waits.  A spill load or store is a VMEM operation:
+    it enters the VM queue the hand-counted `s_waitcnt vmcnt(N)` of the DMA rings index into, so a `scratch_*` between the first and the last MFMA of a
+    function that carries inline asm shifts every count behind it (and costs a memory round trip per k-step).  Spills the compiler places in a prologue
+    or epilogue -- it waits for those itself -- are reported by tools/kernel_resources.py, not here."""
+    findings = []
+    kernel, has_asm, first_mfma, last_mfma, scratch = None, False, None, None, []
+
+    def close():
+        if kernel and has_asm and first_mfma is not None:
+            for ln, code in scratch:
+                if first_mfma < ln < last_mfma:
+                    findings.append(f"{kernel}: line {ln}: `{code}` inside the matrix loop (MFMAs at lines {first_mfma} ... {last_mfma}) of a kernel with hand-counted waits")
+
+    for ln, raw in enumerate(open(path), 1):
+        line = raw.strip()
+        if line.startswith(";;#ASMSTART"):
+            has_asm = True
+            continue
+        if not line or line.startswith(";") or line.startswith("."):
+            continue
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m:
+            close()
+            kernel, has_asm, first_mfma, last_mfma, scratch = m.group(1), False, None, None, []
+            continue
+        code = line.split(";")[0].strip()
+        if not code:
+            continue
+        mn = code.split(None, 1)[0]
+        if mn.startswith("v_mfma"):
+            first_mfma = ln if first_mfma is None else first_mfma
+            last_mfma = ln
+        elif mn.startswith("scratch_"):
+            scratch.append((ln, code))
+    close()
+    return findings
+
 if __name__ == "__main__":
     bad = []
     for p in sys.argv[1:]:
-        f = lint(p) + lint_vm(p) + lint_publication(p)
+        f = lint(p) + lint_vm(p) + lint_publication(p) + lint_scratch(p)
         print(f"{p}: {len(f)} finding(s)")
         for x in f[:40]:
             print("  " + x)
