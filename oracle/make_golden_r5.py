@@ -88,7 +88,7 @@ def run_config2_f16ref(cfg, W):
 
 def main():
     what = set(sys.argv[1:]) or {"unet1024_f16ref"}
-    if what == {"config2b"}:
+    if what <= {"config2b", "config2b_f16w"}:
         return          # (handled at the end of the module)
     cfg, W = base_weights()
     if "unet1024_f16ref" in what:
@@ -123,6 +123,24 @@ def run_config2b(cfg, W):
                         traj=np.stack([trace[k].numpy() for k in CONFIG2_KEEP]), in_checksum=checksum(*i.values()), oracle_seconds=np.array([dt]))
 
 
-if __name__ == "__main__" and "config2b" in sys.argv:
+def run_config2b_f16w(cfg, W):
+    """the second prompt on f16-representable weights (every parameter rounded to IEEE f16 first, as oracle.make_golden_r3.run_config2_f16w): the weights
+    SDXL_DTYPE_F32_SPLIT_MIX_F16W is for -- its 'inside the bound' claim rested on one prompt (tests/test_gpu_baseline_parity.py::test_config2_second_prompt_f16_weights)"""
+    i = config2b_inputs(cfg)
+    W16 = {k: (v if k.endswith(".eps") else v.half().float()) for k, v in W.items()}
+    cond = OP.Conditioning(i["uctx"], None, i["ctx"], None, i["uy"], None, i["y"], None, (1024, 1024))
+    trace = []
+    t0 = time.time()
+    lat = OP.Diffuser(cfg, W16, OC.alphas_cumprod()).sample_latent(cond, 7.5, 30, i["noise"], trace)
+    dt = time.time() - t0
+    print(f"[golden r5] config 2, second prompt, f16-representable weights: {dt:.1f} s, |latent|max {float(lat.abs().max()):.2f}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "fullsize_config2b_f16w.npz"), steps=np.array(CONFIG2_KEEP), latent=lat.numpy(),
+                        traj=np.stack([trace[k].numpy() for k in CONFIG2_KEEP]), in_checksum=checksum(*i.values()), oracle_seconds=np.array([dt]))
+
+
+if __name__ == "__main__" and ("config2b" in sys.argv or "config2b_f16w" in sys.argv):
     _cfg, _W = base_weights()
-    run_config2b(_cfg, _W)
+    if "config2b" in sys.argv:
+        run_config2b(_cfg, _W)
+    if "config2b_f16w" in sys.argv:
+        run_config2b_f16w(_cfg, _W)

@@ -428,6 +428,48 @@ def test_config2_second_prompt(pkg, ctx):
     assert rep["f16"]["final"]["rel"] < F16_TRAJ_REL["f16"], rep["f16"]["final"]
 
 
+def test_config2_second_prompt_f16_weights(pkg, ctx):
+    """The second prompt on f16-representable weights (fixture oracle/make_golden_r5.py config2b_f16w): SDXL_DTYPE_F32_SPLIT_MIX_F16W's claim -- the
+    config-2 latent inside the scaled bound on the weights the reference's records hold -- on a second trajectory, every recorded step.  `knob127`
+    (the seventh class) is recorded beside it and held to the bound at the last step only."""
+    gp = os.path.join(GOLD, "fullsize_config2b_f16w.npz")
+    if not os.path.exists(gp):
+        pytest.skip("tests/golden/fullsize_config2b_f16w.npz not generated (python -m oracle.make_golden_r5 config2b_f16w, ~30 min)")
+    g = np.load(gp)
+    cfg = pkg.sdxl_base_config()
+    i = _inputs(cfg, 230, 128)
+    assert np.allclose(checksum(*i.values()), g["in_checksum"], rtol=1e-9), "torch CPU generator changed: regenerate the fixtures"
+    steps = [int(s_) for s_ in g["steps"]]
+    ref_traj, ref = torch.from_numpy(g["traj"]), torch.from_numpy(g["latent"])
+    rep = {}
+    for name, dt in (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W), ("knob127", pkg.DTYPE_F32_SPLIT_MIX)):
+        if name == "knob127":
+            pkg.debug_set("mix_classes", 127)
+        try:
+            d = pkg.Diffuser(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS)
+        finally:
+            pkg.debug_set("mix_classes", -1)
+        trace = torch.zeros(31, 1, 4, 128, 128, device="cuda")
+        d.set_trace(trace)
+        lat = d.sample_latent(_cond(pkg, i, (1024, 1024)), 7.5, 30, i["noise"].cuda())
+        torch.cuda.synchronize()
+        d.set_trace(None)
+        tr = trace.cpu()
+        rep[name] = {str(s_): errs(tr[s_], ref_traj[j]) for j, s_ in enumerate(steps)}
+        rep[name]["final"] = errs(lat.cpu(), ref)
+        del d
+        print(f"config 2, second prompt, f16-representable weights, {name} vs oracle: final max-abs {rep[name]['final']['max_abs']:.3e} "
+              f"(|ref| {rep[name]['final']['ref_max']:.1f}, bound {lat_bound(ref):.3e}); of the bound per recorded step: "
+              + " ".join(f"{rep[name][str(s_)]['max_abs'] / lat_bound(ref_traj[j]):.2f}" for j, s_ in enumerate(steps)))
+    REPORT["config2_second_prompt_f16_weights"] = rep
+    for j, s_ in enumerate(steps):
+        assert rep["f32_split"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split"][str(s_)])
+        assert rep["f32_split_mix_f16w"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split_mix_f16w"][str(s_)])
+    assert rep["f32_split"]["final"]["max_abs"] < 1e-3
+    assert rep["f32_split_mix_f16w"]["final"]["max_abs"] <= lat_bound(ref)
+    assert rep["knob127"]["final"]["max_abs"] <= lat_bound(ref), rep["knob127"]["final"]
+
+
 def test_config2_trajectory_f16_representable_weights(pkg, ctx):
     """The benchmarked trajectory with the weights a real SDXL record holds (every parameter an f16 value: HalfPrecisionSettings,
     src/bin/sample/main.rs:37) against the oracle's own 31-step trajectory on the same weights.  The split-operand engine then leaves
