@@ -56,7 +56,7 @@ enum {
                              * src/bin/sample/main.rs:37): with exact f16 weights a class on f16 operands only rounds activations, and the measured frontier
                              * affords four more -- the QKV projection, both attentions' out-projections and FF-out.  Config-2 final latent 0.0170 (scaled
                              * bound 0.0212) at a UNet step of 29.7 - 30.6 ms = 1.0 img/s on f16-representable weights; on fp32 weights it is OUTSIDE the bound
-                             * (0.029): use SDXL_DTYPE_F32_SPLIT_MIX there                                                                                       */
+                             * (0.029): use SDXL_DTYPE_F32_SPLIT_MIX there; 1.1-1.2x over the bound on the 4-step inpainting fixture (a precision point, like _MIX)                                                                                       */
 };
 
 /* UNetConfig (src/model/unet/mod.rs:59-69) + DiffuserConfig.is_refiner (src/model/stablediffusion/mod.rs:269-278) */

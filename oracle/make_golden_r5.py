@@ -88,7 +88,7 @@ def run_config2_f16ref(cfg, W):
 
 def main():
     what = set(sys.argv[1:]) or {"unet1024_f16ref"}
-    if what <= {"config2b", "config2b_f16w"}:
+    if what <= {"config2b", "config2b_f16w", "inpaint1024_f16w"}:
         return          # (handled at the end of the module)
     cfg, W = base_weights()
     if "unet1024_f16ref" in what:
@@ -137,6 +137,27 @@ def run_config2b_f16w(cfg, W):
     np.savez_compressed(os.path.join(OUT, "fullsize_config2b_f16w.npz"), steps=np.array(CONFIG2_KEEP), latent=lat.numpy(),
                         traj=np.stack([trace[k].numpy() for k in CONFIG2_KEEP]), in_checksum=checksum(*i.values()), oracle_seconds=np.array([dt]))
 
+
+def run_inpaint1024_f16w(cfg, W):
+    """the inpainting fixture of oracle.make_golden_r3.run_inpaint1024 (4 CFG-7.5 steps, same inputs and reference latent) on f16-representable UNet weights:
+    where SDXL_DTYPE_F32_SPLIT_MIX_F16W stands on the configuration whose 250-step jumps amplify a forward's error most"""
+    from .make_golden_r3 import inpaint1024_inputs, inpaint_mask
+    i = inpaint1024_inputs(cfg)
+    ref_latent = torch.from_numpy(np.load(os.path.join(OUT, "fullsize_inpaint1024.npz"))["reference"])
+    W16 = {k: (v if k.endswith(".eps") else v.half().float()) for k, v in W.items()}
+    cond = OP.Conditioning(i["uctx"], None, i["ctx"], None, i["uy"], None, i["y"], None, (1024, 1024))
+    trace = []
+    t0 = time.time()
+    out = OP.Diffuser(cfg, W16, OC.alphas_cumprod()).sample_latent_with_inpainting(
+        cond, 7.5, 4, ref_latent, inpaint_mask(), i["noise"], [i["step_noise"][k] for k in range(4)], trace)
+    dt = time.time() - t0
+    print(f"[golden r5] inpainting 1024^2, f16-representable weights: {dt:.1f} s, |latent|max per step {[round(float(t.abs().max()), 2) for t in trace]}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "fullsize_inpaint1024_f16w.npz"), traj=np.stack([t.numpy() for t in trace]), latent=out.numpy(),
+                        in_checksum=checksum(*i.values()), oracle_seconds=np.array([dt]))
+
+
+if __name__ == "__main__" and "inpaint1024_f16w" in sys.argv:
+    run_inpaint1024_f16w(*base_weights())
 
 if __name__ == "__main__" and ("config2b" in sys.argv or "config2b_f16w" in sys.argv):
     _cfg, _W = base_weights()
