@@ -307,7 +307,7 @@ def _rel(out, ref):
     return float(d), float(d / ref.abs().max().clamp_min(1e-30))
 
 
-def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str):
+def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str, weights: str = "fp32"):
     """Parity MEASURED IN THIS RUN (rank 0, after the timed region) against the committed oracle fixtures tests/golden/fullsize_*.npz
     (oracle/make_golden_fullsize.py; only the fixture files are read -- nothing under oracle/ executes here):
       * one base UNet::forward at 1024x1024 on the timed engine;
@@ -320,7 +320,8 @@ def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str):
     gold = os.path.join(ROOT, "tests", "golden")
     cfg = pkg.sdxl_base_config()
     out, strict = {}, None
-    g = np.load(os.path.join(gold, "fullsize_unet1024.npz"))
+    wsuf = "_f16w" if weights == "f16" else ""          # the timed engine's own fixtures: the oracle on the SAME (f16-representable) weights
+    g = np.load(os.path.join(gold, f"fullsize_unet1024{wsuf}.npz"))
     x, t = _seeded(1, 4, 128, 128, seed=111), torch.tensor([500], dtype=torch.int32)
     c, y = _seeded(1, 77, cfg.context_dim, seed=112), _seeded(1, cfg.adm_in_channels, seed=113)
     o = diffuser.diffusion.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda())
@@ -337,20 +338,24 @@ def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str):
     if os.path.exists(gp):
         g = np.load(gp)
         ref = torch.from_numpy(g["latent"])
+        ref_timed = torch.from_numpy(np.load(os.path.join(gold, f"fullsize_config2{wsuf}.npz"))["latent"])
         i = dict(noise=_seeded(1, 4, 128, 128, seed=131), ctx=_seeded(1, 77, cfg.context_dim, seed=132), uctx=_seeded(77, cfg.context_dim, seed=133),
                  y=_seeded(1, cfg.adm_in_channels, seed=134), uy=_seeded(cfg.adm_in_channels, seed=135))
         cond = pkg.Conditioning(context_full=i["ctx"].cuda(), channel_context=i["y"].cuda(), unconditional_context_full=i["uctx"].cuda(),
                                 unconditional_channel_context=i["uy"].cuda(), resolution=(1024, 1024))
         lat = diffuser.sample_latent(cond, 7.5, 30, i["noise"].cuda())
-        a, r = _rel(lat, ref)
-        out[f"config2_{prec}_vs_oracle_final_max_abs"], out[f"config2_{prec}_vs_oracle_final_rel"] = a, r
+        a, r = _rel(lat, ref_timed)
+        out[f"config2_{prec}{wsuf}_vs_oracle_final_max_abs"], out[f"config2_{prec}{wsuf}_vs_oracle_final_rel"] = a, r
         strict = {}
         lat_bound = 1e-3 * max(1.0, float(ref.abs().max()) / 4.0)     # the parity tests' bar: north_star's 1e-3 at SDXL's latent scale (|x| <~ 4), scaled with the synthetic trajectory
+        out["timed_engine"] = {"precision": prec, "weights": weights, "config2_final_latent_max_abs_vs_oracle": a, "meets_1e-3": bool(a <= 1e-3),
+                               "lat_bound_scaled": 1e-3 * max(1.0, float(ref_timed.abs().max()) / 4.0),
+                               "inside_lat_bound_scaled": bool(a <= 1e-3 * max(1.0, float(ref_timed.abs().max()) / 4.0))}
         for tag, dtv, what in (("f32", pkg.DTYPE_F32, "SDXL_DTYPE_F32 UNet (exact-fp32 MFMA) + the timed VAE"),
                                ("f32_split", pkg.DTYPE_F32_SPLIT, "SDXL_DTYPE_F32_SPLIT UNet (fp32 stream, (hi, lo) f16 operands x 3 MFMAs in the GEMMs and in the attention) + the timed VAE"),
                                ("f32_split_mix", pkg.DTYPE_F32_SPLIT_MIX, "SDXL_DTYPE_F32_SPLIT_MIX UNet (the split engine with the self-attention and the GEGLU projection on plain f16 "
                                 "operands -- the two classes the measured precision frontier affords, profiles/r05_precision_frontier.json) + the timed VAE")):
-            if prec == tag:
+            if prec == tag and weights == "fp32":
                 continue
             d32 = pkg.Diffuser(ctx, cfg, dtv, seed=0)
             d32.enable_step_timing(True)
@@ -408,18 +413,23 @@ def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str):
             d5.enable_step_timing(True)
             d5.sample_latent(cond, 7.5, 2, i["noise"].cuda())
             torch.cuda.synchronize()
+            N5 = 3                 # images timed (sampling + decode each, same prompt: the arithmetic does not depend on the data)
+            steps5 = []
             t0 = time.perf_counter()
-            lat5 = d5.sample_latent(cond, 7.5, 30, i["noise"].cuda())
-            steps5 = d5.step_times_ms()
-            decoder.latent_to_image(lat5)
+            for _ in range(N5):
+                lat5 = d5.sample_latent(cond, 7.5, 30, i["noise"].cuda())
+                steps5 += d5.step_times_ms()
+                decoder.latent_to_image(lat5)
             torch.cuda.synchronize()
-            dt5 = time.perf_counter() - t0
+            dt5 = (time.perf_counter() - t0) / N5
             a5, r5 = _rel(lat5, refw)
             out["config2_f16weights_f32_split_mix_f16w_vs_oracle_final_max_abs"], out["config2_f16weights_f32_split_mix_f16w_vs_oracle_final_rel"] = a5, r5
             strict["f32_split_mix_f16w_mode_f16_weights"] = {
-                "precision": "SDXL_DTYPE_F32_SPLIT_MIX_F16W UNet (split engine; self-attention, both attentions' out-projections, GEGLU, QKV projection and FF-out on plain f16 operands: the classes the measured "
-                             "frontier affords when the parameters are exact f16 values) on f16-representable weights + the timed VAE; oracle = the same weights",
-                "images_per_sec": round(1.0 / dt5, 4), "unet_step_ms": round(statistics.median(steps5), 2) if steps5 else None, "images_timed": 1,
+                "precision": "SDXL_DTYPE_F32_SPLIT_MIX_F16W UNet (split engine; self-attention, both attentions' out-projections, GEGLU, QKV projection, FF-out and the cross-attention query "
+                             "projection on plain f16 operands, LayerNorms folded through the f16 shadow of the stream: the classes the measured frontier affords when the parameters are exact f16 "
+                             "values) on f16-representable weights + the timed VAE; oracle = the same weights",
+                "mix_classes": d5.diffusion.mix_classes(),
+                "images_per_sec": round(1.0 / dt5, 4), "unet_step_ms": round(statistics.median(steps5), 2) if steps5 else None, "images_timed": N5,
                 "config2_final_latent_max_abs_vs_oracle": a5, "meets_1e-3": bool(a5 <= 1e-3), "lat_bound_scaled": lbw, "inside_lat_bound_scaled": bool(a5 <= lbw),
                 "meets_1_img_per_sec_inside_scaled_bound": bool(a5 <= lbw and 1.0 / dt5 >= 1.0)}
             del d5
@@ -453,9 +463,14 @@ def main():
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--n-steps", type=int, default=None, help="--n-diffusion-steps of the reference CLI (30 -> 31 iterations)")
     ap.add_argument("--cfg", type=float, default=None)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res", "f32_split", "f32_split_mix"],
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res", "f32_split", "f32_split_mix", "f32_split_mix_f16w"],
                     help="UNet arithmetic: f16 (the reference's GPU precision, src/bin/sample/main.rs:122), f16_f32res, f32 (exact-fp32 MFMA: the strict-parity "
-                         "mode) or f32_split (fp32-class: fp32 stream, (hi, lo) f16 operands with three MFMAs per product in the GEMMs and in the attention)")
+                         "mode), f32_split (fp32-class: fp32 stream, (hi, lo) f16 operands with three MFMAs per product in the GEMMs and in the attention), "
+                         "f32_split_mix (+ self-attention and GEGLU on plain f16) or f32_split_mix_f16w (+ six more transformer classes on plain f16: for "
+                         "f16-representable parameters, i.e. with --weights f16; on other weights the engine falls back to f32_split_mix's classes)")
+    ap.add_argument("--weights", default="fp32", choices=["fp32", "f16"],
+                    help="synthetic UNet parameters as drawn (fp32) or rounded to IEEE f16 first -- what the reference's records hold "
+                         "(HalfPrecisionSettings, src/bin/sample/main.rs:37)")
     ap.add_argument("--vae-dtype", default="f32_split", choices=["f16", "f32", "f32_split"],
                     help="arithmetic of the VAE legs; the reference decodes in f32 (src/bin/sample/main.rs:121,271-278): f32 = exact-fp32 "
                          "MFMA, f32_split = fp32-class results from three f16 MFMAs per product on (hi, lo) operand pairs")
@@ -509,20 +524,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dts = {"f16": pkg.DTYPE_F16, "f32": pkg.DTYPE_F32, "f16_f32res": pkg.DTYPE_F16_F32RES, "f32_split": pkg.DTYPE_F32_SPLIT,
-           "f32_split_mix": pkg.DTYPE_F32_SPLIT_MIX}
+           "f32_split_mix": pkg.DTYPE_F32_SPLIT_MIX, "f32_split_mix_f16w": pkg.DTYPE_F32_SPLIT_MIX_F16W}
     dt, vdt = dts[args.dtype], dts[args.vae_dtype]
+    wseed = pkg.SEED_F16_WEIGHTS if args.weights == "f16" else 0      # (flag bit on the synthetic seed: parameters rounded to f16 on the device)
 
     ctx = pkg.Context(local_rank)
     cfg = pkg.sdxl_base_config()
     # rank 0 builds the weights; replicas allocate the identical arena and receive it over RCCL / xGMI
     t0 = time.time()
-    diffuser = pkg.Diffuser(ctx, cfg, dt, seed=0, empty=(rank != 0))
+    diffuser = pkg.Diffuser(ctx, cfg, dt, seed=wseed | 0, empty=(rank != 0))
     decoder = pkg.LatentDecoder(ctx, None, vdt, seed=0, with_encoder=(args.config == 5), empty=(rank != 0))
     refiner = None
     rcfg = pkg.sdxl_refiner_config()
     if args.config == 4:
-        refiner = pkg.Diffuser(ctx, rcfg, dt, seed=1, empty=(rank != 0))
+        refiner = pkg.Diffuser(ctx, rcfg, dt, seed=wseed | 1, empty=(rank != 0))
     ctx.synchronize()
+    # the MIX classes in force: an f32_split_mix_f16w model on parameters that are not f16 values falls back to f32_split_mix's (the engine checks the
+    # tensors).  Replicas are laid out for the mode itself, so a fallen-back root must not broadcast into them.
+    mix_classes = diffuser.diffusion.mix_classes()
+    if world > 1 and args.dtype == "f32_split_mix_f16w" and args.weights != "f16":
+        raise SystemExit("bench.py: --dtype f32_split_mix_f16w across ranks needs --weights f16 (rank 0 would fall back to f32_split_mix and its arena "
+                         "would not match the replicas')")
     t_build = time.time() - t0
     t0 = time.time()
     bcast_path, rccl_ranks = None, 1
@@ -676,22 +698,28 @@ def main():
 
     # --- roofline of the dominant kernel, measured live with hipEvents on the timed configuration (B=2 CFG pair)
     prof = diffuser.diffusion.profile(2 * npc, lat, lat)
-    # The eager profile brackets every launch with two hipEvents; its class times carry that overhead (r4: the classes summed to
-    # 22.47 ms for a 21.05 ms graph-replayed step).  The replayed step IS the sum of its kernels (median gap 0 ns inside the graph,
-    # profiles/r02_trace_gaps_final.json), so the per-launch overhead is (eager class sum - replayed step p50) / launches; it is
-    # subtracted per class by launch count: the adjusted classes sum to the step the line reports.
+    # The eager profile brackets every launch with two hipEvents, so its class times carry the events' own cost.  `frac` is computed from
+    # those RAW times (a lower bound of the kernel's rate).  The overhead is calibrated DIRECTLY (round 6): the same eager chain is
+    # timed once more without the per-launch events (one event pair around the whole forward, sdxl_unet_eager_forward_ms); (class sum - that) /
+    # launches is what a bracketed launch carries, independent of what the captured graph gains elsewhere (warming workgroups, no host
+    # launches).  The class times with that overhead removed are reported next to the raw ones as DERIVED figures; they sum to the un-bracketed
+    # eager forward, not -- by construction -- to the graph-replayed step (r5 booked the whole eager-vs-graph gap as event overhead).
     p50_all = statistics.median(step_ms) if step_ms else None
     raw_ms = {k: float(v[0]) for k, v in prof.items()}
     n_launch = {k: int(v[1]) for k, v in prof.items()}
     class_sum = sum(raw_ms.values())
+    eager_plain_ms = diffuser.diffusion.eager_forward_ms(2 * npc, lat, lat)
     ev_over_ms = 0.0
-    if p50_all is not None and class_sum > p50_all and sum(n_launch.values()) > 0:
-        ev_over_ms = (class_sum - p50_all) / sum(n_launch.values())
+    if class_sum > eager_plain_ms > 0 and sum(n_launch.values()) > 0:
+        ev_over_ms = (class_sum - eager_plain_ms) / sum(n_launch.values())
     adj_ms = {k: max(raw_ms[k] - n_launch[k] * ev_over_ms, 0.0) for k in raw_ms}
-    ig_ms, ig_n, ig_fl = adj_ms["igemm"], prof["igemm"][1], prof["igemm"][2]
-    # f32: exact-fp32 MFMA peak; f32_split: three f16 MFMAs per product -> a third of the f16 matrix peak in algorithmic FLOPs
+    ig_ms, ig_n, ig_fl = raw_ms["igemm"], prof["igemm"][1], prof["igemm"][2]
+    # f32: exact-fp32 MFMA peak; f32_split: three f16 MFMAs per product -> a third of the f16 matrix peak in algorithmic FLOPs; the mixed modes run
+    # one (f16 classes), two (split-operand classes on f16-representable weights) or three MFMAs per product: priced against the split peak for
+    # f32_split_mix and against the full f16 peak for f32_split_mix_f16w (most of its FLOPs are single-MFMA classes) -- `peak_note` says so
     peak = PEAK_F32_TFLOPS if args.dtype == "f32" else (PEAK_F16_TFLOPS / 3.0 if args.dtype in ("f32_split", "f32_split_mix") else PEAK_F16_TFLOPS)
     achieved = ig_fl / 1e12 / (ig_ms / 1e3) if ig_ms > 0 else 0.0
+    achieved_adj = ig_fl / 1e12 / (adj_ms["igemm"] / 1e3) if adj_ms["igemm"] > 0 else 0.0
     # HBM-side traffic of the same launches: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_step.py,
     # summarised by tools/pmc_traffic.py (gfx950 correction applied there); null when no committed summary exists
     traffic, traffic_src = None, None
@@ -708,15 +736,22 @@ def main():
     roofline = {"bound": "mfma", "kernel": "igemm_{pipe,glds}_kernel (NHWC implicit-GEMM conv3x3/1x1/linear, direct-to-LDS f16)",
                 "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
+                "peak_note": {"f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak", "f32_split": "f16 dense MFMA peak / 3 (three MFMAs per product)",
+                              "f32_split_mix": "f16 dense MFMA peak / 3 (split-operand classes: three MFMAs per product; two classes run one)",
+                              "f32_split_mix_f16w": "f16 dense MFMA peak; the eight f16 classes run one MFMA per product, the split-operand classes two on "
+                                                    "f16-representable weights -- algorithmic TFLOP/s understate the matrix work of this mode"}.get(args.dtype, "f16 dense MFMA peak (MI355X_MICROARCH.md)"),
                 "launches_per_unet_step": ig_n, "avg_launch_us": round(1e3 * ig_ms / max(ig_n, 1), 2),
                 "algorithmic_tflop_per_unet_step": round(ig_fl / 1e12, 3),
-                "class_ms_per_unet_step": {k: round(v, 3) for k, v in adj_ms.items()},
-                "class_sum_ms": round(sum(adj_ms.values()), 3),
-                "class_ms_eager_events": {k: round(v, 3) for k, v in raw_ms.items()},
-                "class_sum_ms_eager_events": round(class_sum, 3),
+                # headline class times = the RAW event-bracketed ones (frac / achieved follow them); derived: the same with the calibrated event overhead removed
+                "class_ms_per_unet_step": {k: round(v, 3) for k, v in raw_ms.items()},
+                "class_sum_ms": round(class_sum, 3),
+                "eager_forward_ms_without_events": round(eager_plain_ms, 3),
                 "event_overhead_us_per_launch": round(1e3 * ev_over_ms, 3),
-                "class_method": "eager pass with hipEvents around every launch, minus the per-launch event overhead "
-                                "((eager class sum - graph-replayed step p50) / launches) so that the classes sum to unet_step_ms_p50",
+                "class_ms_event_overhead_removed": {k: round(v, 3) for k, v in adj_ms.items()},
+                "frac_event_overhead_removed": round(achieved_adj / peak, 4),
+                "class_method": "eager pass with hipEvents around every launch (raw: frac / achieved / class_ms_per_unet_step); event overhead per launch = "
+                                "(raw class sum - the same eager chain timed WITHOUT per-launch events) / launches, removed in the *_event_overhead_removed figures; "
+                                "the graph-replayed step (unet_step_ms_p50) additionally gains from weight-warming workgroups and the absence of host launches",
                 # the whole CFG step against the peak (2 UNet forwards = SURVEY 8d's 13.52 TFLOP at 1024^2 over the graph-replayed step p50): attention, norms
                 # and every launch boundary included -- next to the GEMM-class fraction above
                 "whole_step_tflops": None if not p50_all else round(2 * npc * fwd_tf / (p50_all / 1e3), 1),
@@ -743,7 +778,7 @@ def main():
         parity = {"committed_report": committed} if committed else None
         if args.config == 2 and res == 1024 and world == 1 and npc == 1 and not args.no_live_parity:
             try:
-                live, strict = live_parity(pkg, ctx, diffuser, decoder, args.dtype, args.vae_dtype)
+                live, strict = live_parity(pkg, ctx, diffuser, decoder, args.dtype, args.vae_dtype, args.weights)
                 parity = dict(parity or {}, **{"live": live})
             except Exception as e:      # a missing fixture must not cost the bench line; say so on the line
                 parity = dict(parity or {}, **{"live": {"error": repr(e)}})
@@ -755,10 +790,12 @@ def main():
             "metric": "images/sec SDXL-base 1024x1024 30-step CFG7.5 (whole job); UNet step ms p50",
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"f32": "f32", "f32_split": "f32 (split f16 operands)", "f32_split_mix": "f32 (split f16 operands; self-attention and GEGLU projection on plain f16)"}.get(args.dtype, "f16"), "data": "synthetic",
+            "vs_baseline": None, "dtype": {"f32": "f32", "f32_split": "f32 (split f16 operands)", "f32_split_mix": "f32 (split f16 operands; self-attention and GEGLU projection on plain f16)",
+                                           "f32_split_mix_f16w": "f32 stream, split f16 operands in the convolutions / cross-attention, eight transformer classes on plain f16"}.get(args.dtype, "f16"), "data": "synthetic",
             "config": {"workload": wl, "baseline_config_index": args.config - 1,
                        "precision": args.dtype, "vae_dtype": args.vae_dtype,
-                       "weights": "synthetic seeded (random-init SDXL-base architecture)",
+                       "weights": "synthetic seeded (random-init SDXL-base architecture)" + (", every parameter rounded to IEEE f16 (what the reference's records hold)" if args.weights == "f16" else ""),
+                       "mix_classes": mix_classes,
                        "parallelism": f"replica x{world}, 1 prompt per GPU, weights broadcast once over RCCL",
                        "hipgraph": not args.no_graph, "split_cfg": bool(args.split_cfg), "fused_xattn": not args.unfused_xattn,
                        "pipelined_decode": bool(pipelined), "prompts_per_call": npc,

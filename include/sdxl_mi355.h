@@ -155,6 +155,11 @@ int sdxl_unet_set_fused_cross_attention(sdxl_unet* u, int enabled);
  * its kernel can leave them (256-row tiles: the 64^2 / 32^2 levels at 1024^2) -- groupnorm/mod.rs:52-82 without the statistics pass.
  * Like the two options above it is part of the plan: changing it re-sizes the arena and rebuilds the captured graph on the next forward. */
 int sdxl_unet_set_gn_from_producer(sdxl_unet* u, int enabled);
+/* which GEMM classes of a SDXL_DTYPE_F32_SPLIT_MIX* model run on plain f16 operands (bit set: 1 self-attention, 2 GEGLU projection, 4 QKV projection,
+ * 8 FF-out, 16 / 32 the self- / cross-attention out-projections, 128 cross-attention query projection, 256 LayerNorms folded through an f16 shadow of
+ * the stream; 0 for every other dtype).  A SDXL_DTYPE_F32_SPLIT_MIX_F16W model whose parameters are NOT all f16 values (checked on the tensors at
+ * create time) falls back to SDXL_DTYPE_F32_SPLIT_MIX's classes (3): this is how a caller sees it. */
+int sdxl_unet_mix_classes(sdxl_unet* u, int* classes_out);
 
 /* ---- Backend::qkv_attention (src/backend.rs:4-19; generic body :88-128, LibTorch override :32-79)
  * q [B,Nq,n_head*d], k,v [B,Nk,n_head*d], mask additive [Nq,Nk] or NULL, out [B,Nq,n_head*d]; fp32 device tensors.
@@ -269,6 +274,9 @@ int sdxl_bcast_plan(size_t bytes, int world, int rank, size_t* piece_off, size_t
  * kernel class (index: 0 implicit-GEMM conv/linear, 1 fused attention, 2 GroupNorm, 3 LayerNorm, 4 other); arrays of 5 */
 int sdxl_unet_profile(sdxl_unet* u, void* stream, int B, int H, int W, float class_ms[5], int class_launches[5],
                       double class_flops[5]);
+/* the same eager chain without the per-launch events, one event pair around the whole forward (best of three): calibrates the event overhead
+ * the class times of sdxl_unet_profile carry -- (sum of class_ms - *ms_out) / launches */
+int sdxl_unet_eager_forward_ms(sdxl_unet* u, void* stream, int B, int H, int W, float* ms_out);
 /* times the implicit-GEMM kernel alone (conv ksize x ksize, pad ksize/2, stride 1; ksize = 1 -> linear over B*H*W rows)
  * on seeded random f16 data; avg_ms = mean launch duration over `iters` back-to-back launches (hipEvents) */
 int sdxl_bench_igemm(sdxl_ctx* ctx, void* stream, int B, int H, int W, int Cin, int Cout, int ksize, int geglu, int iters,

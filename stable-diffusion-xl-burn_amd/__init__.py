@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "sdxl_last_error", "sdxl_build_info", "sdxl_ctx_create", "sdxl_ctx_destroy", "sdxl_ctx_synchronize",
     "sdxl_unet_config_base", "sdxl_unet_config_refiner", "sdxl_vae_config_default",
     "sdxl_unet_param_count", "sdxl_unet_param_spec", "sdxl_vae_param_count", "sdxl_vae_param_spec",
-    "sdxl_unet_create", "sdxl_unet_create_synthetic", "sdxl_unet_destroy", "sdxl_unet_forward", "sdxl_unet_set_graph", "sdxl_unet_set_split_cfg", "sdxl_unet_set_fused_cross_attention", "sdxl_unet_set_gn_from_producer",
+    "sdxl_unet_create", "sdxl_unet_create_synthetic", "sdxl_unet_destroy", "sdxl_unet_forward", "sdxl_unet_set_graph", "sdxl_unet_set_split_cfg", "sdxl_unet_set_fused_cross_attention", "sdxl_unet_set_gn_from_producer", "sdxl_unet_mix_classes",
     "sdxl_qkv_attention", "sdxl_attn_decoder_mask",
     "sdxl_diffuser_create", "sdxl_diffuser_create_synthetic", "sdxl_diffuser_destroy", "sdxl_diffuser_unet",
     "sdxl_sample_latent", "sdxl_sample_latent_with_inpainting", "sdxl_refine_latent", "sdxl_step_count",
@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "sdxl_vae_create", "sdxl_vae_create_synthetic", "sdxl_vae_destroy", "sdxl_vae_decode_latent",
     "sdxl_latent_to_image", "sdxl_vae_encode_image", "sdxl_image_to_latent",
     "sdxl_unet_weight_arena", "sdxl_vae_weight_arena", "sdxl_diffuser_create_empty", "sdxl_vae_create_empty",
-    "sdxl_unet_profile", "sdxl_bench_igemm", "sdxl_bench_attention", "sdxl_debug_set", "sdxl_debug_warm_schedule",
+    "sdxl_unet_profile", "sdxl_unet_eager_forward_ms", "sdxl_bench_igemm", "sdxl_bench_attention", "sdxl_debug_set", "sdxl_debug_warm_schedule",
     "sdxl_group_norm", "sdxl_layer_norm", "sdxl_conv2d", "sdxl_linear", "sdxl_layer_norm_linear", "sdxl_ln_query_cross_attention", "sdxl_conv2d_group_norm",
     "sdxl_clip_config_clip_l", "sdxl_clip_config_open_clip_bigg", "sdxl_clip_param_count", "sdxl_clip_param_spec",
     "sdxl_clip_create", "sdxl_clip_create_synthetic", "sdxl_clip_destroy", "sdxl_clip_forward_hidden",
@@ -362,6 +362,12 @@ class UNet:
     def set_graph(self, enabled: bool):
         _check(lib().sdxl_unet_set_graph(self.h, int(enabled)))
 
+    def mix_classes(self) -> int:
+        """MIX_* classes on plain f16 operands (F32_SPLIT_MIX* models; an F16W model on parameters that are not f16 values reports F32_SPLIT_MIX's 3)"""
+        v = ctypes.c_int(0)
+        _check(lib().sdxl_unet_mix_classes(self.h, ctypes.byref(v)))
+        return v.value
+
     def weight_arena(self) -> Tuple[int, int]:
         base, n = ctypes.c_void_p(), ctypes.c_size_t()
         _check(lib().sdxl_unet_weight_arena(self.h, ctypes.byref(base), ctypes.byref(n)))
@@ -378,6 +384,12 @@ class UNet:
         ms, ln, fl = (ctypes.c_float * 5)(), (ctypes.c_int * 5)(), (ctypes.c_double * 5)()
         _check(lib().sdxl_unet_profile(self.h, _stream(), B, H, W, ms, ln, fl))
         return {c: (float(ms[i]), int(ln[i]), float(fl[i])) for i, c in enumerate(self.PROFILE_CLASSES)}
+
+    def eager_forward_ms(self, B: int, H: int, W: int) -> float:
+        """the chain profile() runs without the per-launch events (one event pair around it, best of three)"""
+        v = ctypes.c_float(0)
+        _check(lib().sdxl_unet_eager_forward_ms(self.h, _stream(), B, H, W, ctypes.byref(v)))
+        return float(v.value)
 
     def __del__(self):
         if getattr(self, "_owned", False) and getattr(self, "h", None) and _lib is not None:

@@ -907,8 +907,12 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
       const int chunk = dt * 8 + g * 2 + h;
       *reinterpret_cast<f32x4*>(ob + fr * 256 + ((chunk ^ (fr & 15)) << 4)) = v;
     }
-  if (p.o_dt == DT_HL) {        // the out-projection's operand format: 8 consecutive d per lane -> hi / lo octets of an HL16 group
-    half_t* Oh = reinterpret_cast<half_t*>(p.O) + ((size_t)b * p.Nq * p.ldo + hd * 64) * 2;
+  if (p.o_dt != DT_F32) {
+    // DT_HL: the out-projection's operand format: 8 consecutive d per lane -> hi / lo octets of an HL16 group.  DT_F16 (mixed modes: rows for an f16
+    // out-projection): the hi octet alone -- the fp32 result rounded once, no fp32 round trip through memory
+    const bool hl = p.o_dt == DT_HL;
+    half_t* Oh = reinterpret_cast<half_t*>(p.O) + ((size_t)b * p.Nq * p.ldo + hd * 64) * (hl ? 2 : 1);
+    const size_t rstride = hl ? 2 * (size_t)p.ldo : (size_t)p.ldo;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + (lane >> 3), piece = lane & 7;
@@ -922,9 +926,9 @@ __global__ __launch_bounds__(256, 2) void attn_d64_hl_kernel(const AttnParams p,
       }
       const int q = q0 + row;
       if (q < p.Nq) {
-        half_t* dst = Oh + (size_t)q * (2 * p.ldo) + (piece >> 1) * 32 + (piece & 1) * 8;
+        half_t* dst = Oh + (size_t)q * rstride + (hl ? (piece >> 1) * 32 + (piece & 1) * 8 : piece * 8);
         *reinterpret_cast<half8*>(dst) = hi;
-        *reinterpret_cast<half8*>(dst + 16) = lo;
+        if (hl) *reinterpret_cast<half8*>(dst + 16) = lo;
       }
     }
     return;
@@ -1740,7 +1744,7 @@ bool launch_attention_d64_hl(const AttnParams& p, hipStream_t s) {
   const int dev = attn_device();
   const void* zeros = g_attn_zeros[dev];
   if (!zeros || p.mask) return false;
-  if (p.o_dt != DT_F32 && (p.o_dt != DT_HL || (p.ldo & 15) != 0)) return false;
+  if (p.o_dt != DT_F32 && (p.o_dt != DT_HL || (p.ldo & 15) != 0) && (p.o_dt != DT_F16 || (p.ldo & 7) != 0)) return false;
   if (p.q_dt != DT_F32 && (p.q_dt != DT_HL || (p.ldq & 15) != 0)) return false;
   if ((p.ldq & 3) != 0 || (p.ldo & 3) != 0 || (p.ldk & 15) != 0 || (p.vt_ld & 63) != 0 || p.vt_ld < (int)(((p.Nk + 63) / 64) * 64)) return false;
   if (((reinterpret_cast<uintptr_t>(p.Q) | reinterpret_cast<uintptr_t>(p.K) | reinterpret_cast<uintptr_t>(p.Vt) | reinterpret_cast<uintptr_t>(p.O)) & 15) != 0) return false;

@@ -63,7 +63,9 @@ void no_mix(int dtype) {     // the mixed mode is a property of the UNet driver 
 }
 int mix_of(int dtype) {
   return dtype == SDXL_DTYPE_F32_SPLIT_MIX ? (MIX_ATTN_F16 | MIX_GEGLU_F16)
-       : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16) : 0;    // (MIX_XATTN_F16 stays a knob: 7 % faster at 92 % of the bound)
+       : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_Q2_F16 | MIX_LN_SHADOW) : 0;
+       // (round 6: + the cross-attention query projection on f16 with an fp32 q, and the LayerNorms in front of the f16 projections folded through the f16
+       //  shadow of the stream -- DESIGN 12.1; MIX_XATTN_F16 stays a knob: 7 % faster at 92 % of the bound)
 }
 void dtypes(int dtype, int& cdt, int& sdt) {
   switch (dtype) {
@@ -474,6 +476,12 @@ int sdxl_unet_set_gn_from_producer(sdxl_unet* u, int enabled) {
   u->u->set_gn_from_producer(enabled != 0);
   API_END
 }
+int sdxl_unet_mix_classes(sdxl_unet* u, int* classes_out) {
+  API_BEGIN
+  SDXL_REQUIRE(u != nullptr && classes_out != nullptr, "null argument");
+  *classes_out = u->u->mix_classes();
+  API_END
+}
 int sdxl_unet_weight_arena(sdxl_unet* u, void** base, size_t* bytes) {
   API_BEGIN
   SDXL_REQUIRE(u && base && bytes, "null argument");
@@ -730,6 +738,13 @@ int sdxl_unet_profile(sdxl_unet* u, void* stream, int B, int H, int W, float cla
   SDXL_REQUIRE(u && class_ms && class_launches && class_flops, "null argument");
   use(u->ctx);
   u->u->profile(B, H, W, class_ms, class_launches, class_flops, pick(u->ctx, stream));
+  API_END
+}
+int sdxl_unet_eager_forward_ms(sdxl_unet* u, void* stream, int B, int H, int W, float* ms_out) {
+  API_BEGIN
+  SDXL_REQUIRE(u && ms_out, "null argument");
+  use(u->ctx);
+  *ms_out = u->u->eager_ms(B, H, W, pick(u->ctx, stream));
   API_END
 }
 void sdxl_diffuser_destroy(sdxl_diffuser* d) {

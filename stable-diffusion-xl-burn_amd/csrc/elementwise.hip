@@ -616,17 +616,19 @@ void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int K
                      kscale, wscale);
 }
 // cs[r] = sum_k packed[r][k] over the ROUNDED packed values (what the MFMA really multiplies), one wave per packed row
-__global__ void colsum_packed_kernel(const void* wp, int dt, int Kpad, int nrows, float* cs) {
+// kscale (K values, optional): cs[r] = sum_k kscale[k] * packed[r][k] -- the shadow form of a folded LayerNorm, whose gamma rides on the A operand
+__global__ void colsum_packed_kernel(const void* wp, int dt, int Kpad, int nrows, float* cs, const float* kscale, int K) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= nrows) return;
   float acc = 0.f;
-  for (int k = lane; k < Kpad; k += 64) acc += ld_f(wp, (size_t)row * Kpad + k, dt);
+  if (kscale) { for (int k = lane; k < K; k += 64) acc = fmaf(kscale[k], ld_f(wp, (size_t)row * Kpad + k, dt), acc); }
+  else for (int k = lane; k < Kpad; k += 64) acc += ld_f(wp, (size_t)row * Kpad + k, dt);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane == 0) cs[row] = acc;
 }
-void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_packed_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, wp, dt, Kpad, nrows, cs);
+void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s, const float* kscale, int K) {
+  hipLaunchKernelGGL(colsum_packed_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, wp, dt, Kpad, nrows, cs, kscale, K);
 }
 // out[n] = sum_k beta[k] * W[k][n] + bias[n]   (canonical column order; W is the burn [K][N] layout)
 __global__ void beta_dot_kernel(const float* w, const float* beta, const float* bias, float* out, int K, int N) {

@@ -151,7 +151,12 @@ struct WeightBuilder {
   // the same with the preceding LayerNorm(gamma, beta) folded into weight / bias / column sums
   Lin linear_ln(const std::string& name, bool geglu, const std::string& norm);
   Lin fused_linear_ln(const std::vector<std::string>& names, const std::string& norm);
-  Lin fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu);
+  // dt_override / shadow / plain: the SHADOW form (round 6, split-operand models): the weights are packed UN-folded in dt_override (f16) -- gamma rides on
+  // the A operand, an f16 shadow  f16(x o gamma)  the producer of the fp32 stream leaves (IgemmParams::shadow) -- with cs = gamma W over the packed values
+  // and b = beta W + bias; *plain receives the same packed matrix with the canonical bias (for the LayerNorm-launch path where no shadow exists)
+  Lin fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override = -1, bool shadow = false, Lin* plain = nullptr);
+  // AND of "every value of these tensors is exactly one f16" (device flag read back): what SDXL_DTYPE_F32_SPLIT_MIX_F16W asks of the classes it moves to f16
+  bool all_f16_exact(const std::vector<std::string>& names);
   float* tmp2 = nullptr; size_t tmp2_numel = 0;   // scratch for folded biases (device)
   Lin conv(const std::string& name);                                        // name.weight [Cout,Cin,k,k] + bias
   void attach_wfrag(Lin& l, bool fill);    // second image of a plain f16 linear / 1x1 weight in fragment order (arena; no-op for other layers)
@@ -228,8 +233,11 @@ enum MixClass {
   MIX_QKV_F16 = 4,      // QKV projection (implies the f16 self-attention)
   MIX_FF_F16 = 8,       // FF-out (reads the GEGLU kernel's f16 output)
   MIX_OUT1_F16 = 16,    // self-attention out-projection (reads the f16 attention output as it is)
-  MIX_OUT2_F16 = 32,    // cross-attention out-projection (the fp32 attention output narrowed once by a row copy)
-  MIX_XATTN_F16 = 64    // with OUT2: cross-attention + its query projection as the f16 engine's fused launch -- a knob, in no mode
+  MIX_OUT2_F16 = 32,    // cross-attention out-projection (the split-operand attention rounds its fp32 result to f16 once, in its store)
+  MIX_XATTN_F16 = 64,   // with OUT2: cross-attention + its query projection as the f16 engine's fused launch -- a knob, in no mode
+  MIX_Q2_F16 = 128,     // cross-attention QUERY projection alone on f16 operands (HL16 output: the split-operand attention behind it keeps an fp32-class q)
+  MIX_LN_SHADOW = 256   // the LayerNorms in front of the f16 projections (QKV, GEGLU, the query projection with MIX_Q2_F16) folded into them: the producers of
+                        // the fp32 stream leave an f16 shadow f16(x o gamma) + row statistics (IgemmParams::shadow), no LayerNorm launch
 };
 enum DemoteClass { DM_QKV = 1, DM_ATTN = 2, DM_OUT = 4, DM_XATTN = 8, DM_GEGLU = 16, DM_FF = 32, DM_CONV_RES = 64, DM_CONV_SKIP = 128,
                    DM_CONV_IO = 256, DM_CONV_UPDOWN = 512, DM_CONV_PROJ = 1024 };
@@ -254,6 +262,9 @@ struct Epi {
   // filled it (igemm_gn_part_ok), the caller then tags the output Act
   float* gn_part = nullptr;
   int cls = 0;       // DemoteClass bit of this GEMM (UNet call sites): label of the launch in the per-launch profile dump, nothing else
+  // f16 shadow of an fp32 output for the GEMM behind the next LayerNorm (IgemmParams::shadow): asked for by the caller, written only when the kernel the
+  // selection picks can (weights-in-registers kernel) -- *shadow_done tells; stat_out then holds the fp32 rows' statistics
+  void* shadow = nullptr; int shadow_ld = 0; const float* shadow_gamma = nullptr; bool* shadow_done = nullptr;
 };
 bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());   // true: e.gn_part was filled
 bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());
@@ -263,7 +274,8 @@ void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& 
 
 // ------------------------------------------------------------------------------------------ UNet
 struct ResBlockW { NormW norm_in, norm_out; Lin conv_in, conv_out, skip; bool has_skip = false; int emb_off = 0, cin = 0, cout = 0; };
-struct TBlockW { NormW n1, n2, n3; Lin qkv, out1, q2, kv2, out2, geglu, ff; };
+struct TBlockW { NormW n1, n2, n3; Lin qkv, out1, q2, kv2, out2, geglu, ff;
+                 Lin qkv_sh, q2_sh, geglu_sh; };   // *_sh: shadow forms (MIX_LN_SHADOW; .cs set) sharing the packed matrix of their plain twin
 struct STW { NormW norm; Lin proj_in, proj_out; std::vector<TBlockW> blocks; int C = 0, heads = 0; };
 struct BlockW { BlockDesc d; ResBlockW res; STW st; Lin conv; };
 
@@ -286,6 +298,7 @@ class UNet {
   void* unet_in(int B, int H, int W);     // ensures the plan exists
   float* eps_out() { return eps_; }
   int compute_dt() const { return cdt_; }
+  int mix_classes() const { return mix_; }     // MixClass bits in force (a SDXL_DTYPE_F32_SPLIT_MIX_F16W model on parameters that are not f16 values falls back to F32_SPLIT_MIX's)
   // dtype of the NHWC input the sampler writes (unet_in) and of the attention operands: the compute dtype, except that the
   // split-operand mode (DT_HL GEMM operands) keeps the 4-channel input and q / k / V^T in plain fp32
   int input_dt() const { return cdt_ == DT_HL ? DT_F32 : cdt_; }
@@ -299,6 +312,7 @@ class UNet {
   // one eager forward of the current plan/context with hipEvents around every launch, summed per kernel class
   void profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[Profiler::NCLS], double flops[Profiler::NCLS],
                hipStream_t s);
+  float eager_ms(int B, int H, int W, hipStream_t s);     // the chain profile() runs, without the per-launch events (best of three)
   size_t weight_bytes() const { return warena_.off; }
   void* weight_base() const { return warena_.base; }
 
@@ -312,6 +326,7 @@ class UNet {
   UNetCfg cfg_;
   int cdt_, sdt_;
   int mix_ = 0;                          // MixClass bits (split-operand engine): classes on plain f16 operands
+  bool mix_knob_ = false;                // the bits came from sdxl_debug_set "mix_classes" (no f16-exactness fallback)
   DeviceArena warena_;
   std::vector<BlockW> inp_, out_;
   BlockW mid_res1_, mid_res2_;   // middle_block: res1 -> transformer (in mid_res1_.st) -> res2

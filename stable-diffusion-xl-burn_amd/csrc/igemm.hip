@@ -362,12 +362,14 @@ void launch_igemm(const IgemmParams& pin, int compute_dt, hipStream_t s) {
   const int g_igemm_variant = g_igemm_variant_a.load();
   if (compute_dt == DT_F16 && g_igemm_variant >= 0 && launch_igemm_glds(p, g_igemm_variant, s)) return;
   if (compute_dt == DT_F16 && g_igemm_variant > 0 && launch_igemm_glds(p, 0, s)) return;   // forced tile refused the shape
+  if (p.shadow && compute_dt != DT_F16) throw std::runtime_error("an f16 shadow output needs an f16 GEMM (weights-in-registers kernel)");
   if (compute_dt == DT_F32 && g_igemm_variant >= 0 && launch_igemm_f32_pipe(p, s)) return;
   if (compute_dt == DT_HL) {     // no generic twin: layers the HL pipeline cannot take are packed (and launched) as fp32 by the host
     if (launch_igemm_hl_pipe(p, s)) return;
     throw std::runtime_error("split-operand (DT_HL) GEMM: shape / alignment outside the direct-to-LDS pipeline");
   }
   if (p.xa_k) throw std::runtime_error("fused cross-attention needs the f16 direct-to-LDS kernels");
+  if (p.shadow) throw std::runtime_error("an f16 shadow output needs the f16 weights-in-registers kernel");
   // the generic kernels below never write the GroupNorm statistics: a caller that was promised them (run_conv tags the output
   // Act and the consumer skips its statistics pass) must not get uninitialised memory -- forced variants, unaligned A, no zero page
   if (p.gn_part) throw std::runtime_error("GroupNorm statistics from the epilogue (gn_part) need the f16 direct-to-LDS 256x128 kernel");

@@ -1241,6 +1241,10 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
   }
   // plain linear layers / 1x1 convs whose weights also exist in fragment order: the weights-in-registers kernel (igemm_wreg.hip).
   // The rule is static per layer (never the batch), so its k-summation order (even + odd k-tiles) is what such a layer always gets.
+  if (p.shadow) {      // f16 shadow of an fp32 output: written by the weights-in-registers epilogue only (run_conv asks igemm_wreg_selected before it sets the field)
+    if (!launch_igemm_wreg(psk, 0, s)) throw std::runtime_error("igemm: an f16 shadow output needs the weights-in-registers kernel");
+    return true;
+  }
   if ((variant == 0 || (variant >= 60 && variant <= 77)) && launch_igemm_wreg(psk, variant, s)) return true;
   if (variant >= 60 && variant <= 77) return false;
   if (variant == 0 && igemm_splitk_slices(p) > 1) {

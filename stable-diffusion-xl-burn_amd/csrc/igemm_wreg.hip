@@ -70,7 +70,7 @@ void launch_repack_wfrag(const void* w, void* wf, int Npad, int Kpad, hipStream_
 // epilogue, so the (mean, M2) bits do not depend on which kernel produced the rows.  Called by all 8 waves (two barriers when p.stat_out).
 // the epilogue's operands that do not depend on the accumulators -- residual rows, bias -- are requested BEFORE the partial sums
 // cross LDS (~1.7 k cycles of barriers and LDS traffic that would otherwise precede an exposed L2 / Infinity-Cache round trip)
-template <int TM> struct WregEpiOperands { half8 rh[TM]; f32x4 rf[TM][2]; f32x4 bz0, bz1; };
+template <int TM> struct WregEpiOperands { half8 rh[TM]; f32x4 rf[TM][2]; f32x4 bz0, bz1, sg0, sg1; };
 template <int TM>
 __device__ __forceinline__ void wreg_epilogue_request(const IgemmParams& p, int mw, int nw, int lane, int t, const void* zeros, WregEpiOperands<TM>& op) {
   const int fr = lane & 31, fh = lane >> 5;
@@ -91,12 +91,15 @@ __device__ __forceinline__ void wreg_epilogue_request(const IgemmParams& p, int 
   // (no time-embedding bias here: it rides on the 3x3 conv_in of a ResBlock only -- the launcher refuses ebias)
   op.bz0 = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nw + 16 * t + 4 * fh) : zv);
   op.bz1 = *(p.bias ? reinterpret_cast<const f32x4*>(p.bias + nw + 16 * t + 8 + 4 * fh) : zv);
+  // f16 shadow of an fp32 stream (IgemmParams::shadow): the next LayerNorm's gamma over this lane's 8 output columns
+  op.sg0 = *(p.shadow ? reinterpret_cast<const f32x4*>(p.shadow_gamma + n0) : zv);
+  op.sg1 = *(p.shadow ? reinterpret_cast<const f32x4*>(p.shadow_gamma + n0 + 4) : zv);
 }
 template <int TM>
 __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM], int mw, int nw, int lane, int w, int t,
                                               float* xch, const WregEpiOperands<TM>& op) {
   const int fr = lane & 31, fh = lane >> 5;
-  half8 hv[TM];
+  float sv[TM][8];      // what the row statistics are taken of: the stored values (f16 outputs: the rounded ones the consumer will read; fp32 rows as they are)
   int m[TM];
   bool mok[TM];
 #pragma unroll
@@ -135,15 +138,26 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
 #pragma unroll
         for (int e = 0; e < 8; ++e) h[e] = (half_t)wv[e];
         if (mok[i]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.C) + (size_t)m[i] * p.ldc + n0) = h;
-        hv[i] = h;
-      } else if (mok[i]) {
-        float* cp = reinterpret_cast<float*>(p.C) + (size_t)m[i] * p.ldc + n0;
-        *reinterpret_cast<f32x4*>(cp) = f32x4{wv[0], wv[1], wv[2], wv[3]};
-        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{wv[4], wv[5], wv[6], wv[7]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sv[i][e] = (float)h[e];
+      } else {
+        if (mok[i]) {
+          float* cp = reinterpret_cast<float*>(p.C) + (size_t)m[i] * p.ldc + n0;
+          *reinterpret_cast<f32x4*>(cp) = f32x4{wv[0], wv[1], wv[2], wv[3]};
+          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{wv[4], wv[5], wv[6], wv[7]};
+        }
+        if (p.shadow) {      // (kernel argument: uniform) f16(x * gamma of the next LayerNorm): the operand of the GEMM behind it
+          half8 hs;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hs[e] = (half_t)(wv[e] * op.sg0[e]); hs[4 + e] = (half_t)(wv[4 + e] * op.sg1[e]); }
+          if (mok[i]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.shadow) + (size_t)m[i] * p.shadow_ld + n0) = hs;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sv[i][e] = wv[e];
       }
     }
   }
-  if (!p.stat_out) return;          // (kernel argument: uniform over the workgroup; the launcher admits stat_out with f16 outputs only)
+  if (!p.stat_out) return;          // (kernel argument: uniform over the workgroup)
   // ---- row statistics of the stored (rounded) values, slot = the 64 columns of the wave pair (w & ~1, w | 1) x both groups
   const int pair = w >> 1;
   const int part = (w & 1) * 2 + t;                      // position of this wave's 16 columns in the slot: pieces 2 part, 2 part + 1
@@ -153,7 +167,7 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
   if (part == 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      piv[i] = __shfl((float)hv[i][0], fr);              // the slot's first stored value (lanes 0..31 of the first wave hold it)
+      piv[i] = __shfl(sv[i][0], fr);              // the slot's first stored value (lanes 0..31 of the first wave hold it)
       if (fh == 0) xpiv[i * 32 + fr] = piv[i];
     }
   }
@@ -169,7 +183,7 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
   for (int i = 0; i < TM; ++i) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float d = (float)hv[i][e] - piv[i]; s1 += d; s2 = fmaf(d, d, s2); }
+    for (int e = 0; e < 8; ++e) { const float d = sv[i][e] - piv[i]; s1 += d; s2 = fmaf(d, d, s2); }
     A1[i] = s1 + __shfl_xor(s1, 32); A2[i] = s2 + __shfl_xor(s2, 32);        // pieces 2 part (lanes 0..31) + 2 part + 1 (lanes 32..63)
     if (part != 0 && fh == 0) { xsum[((part - 1) * TM * 32 + i * 32 + fr) * 2] = A1[i]; xsum[((part - 1) * TM * 32 + i * 32 + fr) * 2 + 1] = A2[i]; }
   }
@@ -543,7 +557,8 @@ bool igemm_wreg_ok(const IgemmParams& p) {
   if ((p.ldc & 7) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0) return false;
   if (p.R && ((p.ldr & 7) != 0 || (reinterpret_cast<uintptr_t>(p.R) & 15) != 0)) return false;
   if (p.ebias) return false;
-  if (p.stat_out && p.c_dt != DT_F16) return false;
+  // f16 shadow of an fp32 output (+ the fp32 rows' statistics): whole 16-byte pieces
+  if (p.shadow && (p.c_dt != DT_F32 || !p.shadow_gamma || (p.shadow_ld & 7) != 0 || (reinterpret_cast<uintptr_t>(p.shadow) & 15) != 0)) return false;
   return true;
 }
 // variant 0: rows per tile from the grid it makes on 256 CUs (the k-summation order does not depend on it); 60 / 62 force 96 / 64

@@ -73,6 +73,11 @@ struct IgemmParams {
   int wreg_xcd2d;   // A/B knob (sdxl_debug_set "wreg_xcd2d"): weights-in-registers kernel, XCDs own 2-D patches of tiles (half the column tiles x ~ a quarter of
                     // the row tiles each) instead of whole row-tile runs -- fewer unique operand bytes per XCD's L2; set by the launcher
   int epi_staged;   // A/B knob (sdxl_debug_set "igemm_epilogue_staged"): 1 = LDS-staged epilogue everywhere, 0 = direct row-per-lane where it applies
+  // f16 SHADOW of an fp32 residual stream (round 6; weights-in-registers kernel only, igemm_wreg_ok): next to the fp32 rows C the epilogue stores
+  // shadow[m][n] = f16(value * shadow_gamma[n]) -- the A operand of the GEMM behind the NEXT LayerNorm (gamma = that norm's), whose weights stay
+  // un-folded: LN(x) W + b = rstd (x o gamma) W - rstd mu (gamma W) + (beta W + b).  With stat_out (the fp32 rows' statistics) the LayerNorm launch
+  // between two GEMMs of a split-operand transformer block disappears.  null = off.
+  void* shadow; int shadow_ld; const float* shadow_gamma;
 };
 bool igemm_gn_part_ok(const IgemmParams& p);
 // shapes the fused cross-attention epilogue takes (f16 operands, head dim 64, <= 96 context tokens); otherwise run the
@@ -156,7 +161,7 @@ struct AttnParams {
   float scale;                 // 1/sqrt(d)
   const float* mask; int ldmask;   // optional additive [Nq][Nk] fp32 (0 / -inf), null in UNet/VAE
   int q_dt = 0;                // split-operand kernel only: DT_F32 (0) or DT_HL -- Q rows in HL16 (ldq in logical elements)
-  int o_dt = 0;                // split-operand kernel only: DT_F32 (0) or DT_HL -- O written as HL16 rows (ldo in logical elements), the next GEMM's operand
+  int o_dt = 0;                // split-operand kernel only: DT_F32 (0), DT_HL -- O written as HL16 rows (ldo in logical elements), the next GEMM's operand -- or DT_F16 (rounded once: an f16 out-projection's operand)
   // key halves on DIFFERENT workgroups (attn_d64_mix_kernel level 2, round 4): workspace of attention_xsplit_ws_bytes(B, H, Nq) bytes and
   // attention_xsplit_counters(B, H, Nq) zero-initialised tickets (they re-arm themselves); null = that form is never picked
   float* xws = nullptr; unsigned* xcnt = nullptr;
@@ -269,7 +274,7 @@ void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int K
                         int n_offset, hipStream_t s, const float* kscale = nullptr,    // kscale[k]: LayerNorm gamma fold
                         float wscale = 1.0f);                                          // power-of-two factor of the DT_HL packing
 // LayerNorm fold helpers: column sums of the packed (rounded) weight rows; beta . W + bias in canonical column order
-void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s);
+void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s, const float* kscale = nullptr, int K = 0);   // kscale: cs[r] = sum_k kscale[k] packed[r][k]
 void launch_beta_dot(const float* w, const float* beta, const float* bias, float* out, int K, int N, hipStream_t s);
 // canonical conv [Cout][Cin][kh][kw] fp32 -> packed [Npad][Kpad], k = (kh*kw_idx)*Cin + c
 void launch_pack_conv(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad,

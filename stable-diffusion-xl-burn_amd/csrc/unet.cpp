@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstring>
 
 namespace sdxl {
 
@@ -38,7 +39,8 @@ ResBlockW load_res(WeightBuilder& wb, const std::string& p, int cin, int cout, s
 }
 STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln, int mix = 0) {
   const bool geglu_f16 = (mix & MIX_GEGLU_F16) != 0, qkv_f16 = (mix & MIX_QKV_F16) != 0, ff_f16 = (mix & MIX_FF_F16) != 0, out1_f16 = (mix & MIX_OUT1_F16) != 0,
-             out2_f16 = (mix & MIX_OUT2_F16) != 0, q2_f16 = out2_f16 && (mix & MIX_XATTN_F16) != 0;
+             out2_f16 = (mix & MIX_OUT2_F16) != 0, q2_fused = out2_f16 && (mix & MIX_XATTN_F16) != 0, q2_f16 = q2_fused || (mix & MIX_Q2_F16) != 0,
+             ln_sh = (mix & MIX_LN_SHADOW) != 0;
   STW s;
   s.C = C; s.heads = heads;
   s.norm = wb.norm(p + ".norm");
@@ -60,14 +62,22 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
       continue;
     }
     t.n1 = wb.norm(q + ".norm1");
+    // MIX_LN_SHADOW: the f16 projections behind a LayerNorm also exist in the shadow form (same packed matrix, cs = gamma W, b = beta W + bias): where the
+    // producer of the stream left the f16 shadow f16(x o gamma) and the row statistics, the LayerNorm launch is skipped (spatial_transformer)
+    if (ln_sh && qkv_f16) t.qkv_sh = wb.fold_ln({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, q + ".norm1", false, DT_F16, true, &t.qkv);
+    else
     t.qkv = wb.fused_linear({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, qkv_f16 ? (int)DT_F16 : -1);
     t.out1 = wb.linear(q + ".attn1.out", false, out1_f16 ? (int)DT_F16 : -1);
     t.n2 = wb.norm(q + ".norm2");
+    if (ln_sh && q2_f16 && !q2_fused) t.q2_sh = wb.fold_ln({q + ".attn2.query"}, q + ".norm2", false, DT_F16, true, &t.q2);
+    else
     t.q2 = wb.linear(q + ".attn2.query", false, q2_f16 ? (int)DT_F16 : -1);
     t.kv2 = wb.fused_linear({q + ".attn2.key", q + ".attn2.value"});
     t.out2 = wb.linear(q + ".attn2.out", false, out2_f16 ? (int)DT_F16 : -1);
     t.n3 = wb.norm(q + ".norm3");
     // (mixed mode: the GEGLU projection of a split-operand model packed as plain f16 -- it runs on the f16 wide-tile kernel)
+    if (ln_sh && geglu_f16) t.geglu_sh = wb.fold_ln({q + ".mlp.geglu.proj"}, q + ".norm3", true, DT_F16, true, &t.geglu);
+    else
     t.geglu = wb.linear(q + ".mlp.geglu.proj", true, geglu_f16 ? (int)DT_F16 : -1);
     t.ff = wb.linear(q + ".mlp.lin", false, ff_f16 ? (int)DT_F16 : -1);
     s.blocks.push_back(t);
@@ -120,7 +130,7 @@ void attention_hl(Exec& ex, const Act& q, const void* kh, int ldk, const void* v
   p.demote = (ex.demote & demote_cls) ? 1 : 0;
   p.Q = q.p; p.ldq = q.ld; p.K = kh; p.ldk = ldk; p.Vt = vth; p.vt_ld = vt_ld; p.O = o.p; p.ldo = o.ld;
   p.dt = DT_HL; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
-  p.o_dt = o.dt == DT_HL ? DT_HL : DT_F32;
+  p.o_dt = o.dt == DT_HL ? DT_HL : o.dt == DT_F16 ? DT_F16 : DT_F32;
   p.q_dt = q.dt == DT_HL ? DT_HL : DT_F32;
   if (ex.prof) ex.prof->begin(Profiler::ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, ex.s, Nq, Nk, B * H, 0, demote_cls);
   if (!launch_attention_d64_hl(p, ex.s)) throw Error("split-operand attention: unsupported shape / alignment (Nq=" + std::to_string(Nq) + " Nk=" + std::to_string(Nk) + ")");
@@ -171,7 +181,8 @@ void UNet::apply_demote_weights(hipStream_t s) {
 }
 
 UNet::UNet(const UNetCfg& cfg, int compute_dt, int stream_dt, WeightSource& src, hipStream_t st, int mix)
-    : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt), mix_(compute_dt == DT_HL ? (mix && g_mix_classes.load() >= 0 ? g_mix_classes.load() : mix) : 0) {
+    : cfg_(cfg), cdt_(compute_dt), sdt_(stream_dt), mix_(compute_dt == DT_HL ? (mix && g_mix_classes.load() >= 0 ? g_mix_classes.load() : mix) : 0),
+      mix_knob_(compute_dt == DT_HL && mix && g_mix_classes.load() >= 0) {
   SDXL_REQUIRE(cfg.n_head_channels == 64, "this engine's fused attention kernel is specialised for 64 channels per head");
   SDXL_REQUIRE(!((compute_dt == DT_F32 || compute_dt == DT_HL) && stream_dt != DT_F32), "f32 / split-operand compute implies an f32 residual stream");
   SDXL_REQUIRE(cfg.model_channels % 32 == 0, "GroupNorm(32) needs model_channels % 32 == 0");
@@ -189,6 +200,25 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
   const std::vector<ParamSpec> specs = unet_param_specs(cfg_);
   warena_.reserve(WeightBuilder::arena_bound(specs, cdt_));
   WeightBuilder wb(specs, src, warena_, cdt_, st);
+  // SDXL_DTYPE_F32_SPLIT_MIX_F16W moves classes to plain f16 operands whose WEIGHTS must be f16 values (the reference's records are,
+  // src/bin/sample/main.rs:37): on other parameters that would round the weights as well and leave the mode's error bound (0.029 against
+  // 0.0212).  Checked here on the tensors themselves; a model that does not qualify falls back to F32_SPLIT_MIX's two classes (mix_classes() tells).
+  // Not applied to the A/B knob "mix_classes" (the frontier tools run those maps on fp32 weights on purpose) nor on replicas built from an empty
+  // source (they receive rank 0's arena: the caller compares rank 0's mix_classes() with the mode before the broadcast, bench.py does).
+  constexpr int kNeedExact = MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_XATTN_F16 | MIX_Q2_F16;
+  if (cdt_ == DT_HL && (mix_ & kNeedExact) && !mix_knob_ && !src.empty()) {
+    std::vector<std::string> names;
+    auto ends = [](const std::string& n, const char* suf) { const size_t l = std::strlen(suf); return n.size() >= l && n.compare(n.size() - l, l, suf) == 0; };
+    for (const ParamSpec& ps : specs) {
+      const std::string& n = ps.name;
+      if (n.find(".transformer.blocks.") == std::string::npos) continue;
+      if (((mix_ & MIX_QKV_F16) && (ends(n, ".attn1.query.weight") || ends(n, ".attn1.key.weight") || ends(n, ".attn1.value.weight"))) ||
+          ((mix_ & MIX_OUT1_F16) && ends(n, ".attn1.out.weight")) || ((mix_ & MIX_OUT2_F16) && ends(n, ".attn2.out.weight")) ||
+          ((mix_ & MIX_FF_F16) && ends(n, ".mlp.lin.weight")) || ((mix_ & (MIX_XATTN_F16 | MIX_Q2_F16)) && ends(n, ".attn2.query.weight")))
+        names.push_back(n);
+    }
+    if (!wb.all_f16_exact(names)) mix_ &= (MIX_ATTN_F16 | MIX_GEGLU_F16);
+  }
   const int gv = cdt_ == DT_HL ? DT_F32 : -1;     // the M <= 8 GEMV weights of a split-operand model are packed fp32
   lin1_t_ = wb.linear("lin1_time_embed", false, gv);
   lin2_t_ = wb.linear("lin2_time_embed", false, gv);
@@ -397,8 +427,8 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   const bool mix_ff = hl_attn && !w.blocks.empty() && w.blocks[0].ff.dt == DT_F16;
   const bool mix_out1 = hl_attn && !w.blocks.empty() && w.blocks[0].out1.dt == DT_F16;
   const bool mix_out2 = hl_attn && !w.blocks.empty() && w.blocks[0].out2.dt == DT_F16;
-  Act ao32, ao2_16;
-  if (mix_out2) { ao32 = ex.alloc(M, C, DT_F32); ao2_16 = ex.alloc(M, C, DT_F16); }
+  Act ao2_16;      // operand of an f16 cross-attention out-projection: the split-operand attention rounds its fp32 result once, in its own store (AttnParams::o_dt)
+  if (mix_out2) ao2_16 = ex.alloc(M, C, DT_F16);
   const bool mix_attn = hl_attn && ((mix_ & MIX_ATTN_F16) || mix_qkv) && C % 16 == 0;
   SDXL_REQUIRE(!mix_qkv || mix_attn, "mixed mode: an f16 QKV projection feeds the f16 self-attention");
   SDXL_REQUIRE(!mix_out1 || mix_attn, "mixed mode: an f16 out-projection reads the f16 self-attention's output");
@@ -412,9 +442,24 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   }
   // cross-attention of the mixed mode on f16 (MIX_XATTN_F16): the f16 engine's fused launch -- query projection and the 77-key attention in one kernel on
   // the f16 LayerNorm output and the packed f16 context; shapes that launch does not take (tiny nets) widen the f16 query for the split-operand attention
-  const bool mix_q2 = hl_attn && mix_out2 && !w.blocks.empty() && w.blocks[0].q2.dt == DT_F16;
-  const bool mix_xa = mix_q2 && plan_xattn_ && !kv_.empty() && kv_[si][0].xa && igemm_xattn_ok(DT_F16, DT_F16, (int)M, C, C, HW, n_ctx_);
+  const bool mix_q2 = hl_attn && !w.blocks.empty() && w.blocks[0].q2.dt == DT_F16;
+  // the f16 engine's fused launch (MIX_XATTN_F16: the set_context of such a model packed the f16 context, kv.xa) -- otherwise an f16 query projection
+  // (MIX_Q2_F16) writes an fp32 q for the split-operand attention
+  const bool mix_xa = mix_q2 && mix_out2 && (mix_ & MIX_XATTN_F16) && plan_xattn_ && !kv_.empty() && kv_[si][0].xa && igemm_xattn_ok(DT_F16, DT_F16, (int)M, C, C, HW, n_ctx_);
+  const bool mix_q2_widen = mix_q2 && (mix_ & MIX_XATTN_F16) && mix_out2;     // round 5's form of the knob on shapes the fused launch does not take: f16 q, widened
   if (mix_geglu || mix_qkv || mix_q2) ln16 = ex.alloc(M, C, DT_F16);
+  // MIX_LN_SHADOW: f16 shadow of the stream + the fp32 rows' statistics, left by the weights-in-registers producers (out-projections, FF-out) for the f16
+  // projection behind the next LayerNorm; `have_sh` says whether the last producer wrote them (else: LayerNorm launch + the plain form of the projection)
+  const bool any_sh = hl_attn && !w.blocks.empty() && (w.blocks[0].qkv_sh.cs || w.blocks[0].q2_sh.cs || w.blocks[0].geglu_sh.cs);
+  Act sh16; float* shst = nullptr; bool have_sh = false;
+  if (any_sh) { sh16 = ex.alloc(M, C, DT_F16); shst = (float*)ex.act->alloc(M * (size_t)((C + 63) / 64) * 2 * sizeof(float)); }
+  Act q32;     // MIX_Q2_F16: fp32 q of the cross-attention (the f16 projection's fp32 accumulators, never rounded to f16)
+  if (mix_q2 && !mix_q2_widen) q32 = ex.alloc(M, C, DT_F32);
+  auto want_shadow = [&](Epi& e, const Lin& consumer_sh, const NormW& n) {     // ask producer `e` for the shadow the consumer behind LayerNorm n reads
+    have_sh = false;
+    if (!consumer_sh.cs || C % 64 != 0) return;
+    e.shadow = sh16.p; e.shadow_ld = sh16.ld; e.shadow_gamma = n.gamma; e.stat_out = shst; e.shadow_done = &have_sh;
+  };
   // the f16 GEGLU kernels store an HL16 output through the LDS-staged epilogue of the wide / pipelined tiles -- the kernels every SDXL shape runs on
   // (M = 2048 ... 32768).  Small token counts (tiny test nets: M < 256) run on other tiles; they take the form the F16_F32RES engine
   // runs at every size -- f16 output -- and widen it.
@@ -455,10 +500,16 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   } else
   for (size_t j = 0; j < w.blocks.size(); ++j) {
     const TBlockW& b = w.blocks[j];
+    Epi eq; eq.n_split = 2 * C; eq.Ct = mix_attn ? vt16 : vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.cls = DM_QKV;
+    if (have_sh && b.qkv_sh.cs) {      // the previous block's FF-out left f16(t o gamma1) and the row statistics: no LayerNorm launch
+      eq.ln_stat = shst;
+      run_linear(ex, b.qkv_sh, sh16, (int)M, qk16, eq);
+    } else {
     run_layernorm(ex, b.n1, t, (int)M, mix_qkv ? ln16 : ln);
     demote_lo(ex, DM_QKV, ln, M, C);
-    Epi eq; eq.n_split = 2 * C; eq.Ct = mix_attn ? vt16 : vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.cls = DM_QKV;
     run_linear(ex, b.qkv, mix_qkv ? ln16 : ln, (int)M, mix_attn ? qk16 : qk, eq);
+    }
+    have_sh = false;
     if (mix_attn) {
       attention(ex, qk16, qk16.cols(C), vt16, npad, ao16, B, w.heads, HW, HW);
       if (!ex.dry && !mix_out1) launch_f16_to_hl(ao16.p, ao16.ld, ao.p, ao.ld, M, C, ex.s);
@@ -478,9 +529,18 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     else attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
     Epi er; er.R = t; er.rpb = HW; er.cls = DM_OUT;
     demote_lo(ex, DM_OUT, ao, M, C);
-    run_linear(ex, b.out1, mix_out1 ? ao16 : ao, (int)M, t, er);
+    { Epi e1 = er; if (mix_out1) want_shadow(e1, b.q2_sh, b.n2); run_linear(ex, b.out1, mix_out1 ? ao16 : ao, (int)M, t, e1); }
+    if (have_sh && b.q2_sh.cs) {       // f16 query projection on the shadow the out-projection left; fp32 q for the split-operand attention
+      Epi e2q; e2q.cls = DM_XATTN; e2q.rpb = HW; e2q.ln_stat = shst;
+      run_linear(ex, b.q2_sh, sh16, (int)M, q32, e2q);
+      attention_hl(ex, q32, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao2_16 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);
+    } else {
     run_layernorm(ex, b.n2, t, (int)M, mix_q2 ? ln16 : ln);
     demote_lo(ex, DM_XATTN, ln, M, C);
+    if (mix_q2 && !mix_xa && !mix_q2_widen) {
+      { Epi e2q; e2q.cls = DM_XATTN; e2q.rpb = HW; run_linear(ex, b.q2, ln16, (int)M, q32, e2q); }
+      attention_hl(ex, q32, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao2_16 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);
+    } else
     if (mix_xa) {
       Epi e2q; e2q.rpb = HW; e2q.cls = DM_XATTN;
       e2q.xa_k = kv_xa(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
@@ -491,7 +551,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
         if (q.dt == DT_HL) launch_f16_to_hl(ao2_16.p, ao2_16.ld, q.p, q.ld, M, C, ex.s);
         else launch_copy_rows(ao2_16.p, DT_F16, ao2_16.ld, q.p, q.dt, q.ld, (int)M, C, ex.s);
       }
-      attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao32, B, w.heads, HW, n_ctx_, DM_XATTN);
+      attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, ao2_16, B, w.heads, HW, n_ctx_, DM_XATTN);
     } else if (xattn) {
       Epi e2q; e2q.rpb = HW; e2q.cls = DM_XATTN;
       e2q.xa_k = kv_xa(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
@@ -499,15 +559,27 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     } else {
       { Epi e2q; e2q.cls = DM_XATTN; run_linear(ex, b.q2, ln, (int)M, q, e2q); }
       demote_lo(ex, DM_XATTN, q, M, C);
-      if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao32 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);   // caches are HL16 (set_context)
+      if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao2_16 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);   // caches are HL16 (set_context)
       else attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
     }
+    }
+    have_sh = false;
     demote_lo(ex, DM_OUT, ao, M, C);
-    if (mix_out2 && !mix_xa && !ex.dry) launch_copy_rows(ao32.p, DT_F32, ao32.ld, ao2_16.p, DT_F16, ao2_16.ld, (int)M, C, ex.s);
-    run_linear(ex, b.out2, mix_out2 ? ao2_16 : ao, (int)M, t, er);
+    { Epi e2 = er; if (mix_out2) want_shadow(e2, b.geglu_sh, b.n3); run_linear(ex, b.out2, mix_out2 ? ao2_16 : ao, (int)M, t, e2); }
+    Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
+    const bool gg_sh = have_sh && b.geglu_sh.cs;      // GEGLU projection on the shadow the cross-attention's out-projection left: no LayerNorm launch
+    if (gg_sh) eg.ln_stat = shst;
+    else {
     run_layernorm(ex, b.n3, t, (int)M, mix_geglu ? ln16 : ln);
     demote_lo(ex, DM_GEGLU, ln, M, C);
-    Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
+    }
+    have_sh = false;
+    if (gg_sh) {
+      eg.rpb = HW;
+      if (mix_ff) run_linear(ex, b.geglu_sh, sh16, (int)M, gg16, eg);
+      else if (!gg_direct) { run_linear(ex, b.geglu_sh, sh16, (int)M, gg16, eg); if (!ex.dry) launch_f16_to_hl(gg16.p, gg16.ld, gg.p, gg.ld, M, 4 * C, ex.s); }
+      else run_linear(ex, b.geglu_sh, sh16, (int)M, gg, eg);
+    } else
     if (mix_ff) {
       run_linear(ex, b.geglu, mix_geglu ? ln16 : ln, (int)M, gg16, eg);         // f16 output for the f16 FF-out (f16 or split-operand GEGLU compute)
     } else if (mix_geglu && !gg_direct) {
@@ -517,7 +589,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_linear(ex, b.geglu, mix_geglu ? ln16 : ln, (int)M, gg, eg);
     demote_lo(ex, DM_FF, gg, M, 4 * C);
     er.cls = DM_FF;
-    run_linear(ex, b.ff, mix_ff ? gg16 : gg, (int)M, t, er);
+    { Epi ef = er; if (mix_ff && j + 1 < w.blocks.size()) want_shadow(ef, w.blocks[j + 1].qkv_sh, w.blocks[j + 1].n1); run_linear(ex, b.ff, mix_ff ? gg16 : gg, (int)M, t, ef); }
   }
   Epi eo; eo.R = x; eo.rpb = HW; eo.cls = DM_CONV_PROJ;
   run_linear(ex, w.proj_out, hl_op(ex, w.proj_out, t, M, C, DM_CONV_PROJ), (int)M, x, eo);
@@ -799,6 +871,35 @@ void UNet::profile(int B, int H, int W, float ms[Profiler::NCLS], int launches[P
   run(ex, tconv_, 1, 0, B);   // always the batched chain: per-launch events need one stream
   act_.reset(m);
   prof.collect(ms, launches, flops);
+}
+
+// the same eager chain WITHOUT the per-launch events, bracketed by one event pair: what the launches of profile() take when nobody measures them one
+// by one -- (sum of profile()'s class times - this) / launches is the event overhead a bracketed launch carries (bench.py's calibration)
+float UNet::eager_ms(int B, int H, int W, hipStream_t s) {
+  ensure_plan(B, H, W);
+  SDXL_REQUIRE(ctx_B_ == B && !kv_.empty(), "set_context must be called with the same batch before eager_ms");
+  const float t500[8] = {500.f, 500.f, 500.f, 500.f, 500.f, 500.f, 500.f, 500.f};
+  SDXL_HIP(hipMemcpyAsync(tconv_, t500, sizeof(t500), hipMemcpyHostToDevice, s));
+  SDXL_HIP(hipStreamSynchronize(s));
+  hipEvent_t a, b;
+  SDXL_HIP(hipEventCreate(&a)); SDXL_HIP(hipEventCreate(&b));
+  float best = 0.f;
+  for (int rep = 0; rep < 3; ++rep) {
+    Exec ex; ex.s = s; ex.cdt = cdt_; ex.sdt = sdt_; ex.act = &act_; ex.gn_partial = gn_partial_; ex.demote = demote_mask_;
+    ex.splitk_ws = skws_[0]; ex.splitk_ws_bytes = skws_bytes_; ex.splitk_cnt = skcnt_[0];
+    if (cdt_ == DT_F16 || (mix_ & MIX_ATTN_F16)) { ex.attn_xws = attn_xws_[0]; ex.attn_xcnt = attn_xcnt_[0]; }
+    const size_t m = act_.mark();
+    SDXL_HIP(hipEventRecord(a, s));
+    run(ex, tconv_, 1, 0, B);
+    SDXL_HIP(hipEventRecord(b, s));
+    act_.reset(m);
+    SDXL_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    SDXL_HIP(hipEventElapsedTime(&ms, a, b));
+    if (rep == 0 || ms < best) best = ms;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  return best;
 }
 
 void UNet::forward_nchw(const float* x, const int* timesteps, const float* context, int n_ctx, const float* label, int B,

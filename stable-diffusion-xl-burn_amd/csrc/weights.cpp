@@ -251,9 +251,23 @@ Lin WeightBuilder::linear_ln(const std::string& name, bool geglu, const std::str
 Lin WeightBuilder::fused_linear_ln(const std::vector<std::string>& names, const std::string& norm) {
   return fold_ln(names, norm, false);
 }
-Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu) {
+bool WeightBuilder::all_f16_exact(const std::vector<std::string>& names) {
+  if (src.empty() || names.empty()) return true;      // (replica ranks receive rank 0's arena: its decision is theirs -- see UNet::build_weights)
+  float* flag = (float*)tmp2;
+  if (tmp2_numel < 4) { if (tmp2) SDXL_HIP(hipFree(tmp2)); SDXL_HIP(hipMalloc((void**)&tmp2, 64 * sizeof(float))); tmp2_numel = 64; flag = tmp2; }
+  bool first = true;
+  for (const std::string& n : names) { launch_f16_exact(fetch(n), spec(n).numel(), 1.0f, flag, st, !first); first = false; }
+  float h = 0.f;
+  SDXL_HIP(hipMemcpyAsync(&h, flag, sizeof(float), hipMemcpyDeviceToHost, st));
+  SDXL_HIP(hipStreamSynchronize(st));
+  return h != 0.f;
+}
+Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override, bool shadow, Lin* plain) {
   SDXL_REQUIRE(!geglu || names.size() == 1, "GEGLU packing applies to a single projection");
+  const int mdt = dt;                       // the model's dtype
+  const int dt = dt_override >= 0 ? dt_override : mdt;      // (shadows the member below: the dtype THIS matrix is packed in)
   Lin l; l.ksize = 1;
+  if (dt != mdt) l.dt = dt;
   int ntot = 0;
   for (const std::string& n : names) {
     const ParamSpec& s = spec(n + ".weight");
@@ -269,6 +283,8 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
   float* cs = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   float* leps = (float*)arena.alloc(sizeof(float));
   l.w = w; l.b = b; l.cs = cs; l.ln_eps = leps;
+  float* bplain = plain ? (float*)arena.alloc((size_t)l.Npad * sizeof(float)) : nullptr;
+  if (plain) { *plain = l; plain->b = bplain; plain->cs = nullptr; plain->ln_eps = nullptr; }
   if (src.empty()) return l;
   SDXL_HIP(hipMemcpyAsync(leps, fetch(norm + ".eps"), sizeof(float), hipMemcpyDeviceToDevice, st));
   const size_t need = 3 * (size_t)l.Npad + 2 * (size_t)l.K;
@@ -286,6 +302,7 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
   SDXL_HIP(hipMemcpyAsync(beta, fetch(norm + ".beta"), l.K * sizeof(float), hipMemcpyDeviceToDevice, st));
   SDXL_HIP(hipMemsetAsync(w, 0, (size_t)l.Npad * l.Kpad * dt_size(dt), st));
   SDXL_HIP(hipMemsetAsync(b, 0, (size_t)l.Npad * sizeof(float), st));
+  if (bplain) SDXL_HIP(hipMemsetAsync(bplain, 0, (size_t)l.Npad * sizeof(float), st));
   int off = 0;
   for (const std::string& n : names) {
     const ParamSpec& s = spec(n + ".weight");
@@ -293,13 +310,16 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
     const bool hb = has(n + ".bias");
     if (hb) SDXL_HIP(hipMemcpyAsync(bsrc, fetch(n + ".bias"), N * sizeof(float), hipMemcpyDeviceToDevice, st));
     const float* wsrc = fetch(n + ".weight");
-    if (names.size() == 1) launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st, gamma);
-    else launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, N, 0, off, st, gamma);
+    // (shadow form: the matrix stays W -- an f16-representable parameter stays exact -- and gamma multiplies the A operand instead)
+    if (names.size() == 1) launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st, shadow ? nullptr : gamma);
+    else launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, N, 0, off, st, shadow ? nullptr : gamma);
     launch_beta_dot(wsrc, beta, hb ? bsrc : nullptr, bfold, l.K, N, st);
     launch_pack_bias(bfold, b, N, names.size() == 1 ? l.Npad : N, geglu ? 1 : 0, off, st);
+    if (bplain) launch_pack_bias(hb ? bsrc : nullptr, bplain, N, names.size() == 1 ? l.Npad : N, geglu ? 1 : 0, off, st);
     off += N;
   }
-  launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st);
+  if (shadow) launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st, gamma, l.K);      // cs[n] = sum_k gamma[k] W[k][n] over the packed (rounded) values
+  else launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st);
   return l;
 }
 Lin WeightBuilder::conv(const std::string& name) {
@@ -390,6 +410,15 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.stat_out = e.stat_out; p.stat_slots = w.N / 64;
   p.splitk_ws = ex.splitk_ws; p.splitk_ws_bytes = ex.splitk_ws_bytes; p.splitk_cnt = ex.splitk_cnt; p.splitk = 0;
   p.xa_k = e.xa_k; p.xa_nctx = e.xa_nctx; p.xa_scale = e.xa_scale;
+  // f16 shadow of an fp32 output (+ its row statistics) for the GEMM behind the next LayerNorm: only where the selection picks the
+  // weights-in-registers kernel anyway; otherwise neither is written and the caller runs the LayerNorm launch
+  if (e.shadow_done) *e.shadow_done = false;
+  if (e.shadow) {
+    p.shadow = e.shadow; p.shadow_ld = e.shadow_ld; p.shadow_gamma = e.shadow_gamma;
+    const bool ok = (w.dt >= 0 ? w.dt : ex.cdt) == DT_F16 && igemm_wreg_selected(p);
+    if (!ok) { p.shadow = nullptr; p.shadow_gamma = nullptr; p.stat_out = nullptr; }
+    if (e.shadow_done) *e.shadow_done = ok;
+  }
   // GroupNorm statistics of the output from this GEMM's epilogue -- only when the kernel the selection picks anyway can do it
   p.gn_part = nullptr;
   if (e.gn_part && ex.cdt == DT_F16) { p.gn_part = e.gn_part; if (!igemm_gn_part_ok(p)) p.gn_part = nullptr; }

@@ -32,6 +32,18 @@ LAT_REL_F16 = 6.0e-3         # fp16-operand modes: max-abs error relative to max
                              # (5-step inpainting) on the tiny net -> <= 2x measured
 
 
+F16W_CLASSES = 1 | 2 | 4 | 8 | 16 | 32 | 128 | 256     # SDXL_DTYPE_F32_SPLIT_MIX_F16W (capi.hip mix_of): + cross-attention query projection, LayerNorm shadow (round 6)
+
+
+def weights_for(pkg, ocfg, dtype):
+    """(oracle weights, synthetic seed of the engine) for a dtype: SDXL_DTYPE_F32_SPLIT_MIX_F16W is FOR f16-representable parameters (on others the
+    engine falls back to F32_SPLIT_MIX's classes), so dtype 5 is tested on the seeded weights rounded to f16 on both sides"""
+    W = unet_weights(ocfg)
+    if dtype != 5:
+        return W, 0
+    return {k: (v if k.endswith(".eps") else v.half().float()) for k, v in W.items()}, pkg.SEED_F16_WEIGHTS
+
+
 def lat_tol(dtype, ref):
     return LAT_ABS_F32 if dtype in (0, 3) else LAT_REL_F16 * float(ref.abs().max())
 
@@ -60,7 +72,7 @@ def _pkg_cond(pkg, c, res, refiner=False):
 @pytest.mark.parametrize("which", ["tiny", "tiny_refiner"])
 def test_unet_forward(pkg, ctx, dtype, which):
     ocfg = OC.tiny_config() if which == "tiny" else OC.tiny_refiner_config()
-    W = unet_weights(ocfg)
+    W, wseed = weights_for(pkg, ocfg, dtype)
     B, H, Wd = 2, 16, 16
     x = torch.from_numpy(OC.arb_tensor(B, 4, H, Wd))          # reference probe recipe, bin/test/main.rs:133
     context = torch.from_numpy(OC.arb_tensor(B, 5, ocfg.context_dim))
@@ -70,6 +82,7 @@ def test_unet_forward(pkg, ctx, dtype, which):
     specs = pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg))
     flat = pkg.flatten_weights(specs, {k: v.numpy() for k, v in W.items()})
     u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, weights=flat)
+    assert u.mix_classes() == {4: 3, 5: F16W_CLASSES}.get(dtype, 0)
     outs = [u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu() for _ in range(3)]   # eager, capture, replay
     e = rel_err(outs[0], ref)
     print(f"unet_forward[{which}] dtype={dtype}: rel err {e:.3e}")
@@ -77,7 +90,7 @@ def test_unet_forward(pkg, ctx, dtype, which):
     assert e < FWD_TOL[dtype]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "hipGraph replay differs from eager run"
     # device-side synthetic weights are bit-identical to the oracle's numpy recipe -> identical output
-    u2 = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    u2 = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=wseed)
     out2 = u2.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu()
     print(f"  synthetic-vs-host max diff {max_abs(out2, outs[0]):.3e}; replay diffs {max_abs(outs[0], outs[1]):.3e} {max_abs(outs[1], outs[2]):.3e}")
     assert torch.equal(out2, outs[0]), "synthetic device weights differ from the oracle's"
@@ -182,7 +195,7 @@ def test_fused_cross_attention_matches_two_kernel_path(pkg, ctx):
 def test_unet_forward_batch_independence(pkg, ctx, dtype):
     # the engine batches the CFG pair; per-sample results must not depend on what else is in the batch
     ocfg = OC.tiny_config()
-    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=weights_for(pkg, ocfg, dtype)[1])
     x, c, y = seeded(2, 4, 8, 8, seed=1), seeded(2, 5, ocfg.context_dim, seed=2), seeded(2, ocfg.adm_in_channels, seed=3)
     t = torch.tensor([500, 20], dtype=torch.int32)
     both = u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu()
@@ -199,9 +212,10 @@ def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
     c, oc = _cond(ocfg, n, res)
     noise = seeded(n, 4, res[0] // 8, res[1] // 8, seed=40)
     trace = []
-    ref = OP.Diffuser(ocfg, unet_weights(ocfg), OC.alphas_cumprod()).sample_latent(oc, cfg_scale, n_steps, noise, trace)
+    W, wseed = weights_for(pkg, ocfg, dtype)
+    ref = OP.Diffuser(ocfg, W, OC.alphas_cumprod()).sample_latent(oc, cfg_scale, n_steps, noise, trace)
     assert len(trace) == pkg.step_count(n_steps)
-    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=wseed)
     out = d.sample_latent(_pkg_cond(pkg, c, res), cfg_scale, n_steps, noise.cuda()).cpu()
     e = max_abs(out, ref)
     print(f"sample_latent n={n} steps={n_steps} dtype={dtype}: latent max-abs err {e:.3e} (|latent| max {ref.abs().max():.2f})")
@@ -210,21 +224,22 @@ def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
     assert torch.equal(out, out2), "trajectory is not deterministic"
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 3, 4])
+@pytest.mark.parametrize("dtype", [0, 1, 3, 4, 5])
 def test_refine_latent(pkg, ctx, dtype):
     ocfg = OC.tiny_refiner_config()
     res = (64, 64)
     c, oc = _cond(ocfg, 1, res, refiner=True)
     latent, noise = seeded(1, 4, 8, 8, seed=41), seeded(1, 4, 8, 8, seed=42)
-    ref = OP.Diffuser(ocfg, unet_weights(ocfg), OC.alphas_cumprod()).refine_latent(latent, oc, 7.5, 800, 50, noise)
-    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    W, wseed = weights_for(pkg, ocfg, dtype)
+    ref = OP.Diffuser(ocfg, W, OC.alphas_cumprod()).refine_latent(latent, oc, 7.5, 800, 50, noise)
+    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=wseed)
     out = d.refine_latent(latent.cuda(), _pkg_cond(pkg, c, res, True), 7.5, 800, 50, noise.cuda()).cpu()
     e = max_abs(out, ref)
     print(f"refine_latent dtype={dtype}: max-abs err {e:.3e}")
     assert e < lat_tol(dtype, ref)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 3, 4])
+@pytest.mark.parametrize("dtype", [0, 1, 3, 4, 5])
 def test_sample_latent_with_inpainting(pkg, ctx, dtype):
     ocfg = OC.tiny_config()
     res = (64, 64)
@@ -235,9 +250,10 @@ def test_sample_latent_with_inpainting(pkg, ctx, dtype):
     step_noise = seeded(iters, 1, 4, 8, 8, seed=45)
     mask = torch.zeros(1, 4, 8, 8, dtype=torch.bool)
     mask[:, :, 0:3, :] = True      # crop rows in latent coords, broadcast to 4 channels (sample/main.rs:164-185)
-    ref = OP.Diffuser(ocfg, unet_weights(ocfg), OC.alphas_cumprod()).sample_latent_with_inpainting(
+    W, wseed = weights_for(pkg, ocfg, dtype)
+    ref = OP.Diffuser(ocfg, W, OC.alphas_cumprod()).sample_latent_with_inpainting(
         oc, 7.5, n_steps, reference, mask, noise0, [step_noise[i] for i in range(iters)])
-    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=0)
+    d = pkg.Diffuser(ctx, to_pkg_cfg(pkg, ocfg), dtype, seed=wseed)
     out = d.sample_latent_with_inpainting(_pkg_cond(pkg, c, res), 7.5, n_steps, reference.cuda(), mask.cuda(),
                                           noise0.cuda(), step_noise.cuda()).cpu()
     e = max_abs(out, ref)
@@ -305,6 +321,30 @@ def test_against_committed_golden_fixture(pkg, ctx, dtype):
     ref = torch.from_numpy(g["traj"][-1])
     assert max_abs(lat, ref) < lat_tol(dtype, ref)
     del ld
+
+
+def test_f16w_mode_falls_back_on_parameters_that_are_not_f16_values(pkg, ctx):
+    # SDXL_DTYPE_F32_SPLIT_MIX_F16W packs six more transformer classes as plain f16: on parameters that are not f16 values that would round the
+    # WEIGHTS too and leave the mode's error bound.  The engine checks the tensors at create time and falls back to F32_SPLIT_MIX's two
+    # classes: same bits as dtype 4, and sdxl_unet_mix_classes says so.  One perturbed weight is enough.
+    ocfg = OC.tiny_config()
+    cfg = to_pkg_cfg(pkg, ocfg)
+    x = torch.from_numpy(OC.arb_tensor(2, 4, 16, 16)).cuda()
+    c = torch.from_numpy(OC.arb_tensor(2, 5, ocfg.context_dim)).cuda()
+    y = torch.from_numpy(OC.arb_tensor(2, ocfg.adm_in_channels)).cuda()
+    t = torch.tensor([999, 1], dtype=torch.int32).cuda()
+    u5, u4 = pkg.UNet(ctx, cfg, 5, seed=0), pkg.UNet(ctx, cfg, 4, seed=0)
+    assert u5.mix_classes() == 3 == u4.mix_classes()
+    assert torch.equal(u5.forward(x, t, c, y), u4.forward(x, t, c, y))
+    assert pkg.UNet(ctx, cfg, 5, seed=pkg.SEED_F16_WEIGHTS).mix_classes() == F16W_CLASSES
+    specs = pkg.unet_param_specs(cfg)
+    W16 = {k: (v if k.endswith(".eps") else v.half().float()).numpy().copy() for k, v in unet_weights(ocfg).items()}
+    assert pkg.UNet(ctx, cfg, 5, weights=pkg.flatten_weights(specs, W16)).mix_classes() == F16W_CLASSES
+    name = next(k for k in W16 if k.endswith(".mlp.lin.weight"))
+    W16[name].flat[3] = np.float32(W16[name].flat[3]) * np.float32(1.0 + 2.0 ** -16)      # one value that is not an f16
+    assert pkg.UNet(ctx, cfg, 5, weights=pkg.flatten_weights(specs, W16)).mix_classes() == 3
+    for dt in (0, 1, 2, 3):
+        assert pkg.UNet(ctx, cfg, dt, seed=0).mix_classes() == 0
 
 
 def test_host_weights_equal_synthetic(pkg, ctx):
