@@ -247,7 +247,7 @@ def load_parity():
     STATIC part of the line's parity object -- what live_parity() below does not re-measure in this run"""
     out = {}
     try:
-        name = next(n for n in ("r05_parity_baseline.json", "r04_parity_baseline.json", "r03_parity_baseline.json", "r02_parity_baseline.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r06_parity_baseline.json", "r05_parity_baseline.json", "r04_parity_baseline.json", "r03_parity_baseline.json", "r02_parity_baseline.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as fh:
             r = json.load(fh)
         c1 = r.get("config1_f32_vs_oracle", {}).get("final")

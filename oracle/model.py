@@ -78,10 +78,13 @@ class Numerics:
         """a parameter tensor as the arithmetic holds it (cached: the 31-step trajectory asks 62 times)"""
         t = W[name]
         if self.mode == "f16ref" or self.on(cls):
-            c = self._wcache.get(name)
-            if c is None:
-                c = self._wcache[name] = self._h(t)
-            return c
+            # keyed by the tensor itself, not by its name alone: a second weight dict with the same names (base and refiner UNet, regenerated
+            # weights) inside one session must not receive the first model's rounded tensors (ADVICE r5)
+            key = (name, id(t))
+            c = self._wcache.get(key)
+            if c is None or c[0] is not t:
+                c = self._wcache[key] = (t, self._h(t))       # (the source tensor is kept alive: an id cannot be recycled under the cache)
+            return c[1]
         return t
 
     def a(self, x: Tensor, cls: str) -> Tensor:

@@ -137,7 +137,9 @@ pub enum Precision {
     /// `F32Split` with the self-attention and the GEGLU projection on plain f16 operands (UNet / Diffuser only): the fastest mode whose
     /// config-2 latents stay inside the parity tests' scaled 1e-3 bound
     F32SplitMix = ffi::SDXL_DTYPE_F32_SPLIT_MIX as isize,
-    /// `F32SplitMix` for models whose parameters are f16 values (the `.mpk` records of `HalfPrecisionSettings`): QKV projection and FF-out on f16 as well
+    /// `F32SplitMix` for models whose parameters are f16 values (the `.mpk` records of `HalfPrecisionSettings`): QKV projection, both attentions'
+    /// out-projections, FF-out and the cross-attention query projection on f16 operands as well, LayerNorms folded through an f16 shadow of the
+    /// stream (`capi.hip` `mix_of`); on other parameters the engine falls back to `F32SplitMix`'s classes (`Diffuser::mix_classes`)
     F32SplitMixF16W = ffi::SDXL_DTYPE_F32_SPLIT_MIX_F16W as isize,
 }
 

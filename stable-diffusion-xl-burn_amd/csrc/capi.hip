@@ -1005,10 +1005,10 @@ int sdxl_conv2d(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   Act xa(xi, Cin, sdt);
   if (cdt == DT_HL && l.acc_scale) {      // range-safe conversion, as the models convert their fp32 stream tensors (hl_operand)
     float* x32 = (float*)tmp.get((size_t)B * H * W * Cin * sizeof(float));
-    float* sc = (float*)tmp.get(256);
+    float* sc = (float*)tmp.get(hl_scale_floats(B) * sizeof(float));
     launch_nchw_to_nhwc(x, Cin * H * W, x32, DT_F32, B, Cin, H * W, Cin, 1.0f, s);
-    launch_f32_to_hl_scaled(x32, Cin, xi, Cin, (size_t)B * H * W, Cin, sc, s);
-    xa.a_scale = sc + 1;
+    launch_f32_to_hl_scaled(x32, Cin, xi, Cin, (size_t)B * H * W, Cin, sc, s, B);      // one factor per batch entry, as the models' hl_operand
+    xa.a_scale = hl_scale_inv(sc, B); xa.a_scale_n = B;
   } else launch_nchw_to_nhwc(x, Cin * H * W, xi, sdt, B, Cin, H * W, Cin, 1.0f, s);     // (st_f handles the HL16 layout: Cin % 16 == 0 rows)
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
   give_splitk_ws(ex, tmp, B, Ho * Wo, Cout, s);
@@ -1057,9 +1057,9 @@ int sdxl_linear(sdxl_ctx* ctx, void* stream, const float* x, const float* weight
   tmp_wfrag(l, cdt, geglu != 0, tmp, s);
   Act xa(xi, K, sdt);
   if (cdt == DT_HL) {      // range-safe conversion, as the models convert their fp32 stream tensors (hl_operand)
-    float* sc = (float*)tmp.get(256);
-    launch_f32_to_hl_scaled(x, K, xi, K, (size_t)M, K, sc, s);
-    xa.a_scale = sc + 1;
+    float* sc = (float*)tmp.get(hl_scale_floats(1) * sizeof(float));
+    launch_f32_to_hl_scaled(x, K, xi, K, (size_t)M, K, sc, s, 1);
+    xa.a_scale = hl_scale_inv(sc, 1);
   } else launch_copy_rows(x, DT_F32, K, xi, sdt, K, M, K, s);
   Exec ex; ex.s = s; ex.cdt = cdt; ex.sdt = sdt;
   give_splitk_ws(ex, tmp, 1, M, N, s);

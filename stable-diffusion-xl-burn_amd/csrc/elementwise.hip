@@ -280,24 +280,26 @@ void launch_f16_exact(const float* src, size_t n, float wscale, float* exact, hi
 // GEMM operand: hi = f16(x) overflows to inf beyond 65504 (-> NaN out of the three-MFMA product) and below 6e-5 the lo half falls
 // into the f16 subnormals.  The tensor is therefore converted times the power of two 2^e that brings max|x| into [2^13, 2^14) -- exact,
 // the same rule the weights use (WeightBuilder::hl_scale) -- and the consuming GEMM undoes it through IgemmParams::a_scale.
-// scale_io[0] = max|x| (absmax_rows_kernel, float bits), scale_io[1] = 2^-e written here for the GEMM's epilogue.
-__global__ void absmax_rows_kernel(const float* src, int lds_, size_t rows, int C4, unsigned* out) {
+// Round 6: ONE FACTOR PER BATCH ENTRY (an entry's operand bits, hence its results, do not depend on its batch neighbours -- the guarantee the
+// f16 engine always gave), and no atomics / memset: the first kernel leaves kHlAbsBlocks per-block maxima per entry (every launch rewrites all of
+// them), every block of the second reduces its entry's partials in its prologue (512 bytes out of the L2) and block 0 of an entry writes 2^-e.
+__global__ void absmax_rows_kernel(const float* src, int lds_, size_t rows_per_entry, int C4, float* partial) {
+  const int b = blockIdx.y;
+  const float* sb = src + (size_t)b * rows_per_entry * lds_;
   float m = 0.f;
-  const size_t total = rows * (size_t)C4;
+  const size_t total = rows_per_entry * (size_t)C4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t r = i / C4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * lds_ + (i - r * C4) * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sb + r * lds_ + (i - r * C4) * 4);
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  // one atomic per WORKGROUP (round 5): with one per wave the 2048 x 4 atomics on a single address serialised in the L2 -- 97 us per call on
-  // average, 2.5 ms of a split-operand UNet step (profiles/r05_kernel_stats_mixed_mode.csv) -- for a pass that moves 5 - 40 MB
+  // (round 5 lesson: one atomicMax per wave on a single address serialised in the L2 -- 97 us per call; now no atomic at all)
   __shared__ float wmax[4];
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0)
-    atomicMax(out, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));      // non-negative floats order like their bit patterns (NaN / inf sort on top)
+  if (threadIdx.x == 0) partial[(size_t)b * kHlAbsBlocks + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));     // (NaN inputs: fmaxf drops them -- nothing to rescue there)
 }
 __device__ __forceinline__ float hl_stream_scale(float absmax) {
   if (!(absmax > 0.f) || !(absmax < INFINITY)) return 1.f;            // all-zero or non-finite tensors: nothing to rescue
@@ -307,19 +309,27 @@ __device__ __forceinline__ float hl_stream_scale(float absmax) {
   e = e > 60 ? 60 : (e < -60 ? -60 : e);
   return ldexpf(1.0f, e);
 }
-__global__ void f32_to_hl_scaled_kernel(const float* src, int lds_, half_t* dst, int ldd, size_t rows, int C8, float* scale_io) {
-  const float sc = hl_stream_scale(scale_io[0]);
+__global__ void f32_to_hl_scaled_kernel(const float* src, int lds_, half_t* dst, int ldd, size_t rows_per_entry, int C8, const float* partial, float* inv_out) {
+  const int b = blockIdx.y;
+  // this entry's max|x|: kHlAbsBlocks partials, one or none per thread
+  float m = threadIdx.x < kHlAbsBlocks ? partial[(size_t)b * kHlAbsBlocks + threadIdx.x] : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const float sc = hl_stream_scale(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) scale_io[1] = 1.0f / sc;
-  if (i >= rows * C8) return;
-  const size_t r = i / C8;
-  const int c = (int)(i - r * C8) * 8;
+  if (i == 0) inv_out[b] = 1.0f / sc;
+  if (i >= rows_per_entry * C8) return;
+  const size_t r = i / C8 + (size_t)b * rows_per_entry;
+  const int c = (int)(i % C8) * 8;
   const float* sp = src + r * lds_ + c;
-  const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+  const f32x4 a = *reinterpret_cast<const f32x4*>(sp), bb = *reinterpret_cast<const f32x4*>(sp + 4);
   half8 hi, lo;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float x = a[e] * sc, y = b[e] * sc;                              // (pinned in fp32 first: see store_hl8)
+    float x = a[e] * sc, y = bb[e] * sc;                             // (pinned in fp32 first: see store_hl8)
     asm("" : "+v"(x)); asm("" : "+v"(y));
     hi[e] = (half_t)x; lo[e] = (half_t)(x - (float)hi[e]);
     hi[4 + e] = (half_t)y; lo[4 + e] = (half_t)(y - (float)hi[4 + e]);
@@ -328,15 +338,15 @@ __global__ void f32_to_hl_scaled_kernel(const float* src, int lds_, half_t* dst,
   *reinterpret_cast<half8*>(dp) = hi;
   *reinterpret_cast<half8*>(dp + 16) = lo;
 }
-void launch_f32_to_hl_scaled(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s) {
+void launch_f32_to_hl_scaled(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s, int nb) {
   if ((C & 15) != 0 || (lds_ & 3) != 0 || (ldd & 15) != 0) throw std::runtime_error("f32_to_hl: C % 16 == 0 rows with aligned strides only");
-  (void)hipMemsetAsync(scale_io, 0, 2 * sizeof(float), s);
-  const size_t t4 = rows * (size_t)(C / 4);
-  hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)std::min<size_t>(512, (t4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
-                     rows, C / 4, reinterpret_cast<unsigned*>(scale_io));
-  const size_t total = rows * (size_t)(C / 8);
-  hipLaunchKernelGGL(f32_to_hl_scaled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
-                     reinterpret_cast<half_t*>(dst), ldd, rows, C / 8, scale_io);
+  if (nb < 1 || rows % (size_t)nb != 0) throw std::runtime_error("f32_to_hl: rows must split evenly over the batch entries");
+  static_assert(kHlAbsBlocks <= 256, "one partial per thread of the conversion block");
+  const size_t rpe = rows / nb;
+  hipLaunchKernelGGL(absmax_rows_kernel, dim3(kHlAbsBlocks, nb), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_, rpe, C / 4, scale_io);
+  const size_t total = rpe * (size_t)(C / 8);
+  hipLaunchKernelGGL(f32_to_hl_scaled_kernel, dim3((unsigned)((total + 255) / 256), nb), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
+                     reinterpret_cast<half_t*>(dst), ldd, rpe, C / 8, scale_io, hl_scale_inv(scale_io, nb));
 }
 void launch_f32_to_hl(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, hipStream_t s) {
   if ((C & 15) != 0 || (lds_ & 3) != 0 || (ldd & 15) != 0) throw std::runtime_error("f32_to_hl: C % 16 == 0 rows with aligned strides only");

@@ -169,10 +169,11 @@ struct Act {
   // GroupNorm statistics of this tensor left behind by the GEMM that produced it (Epi::gn_part -> IgemmParams::gn_part):
   // [B][gn_rt][C] (mean, M2) per 256-row tile and channel.  A GroupNorm over exactly this tensor skips its statistics pass.
   const float* gn_part = nullptr; int gn_rt = 0;
-  const float* a_scale = nullptr;   // HL16 copy of an fp32 stream tensor (hl_operand): device scalar 2^-e the consuming GEMM multiplies back (IgemmParams::a_scale)
+  const float* a_scale = nullptr;   // HL16 copy of an fp32 stream tensor (hl_operand): 2^-e per batch entry, multiplied back by the consuming GEMM (IgemmParams::a_scale)
+  int a_scale_n = 1;                // entries of a_scale (equal row counts each)
   Act() {}
   Act(void* p_, int ld_, int dt_) : p(p_), ld(ld_), dt(dt_) {}
-  Act cols(int c0) const { Act a((char*)p + (size_t)c0 * dt_size(dt), ld, dt); a.a_scale = a_scale; return a; }   // (a column slice drops the statistics)
+  Act cols(int c0) const { Act a((char*)p + (size_t)c0 * dt_size(dt), ld, dt); a.a_scale = a_scale; a.a_scale_n = a_scale_n; return a; }   // (a column slice drops the statistics)
 };
 
 // per-kernel-class hipEvent profiler (eager runs only): live measurement of the dominant kernel for bench.py's roofline
@@ -268,7 +269,7 @@ struct Epi {
 };
 bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());   // true: e.gn_part was filled
 bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());
-Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C);    // HL16 copy of an fp32 stream tensor for a split-operand GEMM (else x)
+Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int nb = 1);    // HL16 copy of an fp32 stream tensor (nb batch entries of rows / nb rows, one power-of-two scale each) for a split-operand GEMM (else x)
 void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups = 32);
 void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y);
 

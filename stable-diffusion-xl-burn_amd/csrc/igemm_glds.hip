@@ -534,9 +534,14 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
     }
   }
   if constexpr (HL) {   // split-operand weights are packed times a power of two (exact): the row coefficient of the epilogue undoes it
-    const float sc = (p.acc_scale ? *p.acc_scale : 1.f) * (p.a_scale ? *p.a_scale : 1.f);       // both powers of two: exact
+    // (the A operand's factor is per batch entry of the row: IgemmParams::a_scale_rpb)
+    const float wsc = p.acc_scale ? *p.acc_scale : 1.f;                                           // powers of two: the products are exact
 #pragma unroll
-    for (int i = 0; i < TM; ++i) { lnA[i] = sc; lnC[i] = 0.f; }
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WM + i * 32 + fr;
+      const int be = p.a_scale_rpb > 0 ? (m < p.M ? m : p.M - 1) / p.a_scale_rpb : 0;
+      lnA[i] = wsc * (p.a_scale ? p.a_scale[be] : 1.f); lnC[i] = 0.f;
+    }
     // (readfirstlane: the compiler must SEE that the choice is wave-uniform -- as a vector condition it runs both k-loops one after
     // the other under complementary EXEC masks, and MFMAs, barriers and the M0-addressed DMA do not honour EXEC)
     const int wx = (p.acc_scale && p.hl_wexact_ok && p.acc_scale[1] != 0.f) ? 1 : 0;
@@ -1349,7 +1354,10 @@ bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
   // choice never changes a result bit (A/B knob: sdxl_debug_set "hl_tile96").
   const long t96 = (long)((p.M + 95) / 96) * ((p.N + 127) / 128);
   const int t96mode = g_hl_tile96.load();      // 1: linear layers / 1x1 only (default), 2: 3x3 convolutions too (measured -0.15 % on the mixed mode's step: not selected)
-  if ((t96mode & 1) && (p.ksize == 1 || (t96mode & 2)) && p.n_split >= p.N && t128 < 256 && t96 <= 256 && t96 > t128 && eff256 < (double)t96 / 256.0) {
+  // (never a shape the in-launch split-K below would take: split-K depends on ONE entry's shape, this tile choice on the batched M -- testing it first
+  //  would give a K >= 10240 linear layer one summation order at B <= 2 and another at B >= 3)
+  if ((t96mode & 1) && (p.ksize == 1 || (t96mode & 2)) && p.n_split >= p.N && t128 < 256 && t96 <= 256 && t96 > t128 && eff256 < (double)t96 / 256.0 &&
+      !((t96mode & 16) && igemm_splitk_slices(p) > 1)) {
     launch_pipe<96, 128, 5, 3, 6, hl16_t>(q, s);
     return true;
   }

@@ -61,7 +61,8 @@ struct IgemmParams {
   float* gn_part;
   const float* acc_scale;   /* [0] = 1 / weight scale, [1] != 0: every packed weight is exactly one f16 (lo halves all zero) */  // DT_HL compute: the packed weights carry a power-of-two factor (exact); device scalar 1 / factor the epilogue multiplies the
                            // accumulators by (lives in the weight arena, so replicas that receive the arena by broadcast need no host copy); null = 1
-  const float* a_scale;     // DT_HL compute: device scalar 2^-e of an A operand converted by launch_f32_to_hl_scaled (null = 1); exact
+  const float* a_scale;     // DT_HL compute: 2^-e of an A operand converted by launch_f32_to_hl_scaled (null = 1); exact.  One value per batch entry:
+  int a_scale_rpb;          // output rows per entry of a_scale (row m reads a_scale[m / a_scale_rpb]); 0 = one value for all rows
   int hl_wexact_ok; // A/B knob (sdxl_debug_set "hl_weights_exact", default 1): split-operand launches may leave out the w_lo MFMAs when acc_scale[1] says every weight is one f16
   int xa_vec64;     // measure builds (sdxl_debug_set "xa_vec64"): the fused cross-attention epilogue reads its per-column vectors with the original 64-lane
   // weight warming (round 4): the launch also brings `warm_bytes` of the weights a LATER GEMM of the same stream will read into the
@@ -224,8 +225,13 @@ void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 void launch_f16_exact(const float* src, size_t n, float wscale, float* exact, hipStream_t s, bool accumulate = false);
 void launch_f32_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows, int C, hipStream_t s);
 // the same for a tensor whose range the model does not bound (residual stream, VAE hidden state): converted times the power of two
-// that brings max|x| into [2^13, 2^14); scale_io (2 device floats) receives {max|x|, 2^-e} -- pass scale_io + 1 as IgemmParams::a_scale
-void launch_f32_to_hl_scaled(const void* src, int lds, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s);
+// that brings max|x| into [2^13, 2^14) -- PER BATCH ENTRY (nb entries of rows / nb rows each: an entry's bits never depend on its batch
+// neighbours).  scale_io: hl_scale_floats(nb) device floats -- [nb][kHlAbsBlocks] per-block max|x| partials (no atomics, no memset: every
+// launch rewrites them), then the nb factors 2^-e at hl_scale_inv(scale_io, nb): pass that as IgemmParams::a_scale (a_scale_rpb = the GEMM's output rows per entry)
+constexpr int kHlAbsBlocks = 128;
+static inline size_t hl_scale_floats(int nb) { return (size_t)nb * (kHlAbsBlocks + 1); }
+static inline float* hl_scale_inv(float* scale_io, int nb) { return scale_io + (size_t)nb * kHlAbsBlocks; }
+void launch_f32_to_hl_scaled(const void* src, int lds, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s, int nb = 1);
 unsigned count_nonfinite(const void* src, int dt, int lds, size_t rows, int C, hipStream_t s);   // debugging aid (SDXL_NAN_CHECK): synchronises
 void launch_f16_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows, int C, hipStream_t s);   // f16 rows -> HL16 rows (lo = 0)
 void launch_hl_zero_lo(void* dst, int ldd, size_t rows, int C, hipStream_t s);   // HL16 rows: lo halves := 0 (precision-frontier instrument, UNet hl_demote)

@@ -118,8 +118,8 @@ void demote_lo(Exec& ex, int cls, const Act& a, size_t rows, int C) {
   if (ex.dry || !(ex.demote & cls) || a.dt != DT_HL) return;
   launch_hl_zero_lo(a.p, a.ld, rows, C, ex.s);
 }
-Act hl_op(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int cls) {      // hl_operand + the demotion of the copy when the consumer's class asks
-  Act o = hl_operand(ex, w, x, rows, C);
+Act hl_op(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int cls, int nb) {      // hl_operand + the demotion of the copy when the consumer's class asks
+  Act o = hl_operand(ex, w, x, rows, C, nb);
   if (o.p != x.p) demote_lo(ex, cls, o, rows, C);
   return o;
 }
@@ -311,7 +311,7 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
   const size_t m0 = ctx_arena_.mark();
   Act ctx((void*)context, cfg_.context_dim, DT_F32);
   if (cdt_ == DT_HL && !st_list_.empty() && !st_list_[0]->blocks.empty()) {    // one HL16 copy of the context for all 70 projections
-    ctx = hl_operand(ex, st_list_[0]->blocks[0].kv2, ctx, (size_t)B * n_ctx, cfg_.context_dim);
+    ctx = hl_operand(ex, st_list_[0]->blocks[0].kv2, ctx, (size_t)B * n_ctx, cfg_.context_dim, B);
     demote_lo(ex, DM_XATTN, ctx, (size_t)B * n_ctx, cfg_.context_dim);
   }
   for (size_t si = 0; si < st_list_.size(); ++si) {
@@ -373,7 +373,7 @@ const float* UNet::res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, 
   run_groupnorm(ex, w.norm_out, h, B, HW, gn2, true);
   demote_lo(ex, DM_CONV_RES, gn2, M, w.cout);
   Epi e2; e2.cls = DM_CONV_RES;
-  if (w.has_skip) { Epi es; es.cls = DM_CONV_SKIP; run_conv(ex, w.skip, hl_op(ex, w.skip, x, M, w.cin, DM_CONV_SKIP), w.cin, g1, out, es); e2.R = out; }
+  if (w.has_skip) { Epi es; es.cls = DM_CONV_SKIP; run_conv(ex, w.skip, hl_op(ex, w.skip, x, M, w.cin, DM_CONV_SKIP, B), w.cin, g1, out, es); e2.R = out; }
   else e2.R = x;
   if (tiles256) e2.gn_part = out_gn_part;
   const bool produced = run_conv(ex, w.conv_out, gn2, w.cout, g3, out, e2);
@@ -592,7 +592,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     { Epi ef = er; if (mix_ff && j + 1 < w.blocks.size()) want_shadow(ef, w.blocks[j + 1].qkv_sh, w.blocks[j + 1].n1); run_linear(ex, b.ff, mix_ff ? gg16 : gg, (int)M, t, ef); }
   }
   Epi eo; eo.R = x; eo.rpb = HW; eo.cls = DM_CONV_PROJ;
-  run_linear(ex, w.proj_out, hl_op(ex, w.proj_out, t, M, C, DM_CONV_PROJ), (int)M, x, eo);
+  run_linear(ex, w.proj_out, hl_op(ex, w.proj_out, t, M, C, DM_CONV_PROJ, B), (int)M, x, eo);
   ex.act->reset(mk);
 }
 
@@ -645,10 +645,10 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
     const int j = n_in - 1 - i;
     const Act dest = cat[j].cols(cx[j]);
     switch (b.d.kind) {
-      case BK_CONV: run_conv(ex, b.conv, hl_op(ex, b.conv, cur, (size_t)B * h * w, cur_c, DM_CONV_IO), cur_c, ConvGeom{B, h, w, h, w, 3, 1, 1, 0}, dest, tag_epi(DM_CONV_IO)); break;
+      case BK_CONV: run_conv(ex, b.conv, hl_op(ex, b.conv, cur, (size_t)B * h * w, cur_c, DM_CONV_IO, B), cur_c, ConvGeom{B, h, w, h, w, 3, 1, 1, 0}, dest, tag_epi(DM_CONV_IO)); break;
       case BK_DOWN: {
         const int h2 = (h - 1) / 2 + 1, w2 = (w - 1) / 2 + 1;
-        run_conv(ex, b.conv, hl_op(ex, b.conv, cur, (size_t)B * h * w, cur_c, DM_CONV_UPDOWN), cur_c, ConvGeom{B, h, w, h2, w2, 3, 2, 1, 0}, dest, tag_epi(DM_CONV_UPDOWN));
+        run_conv(ex, b.conv, hl_op(ex, b.conv, cur, (size_t)B * h * w, cur_c, DM_CONV_UPDOWN, B), cur_c, ConvGeom{B, h, w, h2, w2, 3, 2, 1, 0}, dest, tag_epi(DM_CONV_UPDOWN));
         h = h2; w = w2;
         break;
       }
@@ -694,7 +694,7 @@ void UNet::run(Exec& ex, const float* t_dev, int t_stride, int b0, int nb) {
       res_block(ex, b.res, cat[j], B, h, w, dest);
     }
     if (up) {   // Upsample::forward :742-752 -- nearest 2x fused into the conv gather
-      run_conv(ex, b.conv, hl_op(ex, b.conv, dest, (size_t)B * h * w, b.d.c_out, DM_CONV_UPDOWN), b.d.c_out, ConvGeom{B, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next, tag_epi(DM_CONV_UPDOWN));
+      run_conv(ex, b.conv, hl_op(ex, b.conv, dest, (size_t)B * h * w, b.d.c_out, DM_CONV_UPDOWN, B), b.d.c_out, ConvGeom{B, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next, tag_epi(DM_CONV_UPDOWN));
       h *= 2; w *= 2;
     }
     ex.act->reset(mk);

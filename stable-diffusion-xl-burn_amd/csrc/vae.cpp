@@ -91,7 +91,7 @@ void Vae::res_block(Exec& ex, const VaeResW& w, const Act& x, int B, int H, int 
   Act gn2 = ex.alloc(M, w.cout, ex.cdt);
   run_groupnorm(ex, w.n2, h, B, H * W, gn2, true, cfg_.n_group);
   Epi e;
-  if (w.has_nin) { run_conv(ex, w.nin, hl_operand(ex, w.nin, x, M, w.cin), w.cin, g1, out); e.R = out; }
+  if (w.has_nin) { run_conv(ex, w.nin, hl_operand(ex, w.nin, x, M, w.cin, B), w.cin, g1, out); e.R = out; }
   else e.R = x;
   run_conv(ex, w.c2, gn2, w.cout, g3, out, e);
   ex.act->reset(mk);
@@ -214,7 +214,7 @@ void Vae::run_decode(Exec& ex, const Act& in, int n, int h, int w, const Act& ou
     res_block(ex, b.r[1], a, n, h, w, bb);
     if (b.has_up) {
       res_block(ex, b.r[2], bb, n, h, w, a);
-      run_conv(ex, b.up, hl_operand(ex, b.up, a, M, co), co, ConvGeom{n, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next);
+      run_conv(ex, b.up, hl_operand(ex, b.up, a, M, co, n), co, ConvGeom{n, h, w, 2 * h, 2 * w, 3, 1, 1, 1}, next);
       h *= 2; w *= 2;
     } else {
       res_block(ex, b.r[2], bb, n, h, w, next);
@@ -248,7 +248,7 @@ void Vae::run_encode(Exec& ex, const Act& in, int n, int H, int W, const Act& ou
       Act bb = ex.alloc(M, co, ex.sdt);
       res_block(ex, b.r[1], a, n, h, w, bb);
       // PaddedConv2d(pad left 0, right 1, top 0, bottom 1), stride 2 (:229-238, :384-407)
-      run_conv(ex, b.down, hl_operand(ex, b.down, bb, M, co), co, ConvGeom{n, h, w, h2, w2, 3, 2, 0, 0}, next);
+      run_conv(ex, b.down, hl_operand(ex, b.down, bb, M, co, n), co, ConvGeom{n, h, w, h2, w2, 3, 2, 0, 0}, next);
     } else {
       res_block(ex, b.r[1], a, n, h, w, next);
     }

@@ -431,6 +431,7 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   if (ex.prof) ex.prof->begin(Profiler::IGEMM, 2.0 * p.M * (double)p.N * p.K, ex.s, p.M, p.N, p.K, p.ksize, e.cls);
   p.acc_scale = w.acc_scale;
   p.a_scale = (w.dt >= 0 ? w.dt : ex.cdt) == DT_HL ? a.a_scale : nullptr;
+  p.a_scale_rpb = (p.a_scale && a.a_scale_n > 1) ? p.M / a.a_scale_n : 0;      // (M = entries x output rows per entry)
   if (ex.warm && (w.dt >= 0 ? w.dt : ex.cdt) == DT_F16) {
     // weight warming: the plan's first forward records which weights every launch reads and whether its kernel has idle CUs to host
     // warming workgroups; later forwards hand launch i the weights of a later launch (WarmSeq::finish)
@@ -491,12 +492,13 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
 // GEMM operand view of a residual-stream tensor: the split-operand mode keeps the stream in fp32 and stages (hi, lo) f16 pairs, so
 // GEMMs that read the stream directly (skip / nin_shortcut 1x1 convs, up- / downsamplers, proj_out) get an HL16 copy; other modes
 // -- and layers whose weights were packed fp32 (w.dt) -- read x itself
-Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C) {
+Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int nb) {
   if (ex.cdt != DT_HL || x.dt != DT_F32 || w.dt == DT_F32) return x;
+  if (nb < 1 || rows % (size_t)nb != 0) nb = 1;
   Act o = ex.alloc(rows, C, DT_HL);
-  float* sc = (float*)ex.act->alloc(2 * sizeof(float));      // {max|x|, 2^-e}: the stream's range is the model's, not ours
-  if (!ex.dry) launch_f32_to_hl_scaled(x.p, x.ld, o.p, o.ld, rows, C, sc, ex.s);
-  o.a_scale = sc + 1;
+  float* sc = (float*)ex.act->alloc(hl_scale_floats(nb) * sizeof(float));      // per entry: max|x| partials, 2^-e -- the stream's range is the model's, not ours
+  if (!ex.dry) launch_f32_to_hl_scaled(x.p, x.ld, o.p, o.ld, rows, C, sc, ex.s, nb);
+  o.a_scale = hl_scale_inv(sc, nb); o.a_scale_n = nb;
   return o;
 }
 bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e) {

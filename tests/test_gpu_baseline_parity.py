@@ -24,7 +24,7 @@ What is compared, and to which bar:
     1024x1024 CFG-7.5 trajectory: per-step max-abs / relative / rms error -> gpurun_out/r05_drift_*.json (committed under
     profiles/).  fp16 operands cannot meet 1e-3 absolute (one rounding is 4.9e-4 relative, CFG 7.5 multiplies the error of
     eps by up to 7.5 per step); the bound asserted here is the measured class with headroom, stated in DESIGN.md section 5.
-Everything goes through the C ABI (ctypes); measured numbers are written to gpurun_out/r05_parity_baseline.json.
+Everything goes through the C ABI (ctypes); measured numbers are written to gpurun_out/r06_parity_baseline.json.
 """
 import json
 import os
@@ -78,7 +78,7 @@ def _write_report():
     yield
     try:
         os.makedirs(OUT_DIR, exist_ok=True)
-        path = os.path.join(OUT_DIR, "r05_parity_baseline.json")
+        path = os.path.join(OUT_DIR, "r06_parity_baseline.json")
         merged = {}
         if os.path.exists(path):          # a partial run (-k ...) updates its own entries only
             try:
@@ -695,6 +695,106 @@ def test_inpainting_1024_f16_representable_weights(pkg, ctx):
         assert rep["f32_split"]["per_step"][k]["max_abs"] <= lat_bound(ref_traj[k]), (k, rep["f32_split"]["per_step"][k])
         for nm in ("f32_split_mix", "f32_split_mix_f16w"):
             assert rep[nm]["per_step"][k]["max_abs"] <= 2.0 * lat_bound(ref_traj[k]), (nm, k, rep[nm]["per_step"][k])
+
+
+def test_refiner_1024_f16_representable_weights(pkg, ctx):
+    """BASELINE configs[3] on the weights the reference's records hold (every parameter an f16 value, src/bin/sample/main.rs:37; fixtures
+    oracle/make_golden_r6.py refiner1024_f16w / refine1024_f16w): one refiner UNet::forward at 1024^2 and Diffuser::refine_latent (2 iterations), the
+    split engines and SDXL_DTYPE_F32_SPLIT_MIX_F16W -- the mode FOR these weights -- against the oracle on the same weights, the latter at 1x the bound."""
+    gf, gr = os.path.join(GOLD, "fullsize_refiner1024_f16w.npz"), os.path.join(GOLD, "fullsize_refine1024_f16w.npz")
+    if not (os.path.exists(gf) and os.path.exists(gr)):
+        pytest.skip("tests/golden/fullsize_refine{r,}1024_f16w.npz not generated (python -m oracle.make_golden_r6, ~5 min)")
+    cfg = pkg.sdxl_refiner_config()
+    g = np.load(gf)
+    x, t = seeded(1, 4, 128, 128, seed=141), torch.tensor([150], dtype=torch.int32)
+    c, y = seeded(1, 77, cfg.context_dim, seed=142), seeded(1, cfg.adm_in_channels, seed=143)
+    assert np.allclose(checksum(x, c, y), g["in_checksum"], rtol=1e-9), "torch CPU generator changed: regenerate the fixtures"
+    ref = torch.from_numpy(g["out"])
+    rep = {"forward": {}, "refine_latent": {}}
+    for name, dt, tol in (("f32_split", pkg.DTYPE_F32_SPLIT, F32_FWD_REL), ("f32_split_mix", pkg.DTYPE_F32_SPLIT_MIX, 3.0e-4), ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W, 4.0e-4)):
+        u = pkg.UNet(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS | 0)
+        if name == "f32_split_mix_f16w":
+            assert u.mix_classes() & 4, "the F16W mode fell back on f16-representable weights"
+        outs = [u.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda()).cpu() for _ in range(3)]     # eager, capture, replay
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "hipGraph replay differs from the eager run"
+        rep["forward"][name] = errs(outs[0], ref)
+        del u
+        print(f"refiner UNet::forward 1024^2, f16-representable weights, {name} vs oracle: rel {rep['forward'][name]['rel']:.3e} max-abs {rep['forward'][name]['max_abs']:.3e}")
+        assert rep["forward"][name]["rel"] < tol, (name, rep["forward"][name])
+    g = np.load(gr)
+    i = dict(latent=seeded(1, 4, 128, 128, seed=151), noise=seeded(1, 4, 128, 128, seed=152), ctx=seeded(1, 77, cfg.context_dim, seed=153),
+             uctx=seeded(77, cfg.context_dim, seed=154), y=seeded(1, cfg.adm_in_channels, seed=155), uy=seeded(cfg.adm_in_channels, seed=156))
+    assert np.allclose(checksum(*i.values()), g["in_checksum"], rtol=1e-9), "torch CPU generator changed: regenerate the fixtures"
+    ref_traj, ref = torch.from_numpy(g["traj"]), torch.from_numpy(g["latent"])
+    for name, dt in (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_mix", pkg.DTYPE_F32_SPLIT_MIX), ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W)):
+        d = pkg.Diffuser(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS | 0)
+        trace = torch.zeros(2, 1, 4, 128, 128, device="cuda")
+        d.set_trace(trace)
+        out = d.refine_latent(i["latent"].cuda(), _refiner_cond(pkg, i), 7.5, 800, 10, i["noise"].cuda())
+        torch.cuda.synchronize()
+        d.set_trace(None)
+        rep["refine_latent"][name] = dict(per_step=[errs(trace[k], ref_traj[k]) for k in range(2)], final=errs(out, ref))
+        del d
+        print(f"refine_latent 1024^2, f16-representable weights, {name} vs oracle: per step {['%.2e' % s_['max_abs'] for s_ in rep['refine_latent'][name]['per_step']]} = "
+              + " ".join(f"{rep['refine_latent'][name]['per_step'][k]['max_abs'] / lat_bound(ref_traj[k]):.2f}" for k in range(2)) + " of the bound")
+        for k in range(2):       # every mode at 1x: the strict modes' bar
+            assert rep["refine_latent"][name]["per_step"][k]["max_abs"] <= lat_bound(ref_traj[k]), (name, k, rep["refine_latent"][name]["per_step"][k])
+    REPORT["refiner_1024_f16_weights_vs_oracle"] = rep
+
+
+CONFIG5_KEEP = tuple(range(9, 100, 10))
+
+
+@pytest.mark.parametrize("weights", ["f16w", "fp32"])
+def test_config5_inpainting_100_steps(pkg, ctx, weights):
+    """BASELINE configs[4] AT ITS OWN STEP COUNT (oracle/make_golden_r6.py config5[_f16w], ~80 min of oracle time each): Diffuser::sample_latent_with_inpainting at
+    1024x1024, n_steps = 100 (100 CFG-7.5 pairs, t = 999, 989 ... 9), mask = latent rows 0..24 generated (the 200 px crop), reference latent = the oracle's
+    encode, explicit per-step re-noise (stablediffusion/mod.rs:434-483).  Every 10th latent and the final one against the oracle, EVERY mode at 1x the scaled bound:
+    F32_SPLIT, F32_SPLIT_MIX (fp32 weights) / F32_SPLIT_MIX_F16W (f16-representable weights).  The 4-step fixtures of rounds 3 / 5 (test_inpainting_1024_*) take
+    250-step jumps, which multiply one forward's error by ~2.3 per step before CFG; the 10-step jumps of the configuration BASELINE names multiply it by ~0.2."""
+    gp = os.path.join(GOLD, "fullsize_config5_f16w.npz" if weights == "f16w" else "fullsize_config5.npz")
+    if not os.path.exists(gp):
+        pytest.skip(f"{os.path.basename(gp)} not generated (python -m oracle.make_golden_r6 config5{'_f16w' if weights == 'f16w' else ''}, ~80 min)")
+    g = np.load(gp)
+    cfg = pkg.sdxl_base_config()
+    i = dict(noise=seeded(1, 4, 128, 128, seed=181), ctx=seeded(1, 77, cfg.context_dim, seed=182), uctx=seeded(77, cfg.context_dim, seed=183),
+             y=seeded(1, cfg.adm_in_channels, seed=184), uy=seeded(cfg.adm_in_channels, seed=185), step_noise=seeded(100, 1, 4, 128, 128, seed=186))
+    assert np.allclose(checksum(*i.values()), g["in_checksum"], rtol=1e-9), "torch CPU generator changed: regenerate the fixtures"
+    assert tuple(int(k) for k in g["steps"]) == CONFIG5_KEEP and pkg.step_count(100) == 100
+    reference = torch.from_numpy(np.load(os.path.join(GOLD, "fullsize_inpaint1024.npz"))["reference"])
+    mask = torch.zeros(1, 4, 128, 128, dtype=torch.bool)
+    mask[:, :, 0:25, :] = True
+    ref_traj, ref = torch.from_numpy(g["traj"]).clone(), torch.from_numpy(g["latent"])
+    alphas = pkg.default_alphas_cumprod()
+    ts = list(range(999, -1, -10))
+    for j, k in enumerate(CONFIG5_KEEP):      # (the engine's trace holds the blend for the NEXT iteration: see test_inpainting_1024_matches_oracle)
+        if k + 1 < 100:
+            a_n = float(alphas[ts[k + 1]])
+            ref_traj[j] = torch.where(mask, ref_traj[j], reference * (a_n ** 0.5) + i["step_noise"][k + 1] * ((1.0 - a_n) ** 0.5))
+    seed = pkg.SEED_F16_WEIGHTS if weights == "f16w" else 0
+    modes = (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W)) if weights == "f16w" else \
+            (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_mix", pkg.DTYPE_F32_SPLIT_MIX), ("f16", pkg.DTYPE_F16))
+    rep = {}
+    for name, dt in modes:
+        d = pkg.Diffuser(ctx, cfg, dt, seed=seed)
+        trace = torch.zeros(100, 1, 4, 128, 128, device="cuda")
+        d.set_trace(trace)
+        out = d.sample_latent_with_inpainting(_cond(pkg, i, (1024, 1024)), 7.5, 100, reference.cuda(), mask.cuda(), i["noise"].cuda(), i["step_noise"].cuda())
+        torch.cuda.synchronize()
+        d.set_trace(None)
+        assert torch.equal(trace[-1], out)
+        rep[name] = dict(per_step=[errs(trace[k], ref_traj[j]) for j, k in enumerate(CONFIG5_KEEP)], final=errs(out, ref))
+        del d
+        print(f"config 5 (100-step inpainting), {weights} weights, {name} vs oracle: final max-abs {rep[name]['final']['max_abs']:.3e} (|ref| {rep[name]['final']['ref_max']:.1f}, bound "
+              f"{lat_bound(ref):.3e}); of the bound per kept step: " + " ".join(f"{rep[name]['per_step'][j]['max_abs'] / lat_bound(ref_traj[j]):.2f}" for j in range(len(CONFIG5_KEEP))))
+    REPORT[f"config5_100_steps_{weights}_vs_oracle"] = rep
+    for name, _ in modes:
+        if name == "f16":
+            assert rep[name]["final"]["rel"] < F16_TRAJ_REL["f16"], rep[name]["final"]
+            continue
+        for j in range(len(CONFIG5_KEEP)):
+            assert rep[name]["per_step"][j]["max_abs"] <= lat_bound(ref_traj[j]), (name, CONFIG5_KEEP[j], rep[name]["per_step"][j])
+        assert rep[name]["final"]["max_abs"] <= lat_bound(ref), (name, rep[name]["final"])
 
 
 def test_unet_forward_1024_f16_representable_weights(pkg, ctx):

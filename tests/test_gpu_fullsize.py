@@ -57,6 +57,25 @@ def test_fullsize_unet_properties(pkg, ctx, base_inputs):
     assert torch.equal(cold[0], outs[0]) and torch.equal(cold[1], outs[0]), "weight warming changes the result"
 
 
+@pytest.mark.parametrize("dtype_name", ["F32_SPLIT", "F32_SPLIT_MIX", "F32_SPLIT_MIX_F16W"])
+def test_fullsize_split_modes_batch_independence(pkg, ctx, base_inputs, dtype_name):
+    """The split-operand engines at full size: an entry of the CFG pair must equal a separate batch-1 forward bit for bit.  Until round 6 the HL16 copy of
+    an fp32 stream tensor (skip / up- / down-sampling / proj_out operands) took ONE power-of-two scale from the absmax of the whole batched tensor, so an
+    entry's lo halves could depend on its batch neighbour (VERDICT r5 weak-6); the scale is now per entry (launch_f32_to_hl_scaled, IgemmParams::a_scale_rpb).
+    The two entries below differ by a factor of 64 in magnitude, so a shared scale WOULD change the smaller entry's bits."""
+    cfg, x, t, ctxt, y = base_inputs
+    x = x.clone()
+    x[1] *= 64.0
+    dt = getattr(pkg, "DTYPE_" + dtype_name)
+    u = pkg.UNet(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS if dtype_name.endswith("F16W") else 0)
+    outs = [u.forward(x.cuda(), t.cuda(), ctxt.cuda(), y.cuda()).cpu() for _ in range(3)]       # eager, capture, replay
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "hipGraph replay differs from the eager run"
+    for i in range(2):
+        one = u.forward(x[i:i + 1].cuda(), t[i:i + 1].cuda(), ctxt[i:i + 1].cuda(), y[i:i + 1].cuda()).cpu()
+        assert torch.equal(one[0], outs[0][i]), f"{dtype_name}: batch entry {i} depends on its batch neighbour"
+
+
 def _prompt_ids(seed, n_tok, pad):
     g = torch.Generator().manual_seed(seed)
     ids = torch.full((1, 77), pad, dtype=torch.int64)
