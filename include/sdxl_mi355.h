@@ -152,7 +152,7 @@ int sdxl_unet_set_fused_cross_attention(sdxl_unet* u, int enabled);
 int sdxl_unet_set_gn_from_producer(sdxl_unet* u, int enabled);
 /* which GEMM classes of a SDXL_DTYPE_F32_SPLIT_MIX* model run on plain f16 operands (bit set: 1 self-attention, 2 GEGLU projection, 4 QKV projection,
  * 8 FF-out, 16 / 32 the self- / cross-attention out-projections, 128 cross-attention query projection, 256 LayerNorms folded through an f16 shadow of
- * the stream; 0 for every other dtype).  A SDXL_DTYPE_F32_SPLIT_MIX_F16W model whose parameters are NOT all f16 values (checked on the tensors at
+ * the stream, 512 the 77-key cross-attention at split precision inside the query projection's epilogue; 0 for every other dtype).  A SDXL_DTYPE_F32_SPLIT_MIX_F16W model whose parameters are NOT all f16 values (checked on the tensors at
  * create time) falls back to SDXL_DTYPE_F32_SPLIT_MIX's classes (3): this is how a caller sees it. */
 int sdxl_unet_mix_classes(sdxl_unet* u, int* classes_out);
 

@@ -871,7 +871,8 @@ def layer_norm_linear(ctx: Context, x, gamma, beta, weight, bias, eps: float = 1
 def ln_query_cross_attention(ctx: Context, x, gamma, beta, wq, k, v, eps: float = 1e-5, fused: bool = True):
     """attn2 of a transformer block up to its output projection (unet/mod.rs:731-795): LayerNorm -> query projection (no
     bias) -> qkv_attention over the projected context k, v [B,Nk,C] with 64 channels per head.  f16 engine arithmetic.
-    fused=True runs the attention inside the projection's epilogue (one launch), False as projection + attention kernel."""
+    fused=True runs the attention inside the projection's epilogue (one launch), False as projection + attention kernel; fused=2: that epilogue at
+    split precision (context, q and P as (hi, lo) f16 pairs, three MFMAs per product: what SDXL_DTYPE_F32_SPLIT_MIX_F16W runs)."""
     torch = _torch()
     x, px = _dev(x)
     gamma, pg = _dev(gamma)

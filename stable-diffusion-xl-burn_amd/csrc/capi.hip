@@ -63,9 +63,9 @@ void no_mix(int dtype) {     // the mixed mode is a property of the UNet driver 
 }
 int mix_of(int dtype) {
   return dtype == SDXL_DTYPE_F32_SPLIT_MIX ? (MIX_ATTN_F16 | MIX_GEGLU_F16)
-       : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_Q2_F16 | MIX_LN_SHADOW) : 0;
-       // (round 6: + the cross-attention query projection on f16 with an fp32 q, and the LayerNorms in front of the f16 projections folded through the f16
-       //  shadow of the stream -- DESIGN 12.1; MIX_XATTN_F16 stays a knob: 7 % faster at 92 % of the bound)
+       : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_Q2_F16 | MIX_LN_SHADOW | MIX_XATTN_SPLIT) : 0;
+       // (round 6: + the cross-attention query projection on f16 with an fp32 q, the split-precision 77-key attention inside its epilogue, and the LayerNorms in
+       //  front of the f16 projections folded through the f16 shadow of the stream -- DESIGN 12.1; MIX_XATTN_F16 stays a knob: DESIGN 11.2b)
 }
 void dtypes(int dtype, int& cdt, int& sdt) {
   switch (dtype) {
@@ -1142,7 +1142,8 @@ int sdxl_ln_query_cross_attention(sdxl_ctx* ctx, void* stream, const float* x, c
                                   float* out) {
   // attn2 of a transformer block up to (not including) the output projection: LayerNorm -> query projection (no bias) ->
   // qkv_attention over the projected context, 64 channels per head.  f16 engine only (the UNet's production mode); fused != 0
-  // runs the attention inside the projection's epilogue, fused == 0 as projection + attention kernel.
+  // runs the attention inside the projection's epilogue, fused == 0 as projection + attention kernel; fused == 2: the epilogue at split precision
+  // (context, q and P as (hi, lo) f16 pairs: the SDXL_DTYPE_F32_SPLIT_MIX_F16W form).
   API_BEGIN
   SDXL_REQUIRE(ctx && x && gamma && beta && wq && k && v && out, "null argument");
   SDXL_REQUIRE(C % 64 == 0 && B >= 1 && Nq >= 1 && Nk >= 1, "State size must be a multiple of head size");
@@ -1201,7 +1202,45 @@ int sdxl_ln_query_cross_attention(sdxl_ctx* ctx, void* stream, const float* x, c
   }
   void* od = tmp.get((size_t)M * C * 2);
   Epi e; e.ln_stat = stat; e.rpb = Nq;
-  if (fused) {
+  if (fused == 3) {
+    // the un-fused twin of fused == 2: fp32 q out of the f16 projection, HL16 context, the stand-alone split-operand attention kernel writing f16 rows
+    float* q32 = (float*)tmp.get((size_t)M * C * 4);
+    run_linear(ex, l, Act(xi, C, DT_F16), M, Act(q32, C, DT_F32), e);
+    void* khl = tmp.get((size_t)B * Nk * C * 4);
+    float* vt32 = (float*)tmp.get((size_t)B * C * vt_ld * 4);
+    void* vhl = tmp.get((size_t)B * C * vt_ld * 4);
+    launch_f32_to_hl(k, C, khl, C, (size_t)B * Nk, C, s);
+    launch_fill_zero(vt32, (size_t)B * C * vt_ld * 4, s);
+    for (int b = 0; b < B; ++b) {
+      const size_t tot = (size_t)Nk * C;
+      hipLaunchKernelGGL(transpose_pad_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, v + (size_t)b * Nk * C, C, Nk, C,
+                         (char*)vt32 + (size_t)b * C * vt_ld * 4, DT_F32, vt_ld);
+    }
+    launch_f32_to_hl(vt32, vt_ld, vhl, vt_ld, (size_t)B * C, vt_ld, s);
+    AttnParams p{};
+    p.Q = q32; p.ldq = C; p.K = khl; p.ldk = C; p.Vt = vhl; p.vt_ld = vt_ld; p.O = od; p.ldo = C;
+    p.dt = DT_HL; p.B = B; p.H = C / 64; p.Nq = Nq; p.Nk = Nk; p.scale = 0.125f; p.mask = nullptr; p.ldmask = 0;
+    p.q_dt = DT_F32; p.o_dt = DT_F16;
+    SDXL_REQUIRE(launch_attention_d64_hl(p, s), "split-operand attention: unsupported shape");
+  } else if (fused == 2) {
+    // split precision (IgemmParams::xa_k_lo): the fp32 context as (hi, lo) f16 pairs, q and P split inside the epilogue -- three MFMAs per product
+    void* kh = tmp.get((size_t)B * Nk * C * 2); void* kl = tmp.get((size_t)B * Nk * C * 2);
+    float* vt32 = (float*)tmp.get((size_t)B * C * vt_ld * 4);
+    void* vh = tmp.get((size_t)B * C * vt_ld * 2); void* vl = tmp.get((size_t)B * C * vt_ld * 2);
+    launch_f32_to_f16_pair(k, C, kh, kl, C, (size_t)B * Nk, C, s);
+    launch_fill_zero(vt32, (size_t)B * C * vt_ld * 4, s);
+    for (int b = 0; b < B; ++b) {
+      const size_t tot = (size_t)Nk * C;
+      hipLaunchKernelGGL(transpose_pad_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, v + (size_t)b * Nk * C, C, Nk, C,
+                         (char*)vt32 + (size_t)b * C * vt_ld * 4, DT_F32, vt_ld);
+    }
+    launch_f32_to_f16_pair(vt32, vt_ld, vh, vl, vt_ld, (size_t)B * C, vt_ld, s);
+    void* xa = tmp.get(xattn_pack_bytes(B, C)); void* xal = tmp.get(xattn_pack_bytes(B, C));
+    launch_xattn_pack(kh, vh, xa, B, C, Nk, vt_ld, s);
+    launch_xattn_pack(kl, vl, xal, B, C, Nk, vt_ld, s);
+    e.xa_k = xa; e.xa_k_lo = xal; e.xa_nctx = Nk; e.xa_scale = 0.125f;
+    run_linear(ex, l, Act(xi, C, DT_F16), M, Act(od, C, DT_F16), e);
+  } else if (fused) {
     void* xa = tmp.get(xattn_pack_bytes(B, C));
     launch_xattn_pack(kd, vt, xa, B, C, Nk, vt_ld, s);
     e.xa_k = xa; e.xa_nctx = Nk; e.xa_scale = 0.125f;

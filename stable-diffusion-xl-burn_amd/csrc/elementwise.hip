@@ -338,15 +338,32 @@ __global__ void f32_to_hl_scaled_kernel(const float* src, int lds_, half_t* dst,
   *reinterpret_cast<half8*>(dp) = hi;
   *reinterpret_cast<half8*>(dp + 16) = lo;
 }
-void launch_f32_to_hl_scaled(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s, int nb) {
+void launch_f32_to_hl_scaled(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s, int nb, bool have_partials) {
   if ((C & 15) != 0 || (lds_ & 3) != 0 || (ldd & 15) != 0) throw std::runtime_error("f32_to_hl: C % 16 == 0 rows with aligned strides only");
   if (nb < 1 || rows % (size_t)nb != 0) throw std::runtime_error("f32_to_hl: rows must split evenly over the batch entries");
   static_assert(kHlAbsBlocks <= 256, "one partial per thread of the conversion block");
   const size_t rpe = rows / nb;
-  hipLaunchKernelGGL(absmax_rows_kernel, dim3(kHlAbsBlocks, nb), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_, rpe, C / 4, scale_io);
+  if (!have_partials) hipLaunchKernelGGL(absmax_rows_kernel, dim3(kHlAbsBlocks, nb), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_, rpe, C / 4, scale_io);
   const size_t total = rpe * (size_t)(C / 8);
   hipLaunchKernelGGL(f32_to_hl_scaled_kernel, dim3((unsigned)((total + 255) / 256), nb), dim3(256), 0, s, reinterpret_cast<const float*>(src), lds_,
                      reinterpret_cast<half_t*>(dst), ldd, rpe, C / 8, scale_io, hl_scale_inv(scale_io, nb));
+}
+__global__ void f32_to_f16_pair_kernel(const float* src, int lds_, half_t* hi, half_t* lo, int ld16, size_t rows, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * (size_t)C) return;
+  const size_t r = i / C;
+  const int c = (int)(i - r * C);
+  float x = src[r * lds_ + c];
+  asm("" : "+v"(x));
+  const half_t h = (half_t)x;
+  hi[r * ld16 + c] = h;
+  lo[r * ld16 + c] = (half_t)(x - (float)h);
+}
+void launch_f32_to_f16_pair(const float* src, int lds_, void* hi, void* lo, int ld16, size_t rows, int C, hipStream_t s) {
+  const size_t total = rows * (size_t)C;
+  if (!total) return;
+  hipLaunchKernelGGL(f32_to_f16_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, lds_, reinterpret_cast<half_t*>(hi),
+                     reinterpret_cast<half_t*>(lo), ld16, rows, C);
 }
 void launch_f32_to_hl(const void* src, int lds_, void* dst, int ldd, size_t rows, int C, hipStream_t s) {
   if ((C & 15) != 0 || (lds_ & 3) != 0 || (ldd & 15) != 0) throw std::runtime_error("f32_to_hl: C % 16 == 0 rows with aligned strides only");

@@ -237,6 +237,8 @@ enum MixClass {
   MIX_OUT2_F16 = 32,    // cross-attention out-projection (the split-operand attention rounds its fp32 result to f16 once, in its store)
   MIX_XATTN_F16 = 64,   // with OUT2: cross-attention + its query projection as the f16 engine's fused launch -- a knob, in no mode
   MIX_Q2_F16 = 128,     // cross-attention QUERY projection alone on f16 operands (HL16 output: the split-operand attention behind it keeps an fp32-class q)
+  MIX_XATTN_SPLIT = 512, // with MIX_Q2_F16: the 77-key cross-attention at SPLIT precision inside the f16 query projection's epilogue (IgemmParams::xa_k_lo) -- the
+                        // arithmetic of the stand-alone split-operand attention without its launch
   MIX_LN_SHADOW = 256   // the LayerNorms in front of the f16 projections (QKV, GEGLU, the query projection with MIX_Q2_F16) folded into them: the producers of
                         // the fp32 stream leave an f16 shadow f16(x o gamma) + row statistics (IgemmParams::shadow), no LayerNorm launch
 };
@@ -259,6 +261,7 @@ struct Epi {
   int rpb = 0;       // rows per batch for ebias / transposed store (0 -> Hout*Wout)
   // cross-attention fused into the projection's epilogue (IgemmParams::xa_*): packed context of this run's batch entries
   const void* xa_k = nullptr; int xa_nctx = 0; float xa_scale = 0.f;   // xa_k: operand-order image (launch_xattn_pack)
+  const void* xa_k_lo = nullptr;     // split precision (IgemmParams::xa_k_lo): xa_k = hi halves, this = lo halves of the context keys / values
   // room for the GroupNorm statistics of the output ([M/256][N] float pairs); run_conv reports whether the kernel it picked
   // filled it (igemm_gn_part_ok), the caller then tags the output Act
   float* gn_part = nullptr;
@@ -269,8 +272,10 @@ struct Epi {
 };
 bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());   // true: e.gn_part was filled
 bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());
-Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int nb = 1);    // HL16 copy of an fp32 stream tensor (nb batch entries of rows / nb rows, one power-of-two scale each) for a split-operand GEMM (else x)
-void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups = 32);
+// have_max: a hl_scale_floats(nb) buffer whose max|x| partials a GroupNorm statistics pass over x already wrote (run_groupnorm absmax_out): no absmax pass
+Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int nb = 1, float* have_max = nullptr);    // HL16 copy of an fp32 stream tensor (nb batch entries of rows / nb rows, one power-of-two scale each) for a split-operand GEMM (else x)
+// absmax_out: hl_scale_floats(B) floats; the statistics pass (fp32 x without producer statistics -- the caller checks) also leaves max|x| partials per entry there
+void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups = 32, float* absmax_out = nullptr);
 void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y);
 
 // ------------------------------------------------------------------------------------------ UNet
@@ -335,7 +340,7 @@ class UNet {
   NormW norm_out_; Lin conv_out_;
   int emb_total_ = 0;
   // cross-attention K / V^T caches (one per transformer block, in execution order)
-  struct KV { void* k = nullptr; void* vt = nullptr; void* xa = nullptr; };   // xa: operand-order image for the fused epilogue (f16)
+  struct KV { void* k = nullptr; void* vt = nullptr; void* xa = nullptr; void* xa_lo = nullptr; };   // xa: operand-order image for the fused epilogue (f16; with xa_lo: hi / lo halves of the fp32-class projection)
   std::vector<std::vector<KV>> kv_;     // [spatial transformer][block]
   std::vector<const STW*> st_list_;
   DeviceArena ctx_arena_;

@@ -1057,6 +1057,115 @@ __device__ __forceinline__ void xattn_inplace(const IgemmParams& p, f32x16 (&acc
   }
 }
 
+// ---- the same fusion at split precision (IgemmParams::xa_k_lo; round 6): q stays what the projection's fp32 accumulators hold -- it is split into
+// (hi, lo) f16 pairs here, like the probabilities (times 2^11, so that the lo halves of small probabilities stay out of the f16 subnormals), and meets
+// context keys / values that were split once per prompt: three MFMAs per product, fp32 accumulation, fp32 softmax -- the arithmetic of the stand-alone
+// split-operand attention kernel (attention.hip attn_d64_hl_kernel), without its launch, without q's round trip through memory.  The 48 context
+// fragments of a head (hi + lo of K and V^T, 48 KiB) do not fit next to the k-loop's registers, so nothing is requested early: K's 24 fragments are
+// loaded at entry, V^T's 24 behind the S MFMAs (they land under the softmax arithmetic).  One 32-query row block per wave (TM = 1 kernels).
+template <int TM>
+__device__ __forceinline__ void xattn_inplace_hl(const IgemmParams& p, f32x16 (&acc)[TM][2], int mw, int nw, int lane,
+                                                 float (&lnA)[TM], float (&lnC)[TM], const void* zeros) {
+  static_assert(TM == 1, "split-precision fused cross-attention: one-MFMA-row wave tiles");
+  if (nw >= p.N) return;                                              // zero-padded weight columns: nothing is stored
+  const int fh = lane >> 5;
+  const int nctx = p.xa_nctx;
+  const int mclamp = mw < p.M ? mw : p.M - 1;
+  const int b = __builtin_amdgcn_readfirstlane(mclamp / p.rpb);       // rpb % WM == 0: one batch entry per wave tile
+  const size_t foff = ((size_t)b * (p.N >> 6) + (nw >> 6)) * (24 * 64) + lane;
+  const half8* fhi = reinterpret_cast<const half8*>(p.xa_k) + foff;
+  const half8* flo = reinterpret_cast<const half8*>(p.xa_k_lo) + foff;
+  half8 kh[3][4], kl[3][4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { kh[t][s4] = fhi[(t * 4 + s4) * 64]; kl[t][s4] = flo[(t * 4 + s4) * 64]; }
+  f32x4 cz[2][4], bz[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nbu = nw + j * 32 + 8 * q;
+      cz[j][q] = col_vec4(p.ln_cs, p.ln_stat != nullptr, nbu, fh, zeros);
+      bz[j][q] = col_vec4(p.bias, p.bias != nullptr, nbu, fh, zeros);
+    }
+  constexpr float PSC = 2048.0f;                                      // P travels as P * 2^11 (attn_d64_hl_kernel)
+  const float sc = p.xa_scale * 1.44269504088896340736f;             // p = exp2(s - m)
+  const float lna = lnA[0], lnc = lnC[0];
+  half8 qh[4], ql[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int j = s4 >> 1, qq = s4 & 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int q = 2 * qq + (e >> 2), r = e & 3;
+      float x = (lna * acc[0][j][8 * qq + e] + lnc * cz[j][q][r] + bz[j][q][r]) * sc;
+      asm("" : "+v"(x));                                             // pinned in fp32: hi and lo come from the SAME rounded value (store_hl8)
+      const half_t hi = (half_t)x;
+      qh[s4][e] = hi; ql[s4][e] = (half_t)(x - (float)hi);
+    }
+  }
+  f32x16 sv[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[t][r] = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      sv[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[t][s4], qh[s4], sv[t], 0, 0, 0);
+      sv[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[t][s4], ql[s4], sv[t], 0, 0, 0);
+      sv[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[t][s4], qh[s4], sv[t], 0, 0, 0);
+    }
+  }
+  half8 vh[2][6], vl[2][6];                                           // requested here: they land under the softmax arithmetic
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) { vh[dt][s6] = fhi[(12 + dt * 6 + s6) * 64]; vl[dt][s6] = flo[(12 + dt * 6 + s6) * 64]; }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (32 * t + 8 * (r >> 2) + 4 * fh + (r & 3) >= nctx) sv[t][r] = -INFINITY;
+      mx = fmaxf(mx, sv[t][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float l = 0.f;
+  half8 ph[6], pl[6];
+#pragma unroll
+  for (int s6 = 0; s6 < 6; ++s6) {
+    float ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float pe = __builtin_amdgcn_exp2f(sv[s6 >> 1][8 * (s6 & 1) + e] - mx);
+      ls += pe;
+      float ps = pe * PSC;
+      asm("" : "+v"(ps));
+      const half_t hi = (half_t)ps;
+      ph[s6][e] = hi; pl[s6][e] = (half_t)(ps - (float)hi);
+    }
+    l += ls;
+  }
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / (l * PSC);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) {
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[dt][s6], ph[s6], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[dt][s6], pl[s6], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[dt][s6], ph[s6], o, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][dt][r] = o[r] * inv;
+  }
+  lnA[0] = 1.f; lnC[0] = 0.f;                                         // the store adds nothing more
+}
+
 // per-device state owned by igemm_glds.hip
 const void* igemm_zero_page();          // null until igemm_glds_init() ran on the current device
 int igemm_current_device();

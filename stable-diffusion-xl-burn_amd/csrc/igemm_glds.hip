@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams
 // lane's accumulators are 4 x 4 consecutive ROWS (keys) of one column: the transposed store is then the direct row-per-lane epilogue
 // (permlane32 half swap, 16-byte stores along the key axis) instead of the LDS-staged transpose (12.6 k cycles per 64x64 wave tile, the
 // longest epilogue of the launch: tools/timeline_probe.py).  Same products, same k order: bit-identical values.
-template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false, bool TSW = false>
+// XH (with XA, round 6): the fused cross-attention at split precision (xattn_inplace_hl: hi / lo context images, three MFMAs per product)
+template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false, bool TSW = false, bool XH = false>
 __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p, const void* zeros) {
   kernarg_prefetch<(int)sizeof(IgemmParams) + 8>();   // every argument line in flight at once (one wait instead of five)
   typedef typename PipeElem<T>::frag frag_t;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   // fused cross-attention, one-MFMA-row wave tiles: the 24 context fragments (96 VGPRs -- these kernels have the room) are
   // requested BEFORE the first DMA piece, so they are the oldest entries of the in-order vmcnt queue and ride under the
   // prologue's wait for tile 0 instead of adding a memory round trip to the epilogue
-  constexpr bool XA_EARLY = XA && TM == 1;
+  constexpr bool XA_EARLY = XA && TM == 1 && !XH;      // (the split-precision form needs 48 fragments per head: loaded inside the epilogue)
   half8 xkf[XA ? 3 : 1][4], xvf[XA ? 2 : 1][6];
   if constexpr (XA_EARLY) xattn_load_frags(p, m0 + wm * WM, n0 + wn * WN, lane, xkf, xvf);
   // folded LayerNorm: the tile's row coefficients, evaluated once per workgroup (LnCoop) where 2 KiB of LDS are left behind the ring
@@ -714,8 +715,13 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   if constexpr (XA) {
     static_assert(TN == 2 && sizeof(T) == 2, "fused cross-attention: wave tile = one 64-wide head, f16");
     static_assert(NW * WM * WN * 4 <= NS * STAGE, "staging regions must fit the dead ring");
+    if constexpr (XH) {
+      static_assert(!XH || (XA && TM == 1), "split-precision fused cross-attention: XA kernels with one-MFMA-row wave tiles");
+      xattn_inplace_hl<TM>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros);
+    } else {
     if constexpr (!XA_EARLY) xattn_load_frags(p, m0 + wm * WM, n0 + wn * WN, lane, xkf, xvf);
     xattn_inplace<TM>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, lnA, lnC, zeros, xkf, xvf);
+    }
     IgemmParams pe = p;                       // bias and the LayerNorm affine went into q: the store adds nothing
     pe.bias = nullptr; pe.ln_stat = nullptr;
     if (!p.epi_staged && igemm_rows_ok<TM, TN, false>(pe, n0 + wn * WN))
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_pipe_kernel(const IgemmParams p
   constexpr bool FITS = NW * WM * WN * 4 <= NS * STAGE;        // full-width staging regions fit the dead ring
   if (FITS || p.act == 1) {
     const int region = p.act == 1 ? WM * (WN / 2) * 4 : WM * WN * 4;   // GEGLU halves the staged width
-    if constexpr (BM == 256 && BN == 128 && NW == 8 && WGM == 4 && sizeof(T) == 2) {
+    if constexpr (BM == 256 && BN == 128 && NW == 8 && WGM == 4 && (sizeof(T) == 2 || HL)) {      // (f16, and -- round 6 -- the split-operand kernel: fp32 rows, same epilogue)
       static_assert(NW * WM * WN * 4 + 4096 <= NS * STAGE, "GroupNorm-statistics scratch must fit behind the staging regions");
       const GnCtx gc{smem + NW * WM * WN * 4, wave, wm, wn, m0, n0};
       igemm_epilogue_staged<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * region, lnA, lnC, zeros, &gc);
@@ -1042,18 +1048,18 @@ static void launch_glds(const IgemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, NS, MINB>), dim3(tilesM * tilesN), dim3(256), lds, s, p, g_zero_pages[dev]);
 }
 
-template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false, bool TSW = false>
+template <int BM, int BN, int NS, int WGM = 4, int NW = 8, typename T = half_t, bool XA = false, bool S2 = false, bool TSW = false, bool XH = false>
 static void launch_pipe(const IgemmParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)pipe_lds_total(NS * (BM + BN) * 128, 0);   // ring + LayerNorm coefficients
   static bool attr_set[kMaxDev] = {};
   const int dev = current_device();
-  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2, TSW>, lds, attr_set, dev);
+  set_lds_attr(&igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2, TSW, XH>, lds, attr_set, dev);
   const int sk = (BN == 128 && p.splitk > 1) ? p.splitk : 1;
   if (sk > 1 && (size_t)tilesM * tilesN * sk * BM * BN * 4 > p.splitk_ws_bytes) throw std::runtime_error("igemm: split-K workspace too small");
   IgemmParams q = p;
   q.splitk = sk;
-  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2, TSW>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
+  hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, NS, WGM, NW, T, XA, S2, TSW, XH>), dim3(tilesM * tilesN * sk), dim3(64 * NW), lds, s, q, g_zero_pages[dev]);
 }
 
 static std::atomic<int> g_wide_db{0};     // measure builds, knob (sdxl_debug_set "wide_db"): 1 = the wide GEGLU kernel with register-double-buffered fragments
@@ -1150,9 +1156,21 @@ static int pick_tile(const IgemmParams& p, bool allow_128x160 = true) {
   return variant;
 }
 
+static std::atomic<int> g_hl_tile96{29};     // bit 0: 96x128 for linears, bit 1: ... for 3x3 convs too (not selected), bit 2: 4-wave 128x160 for N % 160 == 0, N % 128 != 0 layers, bit 3: ... wherever the cost model prefers it, bit 4: in-launch split-K for the K >= 10240 convolutions
+void igemm_set_hl_tile96(int v) { g_hl_tile96 = v; }
 // GroupNorm statistics from the producing GEMM's epilogue (IgemmParams::gn_part): taken by the 256x128 kernel (plain or split-K)
 // when that is the tile the selection picks anyway, whole 256-row tiles inside one batch entry, f16 operands, plain epilogue.
 bool igemm_gn_part_ok(const IgemmParams& p) {
+  if (p.a_dt == DT_HL) {
+    // split-operand convolutions (round 6): where the selection runs the 256x128 kernel anyway -- the in-launch split-K of the K >= 10240 convolutions
+    // of the 32^2 level (launch_igemm_hl_pipe; one entry's shape only) -- its staged epilogue leaves the statistics of the fp32 rows
+    if (p.c_dt != DT_F32 || (p.Cin % 32) != 0 || (p.lda % 4) != 0 || (p.Kpad % 32) != 0) return false;
+    if (p.act != 0 || p.n_split < p.N || p.stat_out || p.ln_stat || p.xa_k) return false;
+    if (p.M % 256 != 0 || p.rpb <= 0 || p.rpb % 256 != 0 || p.N % 64 != 0) return false;
+    if (p.ebias && (p.ebias_ld & 3) != 0) return false;
+    if ((p.ldc & 3) != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0) return false;
+    return (g_hl_tile96.load() & 16) && igemm_splitk_slices(p) > 1;
+  }
   if (p.a_dt != DT_F16 || p.c_dt != DT_F16 || (p.Cin % 64) != 0 || (p.lda % 8) != 0 || (p.Kpad % 64) != 0) return false;
   if (p.act != 0 || p.n_split < p.N || p.stat_out || p.ln_stat || p.xa_k) return false;
   if (p.M % 256 != 0 || p.rpb <= 0 || p.rpb % 256 != 0 || p.N % 64 != 0) return false;
@@ -1229,6 +1247,12 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
         !igemm_xattn_ok(p.a_dt, p.c_dt, p.M, p.N, p.K, p.rpb, p.xa_nctx))
       throw std::runtime_error("igemm: fused cross-attention needs a plain f16 projection (no residual / split outputs)");
     const int nk = p.Kpad / 64;
+    if (p.xa_k_lo) {     // split precision: the one-MFMA-row tiles only (96x128 / 128x128), same cost model
+      const double c128 = tile_cost(p.M, p.N, nk, 128, 128, 1.0), c96 = tile_cost(p.M, p.N, nk, 96, 128, 1.0);
+      if (c96 < c128) launch_pipe<96, 128, 3, 3, 6, half_t, true, false, false, true>(psk, s);
+      else launch_pipe<128, 128, 4, 4, 8, half_t, true, false, false, true>(psk, s);
+      return true;
+    }
     int v = variant;
     if (v != 35 && v != 36 && v != 44 && v != 45) {
       const double c256 = tile_cost(p.M, p.N, nk, 256, 128, 1.0), c128 = tile_cost(p.M, p.N, nk, 128, 128, 1.0), c96 = tile_cost(p.M, p.N, nk, 96, 128, 1.0);
@@ -1323,14 +1347,13 @@ bool launch_igemm_f32_pipe(const IgemmParams& p, hipStream_t s) {
   return true;
 }
 
-static std::atomic<int> g_hl_tile96{29};     // bit 0: 96x128 for linears, bit 1: ... for 3x3 convs too (not selected), bit 2: 4-wave 128x160 for N % 160 == 0, N % 128 != 0 layers, bit 3: ... wherever the cost model prefers it, bit 4: in-launch split-K for the K >= 10240 convolutions
-void igemm_set_hl_tile96(int v) { g_hl_tile96 = v; }
 // Split-operand mode (DT_HL; igemm_common.h): HL16 operands on the same direct-to-LDS pipeline, 3 f16 MFMAs per 16-deep product.
 // Returns false for shapes the generic kernel must take (none in the VAE: its Cin % 32 != 0 layers are packed fp32).
 bool launch_igemm_hl_pipe(const IgemmParams& p, hipStream_t s) {
   if (!g_zero_pages[current_device()]) return false;
-  if (p.act > 1 || p.ln_stat || p.stat_out || p.xa_k || p.gn_part) return false;
+  if (p.act > 1 || p.ln_stat || p.stat_out || p.xa_k) return false;
   if (p.a_dt != DT_HL || (p.Cin % 32) != 0 || (p.lda % 4) != 0 || (p.Kpad % 32) != 0) return false;
+  if (p.gn_part && !igemm_gn_part_ok(p)) throw std::runtime_error("igemm: GroupNorm statistics requested from a split-operand shape the 256x128 split-K epilogue does not take");
   if ((reinterpret_cast<uintptr_t>(p.A) & 15) != 0) return false;
   if (p.n_split < p.N && (p.n_split & 3) != 0) return false;
   if (p.c_dt == DT_HL) {

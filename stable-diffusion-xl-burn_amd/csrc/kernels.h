@@ -56,6 +56,10 @@ struct IgemmParams {
   // softmax(q K_h^T * xa_scale) V_h per 64-column head before the store (igemm_glds.hip xattn_inplace).  xa_k = the context
   // keys / values of the batch entries in MFMA operand order (launch_xattn_pack); batch entry of a row = m / rpb.
   const void* xa_k; int xa_nctx; float xa_scale;
+  // split-precision form (round 6): xa_k holds the HI halves f16(x) of the context keys / values and xa_k_lo the LO halves f16(x - hi), both in the
+  // operand order of launch_xattn_pack; the epilogue then splits q and P the same way and runs three MFMAs per product (Kh qh + Kh ql + Kl qh, likewise
+  // V^T P^T): the arithmetic of attn_d64_hl_kernel inside the projection's epilogue.  null = plain f16 attention.  One-MFMA-row wave tiles only.
+  const void* xa_k_lo;
   // GroupNorm statistics of the stored output, from the epilogue (256x128 kernel; igemm_gn_part_ok): gn_part[M/256][N] (mean, M2)
   // of every column over the 256 rows of a tile -- the consumer's GroupNorm merges row tiles and channels (norm.hip, chan_part)
   float* gn_part;
@@ -117,6 +121,11 @@ int igemm_timeline_words();
 #endif
 void igemm_glds_init();          // allocates the zero page the DMA fast path reads halo pixels from (call once per process)
 
+// per-entry scale workspace of launch_f32_to_hl_scaled (declared further down)
+constexpr int kHlAbsBlocks = 128;
+static inline size_t hl_scale_floats(int nb) { return (size_t)nb * (kHlAbsBlocks + 1); }
+static inline float* hl_scale_inv(float* scale_io, int nb) { return scale_io + (size_t)nb * kHlAbsBlocks; }
+
 // ---------------------------------------------------------------------------------------------------------
 // GroupNorm (32 groups, NHWC) -- reference groupnorm/mod.rs:52-82 (+ SiLU silu.rs:14-16)
 struct GroupNormParams {
@@ -132,6 +141,10 @@ struct GroupNormParams {
   // statistics left by the PRODUCER of X (IgemmParams::gn_part): chan_part[B][chan_rt][C] (mean, M2) over chan_rows rows each;
   // when set, no statistics kernel runs -- the apply kernel merges row tiles and channels in its prologue
   const float* chan_part; int chan_rt; int chan_rows;
+  // optional side output of the statistics pass (fp32 input only): per batch entry kHlAbsBlocks block maxima of |x| -- the partials
+  // launch_f32_to_hl_scaled's conversion kernel reduces (the statistics pass reads the whole tensor anyway: a split-operand skip convolution of the
+  // same ResBlock input then needs no absmax pass).  Layout [B][kHlAbsBlocks]; slots beyond the row splits are written as zeros.
+  float* absmax_out;
 };
 int  groupnorm_nsplit(int B, int HW, int C);
 // workspace of launch_groupnorm for B batch entries (a run over entries [b0, b0+nb) of a larger plan may use the slice at
@@ -228,12 +241,12 @@ void launch_f32_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows,
 // that brings max|x| into [2^13, 2^14) -- PER BATCH ENTRY (nb entries of rows / nb rows each: an entry's bits never depend on its batch
 // neighbours).  scale_io: hl_scale_floats(nb) device floats -- [nb][kHlAbsBlocks] per-block max|x| partials (no atomics, no memset: every
 // launch rewrites them), then the nb factors 2^-e at hl_scale_inv(scale_io, nb): pass that as IgemmParams::a_scale (a_scale_rpb = the GEMM's output rows per entry)
-constexpr int kHlAbsBlocks = 128;
-static inline size_t hl_scale_floats(int nb) { return (size_t)nb * (kHlAbsBlocks + 1); }
-static inline float* hl_scale_inv(float* scale_io, int nb) { return scale_io + (size_t)nb * kHlAbsBlocks; }
-void launch_f32_to_hl_scaled(const void* src, int lds, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s, int nb = 1);
+void launch_f32_to_hl_scaled(const void* src, int lds, void* dst, int ldd, size_t rows, int C, float* scale_io, hipStream_t s, int nb = 1,
+                             bool have_partials = false);   // have_partials: a GroupNorm statistics pass over the same tensor left the maxima (GroupNormParams::absmax_out)
 unsigned count_nonfinite(const void* src, int dt, int lds, size_t rows, int C, hipStream_t s);   // debugging aid (SDXL_NAN_CHECK): synchronises
 void launch_f16_to_hl(const void* src, int lds, void* dst, int ldd, size_t rows, int C, hipStream_t s);   // f16 rows -> HL16 rows (lo = 0)
+// fp32 rows -> two plain f16 row sets hi = f16(x), lo = f16(x - hi) (row stride ld16 each): the context images of the split-precision fused cross-attention
+void launch_f32_to_f16_pair(const float* src, int lds, void* hi, void* lo, int ld16, size_t rows, int C, hipStream_t s);
 void launch_hl_zero_lo(void* dst, int ldd, size_t rows, int C, hipStream_t s);   // HL16 rows: lo halves := 0 (precision-frontier instrument, UNet hl_demote)
 void launch_round_f16(float* p, size_t n, hipStream_t s);   // p[i] = float(half(p[i])): parameters as a HalfPrecisionSettings record holds them
 void launch_i32_to_f32(const int* src, float* dst, int n, hipStream_t s);

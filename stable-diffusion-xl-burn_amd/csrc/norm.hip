@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormParams p) 
   const XT* X = reinterpret_cast<const XT*>(p.X) + (size_t)b * p.HW * p.ldx;
   const int npass = (NV + VPR - 1) / VPR;
   float total_rows = (float)max(0, row_end - row_begin);
+  float amax = 0.f;                   // max |x| of this thread's samples (GroupNormParams::absmax_out)
+  const bool want_amax = p.absmax_out != nullptr;      // kernel argument: uniform
 
   for (int pass = 0; pass < npass; ++pass) {
     const int vc = pass * VPR + vl;
@@ -125,6 +127,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormParams p) 
             s1[j] += d;
             s2[j] = fmaf(d, d, s2[j]);
           }
+        if (want_amax) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[u][j]));
+        }
       }
       for (; row < row_end; row += RL) {
         float v[8];
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormParams p) 
           const float d = v[j] - piv[j];
           s1[j] += d;
           s2[j] = fmaf(d, d, s2[j]);
+          if (want_amax) amax = fmaxf(amax, fabsf(v[j]));
         }
       }
       if (cnt > 0.f) {
@@ -167,6 +176,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormParams p) 
       }
     }
     __syncthreads();
+  }
+  if (want_amax) {     // block maximum of |x| -> this (entry, row split)'s slot; the slots no row split owns are zeroed by their residue class
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    __shared__ float wmax[4];
+    if ((tid & 63) == 0) wmax[tid >> 6] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      float* slot = p.absmax_out + (size_t)b * kHlAbsBlocks;
+      slot[s] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      for (int k = s + p.nsplit; k < kHlAbsBlocks; k += p.nsplit) slot[k] = 0.f;
+    }
   }
   // channels -> groups (every channel of this block has total_rows samples)
   const int cpg = C / p.G;
@@ -317,6 +338,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormParams p, 
   }
 }
 
+static_assert(kGnMaxSplit <= kHlAbsBlocks, "one absmax slot per row split (GroupNormParams::absmax_out)");
 int groupnorm_nsplit(int B, int HW, int C) {
   (void)B; (void)C;
   int n = HW / 32;       // >= 32 rows per block; up to kGnMaxSplit row splits x B blocks keep all 256 CUs streaming

@@ -118,8 +118,8 @@ void demote_lo(Exec& ex, int cls, const Act& a, size_t rows, int C) {
   if (ex.dry || !(ex.demote & cls) || a.dt != DT_HL) return;
   launch_hl_zero_lo(a.p, a.ld, rows, C, ex.s);
 }
-Act hl_op(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int cls, int nb) {      // hl_operand + the demotion of the copy when the consumer's class asks
-  Act o = hl_operand(ex, w, x, rows, C, nb);
+Act hl_op(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int cls, int nb, float* have_max = nullptr) {      // hl_operand + the demotion of the copy when the consumer's class asks
+  Act o = hl_operand(ex, w, x, rows, C, nb, have_max);
   if (o.p != x.p) demote_lo(ex, cls, o, rows, C);
   return o;
 }
@@ -263,7 +263,9 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
   SDXL_REQUIRE(B >= 1 && B <= 8, "batch must be in 1..8");
   const int vt_ld = (int)round_up(n_ctx, 64);
   // operand-order copies for the fused cross-attention epilogue (f16 engines; the split-operand engine when that class runs on f16: MIX_XATTN_F16)
-  const bool pack_xa = (cdt_ == DT_F16 || (cdt_ == DT_HL && (mix_ & MIX_XATTN_F16) && (mix_ & MIX_OUT2_F16))) && n_ctx <= 96;
+  // (MIX_XATTN_SPLIT: TWO images -- the hi and the lo halves of the fp32-class projection -- for the split-precision form of that epilogue)
+  const bool pack_xs = cdt_ == DT_HL && (mix_ & MIX_XATTN_SPLIT) && (mix_ & MIX_Q2_F16) && !(mix_ & MIX_XATTN_F16) && n_ctx <= 96;
+  const bool pack_xa = (cdt_ == DT_F16 || (cdt_ == DT_HL && (mix_ & MIX_XATTN_F16) && (mix_ & MIX_OUT2_F16)) || pack_xs) && n_ctx <= 96;
   const int kvdt = attn_dt();                           // dtype of the K / V^T caches (fp32 in the split-operand mode)
   const int emb = 4 * cfg_.model_channels;
   {   // precision-frontier instrument: the demoted classes take effect from here (weights now, activations in every forward after)
@@ -281,13 +283,13 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
     for (const STW* st : st_list_)
       bytes += st->blocks.size() * (round_up((size_t)B * n_ctx * st->C * dt_size(kvdt), 256) +
                                     round_up((size_t)B * st->C * vt_ld * dt_size(kvdt), 256) +
-                                    (pack_xa ? round_up(xattn_pack_bytes(B, st->C), 256) : 0) + 768);
+                                    (pack_xa ? round_up(xattn_pack_bytes(B, st->C), 256) : 0) + (pack_xs ? round_up(xattn_pack_bytes(B, st->C), 256) : 0) + 768);
     bytes += 3 * round_up((size_t)B * emb * sizeof(float), 256);
     if (cdt_ == DT_HL) bytes += round_up((size_t)B * n_ctx * cfg_.context_dim * 4, 256) + 256;   // HL16 copy of the context
     if (cdt_ == DT_HL) {   // fp32 scratch of one block's K / V^T projection: the caches themselves are HL16 (what the attention kernel reads)
       size_t mx = 0;
       for (const STW* st : st_list_) mx = std::max(mx, round_up((size_t)B * n_ctx * st->C * 4, 256) + round_up((size_t)B * st->C * vt_ld * 4, 256));
-      bytes += (pack_xa ? mx + mx / 2 + 512 : mx) + 512;     // (+ f16 copies of both when the fused f16 cross-attention reads them packed)
+      bytes += (pack_xs ? 2 * mx + 1024 : pack_xa ? mx + mx / 2 + 512 : mx) + 512;     // (+ f16 copies of both -- hi and lo with MIX_XATTN_SPLIT -- when the fused cross-attention reads them packed)
     }
     ctx_arena_.reserve(bytes);
     ctx_arena_.off = 0;
@@ -300,6 +302,7 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
         kv.k = ctx_arena_.alloc((size_t)B * n_ctx * st->C * dt_size(kvdt));
         kv.vt = ctx_arena_.alloc((size_t)B * st->C * vt_ld * dt_size(kvdt));
         if (pack_xa) kv.xa = ctx_arena_.alloc(xattn_pack_bytes(B, st->C));
+        if (pack_xs) kv.xa_lo = ctx_arena_.alloc(xattn_pack_bytes(B, st->C));
         v.push_back(kv);
       }
       kv_.push_back(v);
@@ -328,6 +331,14 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
         launch_f32_to_hl(vt32, vt_ld, kv_[si][j].vt, vt_ld, (size_t)B * st->C, vt_ld, s);
         demote_lo(ex, DM_XATTN, Act(kv_[si][j].k, st->C, DT_HL), (size_t)B * n_ctx, st->C);
         demote_lo(ex, DM_XATTN, Act(kv_[si][j].vt, vt_ld, DT_HL), (size_t)B * st->C, vt_ld);
+        if (kv_[si][j].xa_lo) {  // MIX_XATTN_SPLIT: hi = f16(x), lo = f16(x - hi) of the fp32-class projection, each in the operand order the fused launch reads
+          void* kh = ctx_arena_.alloc((size_t)B * n_ctx * st->C * 2); void* kl = ctx_arena_.alloc((size_t)B * n_ctx * st->C * 2);
+          void* vh = ctx_arena_.alloc((size_t)B * st->C * vt_ld * 2); void* vl = ctx_arena_.alloc((size_t)B * st->C * vt_ld * 2);
+          launch_f32_to_f16_pair((const float*)k32, st->C, kh, kl, st->C, (size_t)B * n_ctx, st->C, s);
+          launch_f32_to_f16_pair((const float*)vt32, vt_ld, vh, vl, vt_ld, (size_t)B * st->C, vt_ld, s);
+          launch_xattn_pack(kh, vh, kv_[si][j].xa, B, st->C, n_ctx, vt_ld, s);
+          launch_xattn_pack(kl, vl, kv_[si][j].xa_lo, B, st->C, n_ctx, vt_ld, s);
+        } else
         if (kv_[si][j].xa) {     // MIX_XATTN_F16: the fp32-class projection rounded once to f16, in the operand order the fused launch reads
           void* k16 = ctx_arena_.alloc((size_t)B * n_ctx * st->C * 2);
           void* vt16 = ctx_arena_.alloc((size_t)B * st->C * vt_ld * 2);
@@ -363,7 +374,12 @@ const float* UNet::res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, 
   const ConvGeom g3{B, H, W, H, W, 3, 1, 1, 0}, g1{B, H, W, H, W, 1, 1, 0, 0};
   const bool tiles256 = gn_from_producer_ && HW % 256 == 0;
   Act gn1 = ex.alloc(M, w.cin, ex.cdt);
-  run_groupnorm(ex, w.norm_in, x, B, HW, gn1, true);
+  // split-operand engines: the 1x1 skip convolution reads x as an HL16 copy scaled per entry by max|x| -- the statistics pass of norm_in reads all
+  // of x anyway and leaves the maxima, so that copy needs no absmax pass of its own (11 launches of a step)
+  float* skip_max = nullptr;
+  if (w.has_skip && ex.cdt == DT_HL && x.dt == DT_F32 && w.skip.dt != DT_F32 && !x.gn_part && M % (size_t)B == 0)
+    skip_max = (float*)ex.act->alloc(hl_scale_floats(B) * sizeof(float));
+  run_groupnorm(ex, w.norm_in, x, B, HW, gn1, true, 32, skip_max);
   demote_lo(ex, DM_CONV_RES, gn1, M, w.cin);
   Act h = ex.alloc(M, w.cout, ex.cdt == DT_HL ? ex.sdt : ex.cdt);     // (read by a GroupNorm only: fp32 in the split-operand mode)
   Epi e1; e1.ebias = ex.ebias + w.emb_off; e1.ebias_ld = emb_total_; e1.cls = DM_CONV_RES;
@@ -373,7 +389,7 @@ const float* UNet::res_block(Exec& ex, const ResBlockW& w, const Act& x, int B, 
   run_groupnorm(ex, w.norm_out, h, B, HW, gn2, true);
   demote_lo(ex, DM_CONV_RES, gn2, M, w.cout);
   Epi e2; e2.cls = DM_CONV_RES;
-  if (w.has_skip) { Epi es; es.cls = DM_CONV_SKIP; run_conv(ex, w.skip, hl_op(ex, w.skip, x, M, w.cin, DM_CONV_SKIP, B), w.cin, g1, out, es); e2.R = out; }
+  if (w.has_skip) { Epi es; es.cls = DM_CONV_SKIP; run_conv(ex, w.skip, hl_op(ex, w.skip, x, M, w.cin, DM_CONV_SKIP, B, skip_max), w.cin, g1, out, es); e2.R = out; }
   else e2.R = x;
   if (tiles256) e2.gn_part = out_gn_part;
   const bool produced = run_conv(ex, w.conv_out, gn2, w.cout, g3, out, e2);
@@ -392,6 +408,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   const int adt = attn_dt();      // q / k / V^T / attention output: the compute dtype, fp32 in the split-operand mode
   auto kv_k = [&](int s_, size_t j) { char* k = (char*)kv_[s_][j].k; return (void*)(k ? k + (size_t)ex.b0 * n_ctx_ * C * dt_size(adt) : k); };
   auto kv_xa = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].xa; return (const void*)(v ? v + xattn_pack_bytes(ex.b0, C) : v); };
+  auto kv_xa_lo = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].xa_lo; return (const void*)(v ? v + xattn_pack_bytes(ex.b0, C) : v); };
   auto kv_vt = [&](int s_, size_t j) { char* v = (char*)kv_[s_][j].vt; return (const void*)(v ? v + (size_t)ex.b0 * C * vt_ld_ctx_ * dt_size(adt) : v); };
   Act gn = ex.alloc(M, C, ex.cdt);
   run_groupnorm(ex, w.norm, x, B, HW, gn, false);
@@ -455,6 +472,9 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   if (any_sh) { sh16 = ex.alloc(M, C, DT_F16); shst = (float*)ex.act->alloc(M * (size_t)((C + 63) / 64) * 2 * sizeof(float)); }
   Act q32;     // MIX_Q2_F16: fp32 q of the cross-attention (the f16 projection's fp32 accumulators, never rounded to f16)
   if (mix_q2 && !mix_q2_widen) q32 = ex.alloc(M, C, DT_F32);
+  // MIX_XATTN_SPLIT: the split-precision attention runs inside that projection's epilogue on q's accumulators (hi / lo context images of set_context), and its
+  // f16 rows are the out-projection's operand: q never reaches memory, no attention launch
+  const bool mix_xs = mix_q2 && !mix_q2_widen && mix_out2 && plan_xattn_ && !kv_.empty() && kv_[si][0].xa_lo && igemm_xattn_ok(DT_F16, DT_F16, (int)M, C, C, HW, n_ctx_);
   auto want_shadow = [&](Epi& e, const Lin& consumer_sh, const NormW& n) {     // ask producer `e` for the shadow the consumer behind LayerNorm n reads
     have_sh = false;
     if (!consumer_sh.cs || C % 64 != 0) return;
@@ -532,14 +552,25 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     { Epi e1 = er; if (mix_out1) want_shadow(e1, b.q2_sh, b.n2); run_linear(ex, b.out1, mix_out1 ? ao16 : ao, (int)M, t, e1); }
     if (have_sh && b.q2_sh.cs) {       // f16 query projection on the shadow the out-projection left; fp32 q for the split-operand attention
       Epi e2q; e2q.cls = DM_XATTN; e2q.rpb = HW; e2q.ln_stat = shst;
+      if (mix_xs) {
+        e2q.xa_k = kv_xa(si, j); e2q.xa_k_lo = kv_xa_lo(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
+        run_linear(ex, b.q2_sh, sh16, (int)M, ao2_16, e2q);
+      } else {
       run_linear(ex, b.q2_sh, sh16, (int)M, q32, e2q);
       attention_hl(ex, q32, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao2_16 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);
+      }
     } else {
     run_layernorm(ex, b.n2, t, (int)M, mix_q2 ? ln16 : ln);
     demote_lo(ex, DM_XATTN, ln, M, C);
     if (mix_q2 && !mix_xa && !mix_q2_widen) {
+      if (mix_xs) {
+        Epi e2q; e2q.cls = DM_XATTN; e2q.rpb = HW;
+        e2q.xa_k = kv_xa(si, j); e2q.xa_k_lo = kv_xa_lo(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
+        run_linear(ex, b.q2, ln16, (int)M, ao2_16, e2q);
+      } else {
       { Epi e2q; e2q.cls = DM_XATTN; e2q.rpb = HW; run_linear(ex, b.q2, ln16, (int)M, q32, e2q); }
       attention_hl(ex, q32, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao2_16 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);
+      }
     } else
     if (mix_xa) {
       Epi e2q; e2q.rpb = HW; e2q.cls = DM_XATTN;

@@ -409,7 +409,7 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.ln_stat = e.ln_stat; p.ln_slots = w.K / 64; p.ln_cs = w.cs; p.ln_invc = 1.0f / (float)w.K; p.ln_eps = 1e-5f; p.ln_eps_ptr = w.ln_eps;
   p.stat_out = e.stat_out; p.stat_slots = w.N / 64;
   p.splitk_ws = ex.splitk_ws; p.splitk_ws_bytes = ex.splitk_ws_bytes; p.splitk_cnt = ex.splitk_cnt; p.splitk = 0;
-  p.xa_k = e.xa_k; p.xa_nctx = e.xa_nctx; p.xa_scale = e.xa_scale;
+  p.xa_k = e.xa_k; p.xa_nctx = e.xa_nctx; p.xa_scale = e.xa_scale; p.xa_k_lo = e.xa_k_lo;
   // f16 shadow of an fp32 output (+ its row statistics) for the GEMM behind the next LayerNorm: only where the selection picks the
   // weights-in-registers kernel anyway; otherwise neither is written and the caller runs the LayerNorm launch
   if (e.shadow_done) *e.shadow_done = false;
@@ -421,7 +421,10 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   }
   // GroupNorm statistics of the output from this GEMM's epilogue -- only when the kernel the selection picks anyway can do it
   p.gn_part = nullptr;
-  if (e.gn_part && ex.cdt == DT_F16) { p.gn_part = e.gn_part; if (!igemm_gn_part_ok(p)) p.gn_part = nullptr; }
+  {
+    const int wdt_ = w.dt >= 0 ? w.dt : ex.cdt;      // (f16 engines; round 6: the split-operand convolutions that run the 256x128 split-K kernel)
+    if (e.gn_part && (wdt_ == DT_F16 || wdt_ == DT_HL) && wdt_ == ex.cdt) { p.gn_part = e.gn_part; if (!igemm_gn_part_ok(p)) p.gn_part = nullptr; }
+  }
   SDXL_REQUIRE(!e.xa_k || igemm_xattn_ok(a.dt, out.dt, p.M, p.N, p.K, p.rpb, e.xa_nctx), "fused cross-attention: unsupported shape");
   SDXL_REQUIRE(!e.ln_stat || w.K % 64 == 0, "LayerNorm-folded GEMM needs K % 64 == 0");
   SDXL_REQUIRE(!e.stat_out || (w.N % 64 == 0 && (e.n_split < 0 || e.n_split >= w.N) && e.act == 0), "row statistics need a plain N % 64 == 0 output");
@@ -492,12 +495,12 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
 // GEMM operand view of a residual-stream tensor: the split-operand mode keeps the stream in fp32 and stages (hi, lo) f16 pairs, so
 // GEMMs that read the stream directly (skip / nin_shortcut 1x1 convs, up- / downsamplers, proj_out) get an HL16 copy; other modes
 // -- and layers whose weights were packed fp32 (w.dt) -- read x itself
-Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int nb) {
+Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int nb, float* have_max) {
   if (ex.cdt != DT_HL || x.dt != DT_F32 || w.dt == DT_F32) return x;
-  if (nb < 1 || rows % (size_t)nb != 0) nb = 1;
+  if (nb < 1 || rows % (size_t)nb != 0) { SDXL_REQUIRE(!have_max, "hl_operand: absmax partials need whole batch entries"); nb = 1; }
   Act o = ex.alloc(rows, C, DT_HL);
-  float* sc = (float*)ex.act->alloc(hl_scale_floats(nb) * sizeof(float));      // per entry: max|x| partials, 2^-e -- the stream's range is the model's, not ours
-  if (!ex.dry) launch_f32_to_hl_scaled(x.p, x.ld, o.p, o.ld, rows, C, sc, ex.s, nb);
+  float* sc = have_max ? have_max : (float*)ex.act->alloc(hl_scale_floats(nb) * sizeof(float));      // per entry: max|x| partials, 2^-e -- the stream's range is the model's, not ours
+  if (!ex.dry) launch_f32_to_hl_scaled(x.p, x.ld, o.p, o.ld, rows, C, sc, ex.s, nb, have_max != nullptr);
   o.a_scale = hl_scale_inv(sc, nb); o.a_scale_n = nb;
   return o;
 }
@@ -507,7 +510,7 @@ bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, con
   if (e2.rpb == 0) e2.rpb = M;
   return run_conv(ex, w, a, w.cin, g, out, e2);
 }
-void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups) {
+void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups, float* absmax_out) {
   if (ex.dry) return;
   SDXL_REQUIRE(groups >= 1 && groups <= 256 && n.C % groups == 0, "The number of channels must be divisible by the number of groups");
   GroupNormParams p{};
@@ -516,6 +519,8 @@ void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const 
   p.gamma = n.gamma; p.beta = n.beta; p.partial = ex.gn_partial;
   p.B = B; p.HW = HW; p.C = n.C; p.G = groups; p.eps = 1e-5f; p.eps_ptr = n.eps; p.silu = silu ? 1 : 0;
   p.chan_part = x.gn_part; p.chan_rt = x.gn_rt; p.chan_rows = 256;          // statistics left by x's producer (Act::gn_part)
+  SDXL_REQUIRE(!absmax_out || (!x.gn_part && x.dt == DT_F32), "GroupNorm absmax side output needs the statistics pass over an fp32 tensor");
+  p.absmax_out = absmax_out;
   SDXL_REQUIRE(!x.gn_part || x.gn_rt * 256 == HW, "producer GroupNorm statistics do not cover the tensor");
   if (ex.prof) ex.prof->begin(Profiler::GROUPNORM, 0.0, ex.s);
   launch_groupnorm(p, ex.s);

@@ -76,6 +76,31 @@ def test_fullsize_split_modes_batch_independence(pkg, ctx, base_inputs, dtype_na
         assert torch.equal(one[0], outs[0][i]), f"{dtype_name}: batch entry {i} depends on its batch neighbour"
 
 
+def test_fullsize_f16w_fused_split_cross_attention_matches_the_attention_kernel(pkg, ctx, base_inputs):
+    """SDXL_DTYPE_F32_SPLIT_MIX_F16W runs the 77-key cross-attention at split precision INSIDE the f16 query projection's epilogue (MIX class 512,
+    IgemmParams::xa_k_lo).  Without that class the same q (fp32) goes through memory into the stand-alone split-operand attention kernel: the same
+    three-MFMA arithmetic, the same single rounding of the result to f16 rows -- the two forwards may differ where an fp32 value sits on an f16 rounding
+    boundary, nowhere else."""
+    cfg, x, t, ctxt, y = base_inputs
+    outs = {}
+    try:
+        for m in (447, 959):
+            pkg.debug_set("mix_classes", m)
+            u = pkg.UNet(ctx, cfg, pkg.DTYPE_F32_SPLIT_MIX, seed=pkg.SEED_F16_WEIGHTS)
+            assert u.mix_classes() == m
+            o = [u.forward(x.cuda(), t.cuda(), ctxt.cuda(), y.cuda()).cpu() for _ in range(3)]
+            assert torch.equal(o[0], o[1]) and torch.equal(o[1], o[2]), "hipGraph replay differs from the eager run"
+            outs[m] = o[0]
+            del u
+    finally:
+        pkg.debug_set("mix_classes", -1)
+    e = rel_err(outs[959], outs[447])
+    print(f"F16W forward 1024^2: fused split-precision cross-attention vs attention kernel: rel diff {e:.3e}")
+    # (op level the two forms agree except for 0.2 % one-ulp boundary flips of the f16 rows -- test_ln_query_cross_attention_split_precision; 70 transformer
+    #  blocks of a random-weight UNet amplify those to ~1.6e-4 of the output, the size of the mode's own distance from the oracle: this bar catches gross errors only)
+    assert e < 4e-4
+
+
 def _prompt_ids(seed, n_tok, pad):
     g = torch.Generator().manual_seed(seed)
     ids = torch.full((1, 77), pad, dtype=torch.int64)

@@ -32,7 +32,7 @@ LAT_REL_F16 = 6.0e-3         # fp16-operand modes: max-abs error relative to max
                              # (5-step inpainting) on the tiny net -> <= 2x measured
 
 
-F16W_CLASSES = 1 | 2 | 4 | 8 | 16 | 32 | 128 | 256     # SDXL_DTYPE_F32_SPLIT_MIX_F16W (capi.hip mix_of): + cross-attention query projection, LayerNorm shadow (round 6)
+F16W_CLASSES = 1 | 2 | 4 | 8 | 16 | 32 | 128 | 256 | 512     # SDXL_DTYPE_F32_SPLIT_MIX_F16W (capi.hip mix_of): + cross-attention query projection, LayerNorm shadow, fused split-precision cross-attention (round 6)
 
 
 def weights_for(pkg, ocfg, dtype):

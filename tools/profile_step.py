@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as ge
 pkg = ge.load_package()
+for kv in filter(None, os.environ.get("SDXL_DEBUG_SET", "").split(",")):      # A/B knobs, e.g. wreg_xcd2d=1
+    k_, v_ = kv.split("="); pkg.debug_set(k_, int(v_))
 ctx = pkg.Context(0)
 cfg = pkg.sdxl_base_config()
 d = pkg.Diffuser(ctx, cfg, pkg.DTYPE_F16, seed=0)
