@@ -723,7 +723,7 @@ def main():
     # HBM-side traffic of the same launches: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_step.py,
     # summarised by tools/pmc_traffic.py (gfx950 correction applied there); null when no committed summary exists
     traffic, traffic_src = None, None
-    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and args.dtype == "f16" and res == 1024:
             try:

@@ -34,7 +34,7 @@ typedef struct sdxl_vae sdxl_vae;
 typedef struct sdxl_clip sdxl_clip;
 
 enum { SDXL_OK = 0, SDXL_ERR_INVALID = 1, SDXL_ERR_RUNTIME = 2 };
-/* precision of a model instance (measurements of every mode: DESIGN.md section 12 and profiles/; the reference runs the UNet in f16 and the VAE in f32,
+/* precision of a model instance (measurements of every mode: DESIGN.md sections 4-6 and profiles/; the reference runs the UNet in f16 and the VAE in f32,
  * src/bin/sample/main.rs:121-122) */
 enum {
   SDXL_DTYPE_F32 = 0,       /* strict parity: fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); meets the unscaled 1e-3 on latents                       */
@@ -153,7 +153,7 @@ int sdxl_unet_set_gn_from_producer(sdxl_unet* u, int enabled);
 /* which GEMM classes of a SDXL_DTYPE_F32_SPLIT_MIX* model run on plain f16 operands (bit set: 1 self-attention, 2 GEGLU projection, 4 QKV projection,
  * 8 FF-out, 16 / 32 the self- / cross-attention out-projections, 128 cross-attention query projection, 256 LayerNorms folded through an f16 shadow of
  * the stream, 512 the 77-key cross-attention at split precision inside the query projection's epilogue; 0 for every other dtype).  A SDXL_DTYPE_F32_SPLIT_MIX_F16W model whose parameters are NOT all f16 values (checked on the tensors at
- * create time) falls back to SDXL_DTYPE_F32_SPLIT_MIX's classes (3): this is how a caller sees it. */
+ * create time) falls back to SDXL_DTYPE_F32_SPLIT_MIX's classes (1 | 2 | 1024 = the GEGLU weights as (hi, lo) f16 pairs along K): this is how a caller sees it. */
 int sdxl_unet_mix_classes(sdxl_unet* u, int* classes_out);
 
 /* ---- Backend::qkv_attention (src/backend.rs:4-19; generic body :88-128, LibTorch override :32-79)

@@ -414,7 +414,7 @@ impl<B: BurnBackend> Diffuser<B> {
         let unet = unsafe { ffi::sdxl_diffuser_unet(self.raw) };
         check(unsafe { ffi::sdxl_unet_set_fused_cross_attention(unet, enabled as c_int) });
     }
-    /// GEMM classes on plain f16 operands (F32SplitMix* precisions; an F32SplitMixF16W model on parameters that are not f16 values falls back to 3)
+    /// GEMM classes on plain f16 operands (F32SplitMix* precisions; an F32SplitMixF16W model on parameters that are not f16 values falls back to F32SplitMix's 1 | 2 | 1024)
     pub fn mix_classes(&self) -> i32 {
         let unet = unsafe { ffi::sdxl_diffuser_unet(self.raw) };
         let mut v: c_int = 0;

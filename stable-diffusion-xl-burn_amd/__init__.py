@@ -363,7 +363,7 @@ class UNet:
         _check(lib().sdxl_unet_set_graph(self.h, int(enabled)))
 
     def mix_classes(self) -> int:
-        """MIX_* classes on plain f16 operands (F32_SPLIT_MIX* models; an F16W model on parameters that are not f16 values reports F32_SPLIT_MIX's 3)"""
+        """MIX_* classes on plain f16 operands (F32_SPLIT_MIX* models; an F16W model on parameters that are not f16 values reports F32_SPLIT_MIX's 1 | 2 | 1024)"""
         v = ctypes.c_int(0)
         _check(lib().sdxl_unet_mix_classes(self.h, ctypes.byref(v)))
         return v.value

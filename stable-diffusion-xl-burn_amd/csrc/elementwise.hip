@@ -642,6 +642,26 @@ void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int K
   hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, K, N, Kpad, Npad, geglu, n_offset,
                      kscale, wscale);
 }
+__global__ void pack_linear_hilo_kernel(const float* src, half_t* dst, int K, int N, int Npad, int geglu, float lo_scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)Npad * 2 * K) return;
+  const int np = (int)(i / (2 * (size_t)K));
+  const int k2 = (int)(i - (size_t)np * 2 * K);
+  const int part = k2 >= K ? 1 : 0, k = k2 - part * K;
+  half_t v = (half_t)0.f;
+  if (np < N) {
+    const int n = geglu ? geglu_unpermute(np, N) : np;
+    float w = src[(size_t)k * N + n];
+    asm("" : "+v"(w));
+    const half_t hi = (half_t)w;
+    v = part ? (half_t)((w - (float)hi) * lo_scale) : hi;
+  }
+  dst[i] = v;
+}
+void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s) {
+  const size_t total = (size_t)Npad * 2 * K;
+  hipLaunchKernelGGL(pack_linear_hilo_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, reinterpret_cast<half_t*>(dst), K, N, Npad, geglu, lo_scale);
+}
 // cs[r] = sum_k packed[r][k] over the ROUNDED packed values (what the MFMA really multiplies), one wave per packed row
 // kscale (K values, optional): cs[r] = sum_k kscale[k] * packed[r][k] -- the shadow form of a folded LayerNorm, whose gamma rides on the A operand
 __global__ void colsum_packed_kernel(const void* wp, int dt, int Kpad, int nrows, float* cs, const float* kscale, int K) {

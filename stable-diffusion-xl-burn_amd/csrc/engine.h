@@ -89,6 +89,7 @@ struct NullSource : WeightSource {   // replica ranks: same arena layout, conten
   void fetch(const ParamSpec&, size_t, float*, hipStream_t) override {}
   bool empty() const override { return true; }
 };
+constexpr float kHiLoScale = 256.0f;    // lo halves of WeightBuilder::linear_hilo travel times 2^8 (out of the f16 subnormals), the A operand's second copy times 2^-8
 constexpr uint64_t kSeedF16Weights = 1ull << 63;   // seed flag (C ABI: SDXL_SEED_F16_WEIGHTS): synthetic parameters rounded to f16
 struct SyntheticSource : WeightSource {
   uint64_t seed;
@@ -147,6 +148,7 @@ struct WeightBuilder {
   // dt_override >= 0: pack in that dtype whatever the model's (the GEMV weights of a split-operand model stay fp32)
   Lin linear(const std::string& name, bool geglu = false, int dt_override = -1);   // name.weight [K,N] (+ name.bias)
   Lin fused_linear(const std::vector<std::string>& names, int dt_override = -1);   // concatenated along N (same K)
+  Lin linear_hilo(const std::string& name, bool geglu);     // f16 GEMM on (hi | lo * kHiLoScale) weight halves along a doubled K: un-rounded weights (MIX_GEGLU_HILO)
   float hl_scale(Lin& l, const std::vector<std::string>& weight_names);     // DT_HL packing: power-of-two factor, inverse into the arena
   // the same with the preceding LayerNorm(gamma, beta) folded into weight / bias / column sums
   Lin linear_ln(const std::string& name, bool geglu, const std::string& norm);
@@ -238,9 +240,11 @@ enum MixClass {
   MIX_XATTN_F16 = 64,   // with OUT2: cross-attention + its query projection as the f16 engine's fused launch -- a knob, in no mode
   MIX_Q2_F16 = 128,     // cross-attention QUERY projection alone on f16 operands (HL16 output: the split-operand attention behind it keeps an fp32-class q)
   MIX_XATTN_SPLIT = 512, // with MIX_Q2_F16: the 77-key cross-attention at SPLIT precision inside the f16 query projection's epilogue (IgemmParams::xa_k_lo) -- the
-                        // arithmetic of the stand-alone split-operand attention without its launch (DESIGN 12.1)
+                        // arithmetic of the stand-alone split-operand attention without its launch (DESIGN 4.1)
+  MIX_GEGLU_HILO = 1024, // with MIX_GEGLU_F16 (and without the shadow form): the GEGLU weights as (hi, lo) f16 pairs along a doubled K against [a | a 2^-8] -- the f16 wide-tile
+                        // kernel at twice the depth, two MFMAs per product: activation rounding only on ANY weights.  SDXL_DTYPE_F32_SPLIT_MIX
   MIX_LN_SHADOW = 256   // the LayerNorms in front of the f16 projections (QKV, GEGLU, the query projection with MIX_Q2_F16) folded into them: the producers of
-                        // the fp32 stream leave an f16 shadow f16(x o gamma) + row statistics (IgemmParams::shadow), no LayerNorm launch (DESIGN 12.1)
+                        // the fp32 stream leave an f16 shadow f16(x o gamma) + row statistics (IgemmParams::shadow), no LayerNorm launch (DESIGN 4.1)
 };
 enum DemoteClass { DM_QKV = 1, DM_ATTN = 2, DM_OUT = 4, DM_XATTN = 8, DM_GEGLU = 16, DM_FF = 32, DM_CONV_RES = 64, DM_CONV_SKIP = 128,
                    DM_CONV_IO = 256, DM_CONV_UPDOWN = 512, DM_CONV_PROJ = 1024 };
@@ -276,7 +280,7 @@ bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, con
 Act hl_operand(Exec& ex, const Lin& w, const Act& x, size_t rows, int C, int nb = 1, float* have_max = nullptr);    // HL16 copy of an fp32 stream tensor (nb batch entries of rows / nb rows, one power-of-two scale each) for a split-operand GEMM (else x)
 // absmax_out: hl_scale_floats(B) floats; the statistics pass (fp32 x without producer statistics -- the caller checks) also leaves max|x| partials per entry there
 void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const Act& y, bool silu, int groups = 32, float* absmax_out = nullptr);
-void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y);
+void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y, float dup_scale = 0.f);   // dup_scale: LayerNormParams::dup_scale
 
 // ------------------------------------------------------------------------------------------ UNet
 struct ResBlockW { NormW norm_in, norm_out; Lin conv_in, conv_out, skip; bool has_skip = false; int emb_off = 0, cin = 0, cout = 0; };

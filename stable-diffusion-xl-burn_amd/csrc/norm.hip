@@ -8,6 +8,7 @@
 // formula (row lanes -> channels -> groups -> row splits), never E[x^2]-E[x]^2.
 #include "kernels.h"
 #include <stdexcept>
+#include <type_traits>
 
 namespace sdxl {
 
@@ -433,6 +434,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
       v[4 + j] = (v[4 + j] - mean) * rstd * g1[j] + b1[j];
     }
     store8r<YT>(y, vc * 8, v);
+    if constexpr (std::is_same<YT, half_t>::value) {
+      if (p.dup_scale != 0.f) {      // second copy of the ROUNDED values, times a power of two (LayerNormParams::dup_scale)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)(half_t)v[j] * p.dup_scale;
+        store8r<YT>(y, p.C + vc * 8, v);
+      }
+    }
   }
 }
 
@@ -482,12 +490,20 @@ __global__ __launch_bounds__(256) void layernorm_cached_kernel(const LayerNormPa
         o[4 + j] = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
       }
       store8r<YT>(y, vc * 8, o);
+      if constexpr (std::is_same<YT, half_t>::value) {
+        if (p.dup_scale != 0.f) {      // second copy of the ROUNDED values, times a power of two (LayerNormParams::dup_scale)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (float)(half_t)o[j] * p.dup_scale;
+          store8r<YT>(y, p.C + vc * 8, o);
+        }
+      }
     }
   }
 }
 
 void launch_layernorm(const LayerNormParams& p, hipStream_t s) {
   dim3 g((p.rows + 3) / 4);
+  if (p.dup_scale != 0.f && (p.y_dt != DT_F16 || p.ldy < 2 * p.C)) throw std::runtime_error("layernorm: the duplicated output needs f16 rows of 2 C elements");
   if (p.y_dt == DT_HL) {     // split-operand output (fp32 rows in): the GEMM operand format of the fp32-class mode
     if (p.x_dt != DT_F32 || (p.C & 15) != 0 || (p.ldy & 15) != 0) throw std::runtime_error("layernorm: HL16 output needs fp32 input and C % 16 == 0 rows");
     if (p.C <= 8 * 64 * 3) hipLaunchKernelGGL((layernorm_cached_kernel<float, hlout_t, 3>), g, dim3(256), 0, s, p);

@@ -37,6 +37,7 @@ ResBlockW load_res(WeightBuilder& wb, const std::string& p, int cin, int cout, s
   emb_off += cout;
   return r;
 }
+bool spec_k_ok(WeightBuilder& wb, const std::string& name) { return wb.spec(name + ".weight").shape[0] % 32 == 0; }
 STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln, int mix = 0) {
   const bool geglu_f16 = (mix & MIX_GEGLU_F16) != 0, qkv_f16 = (mix & MIX_QKV_F16) != 0, ff_f16 = (mix & MIX_FF_F16) != 0, out1_f16 = (mix & MIX_OUT1_F16) != 0,
              out2_f16 = (mix & MIX_OUT2_F16) != 0, q2_fused = out2_f16 && (mix & MIX_XATTN_F16) != 0, q2_f16 = q2_fused || (mix & MIX_Q2_F16) != 0,
@@ -77,6 +78,7 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     t.n3 = wb.norm(q + ".norm3");
     // (mixed mode: the GEGLU projection of a split-operand model packed as plain f16 -- it runs on the f16 wide-tile kernel)
     if (ln_sh && geglu_f16) t.geglu_sh = wb.fold_ln({q + ".mlp.geglu.proj"}, q + ".norm3", true, DT_F16, true, &t.geglu);
+    else if (geglu_f16 && (mix & MIX_GEGLU_HILO) && spec_k_ok(wb, q + ".mlp.geglu.proj")) t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true);
     else
     t.geglu = wb.linear(q + ".mlp.geglu.proj", true, geglu_f16 ? (int)DT_F16 : -1);
     t.ff = wb.linear(q + ".mlp.lin", false, ff_f16 ? (int)DT_F16 : -1);
@@ -217,7 +219,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
           ((mix_ & MIX_FF_F16) && ends(n, ".mlp.lin.weight")) || ((mix_ & (MIX_XATTN_F16 | MIX_Q2_F16)) && ends(n, ".attn2.query.weight")))
         names.push_back(n);
     }
-    if (!wb.all_f16_exact(names)) mix_ &= (MIX_ATTN_F16 | MIX_GEGLU_F16);
+    if (!wb.all_f16_exact(names)) mix_ = MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_GEGLU_HILO;      // = SDXL_DTYPE_F32_SPLIT_MIX (capi.hip mix_of)
   }
   const int gv = cdt_ == DT_HL ? DT_F32 : -1;     // the M <= 8 GEMV weights of a split-operand model are packed fp32
   lin1_t_ = wb.linear("lin1_time_embed", false, gv);
@@ -465,6 +467,10 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   const bool mix_xa = mix_q2 && mix_out2 && (mix_ & MIX_XATTN_F16) && plan_xattn_ && !kv_.empty() && kv_[si][0].xa && igemm_xattn_ok(DT_F16, DT_F16, (int)M, C, C, HW, n_ctx_);
   const bool mix_q2_widen = mix_q2 && (mix_ & MIX_XATTN_F16) && mix_out2;     // round 5's form of the knob on shapes the fused launch does not take: f16 q, widened
   if (mix_geglu || mix_qkv || mix_q2) ln16 = ex.alloc(M, C, DT_F16);
+  // MIX_GEGLU_HILO: the GEGLU projection's weights are (hi | lo 2^8) halves along a doubled K (WeightBuilder::linear_hilo): its A operand is [a | a 2^-8]
+  const bool gg_hilo = mix_geglu && !w.blocks.empty() && w.blocks[0].geglu.K == 2 * C && !w.blocks[0].geglu_sh.cs;
+  Act ln16x2;
+  if (gg_hilo) ln16x2 = ex.alloc(M, 2 * C, DT_F16);
   // MIX_LN_SHADOW: f16 shadow of the stream + the fp32 rows' statistics, left by the weights-in-registers producers (out-projections, FF-out) for the f16
   // projection behind the next LayerNorm; `have_sh` says whether the last producer wrote them (else: LayerNorm launch + the plain form of the projection)
   const bool any_sh = hl_attn && !w.blocks.empty() && (w.blocks[0].qkv_sh.cs || w.blocks[0].q2_sh.cs || w.blocks[0].geglu_sh.cs);
@@ -600,6 +606,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
     const bool gg_sh = have_sh && b.geglu_sh.cs;      // GEGLU projection on the shadow the cross-attention's out-projection left: no LayerNorm launch
     if (gg_sh) eg.ln_stat = shst;
+    else if (gg_hilo) run_layernorm(ex, b.n3, t, (int)M, ln16x2, 1.0f / kHiLoScale);
     else {
     run_layernorm(ex, b.n3, t, (int)M, mix_geglu ? ln16 : ln);
     demote_lo(ex, DM_GEGLU, ln, M, C);
@@ -612,12 +619,12 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       else run_linear(ex, b.geglu_sh, sh16, (int)M, gg, eg);
     } else
     if (mix_ff) {
-      run_linear(ex, b.geglu, mix_geglu ? ln16 : ln, (int)M, gg16, eg);         // f16 output for the f16 FF-out (f16 or split-operand GEGLU compute)
+      run_linear(ex, b.geglu, gg_hilo ? ln16x2 : mix_geglu ? ln16 : ln, (int)M, gg16, eg);         // f16 output for the f16 FF-out (f16 or split-operand GEGLU compute)
     } else if (mix_geglu && !gg_direct) {
-      run_linear(ex, b.geglu, ln16, (int)M, gg16, eg);
+      run_linear(ex, b.geglu, gg_hilo ? ln16x2 : ln16, (int)M, gg16, eg);
       if (!ex.dry) launch_f16_to_hl(gg16.p, gg16.ld, gg.p, gg.ld, M, 4 * C, ex.s);
     } else
-    run_linear(ex, b.geglu, mix_geglu ? ln16 : ln, (int)M, gg, eg);
+    run_linear(ex, b.geglu, gg_hilo ? ln16x2 : mix_geglu ? ln16 : ln, (int)M, gg, eg);
     demote_lo(ex, DM_FF, gg, M, 4 * C);
     er.cls = DM_FF;
     { Epi ef = er; if (mix_ff && j + 1 < w.blocks.size()) want_shadow(ef, w.blocks[j + 1].qkv_sh, w.blocks[j + 1].n1); run_linear(ex, b.ff, mix_ff ? gg16 : gg, (int)M, t, ef); }

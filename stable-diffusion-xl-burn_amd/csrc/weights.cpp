@@ -204,6 +204,24 @@ Lin WeightBuilder::linear(const std::string& name, bool geglu, int dt_override) 
   if (!geglu) attach_wfrag(l, true);
   return l;
 }
+// f16 GEMM with UN-ROUNDED weights (round 6, SDXL_DTYPE_F32_SPLIT_MIX's GEGLU projection): every weight as (hi, lo) f16 values along a doubled K --
+// dst[n] = [f16(w) | f16((w - hi) * kHiLoScale)] -- against the A operand [a | a / kHiLoScale] (run_layernorm dup_scale): two MFMAs per product,
+// the activations rounded once, the weights not at all.  An f16 Lin of K = 2 K0.
+Lin WeightBuilder::linear_hilo(const std::string& name, bool geglu) {
+  const ParamSpec& s = spec(name + ".weight");
+  const int K0 = s.shape[0];
+  SDXL_REQUIRE(K0 % 32 == 0, "linear_hilo: K % 32 == 0");
+  Lin l; l.K = 2 * K0; l.N = s.shape[1]; l.ksize = 1; l.cin = l.K; l.dt = DT_F16;
+  l.Kpad = l.K; l.Npad = (int)round_up(l.N, 128);
+  void* w = arena.alloc((size_t)l.Npad * l.Kpad * 2);
+  float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
+  l.w = w; l.b = b;
+  if (src.empty()) return l;
+  launch_pack_linear_hilo(fetch(name + ".weight"), w, K0, l.N, l.Npad, geglu ? 1 : 0, kHiLoScale, st);
+  const float* bsrc = has(name + ".bias") ? fetch(name + ".bias") : nullptr;
+  launch_pack_bias(bsrc, b, l.N, l.Npad, geglu ? 1 : 0, 0, st);
+  return l;
+}
 Lin WeightBuilder::fused_linear(const std::vector<std::string>& names, int dt_override) {
   Lin l; l.ksize = 1;
   int ntot = 0;
@@ -522,6 +540,10 @@ void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const 
   SDXL_REQUIRE(!absmax_out || (!x.gn_part && x.dt == DT_F32), "GroupNorm absmax side output needs the statistics pass over an fp32 tensor");
   p.absmax_out = absmax_out;
   SDXL_REQUIRE(!x.gn_part || x.gn_rt * 256 == HW, "producer GroupNorm statistics do not cover the tensor");
+  {   // SDXL_GN_DUMP=1 (eager forwards): one line per GroupNorm -- shape and whether its statistics came from the producer
+    static const bool gn_dump = std::getenv("SDXL_GN_DUMP") != nullptr;
+    if (gn_dump) std::fprintf(stderr, "[gn] B %d HW %d C %d x_dt %d %s\n", B, HW, n.C, x.dt, x.gn_part ? "producer statistics" : "statistics pass");
+  }
   if (ex.prof) ex.prof->begin(Profiler::GROUPNORM, 0.0, ex.s);
   launch_groupnorm(p, ex.s);
   {
@@ -530,11 +552,11 @@ void run_groupnorm(Exec& ex, const NormW& n, const Act& x, int B, int HW, const 
   }
   if (ex.prof) ex.prof->end(ex.s);
 }
-void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y) {
+void run_layernorm(Exec& ex, const NormW& n, const Act& x, int rows, const Act& y, float dup_scale) {
   if (ex.dry) return;
   LayerNormParams p{};
   p.X = x.p; p.x_dt = x.dt; p.ldx = x.ld; p.Y = y.p; p.y_dt = y.dt; p.ldy = y.ld;
-  p.gamma = n.gamma; p.beta = n.beta; p.rows = rows; p.C = n.C; p.eps = 1e-5f; p.eps_ptr = n.eps;
+  p.gamma = n.gamma; p.beta = n.beta; p.rows = rows; p.C = n.C; p.eps = 1e-5f; p.eps_ptr = n.eps; p.dup_scale = dup_scale;
   if (ex.prof) ex.prof->begin(Profiler::LAYERNORM, 0.0, ex.s);
   launch_layernorm(p, ex.s);
   {

@@ -35,6 +35,9 @@ LAT_REL_F16 = 6.0e-3         # fp16-operand modes: max-abs error relative to max
 F16W_CLASSES = 1 | 2 | 4 | 8 | 16 | 32 | 128 | 256 | 512     # SDXL_DTYPE_F32_SPLIT_MIX_F16W (capi.hip mix_of): + cross-attention query projection, LayerNorm shadow, fused split-precision cross-attention (round 6)
 
 
+MIX_CLASSES = 1 | 2 | 1024      # SDXL_DTYPE_F32_SPLIT_MIX: f16 self-attention + GEGLU on f16 activations x (hi, lo) weight pairs along K (round 6)
+
+
 def weights_for(pkg, ocfg, dtype):
     """(oracle weights, synthetic seed of the engine) for a dtype: SDXL_DTYPE_F32_SPLIT_MIX_F16W is FOR f16-representable parameters (on others the
     engine falls back to F32_SPLIT_MIX's classes), so dtype 5 is tested on the seeded weights rounded to f16 on both sides"""
@@ -82,7 +85,7 @@ def test_unet_forward(pkg, ctx, dtype, which):
     specs = pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg))
     flat = pkg.flatten_weights(specs, {k: v.numpy() for k, v in W.items()})
     u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, weights=flat)
-    assert u.mix_classes() == {4: 3, 5: F16W_CLASSES}.get(dtype, 0)
+    assert u.mix_classes() == {4: MIX_CLASSES, 5: F16W_CLASSES}.get(dtype, 0)
     outs = [u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu() for _ in range(3)]   # eager, capture, replay
     e = rel_err(outs[0], ref)
     print(f"unet_forward[{which}] dtype={dtype}: rel err {e:.3e}")
@@ -334,7 +337,7 @@ def test_f16w_mode_falls_back_on_parameters_that_are_not_f16_values(pkg, ctx):
     y = torch.from_numpy(OC.arb_tensor(2, ocfg.adm_in_channels)).cuda()
     t = torch.tensor([999, 1], dtype=torch.int32).cuda()
     u5, u4 = pkg.UNet(ctx, cfg, 5, seed=0), pkg.UNet(ctx, cfg, 4, seed=0)
-    assert u5.mix_classes() == 3 == u4.mix_classes()
+    assert u5.mix_classes() == MIX_CLASSES == u4.mix_classes()
     assert torch.equal(u5.forward(x, t, c, y), u4.forward(x, t, c, y))
     assert pkg.UNet(ctx, cfg, 5, seed=pkg.SEED_F16_WEIGHTS).mix_classes() == F16W_CLASSES
     specs = pkg.unet_param_specs(cfg)
@@ -342,7 +345,7 @@ def test_f16w_mode_falls_back_on_parameters_that_are_not_f16_values(pkg, ctx):
     assert pkg.UNet(ctx, cfg, 5, weights=pkg.flatten_weights(specs, W16)).mix_classes() == F16W_CLASSES
     name = next(k for k in W16 if k.endswith(".mlp.lin.weight"))
     W16[name].flat[3] = np.float32(W16[name].flat[3]) * np.float32(1.0 + 2.0 ** -16)      # one value that is not an f16
-    assert pkg.UNet(ctx, cfg, 5, weights=pkg.flatten_weights(specs, W16)).mix_classes() == 3
+    assert pkg.UNet(ctx, cfg, 5, weights=pkg.flatten_weights(specs, W16)).mix_classes() == MIX_CLASSES
     for dt in (0, 1, 2, 3):
         assert pkg.UNet(ctx, cfg, dt, seed=0).mix_classes() == 0
 
