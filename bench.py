@@ -326,7 +326,9 @@ def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str, weights: 
     c, y = _seeded(1, 77, cfg.context_dim, seed=112), _seeded(1, cfg.adm_in_channels, seed=113)
     o = diffuser.diffusion.forward(x.cuda(), t.cuda(), c.cuda(), y.cuda())
     out[f"unet_forward_1024_{prec}_vs_oracle_rel"] = _rel(o, torch.from_numpy(g["out"]))[1]
-    g = np.load(os.path.join(gold, "fullsize_decode1024.npz"))
+    gdec = os.path.join(gold, f"fullsize_decode1024{wsuf}.npz")
+    g = np.load(gdec if os.path.exists(gdec) else os.path.join(gold, "fullsize_decode1024.npz"))
+    out["decode_fixture"] = os.path.basename(gdec) if os.path.exists(gdec) else "fullsize_decode1024.npz (fp32 weights: the f16-weights decode fixture is missing)"
     latent = _seeded(1, 4, 128, 128, seed=121).cuda()
     img = decoder.decode_latent(latent).cpu()
     out[f"decode_1024_{vae_prec}_vs_oracle_image_max_abs"] = _rel(img[:, :, ::5, ::5], torch.from_numpy(g["image_sub"]))[0]
@@ -433,6 +435,26 @@ def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str, weights: 
                 "config2_final_latent_max_abs_vs_oracle": a5, "meets_1e-3": bool(a5 <= 1e-3), "lat_bound_scaled": lbw, "inside_lat_bound_scaled": bool(a5 <= lbw),
                 "meets_1_img_per_sec_inside_scaled_bound": bool(a5 <= lbw and 1.0 / dt5 >= 1.0)}
             del d5
+            if hasattr(pkg, "DTYPE_F32_SPLIT_MIX_F16W_GEGLU2"):
+                d6 = pkg.Diffuser(ctx, cfg, pkg.DTYPE_F32_SPLIT_MIX_F16W_GEGLU2, seed=pkg.SEED_F16_WEIGHTS)
+                d6.enable_step_timing(True)
+                d6.sample_latent(cond, 7.5, 2, i["noise"].cuda())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                lat6 = d6.sample_latent(cond, 7.5, 30, i["noise"].cuda())
+                steps6 = d6.step_times_ms()
+                decoder.latent_to_image(lat6)
+                torch.cuda.synchronize()
+                dt6 = time.perf_counter() - t0
+                a6, r6 = _rel(lat6, refw)
+                out["config2_f16weights_f32_split_mix_f16w_geglu2_vs_oracle_final_max_abs"] = a6
+                strict["f32_split_mix_f16w_geglu2_mode_f16_weights"] = {
+                    "precision": "SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 UNet (F16W with the GEGLU projection's activations as (hi, lo) f16 pairs along a doubled K: the mode that is inside "
+                                 "the scaled bound on every fixture of the parity tests, the 4-step inpainting stress fixture included) on f16-representable weights + the timed VAE",
+                    "mix_classes": d6.diffusion.mix_classes(),
+                    "images_per_sec": round(1.0 / dt6, 4), "unet_step_ms": round(statistics.median(steps6), 2) if steps6 else None, "images_timed": 1,
+                    "config2_final_latent_max_abs_vs_oracle": a6, "meets_1e-3": bool(a6 <= 1e-3), "lat_bound_scaled": lbw, "inside_lat_bound_scaled": bool(a6 <= lbw)}
+                del d6
             strict["f32_split_f16_weights"] = {
                 "precision": "SDXL_DTYPE_F32_SPLIT UNet on f16-representable weights (what the reference's records hold): two MFMAs per GEMM product, "
                              "three in the attention + the timed VAE; oracle = the same weights, tests/golden/fullsize_config2_f16w.npz",
@@ -463,7 +485,7 @@ def main():
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--n-steps", type=int, default=None, help="--n-diffusion-steps of the reference CLI (30 -> 31 iterations)")
     ap.add_argument("--cfg", type=float, default=None)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res", "f32_split", "f32_split_mix", "f32_split_mix_f16w"],
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res", "f32_split", "f32_split_mix", "f32_split_mix_f16w", "f32_split_mix_f16w_geglu2"],
                     help="UNet arithmetic: f16 (the reference's GPU precision, src/bin/sample/main.rs:122), f16_f32res, f32 (exact-fp32 MFMA: the strict-parity "
                          "mode), f32_split (fp32-class: fp32 stream, (hi, lo) f16 operands with three MFMAs per product in the GEMMs and in the attention), "
                          "f32_split_mix (+ self-attention and GEGLU on plain f16) or f32_split_mix_f16w (+ six more transformer classes on plain f16: for "
@@ -524,7 +546,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dts = {"f16": pkg.DTYPE_F16, "f32": pkg.DTYPE_F32, "f16_f32res": pkg.DTYPE_F16_F32RES, "f32_split": pkg.DTYPE_F32_SPLIT,
-           "f32_split_mix": pkg.DTYPE_F32_SPLIT_MIX, "f32_split_mix_f16w": pkg.DTYPE_F32_SPLIT_MIX_F16W}
+           "f32_split_mix": pkg.DTYPE_F32_SPLIT_MIX, "f32_split_mix_f16w": pkg.DTYPE_F32_SPLIT_MIX_F16W,
+           "f32_split_mix_f16w_geglu2": pkg.DTYPE_F32_SPLIT_MIX_F16W_GEGLU2}
     dt, vdt = dts[args.dtype], dts[args.vae_dtype]
     wseed = pkg.SEED_F16_WEIGHTS if args.weights == "f16" else 0      # (flag bit on the synthetic seed: parameters rounded to f16 on the device)
 
@@ -533,7 +556,7 @@ def main():
     # rank 0 builds the weights; replicas allocate the identical arena and receive it over RCCL / xGMI
     t0 = time.time()
     diffuser = pkg.Diffuser(ctx, cfg, dt, seed=wseed | 0, empty=(rank != 0))
-    decoder = pkg.LatentDecoder(ctx, None, vdt, seed=0, with_encoder=(args.config == 5), empty=(rank != 0))
+    decoder = pkg.LatentDecoder(ctx, None, vdt, seed=wseed | 0, with_encoder=(args.config == 5), empty=(rank != 0))      # (--weights f16: the VAE record is f16 too)
     refiner = None
     rcfg = pkg.sdxl_refiner_config()
     if args.config == 4:
@@ -542,7 +565,7 @@ def main():
     # the MIX classes in force: an f32_split_mix_f16w model on parameters that are not f16 values falls back to f32_split_mix's (the engine checks the
     # tensors).  Replicas are laid out for the mode itself, so a fallen-back root must not broadcast into them.
     mix_classes = diffuser.diffusion.mix_classes()
-    if world > 1 and args.dtype == "f32_split_mix_f16w" and args.weights != "f16":
+    if world > 1 and args.dtype.startswith("f32_split_mix_f16w") and args.weights != "f16":
         raise SystemExit("bench.py: --dtype f32_split_mix_f16w across ranks needs --weights f16 (rank 0 would fall back to f32_split_mix and its arena "
                          "would not match the replicas')")
     t_build = time.time() - t0
@@ -739,7 +762,8 @@ def main():
                 "peak_note": {"f32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak", "f32_split": "f16 dense MFMA peak / 3 (three MFMAs per product)",
                               "f32_split_mix": "f16 dense MFMA peak / 3 (split-operand classes: three MFMAs per product; two classes run one)",
                               "f32_split_mix_f16w": "f16 dense MFMA peak; the eight f16 classes run one MFMA per product, the split-operand classes two on "
-                                                    "f16-representable weights -- algorithmic TFLOP/s understate the matrix work of this mode"}.get(args.dtype, "f16 dense MFMA peak (MI355X_MICROARCH.md)"),
+                                                    "f16-representable weights -- algorithmic TFLOP/s understate the matrix work of this mode",
+                              "f32_split_mix_f16w_geglu2": "f16 dense MFMA peak; as f32_split_mix_f16w with the GEGLU projection at two MFMAs per product"}.get(args.dtype, "f16 dense MFMA peak (MI355X_MICROARCH.md)"),
                 "launches_per_unet_step": ig_n, "avg_launch_us": round(1e3 * ig_ms / max(ig_n, 1), 2),
                 "algorithmic_tflop_per_unet_step": round(ig_fl / 1e12, 3),
                 # headline class times = the RAW event-bracketed ones (frac / achieved follow them); derived: the same with the calibrated event overhead removed
@@ -791,7 +815,8 @@ def main():
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"f32": "f32", "f32_split": "f32 (split f16 operands)", "f32_split_mix": "f32 (split f16 operands; self-attention and GEGLU projection on plain f16)",
-                                           "f32_split_mix_f16w": "f32 stream, split f16 operands in the convolutions / cross-attention, eight transformer classes on plain f16"}.get(args.dtype, "f16"), "data": "synthetic",
+                                           "f32_split_mix_f16w": "f32 stream, split f16 operands in the convolutions / cross-attention, eight transformer classes on plain f16",
+                                           "f32_split_mix_f16w_geglu2": "f32 stream, split f16 operands in the convolutions / cross-attention / GEGLU activations, seven transformer classes on plain f16"}.get(args.dtype, "f16"), "data": "synthetic",
             "config": {"workload": wl, "baseline_config_index": args.config - 1,
                        "precision": args.dtype, "vae_dtype": args.vae_dtype,
                        "weights": "synthetic seeded (random-init SDXL-base architecture)" + (", every parameter rounded to IEEE f16 (what the reference's records hold)" if args.weights == "f16" else ""),

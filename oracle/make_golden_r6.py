@@ -1,7 +1,7 @@
 """Round-6 fixtures.  TEST INFRASTRUCTURE (outputs of the ORACLE: fp32 torch-CPU restatement of the reference graph; parity unpinned --
 the reference itself cannot be built here).
 
-    python -m oracle.make_golden_r6 [config5_f16w] [config5] [refiner1024_f16w] [refine1024_f16w]
+    python -m oracle.make_golden_r6 [config5_f16w] [config5] [refiner1024_f16w] [refine1024_f16w] [decode1024_f16w]
 
   fullsize_config5_f16w.npz      BASELINE configs[4] AT ITS OWN STEP COUNT: Diffuser::sample_latent_with_inpainting at 1024x1024, n_steps = 100
                                  (t = 999, 989, ... 9: 100 CFG-7.5 pairs = 200 UNet forwards), mask = latent rows 0..24 generated (the 200 px crop),
@@ -10,6 +10,9 @@ the reference itself cannot be built here).
                                  + the final one are kept.  The 4-step fixtures of rounds 3 / 5 (fullsize_inpaint1024*.npz) take 250-step jumps, which
                                  amplify one forward's error ~10x more than the 10-step jumps of the configuration BASELINE names; this is that configuration.
   fullsize_config5.npz           the same on the synthetic fp32 weights
+  fullsize_decode1024_f16w.npz   LatentDecoder::latent_to_image at 1024^2 (latent of fullsize_decode1024.npz) with the VAE decoder's parameters rounded to f16 -- the
+                                 reference's decoder record is HalfPrecisionSettings too (src/bin/sample/main.rs:37-51); with such weights the split-operand VAE runs
+                                 two MFMAs per product instead of three (bench.py --weights f16)
   fullsize_refiner1024_f16w.npz  one refiner UNet::forward at 1024^2 (inputs of fullsize_refiner1024.npz) on f16-representable weights
   fullsize_refine1024_f16w.npz   Diffuser::refine_latent, 2 refiner iterations (inputs of fullsize_refine1024.npz) on f16-representable weights
 """
@@ -84,11 +87,26 @@ def run_refine1024_f16w(cfg, W16):
                         in_checksum=checksum(*i.values()), oracle_seconds=np.array([dt]))
 
 
+def run_decode1024_f16w():
+    from .make_golden_fullsize import SUB, decode1024_inputs, vae_weights
+    v, Wv = vae_weights()
+    i = decode1024_inputs()
+    ld = OP.LatentDecoder(v, f16w(Wv))
+    t0 = time.time()
+    img = ld.decode_latent(i["latent"])
+    u8 = ld.latent_to_image(i["latent"])
+    print(f"[golden r6] decode 1024^2 (x2), f16-representable VAE weights: {time.time() - t0:.1f} s, |img|max {img.abs().max():.3f}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "fullsize_decode1024_f16w.npz"), image_sub=img[:, :, ::SUB, ::SUB].numpy().copy(), u8_sub=u8[:, ::SUB, ::SUB].copy(),
+                        in_checksum=checksum(i["latent"]))
+
+
 def main():
     what = set(sys.argv[1:]) or {"refiner1024_f16w", "refine1024_f16w"}
     if "--threads" in sys.argv:
         torch.set_num_threads(int(sys.argv[sys.argv.index("--threads") + 1]))
     os.makedirs(OUT, exist_ok=True)
+    if "decode1024_f16w" in what:
+        run_decode1024_f16w()
     if what & {"refiner1024_f16w", "refine1024_f16w"}:
         cfg, W = refiner_weights()
         W16 = f16w(W)

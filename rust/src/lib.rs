@@ -141,6 +141,9 @@ pub enum Precision {
     /// out-projections, FF-out and the cross-attention query projection on f16 operands as well, LayerNorms folded through an f16 shadow of the
     /// stream (`capi.hip` `mix_of`); on other parameters the engine falls back to `F32SplitMix`'s classes (`Diffuser::mix_classes`)
     F32SplitMixF16W = ffi::SDXL_DTYPE_F32_SPLIT_MIX_F16W as isize,
+    /// `F32SplitMixF16W` with the GEGLU projection's activations as (hi, lo) f16 pairs along a doubled K (two MFMAs per product): ~12 % slower, inside the
+    /// scaled bound on every fixture of the parity tests
+    F32SplitMixF16WGeglu2 = ffi::SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 as isize,
 }
 
 /// one per GPU (the reference hard-codes `LibTorchDevice::Cuda(0)`, `src/bin/sample/main.rs:131`)

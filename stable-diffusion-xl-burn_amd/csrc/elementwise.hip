@@ -642,7 +642,7 @@ void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int K
   hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, K, N, Kpad, Npad, geglu, n_offset,
                      kscale, wscale);
 }
-__global__ void pack_linear_hilo_kernel(const float* src, half_t* dst, int K, int N, int Npad, int geglu, float lo_scale) {
+__global__ void pack_linear_hilo_kernel(const float* src, half_t* dst, int K, int N, int Npad, int geglu, float lo_scale, int mode) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)Npad * 2 * K) return;
   const int np = (int)(i / (2 * (size_t)K));
@@ -654,13 +654,13 @@ __global__ void pack_linear_hilo_kernel(const float* src, half_t* dst, int K, in
     float w = src[(size_t)k * N + n];
     asm("" : "+v"(w));
     const half_t hi = (half_t)w;
-    v = part ? (half_t)((w - (float)hi) * lo_scale) : hi;
+    v = !part ? hi : mode == 0 ? (half_t)((w - (float)hi) * lo_scale) : (half_t)((float)hi / lo_scale);
   }
   dst[i] = v;
 }
-void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s) {
+void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s, int mode) {
   const size_t total = (size_t)Npad * 2 * K;
-  hipLaunchKernelGGL(pack_linear_hilo_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, reinterpret_cast<half_t*>(dst), K, N, Npad, geglu, lo_scale);
+  hipLaunchKernelGGL(pack_linear_hilo_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, reinterpret_cast<half_t*>(dst), K, N, Npad, geglu, lo_scale, mode);
 }
 // cs[r] = sum_k packed[r][k] over the ROUNDED packed values (what the MFMA really multiplies), one wave per packed row
 // kscale (K values, optional): cs[r] = sum_k kscale[k] * packed[r][k] -- the shadow form of a folded LayerNorm, whose gamma rides on the A operand

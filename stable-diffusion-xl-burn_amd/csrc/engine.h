@@ -148,7 +148,8 @@ struct WeightBuilder {
   // dt_override >= 0: pack in that dtype whatever the model's (the GEMV weights of a split-operand model stay fp32)
   Lin linear(const std::string& name, bool geglu = false, int dt_override = -1);   // name.weight [K,N] (+ name.bias)
   Lin fused_linear(const std::vector<std::string>& names, int dt_override = -1);   // concatenated along N (same K)
-  Lin linear_hilo(const std::string& name, bool geglu);     // f16 GEMM on (hi | lo * kHiLoScale) weight halves along a doubled K: un-rounded weights (MIX_GEGLU_HILO)
+  Lin linear_hilo(const std::string& name, bool geglu, bool dup = false);     // dup: (w | w / kHiLoScale) for an A operand of (hi | lo * kHiLoScale) ACTIVATION halves
+      // f16 GEMM on (hi | lo * kHiLoScale) weight halves along a doubled K: un-rounded weights (MIX_GEGLU_HILO)
   float hl_scale(Lin& l, const std::vector<std::string>& weight_names);     // DT_HL packing: power-of-two factor, inverse into the arena
   // the same with the preceding LayerNorm(gamma, beta) folded into weight / bias / column sums
   Lin linear_ln(const std::string& name, bool geglu, const std::string& norm);
@@ -243,6 +244,8 @@ enum MixClass {
                         // arithmetic of the stand-alone split-operand attention without its launch
   MIX_GEGLU_HILO = 1024, // with MIX_GEGLU_F16 (and without the shadow form): the GEGLU weights as (hi, lo) f16 pairs along a doubled K against [a | a 2^-8] -- the f16 wide-tile
                         // kernel at twice the depth, two MFMAs per product: activation rounding only on ANY weights.  SDXL_DTYPE_F32_SPLIT_MIX
+  MIX_GEGLU_AHILO = 2048, // a knob, in no mode (f16-representable weights): the GEGLU projection's ACTIVATIONS as (hi, lo) f16 pairs along a doubled K against (w | w 2^-8) --
+                        // the class that carries 70 % of the F16W mode's error variance at two MFMAs per product on the f16 kernel
   MIX_LN_SHADOW = 256   // the LayerNorms in front of the f16 projections (QKV, GEGLU, the query projection with MIX_Q2_F16) folded into them: the producers of
                         // the fp32 stream leave an f16 shadow f16(x o gamma) + row statistics (IgemmParams::shadow), no LayerNorm launch
 };

@@ -160,8 +160,9 @@ struct LayerNormParams {
   const float* gamma; const float* beta;
   int rows, C; float eps;
   const float* eps_ptr;   // optional device scalar overriding eps
-  float dup_scale;        // f16 output only, != 0: the row is written twice -- y[0, C) = f16(LN(x)) and y[C, 2C) = that f16 value * dup_scale (a power of two) --
-                          // the A operand of a GEMM whose weights are packed as (hi | lo / dup_scale) halves along K (launch_pack_linear_hilo)
+  float dup_scale;        // f16 output only, != 0: the row is written twice.  > 0: y[0, C) = f16(LN(x)) and y[C, 2C) = that f16 value * dup_scale (a power of two) --
+                          // the A operand of a GEMM whose weights are packed as (hi | lo / dup_scale) halves along K (launch_pack_linear_hilo mode 0).
+                          // < 0: y[C, 2C) = f16((LN(x) - hi) * |dup_scale|), the LO half of the activation -- against weights packed as (w | w / |dup_scale|) (mode 1)
 };
 void launch_layernorm(const LayerNormParams& p, hipStream_t s);
 
@@ -297,7 +298,8 @@ void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int K
 // the same packing with every weight as TWO f16 values along a doubled K: dst[n][k] = f16(w), dst[n][K + k] = f16((w - f16(w)) * lo_scale) -- against the A
 // operand [a | a / lo_scale] (LayerNormParams::dup_scale) the f16 GEMM multiplies a by hi + lo: the weights are not rounded (22 significand bits), the
 // activations once.  K % 32 == 0; Kpad = 2 K.
-void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s);
+void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s, int mode = 0);
+// mode 1: dst[n][K + k] = f16(f16(w) / lo_scale) -- the weight twice, for an A operand that carries (hi | lo * lo_scale) ACTIVATION halves (exact for f16-representable weights)
 // LayerNorm fold helpers: column sums of the packed (rounded) weight rows; beta . W + bias in canonical column order
 void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s, const float* kscale = nullptr, int K = 0);   // kscale: cs[r] = sum_k kscale[k] packed[r][k]
 void launch_beta_dot(const float* w, const float* beta, const float* bias, float* out, int K, int N, hipStream_t s);

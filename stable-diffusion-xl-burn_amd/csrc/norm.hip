@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     if constexpr (std::is_same<YT, half_t>::value) {
       if (p.dup_scale != 0.f) {      // second copy of the ROUNDED values, times a power of two (LayerNormParams::dup_scale)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (float)(half_t)v[j] * p.dup_scale;
+        for (int j = 0; j < 8; ++j) { const float h = (float)(half_t)v[j]; v[j] = p.dup_scale > 0.f ? h * p.dup_scale : (v[j] - h) * -p.dup_scale; }
         store8r<YT>(y, p.C + vc * 8, v);
       }
     }
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void layernorm_cached_kernel(const LayerNormPa
       if constexpr (std::is_same<YT, half_t>::value) {
         if (p.dup_scale != 0.f) {      // second copy of the ROUNDED values, times a power of two (LayerNormParams::dup_scale)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (float)(half_t)o[j] * p.dup_scale;
+          for (int j = 0; j < 8; ++j) { const float h = (float)(half_t)o[j]; o[j] = p.dup_scale > 0.f ? h * p.dup_scale : (o[j] - h) * -p.dup_scale; }
           store8r<YT>(y, p.C + vc * 8, o);
         }
       }

@@ -77,7 +77,8 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     t.out2 = wb.linear(q + ".attn2.out", false, out2_f16 ? (int)DT_F16 : -1);
     t.n3 = wb.norm(q + ".norm3");
     // (mixed mode: the GEGLU projection of a split-operand model packed as plain f16 -- it runs on the f16 wide-tile kernel)
-    if (ln_sh && geglu_f16) t.geglu_sh = wb.fold_ln({q + ".mlp.geglu.proj"}, q + ".norm3", true, DT_F16, true, &t.geglu);
+    if (geglu_f16 && (mix & MIX_GEGLU_AHILO) && spec_k_ok(wb, q + ".mlp.geglu.proj")) t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true, true);
+    else if (ln_sh && geglu_f16) t.geglu_sh = wb.fold_ln({q + ".mlp.geglu.proj"}, q + ".norm3", true, DT_F16, true, &t.geglu);
     else if (geglu_f16 && (mix & MIX_GEGLU_HILO) && spec_k_ok(wb, q + ".mlp.geglu.proj")) t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true);
     else
     t.geglu = wb.linear(q + ".mlp.geglu.proj", true, geglu_f16 ? (int)DT_F16 : -1);
@@ -207,7 +208,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
   // 0.0212).  Checked here on the tensors themselves; a model that does not qualify falls back to F32_SPLIT_MIX's two classes (mix_classes() tells).
   // Not applied to the A/B knob "mix_classes" (the frontier tools run those maps on fp32 weights on purpose) nor on replicas built from an empty
   // source (they receive rank 0's arena: the caller compares rank 0's mix_classes() with the mode before the broadcast, bench.py does).
-  constexpr int kNeedExact = MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_XATTN_F16 | MIX_Q2_F16;
+  constexpr int kNeedExact = MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_XATTN_F16 | MIX_Q2_F16 | MIX_GEGLU_AHILO;
   if (cdt_ == DT_HL && (mix_ & kNeedExact) && !mix_knob_ && !src.empty()) {
     std::vector<std::string> names;
     auto ends = [](const std::string& n, const char* suf) { const size_t l = std::strlen(suf); return n.size() >= l && n.compare(n.size() - l, l, suf) == 0; };
@@ -216,7 +217,7 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
       if (n.find(".transformer.blocks.") == std::string::npos) continue;
       if (((mix_ & MIX_QKV_F16) && (ends(n, ".attn1.query.weight") || ends(n, ".attn1.key.weight") || ends(n, ".attn1.value.weight"))) ||
           ((mix_ & MIX_OUT1_F16) && ends(n, ".attn1.out.weight")) || ((mix_ & MIX_OUT2_F16) && ends(n, ".attn2.out.weight")) ||
-          ((mix_ & MIX_FF_F16) && ends(n, ".mlp.lin.weight")) || ((mix_ & (MIX_XATTN_F16 | MIX_Q2_F16)) && ends(n, ".attn2.query.weight")))
+          ((mix_ & MIX_FF_F16) && ends(n, ".mlp.lin.weight")) || ((mix_ & MIX_GEGLU_AHILO) && ends(n, ".mlp.geglu.proj.weight")) || ((mix_ & (MIX_XATTN_F16 | MIX_Q2_F16)) && ends(n, ".attn2.query.weight")))
         names.push_back(n);
     }
     if (!wb.all_f16_exact(names)) mix_ = MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_GEGLU_HILO;      // = SDXL_DTYPE_F32_SPLIT_MIX (capi.hip mix_of)
@@ -606,7 +607,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
     const bool gg_sh = have_sh && b.geglu_sh.cs;      // GEGLU projection on the shadow the cross-attention's out-projection left: no LayerNorm launch
     if (gg_sh) eg.ln_stat = shst;
-    else if (gg_hilo) run_layernorm(ex, b.n3, t, (int)M, ln16x2, 1.0f / kHiLoScale);
+    else if (gg_hilo) run_layernorm(ex, b.n3, t, (int)M, ln16x2, (mix_ & MIX_GEGLU_AHILO) ? -kHiLoScale : 1.0f / kHiLoScale);
     else {
     run_layernorm(ex, b.n3, t, (int)M, mix_geglu ? ln16 : ln);
     demote_lo(ex, DM_GEGLU, ln, M, C);

@@ -207,7 +207,7 @@ Lin WeightBuilder::linear(const std::string& name, bool geglu, int dt_override) 
 // f16 GEMM with UN-ROUNDED weights (round 6, SDXL_DTYPE_F32_SPLIT_MIX's GEGLU projection): every weight as (hi, lo) f16 values along a doubled K --
 // dst[n] = [f16(w) | f16((w - hi) * kHiLoScale)] -- against the A operand [a | a / kHiLoScale] (run_layernorm dup_scale): two MFMAs per product,
 // the activations rounded once, the weights not at all.  An f16 Lin of K = 2 K0.
-Lin WeightBuilder::linear_hilo(const std::string& name, bool geglu) {
+Lin WeightBuilder::linear_hilo(const std::string& name, bool geglu, bool dup) {
   const ParamSpec& s = spec(name + ".weight");
   const int K0 = s.shape[0];
   SDXL_REQUIRE(K0 % 32 == 0, "linear_hilo: K % 32 == 0");
@@ -217,7 +217,7 @@ Lin WeightBuilder::linear_hilo(const std::string& name, bool geglu) {
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   l.w = w; l.b = b;
   if (src.empty()) return l;
-  launch_pack_linear_hilo(fetch(name + ".weight"), w, K0, l.N, l.Npad, geglu ? 1 : 0, kHiLoScale, st);
+  launch_pack_linear_hilo(fetch(name + ".weight"), w, K0, l.N, l.Npad, geglu ? 1 : 0, kHiLoScale, st, dup ? 1 : 0);
   const float* bsrc = has(name + ".bias") ? fetch(name + ".bias") : nullptr;
   launch_pack_bias(bsrc, b, l.N, l.Npad, geglu ? 1 : 0, 0, st);
   return l;

@@ -57,7 +57,7 @@ def test_fullsize_unet_properties(pkg, ctx, base_inputs):
     assert torch.equal(cold[0], outs[0]) and torch.equal(cold[1], outs[0]), "weight warming changes the result"
 
 
-@pytest.mark.parametrize("dtype_name", ["F32_SPLIT", "F32_SPLIT_MIX", "F32_SPLIT_MIX_F16W"])
+@pytest.mark.parametrize("dtype_name", ["F32_SPLIT", "F32_SPLIT_MIX", "F32_SPLIT_MIX_F16W", "F32_SPLIT_MIX_F16W_GEGLU2"])
 def test_fullsize_split_modes_batch_independence(pkg, ctx, base_inputs, dtype_name):
     """The split-operand engines at full size: an entry of the CFG pair must equal a separate batch-1 forward bit for bit.  Until round 6 the HL16 copy of
     an fp32 stream tensor (skip / up- / down-sampling / proj_out operands) took ONE power-of-two scale from the absmax of the whole batched tensor, so an
@@ -67,7 +67,7 @@ def test_fullsize_split_modes_batch_independence(pkg, ctx, base_inputs, dtype_na
     x = x.clone()
     x[1] *= 64.0
     dt = getattr(pkg, "DTYPE_" + dtype_name)
-    u = pkg.UNet(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS if dtype_name.endswith("F16W") else 0)
+    u = pkg.UNet(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS if "F16W" in dtype_name else 0)
     outs = [u.forward(x.cuda(), t.cuda(), ctxt.cuda(), y.cuda()).cpu() for _ in range(3)]       # eager, capture, replay
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "hipGraph replay differs from the eager run"
