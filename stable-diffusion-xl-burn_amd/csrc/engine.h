@@ -119,6 +119,7 @@ struct Lin {        // packed dense weight: [Npad][Kpad] compute dtype + fp32 bi
   // packed rows; the GEMM then takes the RAW rows plus their per-64-column (mean, M2) statistics -- see IgemmParams::ln_stat
   const float* cs = nullptr;
   const float* ln_eps = nullptr;   // device scalar: eps of the folded LayerNorm
+  int ln_k = 0;                    // folded LayerNorm over ln_k columns (0: K) -- the (hi | lo) shadow form packs K = 2 ln_k
   int dt = -1;                     // dtype the weight was packed in when it differs from the model's compute dtype (-1: the model's):
                                    // a DT_HL model packs the layers its pipeline cannot take (Cin % 32 != 0) as fp32
   const float* acc_scale = nullptr;   // DT_HL packing: device scalar (weight arena) 1 / (power-of-two factor the packed weights carry)
@@ -157,7 +158,7 @@ struct WeightBuilder {
   // dt_override / shadow / plain: the SHADOW form (round 6, split-operand models): the weights are packed UN-folded in dt_override (f16) -- gamma rides on
   // the A operand, an f16 shadow  f16(x o gamma)  the producer of the fp32 stream leaves (IgemmParams::shadow) -- with cs = gamma W over the packed values
   // and b = beta W + bias; *plain receives the same packed matrix with the canonical bias (for the LayerNorm-launch path where no shadow exists)
-  Lin fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override = -1, bool shadow = false, Lin* plain = nullptr);
+  Lin fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override = -1, bool shadow = false, Lin* plain = nullptr, bool hilo_dup = false);   // hilo_dup: (w | w / kHiLoScale) along a doubled K for a (hi | lo) shadow
   // AND of "every value of these tensors is exactly one f16" (device flag read back): what SDXL_DTYPE_F32_SPLIT_MIX_F16W asks of the classes it moves to f16
   bool all_f16_exact(const std::vector<std::string>& names);
   float* tmp2 = nullptr; size_t tmp2_numel = 0;   // scratch for folded biases (device)
@@ -275,7 +276,7 @@ struct Epi {
   int cls = 0;       // DemoteClass bit of this GEMM (UNet call sites): label of the launch in the per-launch profile dump, nothing else
   // f16 shadow of an fp32 output for the GEMM behind the next LayerNorm (IgemmParams::shadow): asked for by the caller, written only when the kernel the
   // selection picks can (weights-in-registers kernel) -- *shadow_done tells; stat_out then holds the fp32 rows' statistics
-  void* shadow = nullptr; int shadow_ld = 0; const float* shadow_gamma = nullptr; bool* shadow_done = nullptr;
+  void* shadow = nullptr; int shadow_ld = 0; const float* shadow_gamma = nullptr; bool* shadow_done = nullptr; float shadow_lo_scale = 0.f;
 };
 bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, const Act& out, const Epi& e = Epi());   // true: e.gn_part was filled
 bool run_linear(Exec& ex, const Lin& w, const Act& a, int M, const Act& out, const Epi& e = Epi());

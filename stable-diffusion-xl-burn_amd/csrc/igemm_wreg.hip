@@ -151,6 +151,16 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
 #pragma unroll
           for (int e = 0; e < 4; ++e) { hs[e] = (half_t)(wv[e] * op.sg0[e]); hs[4 + e] = (half_t)(wv[4 + e] * op.sg1[e]); }
           if (mok[i]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.shadow) + (size_t)m[i] * p.shadow_ld + n0) = hs;
+          if (p.shadow_lo_scale != 0.f) {      // (uniform) the lo halves of the same products behind the N hi columns
+            half8 hl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x0 = wv[e] * op.sg0[e], x1 = wv[4 + e] * op.sg1[e];
+              asm("" : "+v"(x0)); asm("" : "+v"(x1));      // the SAME rounded products the hi halves came from
+              hl[e] = (half_t)((x0 - (float)(half_t)x0) * p.shadow_lo_scale); hl[4 + e] = (half_t)((x1 - (float)(half_t)x1) * p.shadow_lo_scale);
+            }
+            if (mok[i]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.shadow) + (size_t)m[i] * p.shadow_ld + p.N + n0) = hl;
+          }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) sv[i][e] = wv[e];

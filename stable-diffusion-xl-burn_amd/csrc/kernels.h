@@ -83,6 +83,7 @@ struct IgemmParams {
   // un-folded: LN(x) W + b = rstd (x o gamma) W - rstd mu (gamma W) + (beta W + b).  With stat_out (the fp32 rows' statistics) the LayerNorm launch
   // between two GEMMs of a split-operand transformer block disappears.  null = off.
   void* shadow; int shadow_ld; const float* shadow_gamma;
+  float shadow_lo_scale;    // != 0: the shadow row is [hi (N columns) | lo (N columns)], lo = f16((value * gamma - hi) * shadow_lo_scale): the (hi, lo) A operand of a GEMM packed (w | w / scale)
 };
 bool igemm_gn_part_ok(const IgemmParams& p);
 // shapes the fused cross-attention epilogue takes (f16 operands, head dim 64, <= 96 context tokens); otherwise run the

@@ -77,7 +77,11 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     t.out2 = wb.linear(q + ".attn2.out", false, out2_f16 ? (int)DT_F16 : -1);
     t.n3 = wb.norm(q + ".norm3");
     // (mixed mode: the GEGLU projection of a split-operand model packed as plain f16 -- it runs on the f16 wide-tile kernel)
-    if (geglu_f16 && (mix & MIX_GEGLU_AHILO) && spec_k_ok(wb, q + ".mlp.geglu.proj")) t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true, true);
+    if (geglu_f16 && (mix & MIX_GEGLU_AHILO) && spec_k_ok(wb, q + ".mlp.geglu.proj")) {
+      // activations as (hi | lo 2^8) along a doubled K against (w | w 2^-8); with MIX_LN_SHADOW the producer's shadow carries both halves
+      if (ln_sh && wb.spec(q + ".mlp.geglu.proj.weight").shape[0] % 64 == 0) t.geglu_sh = wb.fold_ln({q + ".mlp.geglu.proj"}, q + ".norm3", true, DT_F16, true, &t.geglu, true);
+      else t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true, true);
+    }
     else if (ln_sh && geglu_f16) t.geglu_sh = wb.fold_ln({q + ".mlp.geglu.proj"}, q + ".norm3", true, DT_F16, true, &t.geglu);
     else if (geglu_f16 && (mix & MIX_GEGLU_HILO) && spec_k_ok(wb, q + ".mlp.geglu.proj")) t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true);
     else
@@ -469,7 +473,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   const bool mix_q2_widen = mix_q2 && (mix_ & MIX_XATTN_F16) && mix_out2;     // round 5's form of the knob on shapes the fused launch does not take: f16 q, widened
   if (mix_geglu || mix_qkv || mix_q2) ln16 = ex.alloc(M, C, DT_F16);
   // MIX_GEGLU_HILO: the GEGLU projection's weights are (hi | lo 2^8) halves along a doubled K (WeightBuilder::linear_hilo): its A operand is [a | a 2^-8]
-  const bool gg_hilo = mix_geglu && !w.blocks.empty() && w.blocks[0].geglu.K == 2 * C && !w.blocks[0].geglu_sh.cs;
+  const bool gg_hilo = mix_geglu && !w.blocks.empty() && w.blocks[0].geglu.K == 2 * C;      // (the LayerNorm-launch path; the shadow form of such a projection reads sh16g)
   Act ln16x2;
   if (gg_hilo) ln16x2 = ex.alloc(M, 2 * C, DT_F16);
   // MIX_LN_SHADOW: f16 shadow of the stream + the fp32 rows' statistics, left by the weights-in-registers producers (out-projections, FF-out) for the f16
@@ -477,6 +481,9 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   const bool any_sh = hl_attn && !w.blocks.empty() && (w.blocks[0].qkv_sh.cs || w.blocks[0].q2_sh.cs || w.blocks[0].geglu_sh.cs);
   Act sh16; float* shst = nullptr; bool have_sh = false;
   if (any_sh) { sh16 = ex.alloc(M, C, DT_F16); shst = (float*)ex.act->alloc(M * (size_t)((C + 63) / 64) * 2 * sizeof(float)); }
+  Act sh16g;       // (hi | lo 2^8) shadow for a GEGLU projection packed (w | w 2^-8) along a doubled K (MIX_GEGLU_AHILO with MIX_LN_SHADOW)
+  const bool sh_g2 = any_sh && w.blocks[0].geglu_sh.cs && w.blocks[0].geglu_sh.K == 2 * C;
+  if (sh_g2) sh16g = ex.alloc(M, 2 * C, DT_F16);
   Act q32;     // MIX_Q2_F16: fp32 q of the cross-attention (the f16 projection's fp32 accumulators, never rounded to f16)
   if (mix_q2 && !mix_q2_widen) q32 = ex.alloc(M, C, DT_F32);
   // MIX_XATTN_SPLIT: the split-precision attention runs inside that projection's epilogue on q's accumulators (hi / lo context images of set_context), and its
@@ -486,6 +493,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     have_sh = false;
     if (!consumer_sh.cs || C % 64 != 0) return;
     e.shadow = sh16.p; e.shadow_ld = sh16.ld; e.shadow_gamma = n.gamma; e.stat_out = shst; e.shadow_done = &have_sh;
+    if (consumer_sh.K == 2 * C) { e.shadow = sh16g.p; e.shadow_ld = sh16g.ld; e.shadow_lo_scale = kHiLoScale; }      // (hi | lo) halves: the consumer's K is doubled
   };
   // the f16 GEGLU kernels store an HL16 output through the LDS-staged epilogue of the wide / pipelined tiles -- the kernels every SDXL shape runs on
   // (M = 2048 ... 32768).  Small token counts (tiny test nets: M < 256) run on other tiles; they take the form the F16_F32RES engine
@@ -615,9 +623,10 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     have_sh = false;
     if (gg_sh) {
       eg.rpb = HW;
-      if (mix_ff) run_linear(ex, b.geglu_sh, sh16, (int)M, gg16, eg);
-      else if (!gg_direct) { run_linear(ex, b.geglu_sh, sh16, (int)M, gg16, eg); if (!ex.dry) launch_f16_to_hl(gg16.p, gg16.ld, gg.p, gg.ld, M, 4 * C, ex.s); }
-      else run_linear(ex, b.geglu_sh, sh16, (int)M, gg, eg);
+      const Act& shg = sh_g2 ? sh16g : sh16;
+      if (mix_ff) run_linear(ex, b.geglu_sh, shg, (int)M, gg16, eg);
+      else if (!gg_direct) { run_linear(ex, b.geglu_sh, shg, (int)M, gg16, eg); if (!ex.dry) launch_f16_to_hl(gg16.p, gg16.ld, gg.p, gg.ld, M, 4 * C, ex.s); }
+      else run_linear(ex, b.geglu_sh, shg, (int)M, gg, eg);
     } else
     if (mix_ff) {
       run_linear(ex, b.geglu, gg_hilo ? ln16x2 : mix_geglu ? ln16 : ln, (int)M, gg16, eg);         // f16 output for the f16 FF-out (f16 or split-operand GEGLU compute)

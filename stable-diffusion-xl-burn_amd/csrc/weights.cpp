@@ -280,7 +280,7 @@ bool WeightBuilder::all_f16_exact(const std::vector<std::string>& names) {
   SDXL_HIP(hipStreamSynchronize(st));
   return h != 0.f;
 }
-Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override, bool shadow, Lin* plain) {
+Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override, bool shadow, Lin* plain, bool hilo_dup) {
   SDXL_REQUIRE(!geglu || names.size() == 1, "GEGLU packing applies to a single projection");
   const int mdt = dt;                       // the model's dtype
   const int dt = dt_override >= 0 ? dt_override : mdt;      // (shadows the member below: the dtype THIS matrix is packed in)
@@ -293,6 +293,9 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
     SDXL_REQUIRE(l.K == s.shape[0], "fused_linear_ln: K mismatch");
     ntot += s.shape[1];
   }
+  SDXL_REQUIRE(!hilo_dup || (shadow && names.size() == 1 && dt == DT_F16 && l.K % 32 == 0), "fold_ln: the (hi | lo) form is a single f16 shadow-form projection");
+  const int K0 = l.K;                       // columns of the LayerNorm
+  if (hilo_dup) { l.ln_k = K0; l.K = 2 * K0; }
   l.N = ntot; l.cin = l.K;
   const int kt = dt == DT_F16 ? 64 : 32;
   l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
@@ -305,7 +308,7 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
   if (plain) { *plain = l; plain->b = bplain; plain->cs = nullptr; plain->ln_eps = nullptr; }
   if (src.empty()) return l;
   SDXL_HIP(hipMemcpyAsync(leps, fetch(norm + ".eps"), sizeof(float), hipMemcpyDeviceToDevice, st));
-  const size_t need = 3 * (size_t)l.Npad + 2 * (size_t)l.K;
+  const size_t need = 3 * (size_t)l.Npad + 2 * (size_t)l.K + 64;
   if (need > tmp2_numel) {
     if (tmp2) SDXL_HIP(hipFree(tmp2));
     SDXL_HIP(hipMalloc((void**)&tmp2, need * sizeof(float)));
@@ -315,9 +318,9 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
   float* beta = tmp2 + l.K;            // [K]
   float* bsrc = beta + l.K;            // [Npad] canonical bias of the current projection
   float* bfold = bsrc + l.Npad;        // [Npad] beta W + bias, canonical order
-  SDXL_REQUIRE(spec(norm + ".gamma").shape[0] == l.K, "fused_linear_ln: norm width mismatch");
-  SDXL_HIP(hipMemcpyAsync(gamma, fetch(norm + ".gamma"), l.K * sizeof(float), hipMemcpyDeviceToDevice, st));
-  SDXL_HIP(hipMemcpyAsync(beta, fetch(norm + ".beta"), l.K * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SDXL_REQUIRE(spec(norm + ".gamma").shape[0] == K0, "fused_linear_ln: norm width mismatch");
+  SDXL_HIP(hipMemcpyAsync(gamma, fetch(norm + ".gamma"), K0 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SDXL_HIP(hipMemcpyAsync(beta, fetch(norm + ".beta"), K0 * sizeof(float), hipMemcpyDeviceToDevice, st));
   SDXL_HIP(hipMemsetAsync(w, 0, (size_t)l.Npad * l.Kpad * dt_size(dt), st));
   SDXL_HIP(hipMemsetAsync(b, 0, (size_t)l.Npad * sizeof(float), st));
   if (bplain) SDXL_HIP(hipMemsetAsync(bplain, 0, (size_t)l.Npad * sizeof(float), st));
@@ -329,14 +332,15 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
     if (hb) SDXL_HIP(hipMemcpyAsync(bsrc, fetch(n + ".bias"), N * sizeof(float), hipMemcpyDeviceToDevice, st));
     const float* wsrc = fetch(n + ".weight");
     // (shadow form: the matrix stays W -- an f16-representable parameter stays exact -- and gamma multiplies the A operand instead)
-    if (names.size() == 1) launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st, shadow ? nullptr : gamma);
+    if (hilo_dup) launch_pack_linear_hilo(wsrc, w, K0, N, l.Npad, geglu ? 1 : 0, kHiLoScale, st, 1);      // (w | w / kHiLoScale): the (hi | lo) shadow's partner
+    else if (names.size() == 1) launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st, shadow ? nullptr : gamma);
     else launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, N, 0, off, st, shadow ? nullptr : gamma);
-    launch_beta_dot(wsrc, beta, hb ? bsrc : nullptr, bfold, l.K, N, st);
+    launch_beta_dot(wsrc, beta, hb ? bsrc : nullptr, bfold, K0, N, st);
     launch_pack_bias(bfold, b, N, names.size() == 1 ? l.Npad : N, geglu ? 1 : 0, off, st);
     if (bplain) launch_pack_bias(hb ? bsrc : nullptr, bplain, N, names.size() == 1 ? l.Npad : N, geglu ? 1 : 0, off, st);
     off += N;
   }
-  if (shadow) launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st, gamma, l.K);      // cs[n] = sum_k gamma[k] W[k][n] over the packed (rounded) values
+  if (shadow) launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st, gamma, K0);      // cs[n] = sum_k gamma[k] W[k][n] over the packed (rounded) values
   else launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st);
   return l;
 }
@@ -424,7 +428,7 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   p.C = out.p; p.ldc = out.ld; p.c_dt = out.dt;
   p.n_split = e.n_split >= 0 ? e.n_split : w.N;
   p.Ct = e.Ct; p.ct_rows = e.ct_rows; p.ct_ld = e.ct_ld;
-  p.ln_stat = e.ln_stat; p.ln_slots = w.K / 64; p.ln_cs = w.cs; p.ln_invc = 1.0f / (float)w.K; p.ln_eps = 1e-5f; p.ln_eps_ptr = w.ln_eps;
+  p.ln_stat = e.ln_stat; p.ln_slots = (w.ln_k ? w.ln_k : w.K) / 64; p.ln_cs = w.cs; p.ln_invc = 1.0f / (float)(w.ln_k ? w.ln_k : w.K); p.ln_eps = 1e-5f; p.ln_eps_ptr = w.ln_eps;
   p.stat_out = e.stat_out; p.stat_slots = w.N / 64;
   p.splitk_ws = ex.splitk_ws; p.splitk_ws_bytes = ex.splitk_ws_bytes; p.splitk_cnt = ex.splitk_cnt; p.splitk = 0;
   p.xa_k = e.xa_k; p.xa_nctx = e.xa_nctx; p.xa_scale = e.xa_scale; p.xa_k_lo = e.xa_k_lo;
@@ -432,9 +436,9 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
   // weights-in-registers kernel anyway; otherwise neither is written and the caller runs the LayerNorm launch
   if (e.shadow_done) *e.shadow_done = false;
   if (e.shadow) {
-    p.shadow = e.shadow; p.shadow_ld = e.shadow_ld; p.shadow_gamma = e.shadow_gamma;
+    p.shadow = e.shadow; p.shadow_ld = e.shadow_ld; p.shadow_gamma = e.shadow_gamma; p.shadow_lo_scale = e.shadow_lo_scale;
     const bool ok = (w.dt >= 0 ? w.dt : ex.cdt) == DT_F16 && igemm_wreg_selected(p);
-    if (!ok) { p.shadow = nullptr; p.shadow_gamma = nullptr; p.stat_out = nullptr; }
+    if (!ok) { p.shadow = nullptr; p.shadow_gamma = nullptr; p.stat_out = nullptr; p.shadow_lo_scale = 0.f; }
     if (e.shadow_done) *e.shadow_done = ok;
   }
   // GroupNorm statistics of the output from this GEMM's epilogue -- only when the kernel the selection picks anyway can do it
@@ -444,7 +448,7 @@ bool run_conv(Exec& ex, const Lin& w, const Act& a, int cin, const ConvGeom& g, 
     if (e.gn_part && (wdt_ == DT_F16 || wdt_ == DT_HL) && wdt_ == ex.cdt) { p.gn_part = e.gn_part; if (!igemm_gn_part_ok(p)) p.gn_part = nullptr; }
   }
   SDXL_REQUIRE(!e.xa_k || igemm_xattn_ok(a.dt, out.dt, p.M, p.N, p.K, p.rpb, e.xa_nctx), "fused cross-attention: unsupported shape");
-  SDXL_REQUIRE(!e.ln_stat || w.K % 64 == 0, "LayerNorm-folded GEMM needs K % 64 == 0");
+  SDXL_REQUIRE(!e.ln_stat || (w.ln_k ? w.ln_k : w.K) % 64 == 0, "LayerNorm-folded GEMM needs K % 64 == 0");
   SDXL_REQUIRE(!e.stat_out || (w.N % 64 == 0 && (e.n_split < 0 || e.n_split >= w.N) && e.act == 0), "row statistics need a plain N % 64 == 0 output");
   SDXL_REQUIRE(!e.ln_stat || w.cs, "ln_stat given but the weight is not LayerNorm-folded");
   SDXL_REQUIRE(!w.cs || e.ln_stat, "LayerNorm-folded weight used without row statistics");
