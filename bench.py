@@ -455,6 +455,26 @@ def live_parity(pkg, ctx, diffuser, decoder, prec: str, vae_prec: str, weights: 
                     "images_per_sec": round(1.0 / dt6, 4), "unet_step_ms": round(statistics.median(steps6), 2) if steps6 else None, "images_timed": 1,
                     "config2_final_latent_max_abs_vs_oracle": a6, "meets_1e-3": bool(a6 <= 1e-3), "lat_bound_scaled": lbw, "inside_lat_bound_scaled": bool(a6 <= lbw)}
                 del d6
+            if hasattr(pkg, "DTYPE_F32_SPLIT_F16W"):
+                d7 = pkg.Diffuser(ctx, cfg, pkg.DTYPE_F32_SPLIT_F16W, seed=pkg.SEED_F16_WEIGHTS)
+                d7.enable_step_timing(True)
+                d7.sample_latent(cond, 7.5, 2, i["noise"].cuda())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                lat7 = d7.sample_latent(cond, 7.5, 30, i["noise"].cuda())
+                steps7 = d7.step_times_ms()
+                decoder.latent_to_image(lat7)
+                torch.cuda.synchronize()
+                dt7 = time.perf_counter() - t0
+                a7, r7 = _rel(lat7, refw)
+                out["config2_f16weights_f32_split_f16w_vs_oracle_final_max_abs"] = a7
+                strict["f32_split_f16w_mode_f16_weights"] = {
+                    "precision": "SDXL_DTYPE_F32_SPLIT_F16W UNet (F32_SPLIT's fp32-class arithmetic with the transformer's linear layers on the f16 kernels: HL16 rows read as f16 rows of twice the width, "
+                                 "weights packed twice per 16-channel group; split-precision cross-attention inside the query projection) on f16-representable weights + the timed VAE",
+                    "mix_classes": d7.diffusion.mix_classes(),
+                    "images_per_sec": round(1.0 / dt7, 4), "unet_step_ms": round(statistics.median(steps7), 2) if steps7 else None, "images_timed": 1,
+                    "config2_final_latent_max_abs_vs_oracle": a7, "meets_1e-3": bool(a7 <= 1e-3)}
+                del d7
             strict["f32_split_f16_weights"] = {
                 "precision": "SDXL_DTYPE_F32_SPLIT UNet on f16-representable weights (what the reference's records hold): two MFMAs per GEMM product, "
                              "three in the attention + the timed VAE; oracle = the same weights, tests/golden/fullsize_config2_f16w.npz",
@@ -485,7 +505,7 @@ def main():
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--n-steps", type=int, default=None, help="--n-diffusion-steps of the reference CLI (30 -> 31 iterations)")
     ap.add_argument("--cfg", type=float, default=None)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res", "f32_split", "f32_split_mix", "f32_split_mix_f16w", "f32_split_mix_f16w_geglu2"],
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f16_f32res", "f32_split", "f32_split_mix", "f32_split_mix_f16w", "f32_split_mix_f16w_geglu2", "f32_split_f16w"],
                     help="UNet arithmetic: f16 (the reference's GPU precision, src/bin/sample/main.rs:122), f16_f32res, f32 (exact-fp32 MFMA: the strict-parity "
                          "mode), f32_split (fp32-class: fp32 stream, (hi, lo) f16 operands with three MFMAs per product in the GEMMs and in the attention), "
                          "f32_split_mix (+ self-attention and GEGLU on plain f16) or f32_split_mix_f16w (+ six more transformer classes on plain f16: for "
@@ -547,7 +567,7 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     dts = {"f16": pkg.DTYPE_F16, "f32": pkg.DTYPE_F32, "f16_f32res": pkg.DTYPE_F16_F32RES, "f32_split": pkg.DTYPE_F32_SPLIT,
            "f32_split_mix": pkg.DTYPE_F32_SPLIT_MIX, "f32_split_mix_f16w": pkg.DTYPE_F32_SPLIT_MIX_F16W,
-           "f32_split_mix_f16w_geglu2": pkg.DTYPE_F32_SPLIT_MIX_F16W_GEGLU2}
+           "f32_split_mix_f16w_geglu2": pkg.DTYPE_F32_SPLIT_MIX_F16W_GEGLU2, "f32_split_f16w": pkg.DTYPE_F32_SPLIT_F16W}
     dt, vdt = dts[args.dtype], dts[args.vae_dtype]
     wseed = pkg.SEED_F16_WEIGHTS if args.weights == "f16" else 0      # (flag bit on the synthetic seed: parameters rounded to f16 on the device)
 
@@ -565,7 +585,7 @@ def main():
     # the MIX classes in force: an f32_split_mix_f16w model on parameters that are not f16 values falls back to f32_split_mix's (the engine checks the
     # tensors).  Replicas are laid out for the mode itself, so a fallen-back root must not broadcast into them.
     mix_classes = diffuser.diffusion.mix_classes()
-    if world > 1 and args.dtype.startswith("f32_split_mix_f16w") and args.weights != "f16":
+    if world > 1 and args.dtype.endswith(("f16w", "geglu2")) and args.weights != "f16":
         raise SystemExit("bench.py: --dtype f32_split_mix_f16w across ranks needs --weights f16 (rank 0 would fall back to f32_split_mix and its arena "
                          "would not match the replicas')")
     t_build = time.time() - t0
@@ -740,7 +760,8 @@ def main():
     # f32: exact-fp32 MFMA peak; f32_split: three f16 MFMAs per product -> a third of the f16 matrix peak in algorithmic FLOPs; the mixed modes run
     # one (f16 classes), two (split-operand classes on f16-representable weights) or three MFMAs per product: priced against the split peak for
     # f32_split_mix and against the full f16 peak for f32_split_mix_f16w (most of its FLOPs are single-MFMA classes) -- `peak_note` says so
-    peak = PEAK_F32_TFLOPS if args.dtype == "f32" else (PEAK_F16_TFLOPS / 3.0 if args.dtype in ("f32_split", "f32_split_mix") else PEAK_F16_TFLOPS)
+    peak = PEAK_F32_TFLOPS if args.dtype == "f32" else (PEAK_F16_TFLOPS / 3.0 if args.dtype in ("f32_split", "f32_split_mix") else
+                                                        PEAK_F16_TFLOPS / 2.0 if args.dtype == "f32_split_f16w" else PEAK_F16_TFLOPS)
     achieved = ig_fl / 1e12 / (ig_ms / 1e3) if ig_ms > 0 else 0.0
     achieved_adj = ig_fl / 1e12 / (adj_ms["igemm"] / 1e3) if adj_ms["igemm"] > 0 else 0.0
     # HBM-side traffic of the same launches: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_step.py,
@@ -763,7 +784,8 @@ def main():
                               "f32_split_mix": "f16 dense MFMA peak / 3 (split-operand classes: three MFMAs per product; two classes run one)",
                               "f32_split_mix_f16w": "f16 dense MFMA peak; the eight f16 classes run one MFMA per product, the split-operand classes two on "
                                                     "f16-representable weights -- algorithmic TFLOP/s understate the matrix work of this mode",
-                              "f32_split_mix_f16w_geglu2": "f16 dense MFMA peak; as f32_split_mix_f16w with the GEGLU projection at two MFMAs per product"}.get(args.dtype, "f16 dense MFMA peak (MI355X_MICROARCH.md)"),
+                              "f32_split_mix_f16w_geglu2": "f16 dense MFMA peak; as f32_split_mix_f16w with the GEGLU projection at two MFMAs per product",
+                              "f32_split_f16w": "f16 dense MFMA peak / 2 (two MFMAs per product on f16-representable weights)"}.get(args.dtype, "f16 dense MFMA peak (MI355X_MICROARCH.md)"),
                 "launches_per_unet_step": ig_n, "avg_launch_us": round(1e3 * ig_ms / max(ig_n, 1), 2),
                 "algorithmic_tflop_per_unet_step": round(ig_fl / 1e12, 3),
                 # headline class times = the RAW event-bracketed ones (frac / achieved follow them); derived: the same with the calibrated event overhead removed
@@ -816,7 +838,8 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"f32": "f32", "f32_split": "f32 (split f16 operands)", "f32_split_mix": "f32 (split f16 operands; self-attention and GEGLU projection on plain f16)",
                                            "f32_split_mix_f16w": "f32 stream, split f16 operands in the convolutions / cross-attention, eight transformer classes on plain f16",
-                                           "f32_split_mix_f16w_geglu2": "f32 stream, split f16 operands in the convolutions / cross-attention / GEGLU activations, seven transformer classes on plain f16"}.get(args.dtype, "f16"), "data": "synthetic",
+                                           "f32_split_mix_f16w_geglu2": "f32 stream, split f16 operands in the convolutions / cross-attention / GEGLU activations, seven transformer classes on plain f16",
+                                           "f32_split_f16w": "f32 (split f16 operands, two MFMAs per product on f16-representable weights)"}.get(args.dtype, "f16"), "data": "synthetic",
             "config": {"workload": wl, "baseline_config_index": args.config - 1,
                        "precision": args.dtype, "vae_dtype": args.vae_dtype,
                        "weights": "synthetic seeded (random-init SDXL-base architecture)" + (", every parameter rounded to IEEE f16 (what the reference's records hold)" if args.weights == "f16" else ""),

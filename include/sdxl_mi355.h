@@ -53,6 +53,11 @@ enum {
   SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 = 6, /* _F16W with the class that carries most of its error at higher precision: the GEGLU projection's ACTIVATIONS as (hi, lo) f16
                              * pairs along a doubled K (two MFMAs per product on the same f16 kernel).  ~12 % slower than _F16W; inside the scaled bound on EVERY
                              * fixture of the parity tests, the 4-step inpainting stress fixture included.  Same f16-parameter requirement and fallback           */
+  SDXL_DTYPE_F32_SPLIT_F16W = 7 /* UNet / Diffuser only: SDXL_DTYPE_F32_SPLIT for models whose PARAMETERS ARE f16 VALUES -- the same fp32-class arithmetic (two MFMAs per product,
+                             * fp32 stream, split-operand attention; meets the unscaled 1e-3) with the transformer's linear layers on the F16 kernels: an HL16
+                             * activation row is read as an f16 row of twice the width against weights packed twice per 16-channel group, and the 77-key
+                             * cross-attention runs at split precision inside the query projection.  ~10 % faster than _F32_SPLIT on such weights; falls back to it
+                             * on others (sdxl_unet_mix_classes: 0)                                                                                              */
 };
 /* sdxl_debug_set knobs ("mix_classes", "hl_demote", "hl_tile96", "igemm_*", "attn_*") are PROCESS-WIDE atomics read when a model is built / planned: A/B and
  * measurement tools only, never set them around handles other threads are creating */

@@ -144,6 +144,8 @@ pub enum Precision {
     /// `F32SplitMixF16W` with the GEGLU projection's activations as (hi, lo) f16 pairs along a doubled K (two MFMAs per product): ~12 % slower, inside the
     /// scaled bound on every fixture of the parity tests
     F32SplitMixF16WGeglu2 = ffi::SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 as isize,
+    /// `F32Split` for models whose parameters are f16 values: the same fp32-class arithmetic with the transformer's linear layers on the f16 kernels (~10 % faster)
+    F32SplitF16W = ffi::SDXL_DTYPE_F32_SPLIT_F16W as isize,
 }
 
 /// one per GPU (the reference hard-codes `LibTorchDevice::Cuda(0)`, `src/bin/sample/main.rs:131`)

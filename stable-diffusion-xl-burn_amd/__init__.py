@@ -29,6 +29,7 @@ DTYPE_F16 = 1        # fp16 storage / MFMA operands, fp32 accumulate
 DTYPE_F16_F32RES = 2  # fp16 MFMA operands, fp32 residual stream
 DTYPE_F32_SPLIT_MIX_F16W = 5  # DTYPE_F32_SPLIT_MIX for f16-representable parameters (the reference's records): + QKV projection, both out-projections, FF-out, cross-attention query projection on f16 operands, LayerNorms through an f16 shadow (csrc/capi.hip mix_of); falls back to _MIX's classes on other parameters (UNet.mix_classes())
 DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 = 6  # DTYPE_F32_SPLIT_MIX_F16W with the GEGLU projection's activations as (hi, lo) f16 pairs along a doubled K: ~12 % slower, inside the scaled bound on every fixture incl. the 4-step stress one
+DTYPE_F32_SPLIT_F16W = 7  # DTYPE_F32_SPLIT for f16-representable parameters: same fp32-class arithmetic, the transformer's linear layers on the f16 kernels (HL16 rows read as f16 rows of twice the width), fused split-precision cross-attention; falls back to DTYPE_F32_SPLIT on other parameters
 DTYPE_F32_SPLIT_MIX = 4  # UNet / Diffuser: DTYPE_F32_SPLIT with the self-attention and the GEGLU projection on plain f16 operands (the two classes the measured precision frontier affords)
 DTYPE_F32_SPLIT = 3   # fp32-class arithmetic on the f16 matrix pipe (operands as (hi, lo) f16 pairs, 3 MFMAs per product): UNet / Diffuser / LatentDecoder and the conv2d / linear / qkv_attention operators
 

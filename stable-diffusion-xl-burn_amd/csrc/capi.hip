@@ -59,12 +59,13 @@ VaeCfg to_vcfg(const sdxl_vae_config* c) {
   return v;
 }
 void no_mix(int dtype) {     // the mixed mode is a property of the UNet driver (which classes run in f16): UNet / Diffuser handles only
-  if (dtype == SDXL_DTYPE_F32_SPLIT_MIX || dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W || dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2) throw Error("SDXL_DTYPE_F32_SPLIT_MIX* are UNet / Diffuser modes (use SDXL_DTYPE_F32_SPLIT here)");
+  if (dtype == SDXL_DTYPE_F32_SPLIT_MIX || dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W || dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 || dtype == SDXL_DTYPE_F32_SPLIT_F16W) throw Error("SDXL_DTYPE_F32_SPLIT_MIX* are UNet / Diffuser modes (use SDXL_DTYPE_F32_SPLIT here)");
 }
 int mix_of(int dtype) {
   return dtype == SDXL_DTYPE_F32_SPLIT_MIX ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_GEGLU_HILO)      // (round 6: GEGLU weights as (hi, lo) pairs along K -- activation rounding only on any weights)
        : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_Q2_F16 | MIX_LN_SHADOW | MIX_XATTN_SPLIT)
-       : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_Q2_F16 | MIX_LN_SHADOW | MIX_XATTN_SPLIT | MIX_GEGLU_AHILO) : 0;
+       : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_Q2_F16 | MIX_LN_SHADOW | MIX_XATTN_SPLIT | MIX_GEGLU_AHILO)
+       : dtype == SDXL_DTYPE_F32_SPLIT_F16W ? (MIX_LINEAR_F16X2 | MIX_XATTN_SPLIT) : 0;      // (no class on f16 OPERANDS: fp32-class arithmetic on the f16 kernels)
        // (round 6: + the cross-attention query projection on f16 with an fp32 q, the split-precision 77-key attention inside its epilogue, and the LayerNorms in
        //  front of the f16 projections folded through the f16 shadow of the stream -- DESIGN 4.1; MIX_XATTN_F16 stays a knob: DESIGN 11.2b)
 }
@@ -74,7 +75,7 @@ void dtypes(int dtype, int& cdt, int& sdt) {
     case SDXL_DTYPE_F16: cdt = DT_F16; sdt = DT_F16; break;
     case SDXL_DTYPE_F16_F32RES: cdt = DT_F16; sdt = DT_F32; break;
     case SDXL_DTYPE_F32_SPLIT: cdt = DT_HL; sdt = DT_F32; break;   // UNet / Diffuser / VAE only (no_split() guards the rest)
-    case SDXL_DTYPE_F32_SPLIT_MIX: case SDXL_DTYPE_F32_SPLIT_MIX_F16W: case SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2: cdt = DT_HL; sdt = DT_F32; break;   // UNet / Diffuser only (mix_of() carries the f16 classes)
+    case SDXL_DTYPE_F32_SPLIT_MIX: case SDXL_DTYPE_F32_SPLIT_MIX_F16W: case SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2: case SDXL_DTYPE_F32_SPLIT_F16W: cdt = DT_HL; sdt = DT_F32; break;   // UNet / Diffuser only (mix_of() carries the f16 classes)
     default: throw Error("unknown dtype");
   }
 }

@@ -647,7 +647,8 @@ __global__ void pack_linear_hilo_kernel(const float* src, half_t* dst, int K, in
   if (i >= (size_t)Npad * 2 * K) return;
   const int np = (int)(i / (2 * (size_t)K));
   const int k2 = (int)(i - (size_t)np * 2 * K);
-  const int part = k2 >= K ? 1 : 0, k = k2 - part * K;
+  int part = k2 >= K ? 1 : 0, k = k2 - part * K;
+  if (mode == 2) { part = 0; k = 16 * (k2 >> 5) + (k2 & 15); }       // HL16 interleave: both copies of a 16-channel group carry the weight itself
   half_t v = (half_t)0.f;
   if (np < N) {
     const int n = geglu ? geglu_unpermute(np, N) : np;

@@ -120,6 +120,8 @@ struct Lin {        // packed dense weight: [Npad][Kpad] compute dtype + fp32 bi
   const float* cs = nullptr;
   const float* ln_eps = nullptr;   // device scalar: eps of the folded LayerNorm
   int ln_k = 0;                    // folded LayerNorm over ln_k columns (0: K) -- the (hi | lo) shadow form packs K = 2 ln_k
+  int k_form = 0;                  // 0 plain; 1: K doubled as two HALVES, weight (hi | lo s) or (w | w / s) against [a | a / s] or [a_hi | a_lo s] (linear_hilo); 2: K doubled in the HL16
+                                   // interleave, the weight twice per 16-channel group: the A operand is an un-scaled HL16 tensor read as f16 (MIX_LINEAR_F16X2)
   int dt = -1;                     // dtype the weight was packed in when it differs from the model's compute dtype (-1: the model's):
                                    // a DT_HL model packs the layers its pipeline cannot take (Cin % 32 != 0) as fp32
   const float* acc_scale = nullptr;   // DT_HL packing: device scalar (weight arena) 1 / (power-of-two factor the packed weights carry)
@@ -149,7 +151,8 @@ struct WeightBuilder {
   // dt_override >= 0: pack in that dtype whatever the model's (the GEMV weights of a split-operand model stay fp32)
   Lin linear(const std::string& name, bool geglu = false, int dt_override = -1);   // name.weight [K,N] (+ name.bias)
   Lin fused_linear(const std::vector<std::string>& names, int dt_override = -1);   // concatenated along N (same K)
-  Lin linear_hilo(const std::string& name, bool geglu, bool dup = false);     // dup: (w | w / kHiLoScale) for an A operand of (hi | lo * kHiLoScale) ACTIVATION halves
+  Lin linear_hilo(const std::string& name, bool geglu, bool dup = false, bool hl_interleave = false);   // hl_interleave: the weight twice in the HL16 interleave (launch_pack_linear_hilo mode 2; + fragment-order image)
+  //     // dup: (w | w / kHiLoScale) for an A operand of (hi | lo * kHiLoScale) ACTIVATION halves
       // f16 GEMM on (hi | lo * kHiLoScale) weight halves along a doubled K: un-rounded weights (MIX_GEGLU_HILO)
   float hl_scale(Lin& l, const std::vector<std::string>& weight_names);     // DT_HL packing: power-of-two factor, inverse into the arena
   // the same with the preceding LayerNorm(gamma, beta) folded into weight / bias / column sums
@@ -247,6 +250,8 @@ enum MixClass {
                         // kernel at twice the depth, two MFMAs per product: activation rounding only on ANY weights.  SDXL_DTYPE_F32_SPLIT_MIX
   MIX_GEGLU_AHILO = 2048, // a knob, in no mode (f16-representable weights): the GEGLU projection's ACTIVATIONS as (hi, lo) f16 pairs along a doubled K against (w | w 2^-8) --
                         // the class that carries 70 % of the F16W mode's error variance at two MFMAs per product on the f16 kernel
+  MIX_LINEAR_F16X2 = 4096, // (f16-representable weights) transformer linears whose A operand is an un-scaled HL16 tensor run on the F16 kernels: an HL16 row of C channels is an f16 row of 2 C
+                        // columns, the weight is packed twice in the same interleave -- two MFMAs per product on the weights-in-registers / wide / pipe kernels
   MIX_LN_SHADOW = 256   // the LayerNorms in front of the f16 projections (QKV, GEGLU, the query projection with MIX_Q2_F16) folded into them: the producers of
                         // the fp32 stream leave an f16 shadow f16(x o gamma) + row statistics (IgemmParams::shadow), no LayerNorm launch
 };

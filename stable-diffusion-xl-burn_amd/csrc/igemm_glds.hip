@@ -1190,7 +1190,8 @@ bool igemm_gn_part_ok(const IgemmParams& p) {
 }
 
 bool igemm_xattn_ok(int a_dt, int c_dt, int M, int N, int K, int rpb, int n_ctx) {
-  return a_dt == DT_F16 && c_dt == DT_F16 && M > 0 && N % 64 == 0 && K % 64 == 0 && rpb > 0 && rpb % 64 == 0 && M % rpb == 0 &&
+  // (c_dt: f16 rows; HL16 rows for the split-precision form behind an fp32-class out-projection -- the row / staged epilogues store either)
+  return a_dt == DT_F16 && (c_dt == DT_F16 || c_dt == DT_HL) && M > 0 && N % 64 == 0 && K % 64 == 0 && rpb > 0 && rpb % 64 == 0 && M % rpb == 0 &&
          n_ctx >= 1 && n_ctx <= 96;
 }
 
@@ -1246,6 +1247,7 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     if (p.act != 0 || p.n_split < p.N || p.stat_out || p.R || p.ebias ||
         !igemm_xattn_ok(p.a_dt, p.c_dt, p.M, p.N, p.K, p.rpb, p.xa_nctx))
       throw std::runtime_error("igemm: fused cross-attention needs a plain f16 projection (no residual / split outputs)");
+    if (!p.xa_k_lo && p.c_dt != DT_F16) throw std::runtime_error("igemm: the f16 fused cross-attention writes f16 rows");
     const int nk = p.Kpad / 64;
     if (p.xa_k_lo) {     // split precision: the one-MFMA-row tiles only (96x128 / 128x128), same cost model
       const double c128 = tile_cost(p.M, p.N, nk, 128, 128, 1.0), c96 = tile_cost(p.M, p.N, nk, 96, 128, 1.0);

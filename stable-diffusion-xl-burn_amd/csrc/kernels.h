@@ -301,6 +301,8 @@ void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int K
 // activations once.  K % 32 == 0; Kpad = 2 K.
 void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s, int mode = 0);
 // mode 1: dst[n][K + k] = f16(f16(w) / lo_scale) -- the weight twice, for an A operand that carries (hi | lo * lo_scale) ACTIVATION halves (exact for f16-representable weights)
+// mode 2: the weight twice in the HL16 INTERLEAVE -- dst[n][32 g + j] = dst[n][32 g + 16 + j] = f16(w[16 g + j]) (K % 16 == 0): an HL16 activation row of C logical channels IS an
+//         f16 row of 2 C columns [16 hi | 16 lo | ...], so any f16 GEMM kernel multiplies (hi + lo) by w -- two MFMAs per product, exact for f16-representable weights
 // LayerNorm fold helpers: column sums of the packed (rounded) weight rows; beta . W + bias in canonical column order
 void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s, const float* kscale = nullptr, int K = 0);   // kscale: cs[r] = sum_k kscale[k] packed[r][k]
 void launch_beta_dot(const float* w, const float* beta, const float* bias, float* out, int K, int N, hipStream_t s);

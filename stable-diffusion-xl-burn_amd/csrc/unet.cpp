@@ -41,7 +41,7 @@ bool spec_k_ok(WeightBuilder& wb, const std::string& name) { return wb.spec(name
 STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth, bool fuse_ln, int mix = 0) {
   const bool geglu_f16 = (mix & MIX_GEGLU_F16) != 0, qkv_f16 = (mix & MIX_QKV_F16) != 0, ff_f16 = (mix & MIX_FF_F16) != 0, out1_f16 = (mix & MIX_OUT1_F16) != 0,
              out2_f16 = (mix & MIX_OUT2_F16) != 0, q2_fused = out2_f16 && (mix & MIX_XATTN_F16) != 0, q2_f16 = q2_fused || (mix & MIX_Q2_F16) != 0,
-             ln_sh = (mix & MIX_LN_SHADOW) != 0;
+             ln_sh = (mix & MIX_LN_SHADOW) != 0, x2 = (mix & MIX_LINEAR_F16X2) != 0;
   STW s;
   s.C = C; s.heads = heads;
   s.norm = wb.norm(p + ".norm");
@@ -68,13 +68,16 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     if (ln_sh && qkv_f16) t.qkv_sh = wb.fold_ln({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, q + ".norm1", false, DT_F16, true, &t.qkv);
     else
     t.qkv = wb.fused_linear({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, qkv_f16 ? (int)DT_F16 : -1);
-    t.out1 = wb.linear(q + ".attn1.out", false, out1_f16 ? (int)DT_F16 : -1);
+    // MIX_LINEAR_F16X2: a projection that stays fp32-class (its A operand an HL16 tensor) runs on the f16 kernels over the weight packed twice in the HL16 interleave
+    auto x2_ok = [&](const std::string& nm) { return x2 && wb.spec(nm + ".weight").shape[0] % 32 == 0 && wb.spec(nm + ".weight").shape[1] % 128 == 0; };
+    t.out1 = !out1_f16 && x2_ok(q + ".attn1.out") ? wb.linear_hilo(q + ".attn1.out", false, false, true) : wb.linear(q + ".attn1.out", false, out1_f16 ? (int)DT_F16 : -1);
     t.n2 = wb.norm(q + ".norm2");
     if (ln_sh && q2_f16 && !q2_fused) t.q2_sh = wb.fold_ln({q + ".attn2.query"}, q + ".norm2", false, DT_F16, true, &t.q2);
+    else if (!q2_f16 && x2_ok(q + ".attn2.query")) t.q2 = wb.linear_hilo(q + ".attn2.query", false, false, true);
     else
     t.q2 = wb.linear(q + ".attn2.query", false, q2_f16 ? (int)DT_F16 : -1);
     t.kv2 = wb.fused_linear({q + ".attn2.key", q + ".attn2.value"});
-    t.out2 = wb.linear(q + ".attn2.out", false, out2_f16 ? (int)DT_F16 : -1);
+    t.out2 = !out2_f16 && x2_ok(q + ".attn2.out") ? wb.linear_hilo(q + ".attn2.out", false, false, true) : wb.linear(q + ".attn2.out", false, out2_f16 ? (int)DT_F16 : -1);
     t.n3 = wb.norm(q + ".norm3");
     // (mixed mode: the GEGLU projection of a split-operand model packed as plain f16 -- it runs on the f16 wide-tile kernel)
     if (geglu_f16 && (mix & MIX_GEGLU_AHILO) && spec_k_ok(wb, q + ".mlp.geglu.proj")) {
@@ -84,9 +87,11 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     }
     else if (ln_sh && geglu_f16) t.geglu_sh = wb.fold_ln({q + ".mlp.geglu.proj"}, q + ".norm3", true, DT_F16, true, &t.geglu);
     else if (geglu_f16 && (mix & MIX_GEGLU_HILO) && spec_k_ok(wb, q + ".mlp.geglu.proj")) t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true);
+    else if (!geglu_f16 && x2 && wb.spec(q + ".mlp.geglu.proj.weight").shape[0] % 32 == 0 && wb.spec(q + ".mlp.geglu.proj.weight").shape[1] % 640 == 0)
+      t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true, false, true);      // fp32-class GEGLU on the f16 wide-tile kernel (HL16 operand read as f16, K = 2 C)
     else
     t.geglu = wb.linear(q + ".mlp.geglu.proj", true, geglu_f16 ? (int)DT_F16 : -1);
-    t.ff = wb.linear(q + ".mlp.lin", false, ff_f16 ? (int)DT_F16 : -1);
+    t.ff = !ff_f16 && x2_ok(q + ".mlp.lin") ? wb.linear_hilo(q + ".mlp.lin", false, false, true) : wb.linear(q + ".mlp.lin", false, ff_f16 ? (int)DT_F16 : -1);
     s.blocks.push_back(t);
   }
   s.proj_out = wb.linear(p + ".proj_out");
@@ -205,14 +210,17 @@ UNet::~UNet() {
 
 void UNet::build_weights(WeightSource& src, hipStream_t st) {
   const std::vector<ParamSpec> specs = unet_param_specs(cfg_);
-  warena_.reserve(WeightBuilder::arena_bound(specs, cdt_));
+  size_t bound = WeightBuilder::arena_bound(specs, cdt_);
+  if (cdt_ == DT_HL && (mix_ & MIX_LINEAR_F16X2))      // f16 x 2 K images carry a fragment-order twin the split-operand bound does not count
+    for (const ParamSpec& ps : specs) if (ps.kind == PK_LINEAR_W) bound += round_up(ps.shape[1], 128) * round_up((size_t)ps.shape[0], 64) * 4 + 256;
+  warena_.reserve(bound);
   WeightBuilder wb(specs, src, warena_, cdt_, st);
   // SDXL_DTYPE_F32_SPLIT_MIX_F16W moves classes to plain f16 operands whose WEIGHTS must be f16 values (the reference's records are,
   // src/bin/sample/main.rs:37): on other parameters that would round the weights as well and leave the mode's error bound (0.029 against
   // 0.0212).  Checked here on the tensors themselves; a model that does not qualify falls back to F32_SPLIT_MIX's two classes (mix_classes() tells).
   // Not applied to the A/B knob "mix_classes" (the frontier tools run those maps on fp32 weights on purpose) nor on replicas built from an empty
   // source (they receive rank 0's arena: the caller compares rank 0's mix_classes() with the mode before the broadcast, bench.py does).
-  constexpr int kNeedExact = MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_XATTN_F16 | MIX_Q2_F16 | MIX_GEGLU_AHILO;
+  constexpr int kNeedExact = MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_XATTN_F16 | MIX_Q2_F16 | MIX_GEGLU_AHILO | MIX_LINEAR_F16X2;
   if (cdt_ == DT_HL && (mix_ & kNeedExact) && !mix_knob_ && !src.empty()) {
     std::vector<std::string> names;
     auto ends = [](const std::string& n, const char* suf) { const size_t l = std::strlen(suf); return n.size() >= l && n.compare(n.size() - l, l, suf) == 0; };
@@ -221,10 +229,11 @@ void UNet::build_weights(WeightSource& src, hipStream_t st) {
       if (n.find(".transformer.blocks.") == std::string::npos) continue;
       if (((mix_ & MIX_QKV_F16) && (ends(n, ".attn1.query.weight") || ends(n, ".attn1.key.weight") || ends(n, ".attn1.value.weight"))) ||
           ((mix_ & MIX_OUT1_F16) && ends(n, ".attn1.out.weight")) || ((mix_ & MIX_OUT2_F16) && ends(n, ".attn2.out.weight")) ||
-          ((mix_ & MIX_FF_F16) && ends(n, ".mlp.lin.weight")) || ((mix_ & MIX_GEGLU_AHILO) && ends(n, ".mlp.geglu.proj.weight")) || ((mix_ & (MIX_XATTN_F16 | MIX_Q2_F16)) && ends(n, ".attn2.query.weight")))
+          ((mix_ & (MIX_FF_F16 | MIX_LINEAR_F16X2)) && ends(n, ".mlp.lin.weight")) || ((mix_ & MIX_LINEAR_F16X2) && (ends(n, ".attn1.out.weight") || ends(n, ".attn2.out.weight"))) || ((mix_ & (MIX_GEGLU_AHILO | MIX_LINEAR_F16X2)) && ends(n, ".mlp.geglu.proj.weight")) || ((mix_ & (MIX_XATTN_F16 | MIX_Q2_F16 | MIX_LINEAR_F16X2)) && ends(n, ".attn2.query.weight")))
         names.push_back(n);
     }
-    if (!wb.all_f16_exact(names)) mix_ = MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_GEGLU_HILO;      // = SDXL_DTYPE_F32_SPLIT_MIX (capi.hip mix_of)
+    if (!wb.all_f16_exact(names))      // = SDXL_DTYPE_F32_SPLIT_MIX (capi.hip mix_of); a mode without f16-OPERAND classes (SDXL_DTYPE_F32_SPLIT_F16W) falls back to plain F32_SPLIT
+      mix_ = (mix_ & (MIX_ATTN_F16 | MIX_GEGLU_F16)) ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_GEGLU_HILO) : 0;
   }
   const int gv = cdt_ == DT_HL ? DT_F32 : -1;     // the M <= 8 GEMV weights of a split-operand model are packed fp32
   lin1_t_ = wb.linear("lin1_time_embed", false, gv);
@@ -271,7 +280,7 @@ void UNet::set_context(const float* context, int n_ctx, const float* label, int 
   const int vt_ld = (int)round_up(n_ctx, 64);
   // operand-order copies for the fused cross-attention epilogue (f16 engines; the split-operand engine when that class runs on f16: MIX_XATTN_F16)
   // (MIX_XATTN_SPLIT: TWO images -- the hi and the lo halves of the fp32-class projection -- for the split-precision form of that epilogue)
-  const bool pack_xs = cdt_ == DT_HL && (mix_ & MIX_XATTN_SPLIT) && (mix_ & MIX_Q2_F16) && !(mix_ & MIX_XATTN_F16) && n_ctx <= 96;
+  const bool pack_xs = cdt_ == DT_HL && (mix_ & MIX_XATTN_SPLIT) && (mix_ & (MIX_Q2_F16 | MIX_LINEAR_F16X2)) && !(mix_ & MIX_XATTN_F16) && n_ctx <= 96;
   const bool pack_xa = (cdt_ == DT_F16 || (cdt_ == DT_HL && (mix_ & MIX_XATTN_F16) && (mix_ & MIX_OUT2_F16)) || pack_xs) && n_ctx <= 96;
   const int kvdt = attn_dt();                           // dtype of the K / V^T caches (fp32 in the split-operand mode)
   const int emb = 4 * cfg_.model_channels;
@@ -448,16 +457,16 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   //   * GEGLU projection on f16 operands (f16 LayerNorm output x f16-packed weights, the f16 wide-tile kernel) -- its output leaves the
   //     epilogue as HL16 (fp32-class), so FF-out's operand is not rounded a second time.
   const bool mix_qkv = hl_attn && !w.blocks.empty() && w.blocks[0].qkv.dt == DT_F16;     // (f16-packed at build: the only path those weights can take)
-  const bool mix_ff = hl_attn && !w.blocks.empty() && w.blocks[0].ff.dt == DT_F16;
-  const bool mix_out1 = hl_attn && !w.blocks.empty() && w.blocks[0].out1.dt == DT_F16;
-  const bool mix_out2 = hl_attn && !w.blocks.empty() && w.blocks[0].out2.dt == DT_F16;
+  const bool mix_ff = hl_attn && !w.blocks.empty() && w.blocks[0].ff.dt == DT_F16 && w.blocks[0].ff.k_form == 0;      // (K = 2 x: the MIX_LINEAR_F16X2 form, an fp32-class projection)
+  const bool mix_out1 = hl_attn && !w.blocks.empty() && w.blocks[0].out1.dt == DT_F16 && w.blocks[0].out1.k_form == 0;
+  const bool mix_out2 = hl_attn && !w.blocks.empty() && w.blocks[0].out2.dt == DT_F16 && w.blocks[0].out2.k_form == 0;
   Act ao2_16;      // operand of an f16 cross-attention out-projection: the split-operand attention rounds its fp32 result once, in its own store (AttnParams::o_dt)
   if (mix_out2) ao2_16 = ex.alloc(M, C, DT_F16);
   const bool mix_attn = hl_attn && ((mix_ & MIX_ATTN_F16) || mix_qkv) && C % 16 == 0;
   SDXL_REQUIRE(!mix_qkv || mix_attn, "mixed mode: an f16 QKV projection feeds the f16 self-attention");
   SDXL_REQUIRE(!mix_out1 || mix_attn, "mixed mode: an f16 out-projection reads the f16 self-attention's output");
   // (the GEGLU weights of a mixed-mode model are PACKED f16 at build: the f16 path is the only one they can take, whatever the token count)
-  const bool mix_geglu = hl_attn && !w.blocks.empty() && w.blocks[0].geglu.dt == DT_F16;
+  const bool mix_geglu = hl_attn && !w.blocks.empty() && w.blocks[0].geglu.dt == DT_F16 && w.blocks[0].geglu.k_form != 2;      // (k_form 2: an fp32-class projection on the f16 kernel, MIX_LINEAR_F16X2)
   Act qk16, ao16, ln16; void* vt16 = nullptr;
   if (mix_attn) {
     qk16 = ex.alloc(M, 2 * C, DT_F16); ao16 = ex.alloc(M, C, DT_F16);
@@ -466,14 +475,15 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   }
   // cross-attention of the mixed mode on f16 (MIX_XATTN_F16): the f16 engine's fused launch -- query projection and the 77-key attention in one kernel on
   // the f16 LayerNorm output and the packed f16 context; shapes that launch does not take (tiny nets) widen the f16 query for the split-operand attention
-  const bool mix_q2 = hl_attn && !w.blocks.empty() && w.blocks[0].q2.dt == DT_F16;
+  const bool mix_q2 = hl_attn && !w.blocks.empty() && w.blocks[0].q2.dt == DT_F16 && w.blocks[0].q2.k_form == 0;
+  const bool x2_q2 = hl_attn && !w.blocks.empty() && w.blocks[0].q2.k_form == 2;      // fp32-class query projection on the f16 kernels (MIX_LINEAR_F16X2)
   // the f16 engine's fused launch (MIX_XATTN_F16: the set_context of such a model packed the f16 context, kv.xa) -- otherwise an f16 query projection
   // (MIX_Q2_F16) writes an fp32 q for the split-operand attention
   const bool mix_xa = mix_q2 && mix_out2 && (mix_ & MIX_XATTN_F16) && plan_xattn_ && !kv_.empty() && kv_[si][0].xa && igemm_xattn_ok(DT_F16, DT_F16, (int)M, C, C, HW, n_ctx_);
   const bool mix_q2_widen = mix_q2 && (mix_ & MIX_XATTN_F16) && mix_out2;     // round 5's form of the knob on shapes the fused launch does not take: f16 q, widened
   if (mix_geglu || mix_qkv || mix_q2) ln16 = ex.alloc(M, C, DT_F16);
   // MIX_GEGLU_HILO: the GEGLU projection's weights are (hi | lo 2^8) halves along a doubled K (WeightBuilder::linear_hilo): its A operand is [a | a 2^-8]
-  const bool gg_hilo = mix_geglu && !w.blocks.empty() && w.blocks[0].geglu.K == 2 * C;      // (the LayerNorm-launch path; the shadow form of such a projection reads sh16g)
+  const bool gg_hilo = mix_geglu && !w.blocks.empty() && w.blocks[0].geglu.k_form == 1;      // (the LayerNorm-launch path; the shadow form of such a projection reads sh16g)
   Act ln16x2;
   if (gg_hilo) ln16x2 = ex.alloc(M, 2 * C, DT_F16);
   // MIX_LN_SHADOW: f16 shadow of the stream + the fp32 rows' statistics, left by the weights-in-registers producers (out-projections, FF-out) for the f16
@@ -489,6 +499,10 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   // MIX_XATTN_SPLIT: the split-precision attention runs inside that projection's epilogue on q's accumulators (hi / lo context images of set_context), and its
   // f16 rows are the out-projection's operand: q never reaches memory, no attention launch
   const bool mix_xs = mix_q2 && !mix_q2_widen && mix_out2 && plan_xattn_ && !kv_.empty() && kv_[si][0].xa_lo && igemm_xattn_ok(DT_F16, DT_F16, (int)M, C, C, HW, n_ctx_);
+  // ... and in the MIX_LINEAR_F16X2 form of the query projection (K = 2 C, HL16 rows out: the out-projection's fp32-class operand)
+  const bool x2_xs = x2_q2 && plan_xattn_ && !kv_.empty() && kv_[si][0].xa_lo && ao.dt == DT_HL && igemm_xattn_ok(DT_F16, DT_HL, (int)M, C, 2 * C, HW, n_ctx_);
+  // MIX_LINEAR_F16X2: an un-scaled HL16 operand of C logical channels handed to an f16 GEMM whose weight is packed twice in the HL16 interleave (K = 2 C)
+  auto x2op = [&](const Lin& l, const Act& a, int Cl) { return (l.dt == DT_F16 && l.k_form == 2 && l.K == 2 * Cl && a.dt == DT_HL && !a.a_scale) ? Act(a.p, 2 * a.ld, DT_F16) : a; };
   auto want_shadow = [&](Epi& e, const Lin& consumer_sh, const NormW& n) {     // ask producer `e` for the shadow the consumer behind LayerNorm n reads
     have_sh = false;
     if (!consumer_sh.cs || C % 64 != 0) return;
@@ -564,7 +578,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     else attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
     Epi er; er.R = t; er.rpb = HW; er.cls = DM_OUT;
     demote_lo(ex, DM_OUT, ao, M, C);
-    { Epi e1 = er; if (mix_out1) want_shadow(e1, b.q2_sh, b.n2); run_linear(ex, b.out1, mix_out1 ? ao16 : ao, (int)M, t, e1); }
+    { Epi e1 = er; if (mix_out1) want_shadow(e1, b.q2_sh, b.n2); run_linear(ex, b.out1, mix_out1 ? ao16 : x2op(b.out1, ao, C), (int)M, t, e1); }
     if (have_sh && b.q2_sh.cs) {       // f16 query projection on the shadow the out-projection left; fp32 q for the split-operand attention
       Epi e2q; e2q.cls = DM_XATTN; e2q.rpb = HW; e2q.ln_stat = shst;
       if (mix_xs) {
@@ -602,8 +616,12 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       Epi e2q; e2q.rpb = HW; e2q.cls = DM_XATTN;
       e2q.xa_k = kv_xa(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
       run_linear(ex, b.q2, ln, (int)M, ao, e2q);
+    } else if (x2_xs) {     // fp32-class projection on the f16 kernel (HL16 operand read as f16) with the split-precision attention in its epilogue: HL16 rows for the out-projection
+      Epi e2q; e2q.rpb = HW; e2q.cls = DM_XATTN;
+      e2q.xa_k = kv_xa(si, j); e2q.xa_k_lo = kv_xa_lo(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
+      run_linear(ex, b.q2, x2op(b.q2, ln, C), (int)M, ao, e2q);
     } else {
-      { Epi e2q; e2q.cls = DM_XATTN; run_linear(ex, b.q2, ln, (int)M, q, e2q); }
+      { Epi e2q; e2q.cls = DM_XATTN; run_linear(ex, b.q2, x2op(b.q2, ln, C), (int)M, q, e2q); }
       demote_lo(ex, DM_XATTN, q, M, C);
       if (hl_attn) attention_hl(ex, q, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao2_16 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);   // caches are HL16 (set_context)
       else attention(ex, q, Act(kv_k(si, j), C, adt), kv_vt(si, j), vt_ld_ctx_, ao, B, w.heads, HW, n_ctx_);
@@ -611,7 +629,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     }
     have_sh = false;
     demote_lo(ex, DM_OUT, ao, M, C);
-    { Epi e2 = er; if (mix_out2) want_shadow(e2, b.geglu_sh, b.n3); run_linear(ex, b.out2, mix_out2 ? ao2_16 : ao, (int)M, t, e2); }
+    { Epi e2 = er; if (mix_out2) want_shadow(e2, b.geglu_sh, b.n3); run_linear(ex, b.out2, mix_out2 ? ao2_16 : x2op(b.out2, ao, C), (int)M, t, e2); }
     Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
     const bool gg_sh = have_sh && b.geglu_sh.cs;      // GEGLU projection on the shadow the cross-attention's out-projection left: no LayerNorm launch
     if (gg_sh) eg.ln_stat = shst;
@@ -634,10 +652,10 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
       run_linear(ex, b.geglu, gg_hilo ? ln16x2 : ln16, (int)M, gg16, eg);
       if (!ex.dry) launch_f16_to_hl(gg16.p, gg16.ld, gg.p, gg.ld, M, 4 * C, ex.s);
     } else
-    run_linear(ex, b.geglu, gg_hilo ? ln16x2 : mix_geglu ? ln16 : ln, (int)M, gg, eg);
+    run_linear(ex, b.geglu, gg_hilo ? ln16x2 : mix_geglu ? ln16 : x2op(b.geglu, ln, C), (int)M, gg, eg);
     demote_lo(ex, DM_FF, gg, M, 4 * C);
     er.cls = DM_FF;
-    { Epi ef = er; if (mix_ff && j + 1 < w.blocks.size()) want_shadow(ef, w.blocks[j + 1].qkv_sh, w.blocks[j + 1].n1); run_linear(ex, b.ff, mix_ff ? gg16 : gg, (int)M, t, ef); }
+    { Epi ef = er; if (mix_ff && j + 1 < w.blocks.size()) want_shadow(ef, w.blocks[j + 1].qkv_sh, w.blocks[j + 1].n1); run_linear(ex, b.ff, mix_ff ? gg16 : x2op(b.ff, gg, 4 * C), (int)M, t, ef); }
   }
   Epi eo; eo.R = x; eo.rpb = HW; eo.cls = DM_CONV_PROJ;
   run_linear(ex, w.proj_out, hl_op(ex, w.proj_out, t, M, C, DM_CONV_PROJ, B), (int)M, x, eo);

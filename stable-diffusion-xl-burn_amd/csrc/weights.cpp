@@ -207,19 +207,20 @@ Lin WeightBuilder::linear(const std::string& name, bool geglu, int dt_override) 
 // f16 GEMM with UN-ROUNDED weights (round 6, SDXL_DTYPE_F32_SPLIT_MIX's GEGLU projection): every weight as (hi, lo) f16 values along a doubled K --
 // dst[n] = [f16(w) | f16((w - hi) * kHiLoScale)] -- against the A operand [a | a / kHiLoScale] (run_layernorm dup_scale): two MFMAs per product,
 // the activations rounded once, the weights not at all.  An f16 Lin of K = 2 K0.
-Lin WeightBuilder::linear_hilo(const std::string& name, bool geglu, bool dup) {
+Lin WeightBuilder::linear_hilo(const std::string& name, bool geglu, bool dup, bool hl_interleave) {
   const ParamSpec& s = spec(name + ".weight");
   const int K0 = s.shape[0];
   SDXL_REQUIRE(K0 % 32 == 0, "linear_hilo: K % 32 == 0");
-  Lin l; l.K = 2 * K0; l.N = s.shape[1]; l.ksize = 1; l.cin = l.K; l.dt = DT_F16;
+  Lin l; l.K = 2 * K0; l.N = s.shape[1]; l.ksize = 1; l.cin = l.K; l.dt = DT_F16; l.k_form = hl_interleave ? 2 : 1;
   l.Kpad = l.K; l.Npad = (int)round_up(l.N, 128);
   void* w = arena.alloc((size_t)l.Npad * l.Kpad * 2);
   float* b = (float*)arena.alloc((size_t)l.Npad * sizeof(float));
   l.w = w; l.b = b;
-  if (src.empty()) return l;
-  launch_pack_linear_hilo(fetch(name + ".weight"), w, K0, l.N, l.Npad, geglu ? 1 : 0, kHiLoScale, st, dup ? 1 : 0);
+  if (src.empty()) { if (hl_interleave && !geglu) attach_wfrag(l, false); return l; }
+  launch_pack_linear_hilo(fetch(name + ".weight"), w, K0, l.N, l.Npad, geglu ? 1 : 0, kHiLoScale, st, hl_interleave ? 2 : dup ? 1 : 0);
   const float* bsrc = has(name + ".bias") ? fetch(name + ".bias") : nullptr;
   launch_pack_bias(bsrc, b, l.N, l.Npad, geglu ? 1 : 0, 0, st);
+  if (hl_interleave && !geglu) attach_wfrag(l, true);
   return l;
 }
 Lin WeightBuilder::fused_linear(const std::vector<std::string>& names, int dt_override) {
@@ -295,7 +296,7 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
   }
   SDXL_REQUIRE(!hilo_dup || (shadow && names.size() == 1 && dt == DT_F16 && l.K % 32 == 0), "fold_ln: the (hi | lo) form is a single f16 shadow-form projection");
   const int K0 = l.K;                       // columns of the LayerNorm
-  if (hilo_dup) { l.ln_k = K0; l.K = 2 * K0; }
+  if (hilo_dup) { l.ln_k = K0; l.K = 2 * K0; l.k_form = 1; }
   l.N = ntot; l.cin = l.K;
   const int kt = dt == DT_F16 ? 64 : 32;
   l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);

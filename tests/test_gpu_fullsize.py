@@ -57,7 +57,7 @@ def test_fullsize_unet_properties(pkg, ctx, base_inputs):
     assert torch.equal(cold[0], outs[0]) and torch.equal(cold[1], outs[0]), "weight warming changes the result"
 
 
-@pytest.mark.parametrize("dtype_name", ["F32_SPLIT", "F32_SPLIT_MIX", "F32_SPLIT_MIX_F16W", "F32_SPLIT_MIX_F16W_GEGLU2"])
+@pytest.mark.parametrize("dtype_name", ["F32_SPLIT", "F32_SPLIT_MIX", "F32_SPLIT_MIX_F16W", "F32_SPLIT_MIX_F16W_GEGLU2", "F32_SPLIT_F16W"])
 def test_fullsize_split_modes_batch_independence(pkg, ctx, base_inputs, dtype_name):
     """The split-operand engines at full size: an entry of the CFG pair must equal a separate batch-1 forward bit for bit.  Until round 6 the HL16 copy of
     an fp32 stream tensor (skip / up- / down-sampling / proj_out operands) took ONE power-of-two scale from the absmax of the whole batched tensor, so an

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 # held to the strict mode's bounds
 # dtype 4 = SDXL_DTYPE_F32_SPLIT_MIX (round 5): dtype 3 with the self-attention and the GEGLU projection on f16 operands -- between 2 and 3
 # dtype 5 = SDXL_DTYPE_F32_SPLIT_MIX_F16W: dtype 4 + QKV projection, self-attention out-projection and FF-out on f16 operands (for f16-representable parameters)
-FWD_TOL = {0: 1e-5, 1: 4.5e-3, 2: 2.5e-3, 3: 1e-5, 4: 1.5e-3, 5: 2.0e-3, 6: 2.0e-3}      # measured 2.3e-6 / 1.4e-3 (16^2), 2.26e-3 (32^2) / 1.2e-3 / 1.8e-6
+FWD_TOL = {0: 1e-5, 1: 4.5e-3, 2: 2.5e-3, 3: 1e-5, 4: 1.5e-3, 5: 2.0e-3, 6: 2.0e-3, 7: 1e-5}      # 7 = SDXL_DTYPE_F32_SPLIT_F16W: dtype 3's arithmetic on the f16 kernels (f16-representable weights)      # measured 2.3e-6 / 1.4e-3 (16^2), 2.26e-3 (32^2) / 1.2e-3 / 1.8e-6
 EPS_TOL = {0: 4e-5, 1: 5.8e-3, 2: 5.5e-3, 3: 4e-5}    # the low-variance per-norm-eps probe (measured 1.2e-5 / 2.9e-3 / 2.7e-3)
 LAT_ABS_F32 = 1e-3           # north_star: latents within 1e-3 of the fp32 CPU reference (strict-parity mode)
 LAT_REL_F16 = 6.0e-3         # fp16-operand modes: max-abs error relative to max|latent|; measured 3.0e-3 (4 CFG-7.5 steps) and 3.8e-3
@@ -42,13 +42,13 @@ def weights_for(pkg, ocfg, dtype):
     """(oracle weights, synthetic seed of the engine) for a dtype: SDXL_DTYPE_F32_SPLIT_MIX_F16W is FOR f16-representable parameters (on others the
     engine falls back to F32_SPLIT_MIX's classes), so dtype 5 is tested on the seeded weights rounded to f16 on both sides"""
     W = unet_weights(ocfg)
-    if dtype not in (5, 6):
+    if dtype not in (5, 6, 7):
         return W, 0
     return {k: (v if k.endswith(".eps") else v.half().float()) for k, v in W.items()}, pkg.SEED_F16_WEIGHTS
 
 
 def lat_tol(dtype, ref):
-    return LAT_ABS_F32 if dtype in (0, 3) else LAT_REL_F16 * float(ref.abs().max())
+    return LAT_ABS_F32 if dtype in (0, 3, 7) else LAT_REL_F16 * float(ref.abs().max())
 
 
 def _cond(ocfg, n, res, n_ctx=9, refiner=False, seed=30):
@@ -71,7 +71,7 @@ def _pkg_cond(pkg, c, res, refiner=False):
                             resolution=res)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("which", ["tiny", "tiny_refiner"])
 def test_unet_forward(pkg, ctx, dtype, which):
     ocfg = OC.tiny_config() if which == "tiny" else OC.tiny_refiner_config()
@@ -85,7 +85,7 @@ def test_unet_forward(pkg, ctx, dtype, which):
     specs = pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg))
     flat = pkg.flatten_weights(specs, {k: v.numpy() for k, v in W.items()})
     u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, weights=flat)
-    assert u.mix_classes() == {4: MIX_CLASSES, 5: F16W_CLASSES, 6: F16W_CLASSES | 2048}.get(dtype, 0)
+    assert u.mix_classes() == {4: MIX_CLASSES, 5: F16W_CLASSES, 6: F16W_CLASSES | 2048, 7: 4096 | 512}.get(dtype, 0)
     outs = [u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu() for _ in range(3)]   # eager, capture, replay
     e = rel_err(outs[0], ref)
     print(f"unet_forward[{which}] dtype={dtype}: rel err {e:.3e}")
@@ -194,7 +194,7 @@ def test_fused_cross_attention_matches_two_kernel_path(pkg, ctx):
     assert e_f < FWD_TOL[1] and e_p < FWD_TOL[1] and e_fp < 4e-3
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_unet_forward_batch_independence(pkg, ctx, dtype):
     # the engine batches the CFG pair; per-sample results must not depend on what else is in the batch
     ocfg = OC.tiny_config()
@@ -207,7 +207,7 @@ def test_unet_forward_batch_independence(pkg, ctx, dtype):
         assert torch.equal(one[0], both[i])
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("n,n_steps,cfg_scale", [(1, 4, 7.5), (2, 8, 1.0)])
 def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
     ocfg = OC.tiny_config()
@@ -227,7 +227,7 @@ def test_sample_latent(pkg, ctx, dtype, n, n_steps, cfg_scale):
     assert torch.equal(out, out2), "trajectory is not deterministic"
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 3, 4, 5, 6])
+@pytest.mark.parametrize("dtype", [0, 1, 3, 4, 5, 6, 7])
 def test_refine_latent(pkg, ctx, dtype):
     ocfg = OC.tiny_refiner_config()
     res = (64, 64)
@@ -242,7 +242,7 @@ def test_refine_latent(pkg, ctx, dtype):
     assert e < lat_tol(dtype, ref)
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 3, 4, 5, 6])
+@pytest.mark.parametrize("dtype", [0, 1, 3, 4, 5, 6, 7])
 def test_sample_latent_with_inpainting(pkg, ctx, dtype):
     ocfg = OC.tiny_config()
     res = (64, 64)
@@ -341,6 +341,7 @@ def test_f16w_mode_falls_back_on_parameters_that_are_not_f16_values(pkg, ctx):
     assert torch.equal(u5.forward(x, t, c, y), u4.forward(x, t, c, y))
     assert pkg.UNet(ctx, cfg, 5, seed=pkg.SEED_F16_WEIGHTS).mix_classes() == F16W_CLASSES
     assert pkg.UNet(ctx, cfg, 6, seed=pkg.SEED_F16_WEIGHTS).mix_classes() == F16W_CLASSES | 2048 and pkg.UNet(ctx, cfg, 6, seed=0).mix_classes() == MIX_CLASSES
+    assert pkg.UNet(ctx, cfg, 7, seed=pkg.SEED_F16_WEIGHTS).mix_classes() == 4096 | 512 and pkg.UNet(ctx, cfg, 7, seed=0).mix_classes() == 0
     specs = pkg.unet_param_specs(cfg)
     W16 = {k: (v if k.endswith(".eps") else v.half().float()).numpy().copy() for k, v in unet_weights(ocfg).items()}
     assert pkg.UNet(ctx, cfg, 5, weights=pkg.flatten_weights(specs, W16)).mix_classes() == F16W_CLASSES
