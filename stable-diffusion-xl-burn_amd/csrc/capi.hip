@@ -65,7 +65,7 @@ int mix_of(int dtype) {
   return dtype == SDXL_DTYPE_F32_SPLIT_MIX ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_GEGLU_HILO)      // (round 6: GEGLU weights as (hi, lo) pairs along K -- activation rounding only on any weights)
        : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_Q2_F16 | MIX_LN_SHADOW | MIX_XATTN_SPLIT)
        : dtype == SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 ? (MIX_ATTN_F16 | MIX_GEGLU_F16 | MIX_QKV_F16 | MIX_FF_F16 | MIX_OUT1_F16 | MIX_OUT2_F16 | MIX_Q2_F16 | MIX_LN_SHADOW | MIX_XATTN_SPLIT | MIX_GEGLU_AHILO)
-       : dtype == SDXL_DTYPE_F32_SPLIT_F16W ? (MIX_LINEAR_F16X2 | MIX_XATTN_SPLIT) : 0;      // (no class on f16 OPERANDS: fp32-class arithmetic on the f16 kernels)
+       : dtype == SDXL_DTYPE_F32_SPLIT_F16W ? (MIX_LINEAR_F16X2 | MIX_XATTN_SPLIT | MIX_LN_SHADOW) : 0;      // (no class on f16 OPERANDS: fp32-class arithmetic on the f16 kernels)
        // (round 6: + the cross-attention query projection on f16 with an fp32 q, the split-precision 77-key attention inside its epilogue, and the LayerNorms in
        //  front of the f16 projections folded through the f16 shadow of the stream -- DESIGN 4.1; MIX_XATTN_F16 stays a knob: DESIGN 11.2b)
 }

@@ -642,7 +642,7 @@ void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int K
   hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, dt, K, N, Kpad, Npad, geglu, n_offset,
                      kscale, wscale);
 }
-__global__ void pack_linear_hilo_kernel(const float* src, half_t* dst, int K, int N, int Npad, int geglu, float lo_scale, int mode) {
+__global__ void pack_linear_hilo_kernel(const float* src, half_t* dst, int K, int N, int Npad, int geglu, float lo_scale, int mode, int n_offset) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)Npad * 2 * K) return;
   const int np = (int)(i / (2 * (size_t)K));
@@ -657,26 +657,29 @@ __global__ void pack_linear_hilo_kernel(const float* src, half_t* dst, int K, in
     const half_t hi = (half_t)w;
     v = !part ? hi : mode == 0 ? (half_t)((w - (float)hi) * lo_scale) : (half_t)((float)hi / lo_scale);
   }
-  dst[i] = v;
+  dst[i + (size_t)n_offset * 2 * K] = v;
 }
-void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s, int mode) {
+void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s, int mode, int n_offset) {
   const size_t total = (size_t)Npad * 2 * K;
-  hipLaunchKernelGGL(pack_linear_hilo_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, reinterpret_cast<half_t*>(dst), K, N, Npad, geglu, lo_scale, mode);
+  hipLaunchKernelGGL(pack_linear_hilo_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, reinterpret_cast<half_t*>(dst), K, N, Npad, geglu, lo_scale, mode, n_offset);
 }
 // cs[r] = sum_k packed[r][k] over the ROUNDED packed values (what the MFMA really multiplies), one wave per packed row
 // kscale (K values, optional): cs[r] = sum_k kscale[k] * packed[r][k] -- the shadow form of a folded LayerNorm, whose gamma rides on the A operand
-__global__ void colsum_packed_kernel(const void* wp, int dt, int Kpad, int nrows, float* cs, const float* kscale, int K) {
+__global__ void colsum_packed_kernel(const void* wp, int dt, int Kpad, int nrows, float* cs, const float* kscale, int K, int interleave) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= nrows) return;
   float acc = 0.f;
+  if (kscale && interleave) {      // K weights twice in the HL16 interleave: k sits at 32 (k >> 4) + (k & 15)
+    for (int k = lane; k < K; k += 64) acc = fmaf(kscale[k], ld_f(wp, (size_t)row * Kpad + 32 * (k >> 4) + (k & 15), dt), acc);
+  } else
   if (kscale) { for (int k = lane; k < K; k += 64) acc = fmaf(kscale[k], ld_f(wp, (size_t)row * Kpad + k, dt), acc); }
   else for (int k = lane; k < Kpad; k += 64) acc += ld_f(wp, (size_t)row * Kpad + k, dt);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane == 0) cs[row] = acc;
 }
-void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s, const float* kscale, int K) {
-  hipLaunchKernelGGL(colsum_packed_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, wp, dt, Kpad, nrows, cs, kscale, K);
+void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s, const float* kscale, int K, int interleave) {
+  hipLaunchKernelGGL(colsum_packed_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, wp, dt, Kpad, nrows, cs, kscale, K, interleave);
 }
 // out[n] = sum_k beta[k] * W[k][n] + bias[n]   (canonical column order; W is the burn [K][N] layout)
 __global__ void beta_dot_kernel(const float* w, const float* beta, const float* bias, float* out, int K, int N) {

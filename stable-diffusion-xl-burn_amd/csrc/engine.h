@@ -161,7 +161,8 @@ struct WeightBuilder {
   // dt_override / shadow / plain: the SHADOW form (round 6, split-operand models): the weights are packed UN-folded in dt_override (f16) -- gamma rides on
   // the A operand, an f16 shadow  f16(x o gamma)  the producer of the fp32 stream leaves (IgemmParams::shadow) -- with cs = gamma W over the packed values
   // and b = beta W + bias; *plain receives the same packed matrix with the canonical bias (for the LayerNorm-launch path where no shadow exists)
-  Lin fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override = -1, bool shadow = false, Lin* plain = nullptr, bool hilo_dup = false);   // hilo_dup: (w | w / kHiLoScale) along a doubled K for a (hi | lo) shadow
+  Lin fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override = -1, bool shadow = false, Lin* plain = nullptr, bool hilo_dup = false,
+              bool hl_interleave = false);   // hl_interleave: the weights twice in the HL16 interleave (K = 2 x, k_form 2) for an HL16 shadow (shadow form only; any number of fused names)   // hilo_dup: (w | w / kHiLoScale) along a doubled K for a (hi | lo) shadow
   // AND of "every value of these tensors is exactly one f16" (device flag read back): what SDXL_DTYPE_F32_SPLIT_MIX_F16W asks of the classes it moves to f16
   bool all_f16_exact(const std::vector<std::string>& names);
   float* tmp2 = nullptr; size_t tmp2_numel = 0;   // scratch for folded biases (device)

@@ -1298,7 +1298,7 @@ bool launch_igemm_glds(const IgemmParams& p, int variant, hipStream_t s) {
     case 4: launch_glds<128, 128, 2>(psk, s); break;                          // 4 waves, 2-3 co-resident blocks: ragged multi-round grids
     case 6: launch_glds<64, 128, 2>(psk, s); break;
     case 35:    // 8 waves, hand-ordered k-loop unrolled by the ring depth; outputs with a transposed part (fused QKV: V^T) take the operand-swap twin
-      if (p.n_split < p.N && g_tsw.load()) launch_pipe<256, 128, 3, 4, 8, half_t, false, false, true>(psk, s);
+      if (p.n_split < p.N && g_tsw.load() && p.c_dt == DT_F16) launch_pipe<256, 128, 3, 4, 8, half_t, false, false, true>(psk, s);      // (the operand-swapped V^T epilogue writes f16 rows)
       else launch_pipe<256, 128, 3, 4, 8>(psk, s);
       break;
     case 36: launch_pipe<128, 128, 4, 4, 8>(psk, s); break;

@@ -146,12 +146,18 @@ __device__ __forceinline__ void wreg_epilogue(const IgemmParams& p, const f32x16
           *reinterpret_cast<f32x4*>(cp) = f32x4{wv[0], wv[1], wv[2], wv[3]};
           *reinterpret_cast<f32x4*>(cp + 4) = f32x4{wv[4], wv[5], wv[6], wv[7]};
         }
+        if (p.shadow && p.shadow_lo_scale < 0.f) {      // (uniform) HL16 shadow: (hi, lo) of x * gamma in the split-operand layout, read as f16 by the GEMM behind the next LayerNorm
+          float xs[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xs[e] = wv[e] * op.sg0[e]; xs[4 + e] = wv[4 + e] * op.sg1[e]; }
+          if (mok[i]) store_hl8(reinterpret_cast<float*>(p.shadow) + (size_t)m[i] * p.shadow_ld, n0, xs);
+        } else
         if (p.shadow) {      // (kernel argument: uniform) f16(x * gamma of the next LayerNorm): the operand of the GEMM behind it
           half8 hs;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { hs[e] = (half_t)(wv[e] * op.sg0[e]); hs[4 + e] = (half_t)(wv[4 + e] * op.sg1[e]); }
           if (mok[i]) *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.shadow) + (size_t)m[i] * p.shadow_ld + n0) = hs;
-          if (p.shadow_lo_scale != 0.f) {      // (uniform) the lo halves of the same products behind the N hi columns
+          if (p.shadow_lo_scale > 0.f) {      // (uniform) the lo halves of the same products behind the N hi columns
             half8 hl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -568,7 +574,7 @@ bool igemm_wreg_ok(const IgemmParams& p) {
   if (p.R && ((p.ldr & 7) != 0 || (reinterpret_cast<uintptr_t>(p.R) & 15) != 0)) return false;
   if (p.ebias) return false;
   // f16 shadow of an fp32 output (+ the fp32 rows' statistics): whole 16-byte pieces
-  if (p.shadow && (p.c_dt != DT_F32 || !p.shadow_gamma || (p.shadow_ld & 7) != 0 || (reinterpret_cast<uintptr_t>(p.shadow) & 15) != 0)) return false;
+  if (p.shadow && (p.c_dt != DT_F32 || !p.shadow_gamma || (p.shadow_ld & (p.shadow_lo_scale < 0.f ? 15 : 7)) != 0 || (reinterpret_cast<uintptr_t>(p.shadow) & 15) != 0)) return false;
   return true;
 }
 // variant 0: rows per tile from the grid it makes on 256 CUs (the k-summation order does not depend on it); 60 / 62 force 96 / 64

@@ -83,7 +83,9 @@ struct IgemmParams {
   // un-folded: LN(x) W + b = rstd (x o gamma) W - rstd mu (gamma W) + (beta W + b).  With stat_out (the fp32 rows' statistics) the LayerNorm launch
   // between two GEMMs of a split-operand transformer block disappears.  null = off.
   void* shadow; int shadow_ld; const float* shadow_gamma;
-  float shadow_lo_scale;    // != 0: the shadow row is [hi (N columns) | lo (N columns)], lo = f16((value * gamma - hi) * shadow_lo_scale): the (hi, lo) A operand of a GEMM packed (w | w / scale)
+  float shadow_lo_scale;    // > 0: the shadow row is [hi (N columns) | lo (N columns)], lo = f16((value * gamma - hi) * shadow_lo_scale): the (hi, lo) A operand of a GEMM packed (w | w / scale).
+                            // < 0: the shadow is an HL16 tensor (shadow_ld in LOGICAL elements, un-scaled lo halves): read as an f16 row of 2 N columns by a GEMM whose weight is
+                            // packed twice in the HL16 interleave (launch_pack_linear_hilo mode 2)
 };
 bool igemm_gn_part_ok(const IgemmParams& p);
 // shapes the fused cross-attention epilogue takes (f16 operands, head dim 64, <= 96 context tokens); otherwise run the
@@ -299,12 +301,12 @@ void launch_pack_linear(const float* src, void* dst, int dt, int K, int N, int K
 // the same packing with every weight as TWO f16 values along a doubled K: dst[n][k] = f16(w), dst[n][K + k] = f16((w - f16(w)) * lo_scale) -- against the A
 // operand [a | a / lo_scale] (LayerNormParams::dup_scale) the f16 GEMM multiplies a by hi + lo: the weights are not rounded (22 significand bits), the
 // activations once.  K % 32 == 0; Kpad = 2 K.
-void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s, int mode = 0);
+void launch_pack_linear_hilo(const float* src, void* dst, int K, int N, int Npad, int geglu, float lo_scale, hipStream_t s, int mode = 0, int n_offset = 0);   // n_offset: first packed row (fused matrices: Npad = this part's rows)
 // mode 1: dst[n][K + k] = f16(f16(w) / lo_scale) -- the weight twice, for an A operand that carries (hi | lo * lo_scale) ACTIVATION halves (exact for f16-representable weights)
 // mode 2: the weight twice in the HL16 INTERLEAVE -- dst[n][32 g + j] = dst[n][32 g + 16 + j] = f16(w[16 g + j]) (K % 16 == 0): an HL16 activation row of C logical channels IS an
 //         f16 row of 2 C columns [16 hi | 16 lo | ...], so any f16 GEMM kernel multiplies (hi + lo) by w -- two MFMAs per product, exact for f16-representable weights
 // LayerNorm fold helpers: column sums of the packed (rounded) weight rows; beta . W + bias in canonical column order
-void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s, const float* kscale = nullptr, int K = 0);   // kscale: cs[r] = sum_k kscale[k] packed[r][k]
+void launch_colsum_packed(const void* wp, int dt, int Kpad, int nrows, float* cs, hipStream_t s, const float* kscale = nullptr, int K = 0, int interleave = 0);   // kscale: cs[r] = sum_k kscale[k] packed[r][k]; interleave: the packed row holds the K weights twice in the HL16 interleave (first copies summed)
 void launch_beta_dot(const float* w, const float* beta, const float* bias, float* out, int K, int N, hipStream_t s);
 // canonical conv [Cout][Cin][kh][kw] fp32 -> packed [Npad][Kpad], k = (kh*kw_idx)*Cin + c
 void launch_pack_conv(const float* src, void* dst, int dt, int Cout, int Cin, int ks, int Kpad, int Npad,

@@ -66,6 +66,9 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     // MIX_LN_SHADOW: the f16 projections behind a LayerNorm also exist in the shadow form (same packed matrix, cs = gamma W, b = beta W + bias): where the
     // producer of the stream left the f16 shadow f16(x o gamma) and the row statistics, the LayerNorm launch is skipped (spatial_transformer)
     if (ln_sh && qkv_f16) t.qkv_sh = wb.fold_ln({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, q + ".norm1", false, DT_F16, true, &t.qkv);
+    else if (ln_sh && !qkv_f16 && x2 && wb.spec(q + ".attn1.query.weight").shape[0] % 64 == 0 && wb.spec(q + ".attn1.query.weight").shape[1] % 128 == 0)
+      // MIX_LINEAR_F16X2 + MIX_LN_SHADOW: fp32-class projection on the f16 kernels over an HL16 shadow (k_form 2); the plain twin reads the LayerNorm launch's HL16 output
+      t.qkv_sh = wb.fold_ln({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, q + ".norm1", false, DT_F16, true, &t.qkv, false, true);
     else
     t.qkv = wb.fused_linear({q + ".attn1.query", q + ".attn1.key", q + ".attn1.value"}, qkv_f16 ? (int)DT_F16 : -1);
     // MIX_LINEAR_F16X2: a projection that stays fp32-class (its A operand an HL16 tensor) runs on the f16 kernels over the weight packed twice in the HL16 interleave
@@ -73,6 +76,8 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     t.out1 = !out1_f16 && x2_ok(q + ".attn1.out") ? wb.linear_hilo(q + ".attn1.out", false, false, true) : wb.linear(q + ".attn1.out", false, out1_f16 ? (int)DT_F16 : -1);
     t.n2 = wb.norm(q + ".norm2");
     if (ln_sh && q2_f16 && !q2_fused) t.q2_sh = wb.fold_ln({q + ".attn2.query"}, q + ".norm2", false, DT_F16, true, &t.q2);
+    else if (!q2_f16 && ln_sh && x2_ok(q + ".attn2.query") && wb.spec(q + ".attn2.query.weight").shape[0] % 64 == 0)
+      t.q2_sh = wb.fold_ln({q + ".attn2.query"}, q + ".norm2", false, DT_F16, true, &t.q2, false, true);
     else if (!q2_f16 && x2_ok(q + ".attn2.query")) t.q2 = wb.linear_hilo(q + ".attn2.query", false, false, true);
     else
     t.q2 = wb.linear(q + ".attn2.query", false, q2_f16 ? (int)DT_F16 : -1);
@@ -87,8 +92,11 @@ STW load_st(WeightBuilder& wb, const std::string& p, int C, int heads, int depth
     }
     else if (ln_sh && geglu_f16) t.geglu_sh = wb.fold_ln({q + ".mlp.geglu.proj"}, q + ".norm3", true, DT_F16, true, &t.geglu);
     else if (geglu_f16 && (mix & MIX_GEGLU_HILO) && spec_k_ok(wb, q + ".mlp.geglu.proj")) t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true);
-    else if (!geglu_f16 && x2 && wb.spec(q + ".mlp.geglu.proj.weight").shape[0] % 32 == 0 && wb.spec(q + ".mlp.geglu.proj.weight").shape[1] % 640 == 0)
-      t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true, false, true);      // fp32-class GEGLU on the f16 wide-tile kernel (HL16 operand read as f16, K = 2 C)
+    else if (!geglu_f16 && x2 && wb.spec(q + ".mlp.geglu.proj.weight").shape[0] % 32 == 0 && wb.spec(q + ".mlp.geglu.proj.weight").shape[1] % 640 == 0) {
+      // fp32-class GEGLU on the f16 wide-tile kernel (HL16 operand read as f16, K = 2 C); with MIX_LN_SHADOW also in the shadow form
+      if (ln_sh && wb.spec(q + ".mlp.geglu.proj.weight").shape[0] % 64 == 0) t.geglu_sh = wb.fold_ln({q + ".mlp.geglu.proj"}, q + ".norm3", true, DT_F16, true, &t.geglu, false, true);
+      else t.geglu = wb.linear_hilo(q + ".mlp.geglu.proj", true, false, true);
+    }
     else
     t.geglu = wb.linear(q + ".mlp.geglu.proj", true, geglu_f16 ? (int)DT_F16 : -1);
     t.ff = !ff_f16 && x2_ok(q + ".mlp.lin") ? wb.linear_hilo(q + ".mlp.lin", false, false, true) : wb.linear(q + ".mlp.lin", false, ff_f16 ? (int)DT_F16 : -1);
@@ -456,7 +464,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   //     handed to the out-projection as HL16 with zero lo halves (an f16 value is its own hi half);
   //   * GEGLU projection on f16 operands (f16 LayerNorm output x f16-packed weights, the f16 wide-tile kernel) -- its output leaves the
   //     epilogue as HL16 (fp32-class), so FF-out's operand is not rounded a second time.
-  const bool mix_qkv = hl_attn && !w.blocks.empty() && w.blocks[0].qkv.dt == DT_F16;     // (f16-packed at build: the only path those weights can take)
+  const bool mix_qkv = hl_attn && !w.blocks.empty() && w.blocks[0].qkv.dt == DT_F16 && w.blocks[0].qkv.k_form == 0;     // (f16-packed at build: the only path those weights can take; k_form 2 = fp32-class, MIX_LINEAR_F16X2)
   const bool mix_ff = hl_attn && !w.blocks.empty() && w.blocks[0].ff.dt == DT_F16 && w.blocks[0].ff.k_form == 0;      // (K = 2 x: the MIX_LINEAR_F16X2 form, an fp32-class projection)
   const bool mix_out1 = hl_attn && !w.blocks.empty() && w.blocks[0].out1.dt == DT_F16 && w.blocks[0].out1.k_form == 0;
   const bool mix_out2 = hl_attn && !w.blocks.empty() && w.blocks[0].out2.dt == DT_F16 && w.blocks[0].out2.k_form == 0;
@@ -492,8 +500,12 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
   Act sh16; float* shst = nullptr; bool have_sh = false;
   if (any_sh) { sh16 = ex.alloc(M, C, DT_F16); shst = (float*)ex.act->alloc(M * (size_t)((C + 63) / 64) * 2 * sizeof(float)); }
   Act sh16g;       // (hi | lo 2^8) shadow for a GEGLU projection packed (w | w 2^-8) along a doubled K (MIX_GEGLU_AHILO with MIX_LN_SHADOW)
-  const bool sh_g2 = any_sh && w.blocks[0].geglu_sh.cs && w.blocks[0].geglu_sh.K == 2 * C;
+  const bool sh_g2 = any_sh && w.blocks[0].geglu_sh.cs && w.blocks[0].geglu_sh.k_form == 1;
   if (sh_g2) sh16g = ex.alloc(M, 2 * C, DT_F16);
+  // MIX_LINEAR_F16X2 with MIX_LN_SHADOW: the shadow is the HL16 image of x o gamma (what the LayerNorm launch would hand the k_form-2 projection, minus the
+  // normalisation the consumer's epilogue applies from the row statistics)
+  Act shhl;
+  if (any_sh && (w.blocks[0].qkv_sh.k_form == 2 || w.blocks[0].q2_sh.k_form == 2 || w.blocks[0].geglu_sh.k_form == 2)) shhl = ex.alloc(M, C, DT_HL);
   Act q32;     // MIX_Q2_F16: fp32 q of the cross-attention (the f16 projection's fp32 accumulators, never rounded to f16)
   if (mix_q2 && !mix_q2_widen) q32 = ex.alloc(M, C, DT_F32);
   // MIX_XATTN_SPLIT: the split-precision attention runs inside that projection's epilogue on q's accumulators (hi / lo context images of set_context), and its
@@ -507,8 +519,12 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     have_sh = false;
     if (!consumer_sh.cs || C % 64 != 0) return;
     e.shadow = sh16.p; e.shadow_ld = sh16.ld; e.shadow_gamma = n.gamma; e.stat_out = shst; e.shadow_done = &have_sh;
-    if (consumer_sh.K == 2 * C) { e.shadow = sh16g.p; e.shadow_ld = sh16g.ld; e.shadow_lo_scale = kHiLoScale; }      // (hi | lo) halves: the consumer's K is doubled
+    if (consumer_sh.k_form == 1) { e.shadow = sh16g.p; e.shadow_ld = sh16g.ld; e.shadow_lo_scale = kHiLoScale; }      // (hi | lo) halves: the consumer's K is doubled
+    if (consumer_sh.k_form == 2) { e.shadow = shhl.p; e.shadow_ld = shhl.ld; e.shadow_lo_scale = -1.f; }      // HL16 rows
   };
+  auto sh_of = [&](const Lin& consumer_sh) { return consumer_sh.k_form == 2 ? Act(shhl.p, 2 * shhl.ld, DT_F16) : consumer_sh.k_form == 1 ? sh16g : sh16; };
+  // producers of the shadow: the projections that run the f16 kernels (f16 class or MIX_LINEAR_F16X2), where the selection picks the weights-in-registers kernel
+  auto sh_prod = [&](const Lin& l) { return hl_attn && l.dt == DT_F16; };
   // the f16 GEGLU kernels store an HL16 output through the LDS-staged epilogue of the wide / pipelined tiles -- the kernels every SDXL shape runs on
   // (M = 2048 ... 32768).  Small token counts (tiny test nets: M < 256) run on other tiles; they take the form the F16_F32RES engine
   // runs at every size -- f16 output -- and widen it.
@@ -552,11 +568,11 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     Epi eq; eq.n_split = 2 * C; eq.Ct = mix_attn ? vt16 : vt; eq.ct_rows = C; eq.ct_ld = npad; eq.rpb = HW; eq.cls = DM_QKV;
     if (have_sh && b.qkv_sh.cs) {      // the previous block's FF-out left f16(t o gamma1) and the row statistics: no LayerNorm launch
       eq.ln_stat = shst;
-      run_linear(ex, b.qkv_sh, sh16, (int)M, qk16, eq);
+      run_linear(ex, b.qkv_sh, sh_of(b.qkv_sh), (int)M, mix_attn ? qk16 : qk, eq);
     } else {
     run_layernorm(ex, b.n1, t, (int)M, mix_qkv ? ln16 : ln);
     demote_lo(ex, DM_QKV, ln, M, C);
-    run_linear(ex, b.qkv, mix_qkv ? ln16 : ln, (int)M, mix_attn ? qk16 : qk, eq);
+    run_linear(ex, b.qkv, mix_qkv ? ln16 : x2op(b.qkv, ln, C), (int)M, mix_attn ? qk16 : qk, eq);
     }
     have_sh = false;
     if (mix_attn) {
@@ -578,15 +594,16 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     else attention(ex, qk, qk.cols(C), vt, npad, ao, B, w.heads, HW, HW);
     Epi er; er.R = t; er.rpb = HW; er.cls = DM_OUT;
     demote_lo(ex, DM_OUT, ao, M, C);
-    { Epi e1 = er; if (mix_out1) want_shadow(e1, b.q2_sh, b.n2); run_linear(ex, b.out1, mix_out1 ? ao16 : x2op(b.out1, ao, C), (int)M, t, e1); }
+    { Epi e1 = er; if (sh_prod(b.out1)) want_shadow(e1, b.q2_sh, b.n2); run_linear(ex, b.out1, mix_out1 ? ao16 : x2op(b.out1, ao, C), (int)M, t, e1); }
     if (have_sh && b.q2_sh.cs) {       // f16 query projection on the shadow the out-projection left; fp32 q for the split-operand attention
       Epi e2q; e2q.cls = DM_XATTN; e2q.rpb = HW; e2q.ln_stat = shst;
-      if (mix_xs) {
+      if (mix_xs || x2_xs) {
         e2q.xa_k = kv_xa(si, j); e2q.xa_k_lo = kv_xa_lo(si, j); e2q.xa_nctx = n_ctx_; e2q.xa_scale = 0.125f;
-        run_linear(ex, b.q2_sh, sh16, (int)M, ao2_16, e2q);
+        run_linear(ex, b.q2_sh, sh_of(b.q2_sh), (int)M, mix_xs ? ao2_16 : ao, e2q);
       } else {
-      run_linear(ex, b.q2_sh, sh16, (int)M, q32, e2q);
-      attention_hl(ex, q32, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao2_16 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);
+      const Act& qo = x2_q2 ? q : q32;
+      run_linear(ex, b.q2_sh, sh_of(b.q2_sh), (int)M, qo, e2q);
+      attention_hl(ex, qo, kv_k(si, j), C, kv_vt(si, j), vt_ld_ctx_, mix_out2 ? ao2_16 : ao, B, w.heads, HW, n_ctx_, DM_XATTN);
       }
     } else {
     run_layernorm(ex, b.n2, t, (int)M, mix_q2 ? ln16 : ln);
@@ -629,7 +646,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     }
     have_sh = false;
     demote_lo(ex, DM_OUT, ao, M, C);
-    { Epi e2 = er; if (mix_out2) want_shadow(e2, b.geglu_sh, b.n3); run_linear(ex, b.out2, mix_out2 ? ao2_16 : x2op(b.out2, ao, C), (int)M, t, e2); }
+    { Epi e2 = er; if (sh_prod(b.out2)) want_shadow(e2, b.geglu_sh, b.n3); run_linear(ex, b.out2, mix_out2 ? ao2_16 : x2op(b.out2, ao, C), (int)M, t, e2); }
     Epi eg; eg.act = 1; eg.cls = DM_GEGLU;
     const bool gg_sh = have_sh && b.geglu_sh.cs;      // GEGLU projection on the shadow the cross-attention's out-projection left: no LayerNorm launch
     if (gg_sh) eg.ln_stat = shst;
@@ -641,7 +658,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     have_sh = false;
     if (gg_sh) {
       eg.rpb = HW;
-      const Act& shg = sh_g2 ? sh16g : sh16;
+      const Act shg = sh_of(b.geglu_sh);
       if (mix_ff) run_linear(ex, b.geglu_sh, shg, (int)M, gg16, eg);
       else if (!gg_direct) { run_linear(ex, b.geglu_sh, shg, (int)M, gg16, eg); if (!ex.dry) launch_f16_to_hl(gg16.p, gg16.ld, gg.p, gg.ld, M, 4 * C, ex.s); }
       else run_linear(ex, b.geglu_sh, shg, (int)M, gg, eg);
@@ -655,7 +672,7 @@ void UNet::spatial_transformer(Exec& ex, const STW& w, int si, const Act& x, int
     run_linear(ex, b.geglu, gg_hilo ? ln16x2 : mix_geglu ? ln16 : x2op(b.geglu, ln, C), (int)M, gg, eg);
     demote_lo(ex, DM_FF, gg, M, 4 * C);
     er.cls = DM_FF;
-    { Epi ef = er; if (mix_ff && j + 1 < w.blocks.size()) want_shadow(ef, w.blocks[j + 1].qkv_sh, w.blocks[j + 1].n1); run_linear(ex, b.ff, mix_ff ? gg16 : x2op(b.ff, gg, 4 * C), (int)M, t, ef); }
+    { Epi ef = er; if (sh_prod(b.ff) && j + 1 < w.blocks.size()) want_shadow(ef, w.blocks[j + 1].qkv_sh, w.blocks[j + 1].n1); run_linear(ex, b.ff, mix_ff ? gg16 : x2op(b.ff, gg, 4 * C), (int)M, t, ef); }
   }
   Epi eo; eo.R = x; eo.rpb = HW; eo.cls = DM_CONV_PROJ;
   run_linear(ex, w.proj_out, hl_op(ex, w.proj_out, t, M, C, DM_CONV_PROJ, B), (int)M, x, eo);

@@ -281,7 +281,7 @@ bool WeightBuilder::all_f16_exact(const std::vector<std::string>& names) {
   SDXL_HIP(hipStreamSynchronize(st));
   return h != 0.f;
 }
-Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override, bool shadow, Lin* plain, bool hilo_dup) {
+Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::string& norm, bool geglu, int dt_override, bool shadow, Lin* plain, bool hilo_dup, bool hl_interleave) {
   SDXL_REQUIRE(!geglu || names.size() == 1, "GEGLU packing applies to a single projection");
   const int mdt = dt;                       // the model's dtype
   const int dt = dt_override >= 0 ? dt_override : mdt;      // (shadows the member below: the dtype THIS matrix is packed in)
@@ -296,7 +296,9 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
   }
   SDXL_REQUIRE(!hilo_dup || (shadow && names.size() == 1 && dt == DT_F16 && l.K % 32 == 0), "fold_ln: the (hi | lo) form is a single f16 shadow-form projection");
   const int K0 = l.K;                       // columns of the LayerNorm
+  SDXL_REQUIRE(!hl_interleave || (shadow && !hilo_dup && dt == DT_F16 && l.K % 32 == 0), "fold_ln: the HL16-interleaved form is an f16 shadow-form projection");
   if (hilo_dup) { l.ln_k = K0; l.K = 2 * K0; l.k_form = 1; }
+  if (hl_interleave) { l.ln_k = K0; l.K = 2 * K0; l.k_form = 2; }
   l.N = ntot; l.cin = l.K;
   const int kt = dt == DT_F16 ? 64 : 32;
   l.Kpad = (int)round_up(l.K, kt); l.Npad = (int)round_up(l.N, 128);
@@ -333,7 +335,8 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
     if (hb) SDXL_HIP(hipMemcpyAsync(bsrc, fetch(n + ".bias"), N * sizeof(float), hipMemcpyDeviceToDevice, st));
     const float* wsrc = fetch(n + ".weight");
     // (shadow form: the matrix stays W -- an f16-representable parameter stays exact -- and gamma multiplies the A operand instead)
-    if (hilo_dup) launch_pack_linear_hilo(wsrc, w, K0, N, l.Npad, geglu ? 1 : 0, kHiLoScale, st, 1);      // (w | w / kHiLoScale): the (hi | lo) shadow's partner
+    if (hl_interleave) launch_pack_linear_hilo(wsrc, w, K0, N, names.size() == 1 ? l.Npad : N, geglu ? 1 : 0, kHiLoScale, st, 2, off);      // the weight twice per 16-channel group
+    else if (hilo_dup) launch_pack_linear_hilo(wsrc, w, K0, N, l.Npad, geglu ? 1 : 0, kHiLoScale, st, 1);      // (w | w / kHiLoScale): the (hi | lo) shadow's partner
     else if (names.size() == 1) launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, l.Npad, geglu ? 1 : 0, 0, st, shadow ? nullptr : gamma);
     else launch_pack_linear(wsrc, w, dt, l.K, N, l.Kpad, N, 0, off, st, shadow ? nullptr : gamma);
     launch_beta_dot(wsrc, beta, hb ? bsrc : nullptr, bfold, K0, N, st);
@@ -341,7 +344,7 @@ Lin WeightBuilder::fold_ln(const std::vector<std::string>& names, const std::str
     if (bplain) launch_pack_bias(hb ? bsrc : nullptr, bplain, N, names.size() == 1 ? l.Npad : N, geglu ? 1 : 0, off, st);
     off += N;
   }
-  if (shadow) launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st, gamma, K0);      // cs[n] = sum_k gamma[k] W[k][n] over the packed (rounded) values
+  if (shadow) launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st, gamma, K0, hl_interleave ? 1 : 0);      // cs[n] = sum_k gamma[k] W[k][n] over the packed (rounded) values
   else launch_colsum_packed(w, dt, l.Kpad, l.Npad, cs, st);
   return l;
 }

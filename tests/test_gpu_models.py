@@ -85,7 +85,7 @@ def test_unet_forward(pkg, ctx, dtype, which):
     specs = pkg.unet_param_specs(to_pkg_cfg(pkg, ocfg))
     flat = pkg.flatten_weights(specs, {k: v.numpy() for k, v in W.items()})
     u = pkg.UNet(ctx, to_pkg_cfg(pkg, ocfg), dtype, weights=flat)
-    assert u.mix_classes() == {4: MIX_CLASSES, 5: F16W_CLASSES, 6: F16W_CLASSES | 2048, 7: 4096 | 512}.get(dtype, 0)
+    assert u.mix_classes() == {4: MIX_CLASSES, 5: F16W_CLASSES, 6: F16W_CLASSES | 2048, 7: 4096 | 512 | 256}.get(dtype, 0)
     outs = [u.forward(x.cuda(), t.cuda(), context.cuda(), y.cuda()).cpu() for _ in range(3)]   # eager, capture, replay
     e = rel_err(outs[0], ref)
     print(f"unet_forward[{which}] dtype={dtype}: rel err {e:.3e}")
@@ -341,7 +341,7 @@ def test_f16w_mode_falls_back_on_parameters_that_are_not_f16_values(pkg, ctx):
     assert torch.equal(u5.forward(x, t, c, y), u4.forward(x, t, c, y))
     assert pkg.UNet(ctx, cfg, 5, seed=pkg.SEED_F16_WEIGHTS).mix_classes() == F16W_CLASSES
     assert pkg.UNet(ctx, cfg, 6, seed=pkg.SEED_F16_WEIGHTS).mix_classes() == F16W_CLASSES | 2048 and pkg.UNet(ctx, cfg, 6, seed=0).mix_classes() == MIX_CLASSES
-    assert pkg.UNet(ctx, cfg, 7, seed=pkg.SEED_F16_WEIGHTS).mix_classes() == 4096 | 512 and pkg.UNet(ctx, cfg, 7, seed=0).mix_classes() == 0
+    assert pkg.UNet(ctx, cfg, 7, seed=pkg.SEED_F16_WEIGHTS).mix_classes() == 4096 | 512 | 256 and pkg.UNet(ctx, cfg, 7, seed=0).mix_classes() == 0
     specs = pkg.unet_param_specs(cfg)
     W16 = {k: (v if k.endswith(".eps") else v.half().float()).numpy().copy() for k, v in unet_weights(ocfg).items()}
     assert pkg.UNet(ctx, cfg, 5, weights=pkg.flatten_weights(specs, W16)).mix_classes() == F16W_CLASSES
