@@ -56,7 +56,8 @@ enum {
   SDXL_DTYPE_F32_SPLIT_F16W = 7 /* UNet / Diffuser only: SDXL_DTYPE_F32_SPLIT for models whose PARAMETERS ARE f16 VALUES -- the same fp32-class arithmetic (two MFMAs per product,
                              * fp32 stream, split-operand attention; meets the unscaled 1e-3) with the transformer's linear layers on the F16 kernels: an HL16
                              * activation row is read as an f16 row of twice the width against weights packed twice per 16-channel group, and the 77-key
-                             * cross-attention runs at split precision inside the query projection.  ~10 % faster than _F32_SPLIT on such weights; falls back to it
+                             * cross-attention runs at split precision inside the query projection, LayerNorms folded through an HL16 shadow of the stream.
+                             * ~12 % faster than _F32_SPLIT on such weights; falls back to it
                              * on others (sdxl_unet_mix_classes: 0)                                                                                              */
 };
 /* sdxl_debug_set knobs ("mix_classes", "hl_demote", "hl_tile96", "igemm_*", "attn_*") are PROCESS-WIDE atomics read when a model is built / planned: A/B and
