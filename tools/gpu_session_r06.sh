@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-6 GPU-box session.  usage: tools/gpu_session_r06.sh <tag> [parts...]   (parts: tests smoke bench benchf16w benchg2 benchmix cfg1 cfg4 cfg5 cfg5f16w trace rocprof rocproff16w pmc traffic)
+# Round-6 GPU-box session.  usage: tools/gpu_session_r06.sh <tag> [parts...]   (parts: tests smoke bench benchf16w benchg2 bench7 benchmix cfg1 cfg4 cfg5 cfg5f16w trace rocprof rocproff16w pmc traffic)
 set -u
 TAG=${1:-s}; shift || true
 PARTS=${*:-tests smoke bench}
@@ -13,6 +13,7 @@ for p in $PARTS; do
     bench) SDXL_PROFILE_DUMP=$OUT/step_launches.csv timeout 900 python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; line $OUT/bench.json f16; python -c "import json; d=json.load(open('$OUT/bench.json')); [print(' strict', k, v.get('images_per_sec'), v.get('unet_step_ms'), v.get('config2_final_latent_max_abs_vs_oracle'), v.get('inside_lat_bound_scaled')) for k, v in (d.get('strict_f32') or {}).items()]";;
     benchf16w) SDXL_PROFILE_DUMP=$OUT/step_launches_f16w.csv timeout 900 python bench.py --dtype f32_split_mix_f16w --weights f16 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_f16w.json 2> $OUT/bench_f16w.err; line $OUT/bench_f16w.json f16w; python -c "import json; d=json.load(open('$OUT/bench_f16w.json')); print(' timed engine parity', d['parity']['live'].get('timed_engine'))";;
     benchg2) timeout 900 python bench.py --dtype f32_split_mix_f16w_geglu2 --weights f16 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_geglu2.json 2> $OUT/bench_geglu2.err; line $OUT/bench_geglu2.json f16w-geglu2; python -c "import json; d=json.load(open('$OUT/bench_geglu2.json')); print(' timed engine parity', d['parity']['live'].get('timed_engine'))";;
+    bench7) timeout 900 python bench.py --dtype f32_split_f16w --weights f16 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_f32_split_f16w.json 2> $OUT/bench_f32_split_f16w.err; line $OUT/bench_f32_split_f16w.json f32_split_f16w; python -c "import json; d=json.load(open('$OUT/bench_f32_split_f16w.json')); print(' timed engine parity', d['parity']['live'].get('timed_engine'))";;
     benchmix) timeout 900 python bench.py --dtype f32_split_mix --steps 3 --warmup 1 --no-cpu-baseline --no-live-parity > $OUT/bench_mix.json 2> $OUT/bench_mix.err; line $OUT/bench_mix.json f32_split_mix;;
     cfg1) timeout 900 python bench.py --config 1 --steps 3 --warmup 1 > $OUT/bench_cfg1.json 2> $OUT/bench_cfg1.err; line $OUT/bench_cfg1.json cfg1;;
     cfg4) timeout 900 python bench.py --config 4 --steps 2 --warmup 1 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; line $OUT/bench_cfg4.json cfg4;;
