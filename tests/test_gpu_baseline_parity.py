@@ -477,8 +477,8 @@ def test_config2_second_prompt_f16_weights(pkg, ctx):
     steps = [int(s_) for s_ in g["steps"]]
     ref_traj, ref = torch.from_numpy(g["traj"]), torch.from_numpy(g["latent"])
     rep = {}
-    for name, dt in (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W), ("f32_split_mix_f16w_geglu2", pkg.DTYPE_F32_SPLIT_MIX_F16W_GEGLU2),
-                     ("knob127", pkg.DTYPE_F32_SPLIT_MIX)):
+    for name, dt in (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_f16w", pkg.DTYPE_F32_SPLIT_F16W), ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W),
+                     ("f32_split_mix_f16w_geglu2", pkg.DTYPE_F32_SPLIT_MIX_F16W_GEGLU2), ("knob127", pkg.DTYPE_F32_SPLIT_MIX)):
         if name == "knob127":
             pkg.debug_set("mix_classes", 127)
         try:
@@ -502,6 +502,7 @@ def test_config2_second_prompt_f16_weights(pkg, ctx):
         assert rep["f32_split"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split"][str(s_)])
         assert rep["f32_split_mix_f16w"][str(s_)]["max_abs"] <= lat_bound(ref_traj[j]), (s_, rep["f32_split_mix_f16w"][str(s_)])
     assert rep["f32_split"]["final"]["max_abs"] < 1e-3
+    assert rep["f32_split_f16w"]["final"]["max_abs"] < 1e-3      # F32_SPLIT's arithmetic on the f16 kernels: the UNSCALED 1e-3, like F32_SPLIT
     assert rep["f32_split_mix_f16w"]["final"]["max_abs"] <= lat_bound(ref)
     assert rep["knob127"]["final"]["max_abs"] <= lat_bound(ref), rep["knob127"]["final"]
 
@@ -721,8 +722,8 @@ def test_inpainting_1024_f16_representable_weights(pkg, ctx):
         a_n = float(alphas[ts[k + 1]])
         ref_traj[k] = torch.where(mask, ref_traj[k], reference * (a_n ** 0.5) + i["step_noise"][k + 1] * ((1.0 - a_n) ** 0.5))
     rep = {}
-    for name, dt in (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_mix", pkg.DTYPE_F32_SPLIT_MIX), ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W),
-                     ("f32_split_mix_f16w_geglu2", pkg.DTYPE_F32_SPLIT_MIX_F16W_GEGLU2)):
+    for name, dt in (("f32_split", pkg.DTYPE_F32_SPLIT), ("f32_split_f16w", pkg.DTYPE_F32_SPLIT_F16W), ("f32_split_mix", pkg.DTYPE_F32_SPLIT_MIX),
+                     ("f32_split_mix_f16w", pkg.DTYPE_F32_SPLIT_MIX_F16W), ("f32_split_mix_f16w_geglu2", pkg.DTYPE_F32_SPLIT_MIX_F16W_GEGLU2)):
         d = pkg.Diffuser(ctx, cfg, dt, seed=pkg.SEED_F16_WEIGHTS)
         trace = torch.zeros(4, 1, 4, 128, 128, device="cuda")
         d.set_trace(trace)
@@ -737,6 +738,7 @@ def test_inpainting_1024_f16_representable_weights(pkg, ctx):
     REPORT["inpainting_1024_f16_weights_vs_oracle"] = rep
     for k in range(4):
         assert rep["f32_split"]["per_step"][k]["max_abs"] <= lat_bound(ref_traj[k]), (k, rep["f32_split"]["per_step"][k])
+        assert rep["f32_split_f16w"]["per_step"][k]["max_abs"] <= lat_bound(ref_traj[k]), (k, rep["f32_split_f16w"]["per_step"][k])      # (the same arithmetic on the f16 kernels)
         for nm in ("f32_split_mix", "f32_split_mix_f16w"):
             assert rep[nm]["per_step"][k]["max_abs"] <= 2.0 * lat_bound(ref_traj[k]), (nm, k, rep[nm]["per_step"][k])
         # SDXL_DTYPE_F32_SPLIT_MIX_F16W_GEGLU2 (round 6): the class that takes the mixed modes over the bound on this stress fixture -- the GEGLU projection, every
