@@ -85,13 +85,20 @@ void Vae::res_block(Exec& ex, const VaeResW& w, const Act& x, int B, int H, int 
   const size_t M = (size_t)B * H * W;
   const ConvGeom g3{B, H, W, H, W, 3, 1, 1, 0}, g1{B, H, W, H, W, 1, 1, 0, 0};
   Act gn1 = ex.alloc(M, w.cin, ex.cdt);
-  run_groupnorm(ex, w.n1, x, B, H * W, gn1, true, cfg_.n_group);
+  // split-operand mode: the 1x1 nin_shortcut reads x as an HL16 copy scaled per entry by max|x| -- the statistics pass of norm1 reads all of x anyway and leaves
+  // the maxima (GroupNormParams::absmax_out), so that copy needs no absmax pass of its own (0.5 / 1.1 GB tensors at the 512^2 / 1024^2 levels of a 1024^2 decode).
+  // (GroupNorm statistics from the producing convolutions' epilogues, as in the UNet, were built and measured here: the staged epilogue they need costs these
+  //  16-round launches more than the statistics passes it saves -- decode 39.4 -> 42.4 ms, f16 17.8 -> 21.8; not kept)
+  float* nin_max = nullptr;
+  if (w.has_nin && ex.cdt == DT_HL && x.dt == DT_F32 && w.nin.dt != DT_F32 && !x.gn_part && M % (size_t)B == 0)
+    nin_max = (float*)ex.act->alloc(hl_scale_floats(B) * sizeof(float));
+  run_groupnorm(ex, w.n1, x, B, H * W, gn1, true, cfg_.n_group, nin_max);
   Act h = ex.alloc(M, w.cout, ex.sdt);          // (read by a GroupNorm only: stays in the stream dtype)
   run_conv(ex, w.c1, gn1, w.cin, g3, h);
   Act gn2 = ex.alloc(M, w.cout, ex.cdt);
   run_groupnorm(ex, w.n2, h, B, H * W, gn2, true, cfg_.n_group);
   Epi e;
-  if (w.has_nin) { run_conv(ex, w.nin, hl_operand(ex, w.nin, x, M, w.cin, B), w.cin, g1, out); e.R = out; }
+  if (w.has_nin) { run_conv(ex, w.nin, hl_operand(ex, w.nin, x, M, w.cin, B, nin_max), w.cin, g1, out); e.R = out; }
   else e.R = x;
   run_conv(ex, w.c2, gn2, w.cout, g3, out, e);
   ex.act->reset(mk);
