@@ -151,8 +151,10 @@ void Vae::mid(Exec& ex, const VaeMidW& w, const Act& x, int B, int H, int W) {
     void* vt = ex.act->alloc((size_t)B * rows_v * kpad * dt_size(ex.cdt));
     Act o = ex.alloc(M, C, ex.cdt);
     // scores are never materialised for the whole image: queries go through in passes of QT rows, so S / P stay bounded
-    // (QT x HW: 134 MB + 67..134 MB at a 128x128 latent instead of 1.07 GB + 0.5..1 GB, and linear in HW beyond it)
-    const int QT = HW < 2048 ? HW : 2048;
+    // (QT x HW: 0.54 GB + 0.27..0.54 GB at a 128x128 latent instead of 1.07 GB + 0.5..1 GB, and linear in HW beyond it).  QT = 8192 (round 6; was 2048): the
+    // P V product of a pass is QT x C with K = HW -- at 2048 rows that is 88 tiles of 96x128 on 256 CUs, 281 us a pass whatever the rows; at 8192 rows 256
+    // tiles of 128x128 fill the chip: 8 x 281 us -> 2 x ~330 us per decode, same k order per output (bit-identical)
+    const int QT = HW < 8192 ? HW : 8192;
     float* S = (float*)ex.act->alloc((size_t)QT * HW * sizeof(float));
     void* P = ex.act->alloc((size_t)QT * kpad * dt_size(ex.cdt));
     // split-operand mode: P = softmax over up to 16 384 keys is ~6e-5 per entry -- stored times 2^12 so the lo halves of the HL16 image stay
