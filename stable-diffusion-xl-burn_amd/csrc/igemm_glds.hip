@@ -1104,13 +1104,17 @@ int igemm_splitk_slices(const IgemmParams& p) {
   const int nk = p.Kpad / 64;
   // measured (profiles/r02_splitk_sweep.txt): pays from K ~ 11520 (the 32^2 convs: +4 % at K = 11520, +22 % at K = 23040); at
   // K = 5120 (FF-out) the serial combine costs more than the 24 % fewer bytes moved buy (57 vs 44 us), so the bar is 160 k-tiles
-  if (p.rpb <= 0 || p.rpb > 1024 || p.N > 1280 || nk < 160) return 1;
-  return 3;
+  // (round 6: N up to 1536 -- the refiner's 32^2 / 16^2 levels were excluded by the base model's 1280 and ran their K = 13824 ... 27648 convolutions on 12 - 48
+  //  workgroups; and EIGHT slices where an entry has one 256-row tile: the 16^2 level of the refiner / of a 512^2 base image streams 42 - 85 MB of weights through
+  //  12 x 8 workgroups instead of 12 x 3 -- profiles/r06_refiner_shape_profile.txt)
+  if (p.rpb <= 0 || p.rpb > 1024 || p.N > 1536 || nk < 160) return 1;
+  return p.rpb <= 256 ? 8 : 3;
 }
 size_t igemm_splitk_ws_bytes(int batch, int rows_per_entry, int n_max) {
-  const long rows = (long)batch * (rows_per_entry < 1024 ? rows_per_entry : 1024);
-  if (n_max > 1280) n_max = 1280;          // wider outputs never split (igemm_splitk_slices)
-  return (size_t)((rows + 255) / 256) * (size_t)((n_max + 127) / 128) * 3 * 256 * 128 * 4;
+  if (n_max > 1536) n_max = 1536;          // wider outputs never split (igemm_splitk_slices)
+  const long rows3 = (long)batch * (rows_per_entry < 1024 ? rows_per_entry : 1024), rows8 = (long)batch * (rows_per_entry < 256 ? rows_per_entry : 256);
+  const size_t slabs3 = (size_t)((rows3 + 255) / 256) * 3, slabs8 = (size_t)((rows8 + 255) / 256) * 8;
+  return (slabs3 > slabs8 ? slabs3 : slabs8) * (size_t)((n_max + 127) / 128) * 256 * 128 * 4;
 }
 
 // Cost of a grid of bm x bn tiles over an M x N output with nk k-tiles (arbitrary units, ~ns).  A workgroup's k-loop time goes

@@ -833,7 +833,7 @@ void UNet::ensure_plan(int B, int H, int W) {
       }
     }
     if (cdt_ == DT_F16 || cdt_ == DT_HL) {   // split-K slabs + counters: chain 0 (and the second split-CFG chain)
-      skws_bytes_ = igemm_splitk_ws_bytes(B, 1024, 1280);
+      skws_bytes_ = igemm_splitk_ws_bytes(B, 1024, 1536);
       skws_[1] = nullptr; skcnt_[1] = nullptr;
       for (int c = 0; c < (split ? 2 : 1); ++c) {   // the second set only exists for the second split-CFG chain
         skws_[c] = (float*)act_.alloc(skws_bytes_);
